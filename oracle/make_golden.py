@@ -1,0 +1,278 @@
+"""
+make_golden.py -- generate the golden vectors under tests/golden/ from the REAL reference pieces.
+
+Runs ONLY in the authoring container (it reads /root/reference and imports `transformers`); the GPU box never runs it.
+It commits DATA (inputs + expected outputs), never reference source.  What it pins:
+
+  G1 action_decode.npz      ids -> actions through the reference's ActionTokenizer (prismatic/vla/action_tokenizer.py:49-68)
+  G2 (inside G5)            un-normalisation through OpenVLAForActionPrediction.predict_action (modeling_prismatic.py:522-535)
+  G3 projector.npz          reference FusedMLPProjector (prismatic/util/nn_utils.py:37-53), seeded weights stored
+  G4 llama_{mha,gqa}.npz    HF LlamaForCausalLM CPU fp32: prefill logits, per-step decode logits, greedy ids (weights stored)
+  G5 wrapper.npz            reference OpenVLAForActionPrediction (modeling_prismatic.py) run through a stub-timm shim:
+                            forward logits, predict_action ids + 7-vector  (weights = emmax synthetic seed, checksum stored)
+  G6 prompts.json           PurePromptBuilder strings (base_prompter.py:28-73)
+  G7 solver.json            Solver.extract_action_policies / extract_movement_plan (solver.py:8-137) with a stub tokenizer
+
+Usage:  python oracle/make_golden.py
+"""
+
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "emma-x_amd"))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from emmax.config import EmmaXConfig, LlmConfig  # noqa: E402
+from emmax.tokenizer_stub import StubTokenizer  # noqa: E402
+from emmax.weights import synthetic_state_dict  # noqa: E402
+from oracle import emmax_oracle as orc  # noqa: E402
+
+
+def load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def checksum(sd):
+    return float(sum(float(v.double().abs().sum()) for v in sd.values()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def g1_action_decode():
+    at = load(f"{REF}/prismatic/vla/action_tokenizer.py", "ref_at")
+    tok = types.SimpleNamespace(vocab_size=32000)
+    ref = at.ActionTokenizer(tok)
+    rng = np.random.default_rng(7)
+    ids = np.concatenate([np.array([31999, 31998, 31872, 31871, 31745, 31744, 31743, 30000, 5, 32000, 32063]),
+                          rng.integers(31700, 32064, size=64)])
+    acts = ref.decode_token_ids_to_actions(ids)
+    # forward direction too: continuous -> token ids (digitize), for round-trip tests
+    cont = rng.uniform(-1.2, 1.2, size=64)
+    disc = np.digitize(np.clip(cont, -1.0, 1.0), ref.bins)
+    np.savez(os.path.join(OUT, "action_decode.npz"), ids=ids, actions=acts, bin_centers=ref.bin_centers,
+             cont=cont, cont_token_ids=32000 - disc)
+    print("G1 ok", acts[:6])
+
+
+def g3_projector():
+    nnu = load(f"{REF}/prismatic/util/nn_utils.py", "ref_nn")
+    torch.manual_seed(3)
+    m = nnu.FusedMLPProjector(fused_vision_dim=34, llm_dim=64).eval()
+    x = torch.randn(2, 5, 34)
+    with torch.no_grad():
+        y = m(x)
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}   # projector.{0,2,4}.{weight,bias}
+    np.savez(os.path.join(OUT, "projector.npz"), x=x.numpy(), y=y.numpy(), **{k.replace(".", "__"): v for k, v in sd.items()})
+    print("G3 ok", y.abs().mean().item())
+
+
+def g4_llama(name, heads, kv_heads, head_dim):
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    lc = LlmConfig(hidden_size=64, intermediate_size=176, num_layers=2, num_heads=heads, num_kv_heads=kv_heads,
+                   head_dim=head_dim, vocab_size=512, rms_eps=1e-5, rope_theta=10000.0)
+    hf_cfg = LlamaConfig(hidden_size=64, intermediate_size=176, num_hidden_layers=2, num_attention_heads=heads,
+                         num_key_value_heads=kv_heads, head_dim=head_dim, vocab_size=512, rms_norm_eps=1e-5,
+                         rope_theta=10000.0, max_position_embeddings=2048, attention_bias=False, tie_word_embeddings=False)
+    hf_cfg._attn_implementation = "eager"
+    torch.manual_seed(11)
+    m = LlamaForCausalLM(hf_cfg).eval().to(torch.float32)
+    # widen the init so logits are not flat
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.ndim == 2:
+                p.normal_(0, 0.08)
+            else:
+                p.copy_(1.0 + 0.1 * torch.randn_like(p))
+    sd = {"language_model." + k: v.detach().clone() for k, v in m.state_dict().items()}
+    T_prompt, T_new = 9, 16
+    embeds = torch.randn(1, T_prompt, 64)
+    with torch.no_grad():
+        out = m(inputs_embeds=embeds, use_cache=True)
+        prefill_logits = out.logits[0].clone()
+        cache = out.past_key_values
+        ids, step_logits = [], []
+        nxt = int(out.logits[0, -1].argmax())
+        for _ in range(T_new):
+            ids.append(nxt)
+            o = m(input_ids=torch.tensor([[nxt]]), past_key_values=cache, use_cache=True)
+            cache = o.past_key_values
+            step_logits.append(o.logits[0, -1].clone())
+            nxt = int(o.logits[0, -1].argmax())
+    np.savez(os.path.join(OUT, f"llama_{name}.npz"), embeds=embeds.numpy(), prefill_logits=prefill_logits.numpy(),
+             step_logits=torch.stack(step_logits).numpy(), ids=np.array(ids),
+             cfg=np.array([lc.hidden_size, lc.intermediate_size, lc.num_layers, lc.num_heads, lc.num_kv_heads,
+                           lc.head_dim, lc.vocab_size]),
+             **{k.replace(".", "__"): v.numpy() for k, v in sd.items() if "rotary" not in k})
+    # self-check: the oracle must reproduce HF here, otherwise do not write a misleading fixture silently
+    lg, c = orc.llama_forward(embeds, sd, lc, None)
+    err = (lg[0] - prefill_logits).abs().max().item()
+    print(f"G4 {name} ok; oracle-vs-HF prefill max err {err:.2e}; ids {ids[:8]}")
+    assert err < 1e-4
+
+
+def g5_wrapper():
+    """Reference HF wrapper (splice, cache dispatch, 29871 append, de-tokenise, un-normalise) with OUR tower restatement."""
+    import torch.nn as nn
+    import transformers  # noqa: F401  (import before stubbing timm)
+    from transformers import GenerationMixin
+
+    cfg = EmmaXConfig.tiny()
+    sd = synthetic_state_dict(cfg, seed=5, planted=True)
+
+    class OurCpuViT(nn.Module):
+        def __init__(self, tower_index):
+            super().__init__()
+            self.tw = cfg.towers[tower_index]
+            self.prefix = orc.TOWER_PREFIXES[tower_index]
+            self.blocks = [None] * self.tw.depth
+            self.embed_dim = self.tw.embed_dim
+
+        def get_intermediate_layers(self, x, n=None):
+            assert n == {self.tw.depth - 2}
+            return (orc.vit_tower(x.float(), sd, self.prefix, self.tw),)
+
+    timm = types.ModuleType("timm")
+    timm.__version__ = "0.9.10"
+    tv = types.ModuleType("timm.models.vision_transformer")
+    tm = types.ModuleType("timm.models")
+
+    class LayerScale(nn.Module):
+        pass
+
+    tv.LayerScale = LayerScale
+    tm.vision_transformer = tv
+    timm.models = tm
+    counter = {"i": 0}
+
+    def create_model(name, **kw):
+        i = counter["i"]
+        counter["i"] += 1
+        return OurCpuViT(i)
+
+    timm.create_model = create_model
+    sys.modules.update({"timm": timm, "timm.models": tm, "timm.models.vision_transformer": tv})
+    pkg = types.ModuleType("refhf")
+    pkg.__path__ = [f"{REF}/prismatic/extern/hf"]
+    sys.modules["refhf"] = pkg
+    cfgm = load(f"{REF}/prismatic/extern/hf/configuration_prismatic.py", "refhf.configuration_prismatic")
+    mod = load(f"{REF}/prismatic/extern/hf/modeling_prismatic.py", "refhf.modeling_prismatic")
+    mod.PrismaticForConditionalGeneration.tie_weights = lambda self, *a, **k: None
+
+    class Shim(mod.OpenVLAForActionPrediction, GenerationMixin):
+        pass
+
+    L = cfg.llm
+    hcfg = cfgm.OpenVLAConfig(
+        vision_backbone_id="dinosiglip-vit-so-224px", llm_backbone_id="llama2-7b-pure",
+        arch_specifier="no-align+fused-gelu-mlp", image_resize_strategy="resize-naive",
+        text_config=dict(hidden_size=L.hidden_size, intermediate_size=L.intermediate_size,
+                         num_hidden_layers=L.num_layers, num_attention_heads=L.num_heads,
+                         num_key_value_heads=L.num_kv_heads, head_dim=L.head_dim, vocab_size=L.vocab_size,
+                         pad_token_id=32000, rms_norm_eps=L.rms_eps, rope_theta=L.rope_theta,
+                         max_position_embeddings=2048),
+        norm_stats=cfg.norm_stats)
+    hcfg._attn_implementation = "eager"
+    m = Shim(hcfg).eval().to(torch.float32)
+    # the wrapper's projector takes vision_dim from the stub towers: must equal ours
+    own = {k: v for k, v in sd.items() if k.startswith("projector.") or k.startswith("language_model.")}
+    missing, unexpected = m.load_state_dict(own, strict=False)
+    missing = [k for k in missing if "rotary" not in k]
+    assert not missing and not unexpected, (missing, unexpected)
+    m.generation_config.eos_token_id = 2
+    m.generation_config.pad_token_id = 32000
+    m.generation_config.bos_token_id = 1
+
+    rng = np.random.default_rng(1234)
+    frames = rng.integers(0, 256, size=(1, 224, 224, 3), dtype=np.uint8)
+    pix = orc.preprocess_frames(frames, cfg)
+    from emmax.weights import planted_start_token
+    prompt = [1] + [int(x) for x in rng.integers(3, 31744, size=10)] + [planted_start_token(cfg, 3)]
+    ids = torch.tensor([prompt])
+    with torch.no_grad():
+        out = m(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values=pix, use_cache=True, return_dict=True)
+        logits = out.logits[0]
+        gen = m.generate(ids, pixel_values=pix, attention_mask=torch.ones_like(ids), max_new_tokens=20, do_sample=False)
+        ids2 = torch.tensor([prompt[:-1] + [31000]])   # predict_action appends 29871 itself
+        act = m.predict_action(ids2, unnorm_key="bridge_orig", pixel_values=pix, do_sample=False)
+    np.savez(os.path.join(OUT, "wrapper.npz"), frames=frames, prompt=np.array(prompt), last_logits=logits[-1].numpy(),
+             logits_argmax=logits.argmax(-1).numpy(), logits_rowsum=logits.double().sum(-1).numpy(),
+             generated=gen[0].numpy(), predict_prompt=ids2[0].numpy(), action=np.asarray(act),
+             seed=np.array(5), weights_checksum=np.array(checksum(sd)))
+    print("G5 ok; generated", gen[0, len(prompt):].tolist(), "action", np.asarray(act))
+    for k in ("timm", "timm.models", "timm.models.vision_transformer"):
+        sys.modules.pop(k, None)
+
+
+def g6_prompts():
+    pb = load(f"{REF}/prismatic/models/backbones/llm/prompting/base_prompter.py", "ref_pb")
+    cases = ["What action should the robot take to achieve the instruction\nINSTRUCTION: \nPut the pot next to the cans.\n",
+             "  pick up the <image> spoon  ", "x", "What action should the robot take to achieve the instruction\nINSTRUCTION: \nclose the drawer\nCURRENT GRIPPER: [48, 63]\n"]
+    out = []
+    for c in cases:
+        b = pb.PurePromptBuilder("prismatic")
+        b.add_turn("human", c)
+        out.append({"message": c, "prompt": b.get_prompt(), "potential": pb.PurePromptBuilder("prismatic").get_potential_prompt(c)})
+    with open(os.path.join(OUT, "prompts.json"), "w") as f:
+        json.dump(out, f, indent=1, ensure_ascii=False)
+    print("G6 ok")
+
+
+def g7_solver():
+    """Exec the reference Solver class body (solver.py:1-137 minus the hub tokenizer download at :188-190)."""
+    at = load(f"{REF}/prismatic/vla/action_tokenizer.py", "ref_at2")
+    src = open(f"{REF}/prismatic/vla/solver.py", encoding="utf-8").read()
+    body = src[: src.index("tokenizer = AutoTokenizer.from_pretrained")]
+    body = body.replace("from prismatic.vla.action_tokenizer import ActionTokenizer", "")
+    body = body.replace("from transformers import AutoTokenizer", "")
+    ns = {"ActionTokenizer": at.ActionTokenizer}
+    exec(compile(body, "ref_solver", "exec"), ns)
+    tok = StubTokenizer()
+    solver = ns["Solver"](at.ActionTokenizer(tok), verbose=False)
+
+    def act_text(ids):
+        return tok.decode(ids)
+
+    a1 = [31900, 31800, 31850, 31760, 31990, 31872, 31871, 31745]
+    a2 = [31901, 31744, 31999, 31800, 31801, 31802, 31803, 31804]
+    cases = [
+        "REASONING:\nmove it.\nSUBTASK: lift\n\nNEXT GRIPPER: [105, 74]\n\nMOVEMENT:\n" + act_text(a2) + "\nPOLICIES:\n" + act_text(a1) + ";" + act_text(a2) + "\n",
+        "MOVEMENT:\n" + act_text(a2) + "\nPOLICIES:\n" + act_text(a1) + "\n",
+        act_text(a1),                                      # no key -> whole text is the policy
+        "POLICIES:\n" + act_text(a1[:5]) + "\n",           # wrong length -> reference's exception path -> [[0]*7]
+        "POLICIES:\n\n\n",                                 # empty -> exception path
+        "no actions here",
+        "MOVEMENT:\nmove forward 3; move left 2; rotate clockwise 10; close gripper\nPOLICIES:\n" + act_text(a1),
+        "MOVEMENT:\nmove sideways 3; close gripper\n",     # unknown direction -> [-100]*7
+    ]
+    out = []
+    for c in cases:
+        pol, remain = solver.extract_action_policies(c)
+        req, mv = solver.extract_movement_plan(c)
+        out.append({"text": c, "policies": pol, "remain": remain, "require_unorm": req, "movement": np.asarray(mv).tolist()})
+    with open(os.path.join(OUT, "solver.json"), "w") as f:
+        json.dump(out, f, indent=1, ensure_ascii=False)
+    print("G7 ok", [len(o["policies"]) for o in out])
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    g1_action_decode()
+    g3_projector()
+    g4_llama("mha", 4, 4, 16)
+    g4_llama("gqa", 4, 2, 32)
+    g6_prompts()
+    g7_solver()
+    g5_wrapper()
