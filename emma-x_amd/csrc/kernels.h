@@ -1,0 +1,119 @@
+// kernels.h -- parameter blocks and host launchers of the gfx950 kernels (internal to libemmax_hip.so).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---- gemm.hip ----
+struct GemmParams {
+    const void* A;         // bf16 [M, lda]
+    const void* W;         // bf16 [N, ldw]  (K contiguous)
+    void* C;               // bf16 / f32 [M, ldc]
+    const void* bias;      // bf16 [N] or null
+    const void* scale;     // bf16 [N] or null (LayerScale)
+    const void* residual;  // bf16 [M, ldr] or null
+    int M, N, K;
+    int lda, ldw, ldc, ldr;
+    int N_store;           // columns >= N_store are not written
+    int act;               // 0 none, 1 gelu(erf), 2 swiglu over 16-col interleaved (gate,up)
+    int out_f32;
+};
+int launch_gemm(const GemmParams& p, hipStream_t stream);
+
+// ---- norm.hip ----
+int launch_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, int ldx, int ldy, float eps,
+                     hipStream_t stream);
+int launch_rmsnorm(const void* x, void* y, const void* w, int rows, int D, int ldx, int ldy, float eps, hipStream_t stream);
+
+// ---- attention.hip ----
+struct AttnParams {
+    const void* qkv;
+    void* out;
+    const int32_t* cu_seqlens;
+    int ld_qkv, q_off, k_off, v_off, ld_out;
+    int B, max_seqlen, Hq, Hkv;
+    float scale;
+    int causal;
+};
+int launch_attention(const AttnParams& p, int head_dim, hipStream_t stream);
+
+// ---- misc.hip ----
+int launch_patch_gather(bool from_u8, const void* src, void* out, int B, int img, int patch, int kpad, int chan0,
+                        const float* mean, const float* std, hipStream_t stream);
+int launch_assemble_tokens(const void* pe, const void* pos, const void* cls, const void* reg, void* tokens, int B,
+                           int n_patches, int n_prefix, int has_cls, int D, int ld, hipStream_t stream);
+int launch_copy_rows(const void* in, int ld_in, void* out, int B, int rows_in, int r_off, int rows_out, int D, int ld_out,
+                     int col_off, hipStream_t stream);
+#define EMMAX_MAX_DECODE_BATCH 8
+struct PrefillState {
+    int B;
+    int S[EMMAX_MAX_DECODE_BATCH];
+};
+int launch_prefill_state(const PrefillState& st, int32_t* cu, int32_t* ctx_len, int32_t* done, int32_t* n_out, hipStream_t stream);
+int launch_set_int(int32_t* p, int32_t v, hipStream_t stream);
+int launch_embed_splice(const int32_t* ids, int P_max, const int32_t* cu, const void* E, const void* patches, void* h, int B,
+                        int max_seqlen, int n_patches, int hidden, int vocab, hipStream_t stream);
+int launch_rope_kv_write(void* qkv, int ld, int q_off, int k_off, int v_off, const int32_t* cu, int B, int total_rows,
+                         const float* cos_t, const float* sin_t, void* kcache, void* vcache, const int32_t* page_table,
+                         int max_pages, int Hq, int Hkv, int hd, int page, hipStream_t stream);
+int launch_gather_last_rows(const void* in, void* out, const int32_t* cu, int B, int D, hipStream_t stream);
+
+// ---- decode.hip ----
+enum { GEMV_QKV = 0, GEMV_RESID = 1, GEMV_GATEUP = 2, GEMV_LMHEAD = 3, GEMV_PLAIN = 4 };
+struct GemvParams {
+    const void* x;          // bf16 [B, ldx] activations
+    const void* W;          // bf16 [rows, ldw]
+    void* y;                // output (mode dependent): q buffer / h (in place) / act / plain
+    const void* norm_w;     // bf16 [K] RMSNorm weight (NORM modes)
+    int K, ldw, ldx, ldy;
+    int n_slots;            // QKV: (Hq+2Hkv)*hd/2 pairs; GATEUP: inter pairs; else: rows
+    int kc;                 // K phase length (set by the launcher)
+    float eps;
+    // QKV epilogue
+    int head_dim, Hq, Hkv, page, max_pages;
+    const int32_t* ctx_len;
+    const int32_t* page_table;
+    const float* cos_t;
+    const float* sin_t;
+    void* kcache;
+    void* vcache;
+    // LMHEAD epilogue
+    float* part_val;
+    int32_t* part_idx;
+    float* logits_out;      // optional f32 [B, n_slots]
+};
+int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream);
+int decode_gemv_init();   // raise the dynamic-LDS limit of every GEMV instantiation (call once, outside graph capture)
+int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, hipStream_t stream);
+
+struct DecodeAttnParams {
+    const void* q;          // bf16 [B, ldq] rotated queries
+    const void* kcache;     // bf16 [pages][Hkv][page][hd]
+    const void* vcache;
+    const int32_t* page_table;
+    const int32_t* ctx_len;
+    float* part;            // f32 [B][Hq][nsplit][hd+2]
+    int ldq, Hkv, page, max_pages;
+    float scale;
+};
+int decode_attn_nsplit(int B, int Hkv);
+int launch_decode_attn(const DecodeAttnParams& p, int B, int Hq, int head_dim, int nsplit, int max_ctx, void* out, int ldo,
+                       hipStream_t stream);
+
+struct FinishParams {
+    const float* part_val;
+    const int32_t* part_idx;
+    int n_part, B;
+    int32_t* cur_tok;
+    int32_t* ctx_len;
+    int32_t* done;
+    int32_t* n_out;
+    int32_t* out_ids;
+    const int32_t* max_new_p;   // device int: token budget of the running generate() call
+    int max_out, max_ctx;
+    int eos_id, pad_id;
+    int is_prefill;
+};
+int launch_decode_finish(const FinishParams& p, hipStream_t stream);
+int launch_set_tokens(int32_t* cur_tok, const int32_t* toks, int B, hipStream_t stream);
+

@@ -1,0 +1,218 @@
+// misc.hip -- the HBM-bound glue kernels around the GEMMs:
+//   patch gather (+ fused per-tower normalisation)   = PrismaticImageProcessor.apply_transform tail
+//                                                      (processing_prismatic.py:136-143) + timm PatchEmbed im2col
+//   token assembly (pos-embed add, cls/reg prefix)   = timm VisionTransformer._pos_embed (no_embed_class for DINOv2)
+//   feature extraction / concat                       = modeling_prismatic.py:120-123 (drop prefix tokens, cat dim=2)
+//   embedding gather + multimodal splice              = modeling_prismatic.py:380-385
+//   RoPE + KV-cache append for the prefill            = HF apply_rotary_pos_emb + DynamicCache.update
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// One block per (image, patch). Output row = [3*P*P (+pad)] bf16 in conv-weight order k = c*P*P + dy*P + dx.
+template <bool FROM_U8>
+__global__ __launch_bounds__(256) void emmax_patch_gather_kernel(const void* __restrict__ src, bf16_t* __restrict__ out,
+                                                                int img, int patch, int kpad, int chan0, float m0,
+                                                                float m1, float m2, float s0, float s1, float s2) {
+    const int gp = img / patch;
+    const int b = blockIdx.x / (gp * gp), pidx = blockIdx.x % (gp * gp);
+    const int py = pidx / gp, px = pidx % gp;
+    const int pp = patch * patch;
+    bf16_t* o = out + (size_t)blockIdx.x * kpad;
+    for (int k = threadIdx.x; k < kpad; k += blockDim.x) {
+        float v = 0.f;
+        if (k < 3 * pp) {
+            const int c = k / pp, rem = k - c * pp, dy = rem / patch, dx = rem - dy * patch;
+            const int y = py * patch + dy, x = px * patch + dx;
+            if (FROM_U8) {
+                const uint8_t u = ((const uint8_t*)src)[(((size_t)b * img + y) * img + x) * 3 + c];
+                const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+                v = ((float)u / 255.0f - mean) / sd;   // to_tensor then normalize, in fp32 as torchvision does
+            } else {
+                // pixel_values bf16 [B,6,img,img]: channels chan0..chan0+2 belong to this tower
+                v = bf2f(((const bf16_t*)src)[(((size_t)b * 6 + chan0 + c) * img + y) * img + x]);
+            }
+        }
+        o[k] = f2bf(v);
+    }
+}
+
+// tokens[b, 0] = cls, tokens[b, 1..n_reg] = reg, tokens[b, n_prefix + p] = pe[b, p] + pos[p]   (pe / tokens row pitch = ld)
+__global__ __launch_bounds__(256) void emmax_assemble_tokens_kernel(const bf16_t* __restrict__ pe, const bf16_t* __restrict__ pos,
+                                                                   const bf16_t* __restrict__ cls, const bf16_t* __restrict__ reg,
+                                                                   bf16_t* __restrict__ tokens, int n_patches, int n_prefix,
+                                                                   int has_cls, int D, int ld) {
+    const int N = n_prefix + n_patches;
+    const int b = blockIdx.x / N, t = blockIdx.x % N;
+    bf16_t* o = tokens + (size_t)blockIdx.x * ld;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        bf16_t v;
+        if (t < n_prefix) {
+            v = (has_cls && t == 0) ? cls[d] : reg[(size_t)(t - has_cls) * D + d];
+        } else {
+            const int pi = t - n_prefix;
+            v = f2bf(bf2f(pe[((size_t)b * n_patches + pi) * ld + d]) + bf2f(pos[(size_t)pi * D + d]));
+        }
+        o[d] = v;
+    }
+}
+
+// out[(b*rows_out + r) * ld_out + col_off + d] = in[(b*rows_in + r_off + r) * ld_in + d]
+__global__ __launch_bounds__(256) void emmax_copy_rows_kernel(const bf16_t* __restrict__ in, int ld_in, bf16_t* __restrict__ out,
+                                                             int rows_in, int r_off, int rows_out, int D, int ld_out, int col_off) {
+    const int b = blockIdx.x / rows_out, r = blockIdx.x % rows_out;
+    const u32x4_t* s = (const u32x4_t*)(in + ((size_t)b * rows_in + r_off + r) * ld_in);
+    u32x4_t* o = (u32x4_t*)(out + ((size_t)b * rows_out + r) * ld_out + col_off);
+    for (int c = threadIdx.x; c < D / 8; c += blockDim.x) o[c] = s[c];
+}
+
+// h[cu[b] + s] = s==0 ? E[ids[b][0]] : (s <= n_patches ? patches[b][s-1] : E[ids[b][s - n_patches]])
+__global__ __launch_bounds__(256) void emmax_embed_splice_kernel(const int32_t* __restrict__ ids, int P_max,
+                                                                const int32_t* __restrict__ cu, const bf16_t* __restrict__ E,
+                                                                const bf16_t* __restrict__ patches, bf16_t* __restrict__ h,
+                                                                int n_patches, int hidden, int vocab) {
+    const int b = blockIdx.y, s = blockIdx.x;
+    const int start = cu[b], len = cu[b + 1] - start;
+    if (s >= len) return;
+    const u32x4_t* src;
+    if (s >= 1 && s <= n_patches) {
+        src = (const u32x4_t*)(patches + ((size_t)b * n_patches + (s - 1)) * hidden);
+    } else {
+        int id = ids[(size_t)b * P_max + (s == 0 ? 0 : s - n_patches)];
+        id = min(max(id, 0), vocab - 1);
+        src = (const u32x4_t*)(E + (size_t)id * hidden);
+    }
+    u32x4_t* o = (u32x4_t*)(h + (size_t)(start + s) * hidden);
+    for (int c = threadIdx.x; c < hidden / 8; c += blockDim.x) o[c] = src[c];
+}
+
+// Prefill RoPE (rotate-half convention) on q,k in place + K/V append into the paged cache.
+// One block per packed token row; threads over (head, pair index).
+__global__ __launch_bounds__(256) void emmax_rope_kv_write_kernel(bf16_t* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+                                                                 const int32_t* __restrict__ cu, int B,
+                                                                 const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                                 bf16_t* __restrict__ kcache, bf16_t* __restrict__ vcache,
+                                                                 const int32_t* __restrict__ page_table, int max_pages,
+                                                                 int Hq, int Hkv, int hd, int page) {
+    const int row = blockIdx.x;
+    // locate the sequence of this packed row (B is small)
+    int b = 0;
+    while (b + 1 < B && row >= cu[b + 1]) ++b;
+    const int pos = row - cu[b];
+    const int half = hd >> 1;
+    bf16_t* r = qkv + (size_t)row * ld;
+    const float* cs = cos_t + (size_t)pos * half;
+    const float* sn = sin_t + (size_t)pos * half;
+    const int pg = page_table[(size_t)b * max_pages + pos / page], slot = pos % page;
+    for (int i = threadIdx.x; i < (Hq + Hkv) * half; i += blockDim.x) {
+        const int hh = i / half, d = i - hh * half;
+        bf16_t* x = (hh < Hq) ? (r + q_off + hh * hd) : (r + k_off + (hh - Hq) * hd);
+        const float x0 = bf2f(x[d]), x1 = bf2f(x[d + half]);
+        const float c = cs[d], s = sn[d];
+        const bf16_t y0 = f2bf(x0 * c - x1 * s), y1 = f2bf(x1 * c + x0 * s);
+        x[d] = y0;
+        x[d + half] = y1;
+        if (hh >= Hq) {
+            bf16_t* kc = kcache + (((size_t)pg * Hkv + (hh - Hq)) * page + slot) * hd;
+            kc[d] = y0;
+            kc[d + half] = y1;
+        }
+    }
+    for (int i = threadIdx.x; i < Hkv * hd / 8; i += blockDim.x) {
+        const int hk = i / (hd / 8), ch = i - hk * (hd / 8);
+        const u32x4_t v = *(const u32x4_t*)(r + v_off + hk * hd + ch * 8);
+        *(u32x4_t*)(vcache + (((size_t)pg * Hkv + hk) * page + slot) * hd + ch * 8) = v;
+    }
+}
+
+// gather the last row of every packed sequence: out[b] = in[cu[b+1]-1]
+__global__ __launch_bounds__(256) void emmax_gather_last_rows_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                                    const int32_t* __restrict__ cu, int D) {
+    const int b = blockIdx.x;
+    const u32x4_t* s = (const u32x4_t*)(in + (size_t)(cu[b + 1] - 1) * D);
+    u32x4_t* o = (u32x4_t*)(out + (size_t)b * D);
+    for (int c = threadIdx.x; c < D / 8; c += blockDim.x) o[c] = s[c];
+}
+
+// device-side (re)initialisation of the per-sequence state at prefill: cu_seqlens, ctx_len, done, n_out.
+// Values travel as kernel arguments, so there is no host staging buffer to race with.
+__global__ void emmax_prefill_state_kernel(PrefillState st, int32_t* cu, int32_t* ctx_len, int32_t* done, int32_t* n_out) {
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        cu[0] = 0;
+        for (int b = 0; b < st.B; ++b) {
+            acc += st.S[b];
+            cu[b + 1] = acc;
+            ctx_len[b] = st.S[b];
+            done[b] = 0;
+            n_out[b] = 0;
+        }
+    }
+}
+__global__ void emmax_set_int_kernel(int32_t* p, int32_t v) { *p = v; }
+
+}  // namespace
+
+int launch_prefill_state(const PrefillState& st, int32_t* cu, int32_t* ctx_len, int32_t* done, int32_t* n_out, hipStream_t stream) {
+    hipLaunchKernelGGL(emmax_prefill_state_kernel, dim3(1), dim3(64), 0, stream, st, cu, ctx_len, done, n_out);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+int launch_set_int(int32_t* p, int32_t v, hipStream_t stream) {
+    hipLaunchKernelGGL(emmax_set_int_kernel, dim3(1), dim3(1), 0, stream, p, v);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_patch_gather(bool from_u8, const void* src, void* out, int B, int img, int patch, int kpad, int chan0,
+                        const float* mean, const float* std, hipStream_t stream) {
+    const int gp = img / patch;
+    dim3 grid(B * gp * gp), block(256);
+    if (from_u8)
+        hipLaunchKernelGGL(emmax_patch_gather_kernel<true>, grid, block, 0, stream, src, (bf16_t*)out, img, patch, kpad, chan0,
+                           mean[0], mean[1], mean[2], std[0], std[1], std[2]);
+    else
+        hipLaunchKernelGGL(emmax_patch_gather_kernel<false>, grid, block, 0, stream, src, (bf16_t*)out, img, patch, kpad, chan0,
+                           mean[0], mean[1], mean[2], std[0], std[1], std[2]);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_assemble_tokens(const void* pe, const void* pos, const void* cls, const void* reg, void* tokens, int B,
+                           int n_patches, int n_prefix, int has_cls, int D, int ld, hipStream_t stream) {
+    dim3 grid(B * (n_prefix + n_patches)), block(256);
+    hipLaunchKernelGGL(emmax_assemble_tokens_kernel, grid, block, 0, stream, (const bf16_t*)pe, (const bf16_t*)pos,
+                       (const bf16_t*)cls, (const bf16_t*)reg, (bf16_t*)tokens, n_patches, n_prefix, has_cls, D, ld);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_copy_rows(const void* in, int ld_in, void* out, int B, int rows_in, int r_off, int rows_out, int D, int ld_out,
+                     int col_off, hipStream_t stream) {
+    if (D % 8 || ld_out % 8 || col_off % 8 || ld_in % 8) return -1;
+    dim3 grid(B * rows_out), block(128);
+    hipLaunchKernelGGL(emmax_copy_rows_kernel, grid, block, 0, stream, (const bf16_t*)in, ld_in, (bf16_t*)out, rows_in, r_off, rows_out,
+                       D, ld_out, col_off);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_embed_splice(const int32_t* ids, int P_max, const int32_t* cu, const void* E, const void* patches, void* h, int B,
+                        int max_seqlen, int n_patches, int hidden, int vocab, hipStream_t stream) {
+    if (hidden % 8) return -1;
+    dim3 grid(max_seqlen, B), block(256);
+    hipLaunchKernelGGL(emmax_embed_splice_kernel, grid, block, 0, stream, ids, P_max, cu, (const bf16_t*)E,
+                       (const bf16_t*)patches, (bf16_t*)h, n_patches, hidden, vocab);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_rope_kv_write(void* qkv, int ld, int q_off, int k_off, int v_off, const int32_t* cu, int B, int total_rows,
+                         const float* cos_t, const float* sin_t, void* kcache, void* vcache, const int32_t* page_table,
+                         int max_pages, int Hq, int Hkv, int hd, int page, hipStream_t stream) {
+    dim3 grid(total_rows), block(256);
+    hipLaunchKernelGGL(emmax_rope_kv_write_kernel, grid, block, 0, stream, (bf16_t*)qkv, ld, q_off, k_off, v_off, cu, B, cos_t,
+                       sin_t, (bf16_t*)kcache, (bf16_t*)vcache, page_table, max_pages, Hq, Hkv, hd, page);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_gather_last_rows(const void* in, void* out, const int32_t* cu, int B, int D, hipStream_t stream) {
+    dim3 grid(B), block(256);
+    hipLaunchKernelGGL(emmax_gather_last_rows_kernel, grid, block, 0, stream, (const bf16_t*)in, (bf16_t*)out, cu, D);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}

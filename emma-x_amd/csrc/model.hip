@@ -1,0 +1,841 @@
+// model.hip -- host side of libemmax_hip.so: weight binding + re-layout (finalize), session buffers, the stage
+// orchestration (vision encode / prefill / decode step / generate with a captured hipGraph) and the C ABI of
+// include/emmax.h.  No device code lives here; kernels are in gemm / norm / attention / misc / decode .hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/emmax.h"
+#include "common.h"
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x)                                                                                                   \
+    do {                                                                                                            \
+        hipError_t e_ = (x);                                                                                        \
+        if (e_ != hipSuccess) return fail(EMMAX_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define KCHK(x)                                                                                                     \
+    do {                                                                                                            \
+        int r_ = (x);                                                                                               \
+        if (r_ != 0) return fail(r_ == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "%s failed (%d) (%s:%d)", #x, r_, __FILE__, __LINE__); \
+    } while (0)
+
+static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
+static const int PAGE = 64;   // KV page: 64 tokens x head_dim bf16 per kv head
+
+typedef uint16_t bf16;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------------------------------------------------
+struct Bound {
+    const void* ptr;
+    int dtype;
+    std::vector<int64_t> shape;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+struct BlockW {
+    bf16 *n1w, *n1b, *qkv_w, *qkv_b, *proj_w, *proj_b, *ls1, *n2w, *n2b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ls2;
+};
+struct TowerW {
+    int D, Dp, D3p, M, Mp, N, n_prefix, n_patches, hd, Kpe, n_blocks;
+    bf16 *patch_w, *patch_b, *pos, *cls, *reg;
+    std::vector<BlockW> blk;
+};
+struct LayerW {
+    bf16 *ln1, *wqkv, *wo, *ln2, *wgu, *wdown;
+};
+
+struct emmax_model {
+    emmax_config cfg;
+    std::unordered_map<std::string, Bound> bound;
+    bool finalized = false;
+    // derived dims
+    int H, inter, inter_p, q_dim, kv_dim, qkv_dim, vocab, vocab_p, V, Vp, P1, P1p;
+    TowerW tw[2];
+    bf16 *pj1_w, *pj1_b, *pj2_w, *pj2_b, *pj3_w, *pj3_b;
+    bf16 *embed, *final_norm, *lm_head;
+    std::vector<LayerW> layers;
+};
+
+static int check_config(const emmax_config& c) {
+    for (int t = 0; t < 2; ++t) {
+        const auto& w = c.tower[t];
+        if (w.embed_dim <= 0 || w.num_heads <= 0 || w.embed_dim % w.num_heads) return fail(EMMAX_ERR_INVALID, "tower %d: bad embed_dim/num_heads", t);
+        const int hd = w.embed_dim / w.num_heads;
+        if (hd != 64 && hd != 72) return fail(EMMAX_ERR_INVALID, "tower %d: head_dim %d outside the hot path (64 or 72)", t, hd);
+        if (w.embed_dim % 8 || w.mlp_hidden % 8) return fail(EMMAX_ERR_INVALID, "tower %d: dims must be multiples of 8", t);
+        if (w.take_index < 0 || w.take_index >= w.depth) return fail(EMMAX_ERR_INVALID, "tower %d: take_index out of range", t);
+        if (w.image_size % w.patch) return fail(EMMAX_ERR_INVALID, "tower %d: image_size %% patch != 0", t);
+    }
+    if (c.tower[0].image_size != c.tower[1].image_size || c.tower[0].patch != c.tower[1].patch)
+        return fail(EMMAX_ERR_INVALID, "towers must share image size and patch size");
+    if (c.head_dim != 128) return fail(EMMAX_ERR_INVALID, "LLM head_dim %d outside the hot path (128)", c.head_dim);
+    if (c.hidden % 128) return fail(EMMAX_ERR_INVALID, "LLM hidden must be a multiple of 128");
+    if (c.n_heads % c.n_kv_heads) return fail(EMMAX_ERR_INVALID, "n_heads %% n_kv_heads != 0");
+    const int G = c.n_heads / c.n_kv_heads;
+    if (G != 1 && G != 2 && G != 4 && G != 8) return fail(EMMAX_ERR_INVALID, "GQA group %d unsupported (1,2,4,8)", G);
+    if (c.inter % 16) return fail(EMMAX_ERR_INVALID, "LLM intermediate size must be a multiple of 16");
+    if (c.vocab % 8) return fail(EMMAX_ERR_INVALID, "vocab must be a multiple of 8");
+    return 0;
+}
+
+static void derive(emmax_model* m) {
+    const auto& c = m->cfg;
+    m->H = c.hidden;
+    m->inter = c.inter;
+    m->inter_p = pad_to(c.inter, 64);
+    m->q_dim = c.n_heads * c.head_dim;
+    m->kv_dim = c.n_kv_heads * c.head_dim;
+    m->qkv_dim = m->q_dim + 2 * m->kv_dim;
+    m->vocab = c.vocab;
+    m->vocab_p = pad_to(c.vocab, 128);
+    m->V = c.tower[0].embed_dim + c.tower[1].embed_dim;
+    m->Vp = pad_to(m->V, 128);
+    m->P1 = 4 * m->V;
+    m->P1p = pad_to(m->P1, 128);
+    for (int t = 0; t < 2; ++t) {
+        const auto& w = c.tower[t];
+        TowerW& T = m->tw[t];
+        T.D = w.embed_dim;
+        T.Dp = pad_to(T.D, 128);
+        T.D3p = pad_to(3 * T.D, 128);
+        T.M = w.mlp_hidden;
+        T.Mp = pad_to(T.M, 128);
+        T.n_prefix = (w.has_cls ? 1 : 0) + w.n_reg;
+        T.n_patches = (w.image_size / w.patch) * (w.image_size / w.patch);
+        T.N = T.n_prefix + T.n_patches;
+        T.hd = T.D / w.num_heads;
+        T.Kpe = pad_to(3 * w.patch * w.patch, 64);
+        T.n_blocks = w.take_index + 1;   // blocks after take_index never influence the output
+        T.blk.resize(T.n_blocks);
+    }
+    m->layers.resize(c.n_layers);
+}
+
+// Arena plan.  `base == nullptr` only sizes.  Every tensor is 256-byte aligned.
+struct Bump {
+    char* base;
+    int64_t off = 0;
+    bf16* take(int64_t elems) {
+        off = (off + 255) / 256 * 256;
+        bf16* p = base ? (bf16*)(base + off) : nullptr;
+        off += elems * 2;
+        return p;
+    }
+};
+
+static void plan_arena(emmax_model* m, Bump& b) {
+    for (int t = 0; t < 2; ++t) {
+        TowerW& T = m->tw[t];
+        T.patch_w = b.take((int64_t)T.Dp * T.Kpe);
+        T.patch_b = b.take(T.Dp);
+        T.pos = b.take((int64_t)T.n_patches * T.D);
+        T.cls = b.take(T.D);
+        T.reg = b.take((int64_t)std::max(1, m->cfg.tower[t].n_reg) * T.D);
+        for (auto& k : T.blk) {
+            k.n1w = b.take(T.D); k.n1b = b.take(T.D);
+            k.qkv_w = b.take((int64_t)T.D3p * T.Dp); k.qkv_b = b.take(T.D3p);
+            k.proj_w = b.take((int64_t)T.Dp * T.Dp); k.proj_b = b.take(T.Dp);
+            k.ls1 = b.take(T.Dp);
+            k.n2w = b.take(T.D); k.n2b = b.take(T.D);
+            k.fc1_w = b.take((int64_t)T.Mp * T.Dp); k.fc1_b = b.take(T.Mp);
+            k.fc2_w = b.take((int64_t)T.Dp * T.Mp); k.fc2_b = b.take(T.Dp);
+            k.ls2 = b.take(T.Dp);
+        }
+    }
+    m->pj1_w = b.take((int64_t)m->P1p * m->Vp); m->pj1_b = b.take(m->P1p);
+    m->pj2_w = b.take((int64_t)m->H * m->P1p); m->pj2_b = b.take(m->H);
+    m->pj3_w = b.take((int64_t)m->H * m->H); m->pj3_b = b.take(m->H);
+    m->embed = b.take((int64_t)m->vocab * m->H);
+    for (auto& L : m->layers) {
+        L.ln1 = b.take(m->H);
+        L.wqkv = b.take((int64_t)m->qkv_dim * m->H);
+        L.wo = b.take((int64_t)m->H * m->q_dim);
+        L.ln2 = b.take(m->H);
+        L.wgu = b.take((int64_t)2 * m->inter_p * m->H);
+        L.wdown = b.take((int64_t)m->H * m->inter_p);
+    }
+    m->final_norm = b.take(m->H);
+    m->lm_head = b.take((int64_t)m->vocab_p * m->H);
+}
+
+// copy a bound [rows, cols] bf16 matrix into dst (row pitch dst_ld elements) starting at dst row `row0`
+static int put2d(emmax_model* m, const std::string& key, int rows, int cols, bf16* dst, int dst_ld, int row0, hipStream_t st) {
+    auto it = m->bound.find(key);
+    if (it == m->bound.end()) return fail(EMMAX_ERR_MISSING, "finalize: weight `%s` was never bound", key.c_str());
+    const Bound& w = it->second;
+    if (w.dtype != EMMAX_BF16) return fail(EMMAX_ERR_INVALID, "weight `%s` must be bf16", key.c_str());
+    if (w.numel() != (int64_t)rows * cols)
+        return fail(EMMAX_ERR_INVALID, "weight `%s`: expected %d x %d = %lld elements, got %lld", key.c_str(), rows, cols,
+                    (long long)rows * cols, (long long)w.numel());
+    HIPCHK(hipMemcpy2DAsync(dst + (size_t)row0 * dst_ld, (size_t)dst_ld * 2, w.ptr, (size_t)cols * 2, (size_t)cols * 2, rows,
+                            hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+static int put1d(emmax_model* m, const std::string& key, int n, bf16* dst, hipStream_t st) { return put2d(m, key, 1, n, dst, n, 0, st); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// session
+// ---------------------------------------------------------------------------------------------------------------------
+struct emmax_session {
+    emmax_model* m;
+    int max_batch, max_prompt, max_ctx, max_pages, max_rows /* packed prefill rows */, max_out;
+    // vision scratch
+    bf16 *vA, *vpe, *vtok, *vln, *vqkv, *vatt, *vmlp, *feats, *pj1, *pj2, *patch_embeds;
+    int32_t* cu_vit[2];
+    // prefill scratch
+    bf16 *ph, *pxn, *pqkv, *patt, *pact;
+    int32_t* cu;
+    // decode
+    bf16 *dh, *dq, *datt, *dact;
+    float *part, *part_val, *logits;
+    int32_t *part_idx, *cur_tok, *ctx_len, *done, *n_out, *out_ids, *max_new_d, *page_table;
+    float *cos_t, *sin_t;
+    int n_lm_blocks;
+    // kv
+    bf16* kv;
+    int64_t kv_layer_stride;   // elements between layers; K at +0, V at +kv_layer_stride/2
+    // host state
+    int cur_B = 0, total_rows = 0, max_seqlen = 0, vision_B = 0;
+    bool prefilled = false;
+    std::vector<int> S;         // per-row prefill lengths
+    int32_t* pinned = nullptr;  // small pinned host buffer for control uploads / done read-backs
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_B = 0;
+    hipStream_t graph_stream = nullptr;
+    int graph_failed = 0;
+    hipEvent_t ev = nullptr;
+};
+
+struct SBump {
+    char* base;
+    int64_t off = 0;
+    void* take(int64_t bytes) {
+        off = (off + 255) / 256 * 256;
+        void* p = base ? (void*)(base + off) : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+static void plan_session(emmax_session* s, SBump& b) {
+    emmax_model* m = s->m;
+    const int Bv = s->max_batch;
+    int maxN = 0, maxDp = 0, maxD3p = 0, maxMp = 0, maxK = 0;
+    for (int t = 0; t < 2; ++t) {
+        const TowerW& T = m->tw[t];
+        maxN = std::max(maxN, T.N); maxDp = std::max(maxDp, T.Dp); maxD3p = std::max(maxD3p, T.D3p);
+        maxMp = std::max(maxMp, T.Mp); maxK = std::max(maxK, T.Kpe);
+    }
+    const int np = m->tw[0].n_patches;
+    const int64_t vr = (int64_t)Bv * maxN;
+    s->vA = (bf16*)b.take((int64_t)Bv * np * maxK * 2);
+    s->vpe = (bf16*)b.take((int64_t)Bv * np * maxDp * 2);
+    s->vtok = (bf16*)b.take(vr * maxDp * 2);
+    s->vln = (bf16*)b.take(vr * maxDp * 2);
+    s->vqkv = (bf16*)b.take(vr * maxD3p * 2);
+    s->vatt = (bf16*)b.take(vr * maxDp * 2);
+    s->vmlp = (bf16*)b.take(vr * maxMp * 2);
+    s->feats = (bf16*)b.take((int64_t)Bv * np * m->Vp * 2);
+    s->pj1 = (bf16*)b.take((int64_t)Bv * np * m->P1p * 2);
+    s->pj2 = (bf16*)b.take((int64_t)Bv * np * m->H * 2);
+    s->patch_embeds = (bf16*)b.take((int64_t)Bv * np * m->H * 2);
+    for (int t = 0; t < 2; ++t) s->cu_vit[t] = (int32_t*)b.take((Bv + 1) * 4);
+    const int64_t R = s->max_rows;
+    s->ph = (bf16*)b.take(R * m->H * 2);
+    s->pxn = (bf16*)b.take(R * m->H * 2);
+    s->pqkv = (bf16*)b.take(R * m->qkv_dim * 2);
+    s->patt = (bf16*)b.take(R * m->q_dim * 2);
+    s->pact = (bf16*)b.take(R * m->inter_p * 2);
+    s->cu = (int32_t*)b.take((s->max_batch + 1) * 4);
+    const int Bd = s->max_batch;
+    s->dh = (bf16*)b.take((int64_t)Bd * m->H * 2);
+    s->dq = (bf16*)b.take((int64_t)Bd * m->q_dim * 2);
+    s->datt = (bf16*)b.take((int64_t)Bd * m->q_dim * 2);
+    s->dact = (bf16*)b.take((int64_t)Bd * m->inter_p * 2);
+    s->part = (float*)b.take((int64_t)Bd * m->cfg.n_heads * 16 * (m->cfg.head_dim + 2) * 4);
+    s->n_lm_blocks = (m->vocab + 7) / 8;
+    s->part_val = (float*)b.take((int64_t)s->n_lm_blocks * Bd * 4);
+    s->part_idx = (int32_t*)b.take((int64_t)s->n_lm_blocks * Bd * 4);
+    s->logits = (float*)b.take((int64_t)Bd * m->vocab * 4);
+    s->cur_tok = (int32_t*)b.take(Bd * 4);
+    s->ctx_len = (int32_t*)b.take(Bd * 4);
+    s->done = (int32_t*)b.take(Bd * 4);
+    s->n_out = (int32_t*)b.take(Bd * 4);
+    s->out_ids = (int32_t*)b.take((int64_t)Bd * s->max_out * 4);
+    s->max_new_d = (int32_t*)b.take(4);
+    s->page_table = (int32_t*)b.take((int64_t)Bd * s->max_pages * 4);
+    s->cos_t = (float*)b.take((int64_t)s->max_ctx * (m->cfg.head_dim / 2) * 4);
+    s->sin_t = (float*)b.take((int64_t)s->max_ctx * (m->cfg.head_dim / 2) * 4);
+}
+
+static int64_t kv_bytes_for(const emmax_model* m, int max_batch, int max_pages) {
+    return (int64_t)m->cfg.n_layers * 2 * max_batch * max_pages * m->cfg.n_kv_heads * PAGE * m->cfg.head_dim * 2;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// stages
+// ---------------------------------------------------------------------------------------------------------------------
+static GemmParams gp(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.N_store = N;
+    return p;
+}
+
+static int run_vision(emmax_session* s, bool from_u8, const void* src, int B, void* out, hipStream_t st) {
+    emmax_model* m = s->m;
+    if (!m->finalized) return fail(EMMAX_ERR_STATE, "model not finalized");
+    if (B <= 0 || B > s->max_batch) return fail(EMMAX_ERR_INVALID, "vision batch %d outside 1..%d", B, s->max_batch);
+    const int np = m->tw[0].n_patches;
+    int col_off = 0;
+    for (int t = 0; t < 2; ++t) {
+        const TowerW& T = m->tw[t];
+        const emmax_tower_config& tc = m->cfg.tower[t];
+        KCHK(launch_patch_gather(from_u8, src, s->vA, B, tc.image_size, tc.patch, T.Kpe, 3 * t, tc.mean, tc.std, st));
+        GemmParams g = gp(s->vA, T.Kpe, T.patch_w, T.Kpe, s->vpe, T.Dp, B * np, T.Dp, T.Kpe);
+        g.bias = T.patch_b;
+        KCHK(launch_gemm(g, st));
+        KCHK(launch_assemble_tokens(s->vpe, T.pos, T.cls, T.reg, s->vtok, B, np, T.n_prefix, tc.has_cls, T.D, T.Dp, st));
+        const int rows = B * T.N;
+        for (int i = 0; i < T.n_blocks; ++i) {
+            const BlockW& k = T.blk[i];
+            KCHK(launch_layernorm(s->vtok, s->vln, k.n1w, k.n1b, rows, T.D, T.Dp, T.Dp, tc.ln_eps, st));
+            g = gp(s->vln, T.Dp, k.qkv_w, T.Dp, s->vqkv, T.D3p, rows, T.D3p, T.Dp);
+            g.bias = k.qkv_b;
+            KCHK(launch_gemm(g, st));
+            AttnParams a;
+            a.qkv = s->vqkv; a.out = s->vatt; a.cu_seqlens = s->cu_vit[t];
+            a.ld_qkv = T.D3p; a.q_off = 0; a.k_off = T.D; a.v_off = 2 * T.D; a.ld_out = T.Dp;
+            a.B = B; a.max_seqlen = T.N; a.Hq = tc.num_heads; a.Hkv = tc.num_heads;
+            a.scale = 1.0f / sqrtf((float)T.hd); a.causal = 0;
+            KCHK(launch_attention(a, T.hd, st));
+            g = gp(s->vatt, T.Dp, k.proj_w, T.Dp, s->vtok, T.Dp, rows, T.Dp, T.Dp);
+            g.bias = k.proj_b; g.scale = tc.layerscale ? k.ls1 : nullptr; g.residual = s->vtok; g.ldr = T.Dp;
+            KCHK(launch_gemm(g, st));
+            KCHK(launch_layernorm(s->vtok, s->vln, k.n2w, k.n2b, rows, T.D, T.Dp, T.Dp, tc.ln_eps, st));
+            g = gp(s->vln, T.Dp, k.fc1_w, T.Dp, s->vmlp, T.Mp, rows, T.Mp, T.Dp);
+            g.bias = k.fc1_b; g.act = 1;
+            KCHK(launch_gemm(g, st));
+            g = gp(s->vmlp, T.Mp, k.fc2_w, T.Mp, s->vtok, T.Dp, rows, T.Dp, T.Mp);
+            g.bias = k.fc2_b; g.scale = tc.layerscale ? k.ls2 : nullptr; g.residual = s->vtok; g.ldr = T.Dp;
+            KCHK(launch_gemm(g, st));
+        }
+        // drop prefix tokens, no final norm, concat along the feature axis (modeling_prismatic.py:120-123)
+        KCHK(launch_copy_rows(s->vtok, T.Dp, s->feats, B, T.N, T.n_prefix, np, T.D, m->Vp, col_off, st));
+        col_off += T.D;
+    }
+    GemmParams g = gp(s->feats, m->Vp, m->pj1_w, m->Vp, s->pj1, m->P1p, B * np, m->P1p, m->Vp);
+    g.bias = m->pj1_b; g.act = 1;
+    KCHK(launch_gemm(g, st));
+    g = gp(s->pj1, m->P1p, m->pj2_w, m->P1p, s->pj2, m->H, B * np, m->H, m->P1p);
+    g.bias = m->pj2_b; g.act = 1;
+    KCHK(launch_gemm(g, st));
+    g = gp(s->pj2, m->H, m->pj3_w, m->H, s->patch_embeds, m->H, B * np, m->H, m->H);
+    g.bias = m->pj3_b;
+    KCHK(launch_gemm(g, st));
+    if (out && out != s->patch_embeds)
+        HIPCHK(hipMemcpyAsync(out, s->patch_embeds, (size_t)B * np * m->H * 2, hipMemcpyDeviceToDevice, st));
+    s->vision_B = B;
+    return 0;
+}
+
+static bf16* kcache_of(emmax_session* s, int layer) { return s->kv + (size_t)layer * s->kv_layer_stride; }
+static bf16* vcache_of(emmax_session* s, int layer) { return s->kv + (size_t)layer * s->kv_layer_stride + s->kv_layer_stride / 2; }
+
+static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st) {
+    emmax_model* m = s->m;
+    GemvParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = s->dh; p.ldx = m->H; p.W = m->lm_head; p.ldw = m->H; p.K = m->H; p.norm_w = m->final_norm; p.eps = m->cfg.rms_eps;
+    p.n_slots = m->vocab; p.part_val = s->part_val; p.part_idx = s->part_idx; p.logits_out = logits_out;
+    KCHK(launch_decode_gemv(GEMV_LMHEAD, p, B, st));
+    if (do_finish) {
+        FinishParams f;
+        memset(&f, 0, sizeof(f));
+        f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = s->n_lm_blocks; f.B = B;
+        f.cur_tok = s->cur_tok; f.ctx_len = s->ctx_len; f.done = s->done; f.n_out = s->n_out; f.out_ids = s->out_ids;
+        f.max_new_p = s->max_new_d; f.max_out = s->max_out; f.max_ctx = s->max_ctx;
+        f.eos_id = m->cfg.eos_id; f.pad_id = m->cfg.pad_id; f.is_prefill = is_prefill ? 1 : 0;
+        KCHK(launch_decode_finish(f, st));
+    }
+    return 0;
+}
+
+static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens, int B, int P_max, const void* patches,
+                       hipStream_t st) {
+    emmax_model* m = s->m;
+    const auto& c = m->cfg;
+    if (!m->finalized) return fail(EMMAX_ERR_STATE, "model not finalized");
+    if (B <= 0 || B > s->max_batch || B > EMMAX_MAX_DECODE_BATCH)
+        return fail(EMMAX_ERR_INVALID, "prefill batch %d outside 1..min(max_batch=%d, %d)", B, s->max_batch, EMMAX_MAX_DECODE_BATCH);
+    const int np = m->tw[0].n_patches;
+    s->S.assign(B, 0);
+    int total = 0, maxS = 0;
+    PrefillState ps;
+    ps.B = B;
+    for (int b = 0; b < B; ++b) {
+        if (lens[b] < 1 || lens[b] > P_max || lens[b] > s->max_prompt)
+            return fail(EMMAX_ERR_INVALID, "row %d: prompt length %d outside 1..min(P_max=%d, max_prompt=%d)", b, lens[b], P_max, s->max_prompt);
+        const int Sb = np + lens[b];
+        if (Sb + 1 > s->max_ctx) return fail(EMMAX_ERR_NOMEM, "row %d: %d prompt+patch tokens do not fit max_ctx %d", b, Sb, s->max_ctx);
+        s->S[b] = Sb;
+        ps.S[b] = Sb;
+        total += Sb;
+        maxS = std::max(maxS, Sb);
+    }
+    if (total > s->max_rows) return fail(EMMAX_ERR_NOMEM, "packed prefill rows %d exceed capacity %d", total, s->max_rows);
+    KCHK(launch_prefill_state(ps, s->cu, s->ctx_len, s->done, s->n_out, st));
+    s->cur_B = B; s->total_rows = total; s->max_seqlen = maxS;
+
+    KCHK(launch_embed_splice(ids, P_max, s->cu, m->embed, patches, s->ph, B, maxS, np, m->H, m->vocab, st));
+    for (int li = 0; li < c.n_layers; ++li) {
+        const LayerW& L = m->layers[li];
+        KCHK(launch_rmsnorm(s->ph, s->pxn, L.ln1, total, m->H, m->H, m->H, c.rms_eps, st));
+        GemmParams g = gp(s->pxn, m->H, L.wqkv, m->H, s->pqkv, m->qkv_dim, total, m->qkv_dim, m->H);
+        KCHK(launch_gemm(g, st));
+        KCHK(launch_rope_kv_write(s->pqkv, m->qkv_dim, 0, m->q_dim, m->q_dim + m->kv_dim, s->cu, B, total, s->cos_t, s->sin_t,
+                                  kcache_of(s, li), vcache_of(s, li), s->page_table, s->max_pages, c.n_heads, c.n_kv_heads,
+                                  c.head_dim, PAGE, st));
+        AttnParams a;
+        a.qkv = s->pqkv; a.out = s->patt; a.cu_seqlens = s->cu;
+        a.ld_qkv = m->qkv_dim; a.q_off = 0; a.k_off = m->q_dim; a.v_off = m->q_dim + m->kv_dim; a.ld_out = m->q_dim;
+        a.B = B; a.max_seqlen = maxS; a.Hq = c.n_heads; a.Hkv = c.n_kv_heads;
+        a.scale = 1.0f / sqrtf((float)c.head_dim); a.causal = 1;
+        KCHK(launch_attention(a, c.head_dim, st));
+        g = gp(s->patt, m->q_dim, L.wo, m->q_dim, s->ph, m->H, total, m->H, m->q_dim);
+        g.residual = s->ph; g.ldr = m->H;
+        KCHK(launch_gemm(g, st));
+        KCHK(launch_rmsnorm(s->ph, s->pxn, L.ln2, total, m->H, m->H, m->H, c.rms_eps, st));
+        g = gp(s->pxn, m->H, L.wgu, m->H, s->pact, m->inter_p, total, 2 * m->inter_p, m->H);
+        g.act = 2;
+        KCHK(launch_gemm(g, st));
+        g = gp(s->pact, m->inter_p, L.wdown, m->inter_p, s->ph, m->H, total, m->H, m->inter_p);
+        g.residual = s->ph; g.ldr = m->H;
+        KCHK(launch_gemm(g, st));
+    }
+    KCHK(launch_gather_last_rows(s->ph, s->dh, s->cu, B, m->H, st));
+    int r = run_lm_head_step(s, B, true, nullptr, true, st);
+    if (r) return r;
+    s->prefilled = true;
+    return 0;
+}
+
+static int run_decode_step(emmax_session* s, int B, hipStream_t st) {
+    emmax_model* m = s->m;
+    const auto& c = m->cfg;
+    KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st));
+    const int nsplit = decode_attn_nsplit(B, c.n_kv_heads);
+    for (int li = 0; li < c.n_layers; ++li) {
+        const LayerW& L = m->layers[li];
+        GemvParams p;
+        memset(&p, 0, sizeof(p));
+        p.x = s->dh; p.ldx = m->H; p.W = L.wqkv; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln1; p.eps = c.rms_eps;
+        p.y = s->dq; p.ldy = m->q_dim; p.n_slots = m->qkv_dim / 2;
+        p.head_dim = c.head_dim; p.Hq = c.n_heads; p.Hkv = c.n_kv_heads; p.page = PAGE; p.max_pages = s->max_pages;
+        p.ctx_len = s->ctx_len; p.page_table = s->page_table; p.cos_t = s->cos_t; p.sin_t = s->sin_t;
+        p.kcache = kcache_of(s, li); p.vcache = vcache_of(s, li);
+        KCHK(launch_decode_gemv(GEMV_QKV, p, B, st));
+
+        DecodeAttnParams a;
+        a.q = s->dq; a.ldq = m->q_dim; a.kcache = kcache_of(s, li); a.vcache = vcache_of(s, li);
+        a.page_table = s->page_table; a.ctx_len = s->ctx_len; a.part = s->part; a.Hkv = c.n_kv_heads; a.page = PAGE;
+        a.max_pages = s->max_pages; a.scale = 1.0f / sqrtf((float)c.head_dim);
+        KCHK(launch_decode_attn(a, B, c.n_heads, c.head_dim, nsplit, s->max_ctx, s->datt, m->q_dim, st));
+
+        memset(&p, 0, sizeof(p));
+        p.x = s->datt; p.ldx = m->q_dim; p.W = L.wo; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_slots = m->H;
+        KCHK(launch_decode_gemv(GEMV_RESID, p, B, st));
+
+        memset(&p, 0, sizeof(p));
+        p.x = s->dh; p.ldx = m->H; p.W = L.wgu; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln2; p.eps = c.rms_eps;
+        p.y = s->dact; p.ldy = m->inter_p; p.n_slots = m->inter_p;
+        KCHK(launch_decode_gemv(GEMV_GATEUP, p, B, st));
+
+        memset(&p, 0, sizeof(p));
+        p.x = s->dact; p.ldx = m->inter_p; p.W = L.wdown; p.ldw = m->inter_p; p.K = m->inter_p; p.y = s->dh; p.ldy = m->H; p.n_slots = m->H;
+        KCHK(launch_decode_gemv(GEMV_RESID, p, B, st));
+    }
+    return run_lm_head_step(s, B, false, nullptr, true, st);
+}
+
+static void drop_graph(emmax_session* s) {
+    if (s->graph_exec) hipGraphExecDestroy(s->graph_exec);
+    if (s->graph) hipGraphDestroy(s->graph);
+    s->graph_exec = nullptr;
+    s->graph = nullptr;
+    s->graph_B = 0;
+}
+
+static int ensure_graph(emmax_session* s, int B, hipStream_t st) {
+    if (s->graph_exec && s->graph_B == B) return 0;
+    drop_graph(s);
+    if (s->graph_failed) return 1;
+    // one eager step first would advance the state; capture does not execute, so just record
+    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { s->graph_failed = 1; (void)hipGetLastError(); return 1; }
+    int r = run_decode_step(s, B, st);
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(st, &g);
+    if (r != 0 || e != hipSuccess || !g) { s->graph_failed = 1; (void)hipGetLastError(); if (g) hipGraphDestroy(g); return 1; }
+    hipGraphExec_t ge = nullptr;
+    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) { s->graph_failed = 1; (void)hipGetLastError(); hipGraphDestroy(g); return 1; }
+    s->graph = g; s->graph_exec = ge; s->graph_B = B;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* emmax_version(void) { return "emmax-hip 0.1.0 (gfx950)"; }
+const char* emmax_last_error(void) { return g_err.c_str(); }
+int emmax_abi_version(void) { return EMMAX_ABI_VERSION; }
+
+int emmax_model_create(const emmax_config* cfg, emmax_model** out) {
+    if (!cfg || !out) return fail(EMMAX_ERR_INVALID, "null argument");
+    int r = check_config(*cfg);
+    if (r) return r;
+    emmax_model* m = new emmax_model();
+    m->cfg = *cfg;
+    derive(m);
+    *out = m;
+    return 0;
+}
+
+void emmax_model_destroy(emmax_model* m) { delete m; }
+
+int emmax_model_bind_weight(emmax_model* m, const char* key, const void* ptr, int dtype, const int64_t* shape, int ndim) {
+    if (!m || !key || !ptr || (ndim > 0 && !shape)) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (m->finalized) return fail(EMMAX_ERR_STATE, "model already finalized");
+    Bound b;
+    b.ptr = ptr; b.dtype = dtype;
+    b.shape.assign(shape, shape + ndim);
+    m->bound[key] = b;
+    return 0;
+}
+
+int64_t emmax_model_arena_bytes(const emmax_model* m) {
+    if (!m) return -1;
+    Bump b{nullptr};
+    plan_arena(const_cast<emmax_model*>(m), b);
+    return b.off + 256;
+}
+
+int emmax_model_finalize(emmax_model* m, void* arena, int64_t arena_bytes, emmax_stream stream) {
+    if (!m || !arena) return fail(EMMAX_ERR_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t need = emmax_model_arena_bytes(m);
+    if (arena_bytes < need) return fail(EMMAX_ERR_NOMEM, "arena too small: %lld < %lld", (long long)arena_bytes, (long long)need);
+    if ((uintptr_t)arena % 256) return fail(EMMAX_ERR_INVALID, "arena must be 256-byte aligned");
+    Bump b{(char*)arena};
+    plan_arena(m, b);
+    HIPCHK(hipMemsetAsync(arena, 0, need, st));   // all padding is zero
+    const char* pre[2] = {"vision_backbone.featurizer.", "vision_backbone.fused_featurizer."};
+    int r;
+#define PUT2(key, rows, cols, dst, ld, row0) if ((r = put2d(m, key, rows, cols, dst, ld, row0, st))) return r
+#define PUT1(key, n, dst) if ((r = put1d(m, key, n, dst, st))) return r
+    for (int t = 0; t < 2; ++t) {
+        TowerW& T = m->tw[t];
+        const emmax_tower_config& tc = m->cfg.tower[t];
+        const std::string P = pre[t];
+        PUT2(P + "patch_embed.proj.weight", T.D, 3 * tc.patch * tc.patch, T.patch_w, T.Kpe, 0);
+        PUT1(P + "patch_embed.proj.bias", T.D, T.patch_b);
+        PUT1(P + "pos_embed", T.n_patches * T.D, T.pos);
+        if (tc.has_cls) PUT1(P + "cls_token", T.D, T.cls);
+        if (tc.n_reg) PUT1(P + "reg_token", tc.n_reg * T.D, T.reg);
+        for (int i = 0; i < T.n_blocks; ++i) {
+            BlockW& k = T.blk[i];
+            const std::string Bp = P + "blocks." + std::to_string(i) + ".";
+            PUT1(Bp + "norm1.weight", T.D, k.n1w); PUT1(Bp + "norm1.bias", T.D, k.n1b);
+            PUT2(Bp + "attn.qkv.weight", 3 * T.D, T.D, k.qkv_w, T.Dp, 0); PUT1(Bp + "attn.qkv.bias", 3 * T.D, k.qkv_b);
+            PUT2(Bp + "attn.proj.weight", T.D, T.D, k.proj_w, T.Dp, 0); PUT1(Bp + "attn.proj.bias", T.D, k.proj_b);
+            PUT1(Bp + "norm2.weight", T.D, k.n2w); PUT1(Bp + "norm2.bias", T.D, k.n2b);
+            PUT2(Bp + "mlp.fc1.weight", T.M, T.D, k.fc1_w, T.Dp, 0); PUT1(Bp + "mlp.fc1.bias", T.M, k.fc1_b);
+            PUT2(Bp + "mlp.fc2.weight", T.D, T.M, k.fc2_w, T.Mp, 0); PUT1(Bp + "mlp.fc2.bias", T.D, k.fc2_b);
+            if (tc.layerscale) { PUT1(Bp + "ls1.scale_factor", T.D, k.ls1); PUT1(Bp + "ls2.scale_factor", T.D, k.ls2); }
+        }
+    }
+    PUT2("projector.fc1.weight", m->P1, m->V, m->pj1_w, m->Vp, 0); PUT1("projector.fc1.bias", m->P1, m->pj1_b);
+    PUT2("projector.fc2.weight", m->H, m->P1, m->pj2_w, m->P1p, 0); PUT1("projector.fc2.bias", m->H, m->pj2_b);
+    PUT2("projector.fc3.weight", m->H, m->H, m->pj3_w, m->H, 0); PUT1("projector.fc3.bias", m->H, m->pj3_b);
+    PUT2("language_model.model.embed_tokens.weight", m->vocab, m->H, m->embed, m->H, 0);
+    for (int li = 0; li < m->cfg.n_layers; ++li) {
+        LayerW& L = m->layers[li];
+        const std::string P = "language_model.model.layers." + std::to_string(li) + ".";
+        PUT1(P + "input_layernorm.weight", m->H, L.ln1);
+        PUT2(P + "self_attn.q_proj.weight", m->q_dim, m->H, L.wqkv, m->H, 0);
+        PUT2(P + "self_attn.k_proj.weight", m->kv_dim, m->H, L.wqkv, m->H, m->q_dim);
+        PUT2(P + "self_attn.v_proj.weight", m->kv_dim, m->H, L.wqkv, m->H, m->q_dim + m->kv_dim);
+        PUT2(P + "self_attn.o_proj.weight", m->H, m->q_dim, L.wo, m->q_dim, 0);
+        PUT1(P + "post_attention_layernorm.weight", m->H, L.ln2);
+        // gate/up interleaved in 16-row groups: dst rows [32j, 32j+16) = gate rows [16j, 16j+16), next 16 = up
+        {
+            auto ig = m->bound.find(P + "mlp.gate_proj.weight");
+            auto iu = m->bound.find(P + "mlp.up_proj.weight");
+            if (ig == m->bound.end() || iu == m->bound.end()) return fail(EMMAX_ERR_MISSING, "finalize: gate/up of layer %d not bound", li);
+            if (ig->second.numel() != (int64_t)m->inter * m->H || iu->second.numel() != (int64_t)m->inter * m->H)
+                return fail(EMMAX_ERR_INVALID, "gate/up of layer %d have the wrong size", li);
+            const size_t grp = (size_t)16 * m->H * 2;
+            HIPCHK(hipMemcpy2DAsync(L.wgu, 2 * grp, ig->second.ptr, grp, grp, m->inter / 16, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpy2DAsync((char*)L.wgu + grp, 2 * grp, iu->second.ptr, grp, grp, m->inter / 16, hipMemcpyDeviceToDevice, st));
+        }
+        PUT2(P + "mlp.down_proj.weight", m->H, m->inter, L.wdown, m->inter_p, 0);
+    }
+    PUT1("language_model.model.norm.weight", m->H, m->final_norm);
+    PUT2("language_model.lm_head.weight", m->vocab, m->H, m->lm_head, m->H, 0);
+#undef PUT2
+#undef PUT1
+    HIPCHK(hipStreamSynchronize(st));
+    m->finalized = true;
+    m->bound.clear();
+    return 0;
+}
+
+static int session_dims(const emmax_model* m, int max_batch, int max_prompt, int max_ctx, int* max_pages, int* max_rows) {
+    if (!m) return fail(EMMAX_ERR_INVALID, "null model");
+    if (max_batch < 1 || max_batch > 256) return fail(EMMAX_ERR_INVALID, "max_batch outside 1..256");
+    const int np = m->tw[0].n_patches;
+    if (max_prompt < 1) return fail(EMMAX_ERR_INVALID, "max_prompt < 1");
+    if (max_ctx < np + max_prompt + 1) return fail(EMMAX_ERR_INVALID, "max_ctx %d < patches %d + max_prompt %d + 1", max_ctx, np, max_prompt);
+    *max_pages = (max_ctx + PAGE - 1) / PAGE;
+    *max_rows = max_batch * (np + max_prompt);
+    return 0;
+}
+
+int emmax_session_bytes(const emmax_model* m, int max_batch, int max_prompt, int max_ctx, int64_t* ws, int64_t* kv) {
+    int mp, mr, r;
+    if ((r = session_dims(m, max_batch, max_prompt, max_ctx, &mp, &mr))) return r;
+    emmax_session tmp;
+    tmp.m = const_cast<emmax_model*>(m);
+    tmp.max_batch = max_batch; tmp.max_prompt = max_prompt; tmp.max_ctx = max_ctx; tmp.max_pages = mp; tmp.max_rows = mr;
+    tmp.max_out = max_ctx;
+    SBump b{nullptr};
+    plan_session(&tmp, b);
+    if (ws) *ws = b.off + 256;
+    if (kv) *kv = kv_bytes_for(m, max_batch, mp);
+    return 0;
+}
+
+int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_ctx, void* ws, int64_t ws_bytes, void* kv,
+                         int64_t kvb, emmax_session** out) {
+    if (!m || !ws || !kv || !out) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (!m->finalized) return fail(EMMAX_ERR_STATE, "model not finalized");
+    int64_t need_ws, need_kv;
+    int r = emmax_session_bytes(m, max_batch, max_prompt, max_ctx, &need_ws, &need_kv);
+    if (r) return r;
+    if (ws_bytes < need_ws || kvb < need_kv)
+        return fail(EMMAX_ERR_NOMEM, "session memory too small: workspace %lld/%lld, kv %lld/%lld", (long long)ws_bytes,
+                    (long long)need_ws, (long long)kvb, (long long)need_kv);
+    if (((uintptr_t)ws % 256) || ((uintptr_t)kv % 256)) return fail(EMMAX_ERR_INVALID, "workspace / kv must be 256-byte aligned");
+    emmax_session* s = new emmax_session();
+    s->m = m;
+    s->max_batch = max_batch; s->max_prompt = max_prompt; s->max_ctx = max_ctx;
+    session_dims(m, max_batch, max_prompt, max_ctx, &s->max_pages, &s->max_rows);
+    s->max_out = max_ctx;
+    SBump b{(char*)ws};
+    plan_session(s, b);
+    s->kv = (bf16*)kv;
+    s->kv_layer_stride = (int64_t)2 * max_batch * s->max_pages * m->cfg.n_kv_heads * PAGE * m->cfg.head_dim;
+    HIPCHK(hipMemset(ws, 0, need_ws));   // padding columns of every activation buffer stay zero forever
+    HIPCHK(hipMemset(kv, 0, need_kv));
+    HIPCHK(hipDeviceSynchronize());
+    if (decode_gemv_init() != 0) return fail(EMMAX_ERR_HIP, "could not raise the dynamic LDS limit of the GEMV kernels");
+    HIPCHK(hipHostMalloc((void**)&s->pinned, 4096 * 4, hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&s->ev, hipEventDisableTiming));
+    // static page assignment: row b owns pages [b*max_pages, (b+1)*max_pages)
+    {
+        std::vector<int32_t> pt((size_t)max_batch * s->max_pages);
+        for (size_t i = 0; i < pt.size(); ++i) pt[i] = (int32_t)i;
+        HIPCHK(hipMemcpy(s->page_table, pt.data(), pt.size() * 4, hipMemcpyHostToDevice));
+        for (int t = 0; t < 2; ++t) {
+            std::vector<int32_t> cu(max_batch + 1);
+            for (int i = 0; i <= max_batch; ++i) cu[i] = i * m->tw[t].N;
+            HIPCHK(hipMemcpy(s->cu_vit[t], cu.data(), cu.size() * 4, hipMemcpyHostToDevice));
+        }
+        // RoPE tables, fp32, HF LlamaRotaryEmbedding order of operations (inv_freq fp32, pos*inv_freq fp32, cos/sin)
+        const int half = m->cfg.head_dim / 2;
+        std::vector<float> cs((size_t)max_ctx * half), sn((size_t)max_ctx * half);
+        for (int i = 0; i < half; ++i) {
+            const float inv = 1.0f / powf(m->cfg.rope_theta, (float)(2 * i) / (float)m->cfg.head_dim);
+            for (int p = 0; p < max_ctx; ++p) {
+                const float f = (float)p * inv;
+                cs[(size_t)p * half + i] = (float)cos((double)f);
+                sn[(size_t)p * half + i] = (float)sin((double)f);
+            }
+        }
+        HIPCHK(hipMemcpy(s->cos_t, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(s->sin_t, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+    }
+    *out = s;
+    return 0;
+}
+
+void emmax_session_destroy(emmax_session* s) {
+    if (!s) return;
+    drop_graph(s);
+    if (s->pinned) hipHostFree(s->pinned);
+    if (s->ev) hipEventDestroy(s->ev);
+    delete s;
+}
+
+int emmax_vision_encode(emmax_session* s, const uint8_t* frames, int B, void* out, emmax_stream st) {
+    if (!s || !frames) return fail(EMMAX_ERR_INVALID, "null argument");
+    return run_vision(s, true, frames, B, out, (hipStream_t)st);
+}
+int emmax_vision_encode_pixels(emmax_session* s, const void* px, int B, void* out, emmax_stream st) {
+    if (!s || !px) return fail(EMMAX_ERR_INVALID, "null argument");
+    return run_vision(s, false, px, B, out, (hipStream_t)st);
+}
+int emmax_vision_features(emmax_session* s, int B, void* out, emmax_stream st) {
+    if (!s || !out) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (B != s->vision_B) return fail(EMMAX_ERR_STATE, "no vision result for batch %d", B);
+    emmax_model* m = s->m;
+    HIPCHK(hipMemcpy2DAsync(out, (size_t)m->V * 2, s->feats, (size_t)m->Vp * 2, (size_t)m->V * 2, (size_t)B * m->tw[0].n_patches,
+                            hipMemcpyDeviceToDevice, (hipStream_t)st));
+    return 0;
+}
+
+int emmax_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens, int B, int P_max, const void* patches, emmax_stream st) {
+    if (!s || !ids || !lens) return fail(EMMAX_ERR_INVALID, "null argument");
+    const void* pe = patches ? patches : s->patch_embeds;
+    if (!patches && s->vision_B != B) return fail(EMMAX_ERR_STATE, "no patch embeddings for batch %d (call emmax_vision_encode first)", B);
+    return run_prefill(s, ids, lens, B, P_max, pe, (hipStream_t)st);
+}
+
+int emmax_prefill_logits(emmax_session* s, float* out, emmax_stream stream) {
+    if (!s || !out) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (!s->prefilled) return fail(EMMAX_ERR_STATE, "prefill has not run");
+    emmax_model* m = s->m;
+    hipStream_t st = (hipStream_t)stream;
+    KCHK(launch_rmsnorm(s->ph, s->pxn, m->final_norm, s->total_rows, m->H, m->H, m->H, m->cfg.rms_eps, st));
+    GemmParams g = gp(s->pxn, m->H, m->lm_head, m->H, out, m->vocab, s->total_rows, m->vocab_p, m->H);
+    g.N_store = m->vocab; g.out_f32 = 1;
+    KCHK(launch_gemm(g, st));
+    return 0;
+}
+
+int emmax_last_logits(emmax_session* s, float* out, emmax_stream stream) {
+    if (!s || !out) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (!s->prefilled) return fail(EMMAX_ERR_STATE, "prefill has not run");
+    return run_lm_head_step(s, s->cur_B, false, out, false, (hipStream_t)stream);
+}
+
+int emmax_decode_step(emmax_session* s, emmax_stream st) {
+    if (!s) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (!s->prefilled) return fail(EMMAX_ERR_STATE, "decode before prefill");
+    return run_decode_step(s, s->cur_B, (hipStream_t)st);
+}
+
+int emmax_set_current_tokens(emmax_session* s, const int32_t* toks, emmax_stream st) {
+    if (!s || !toks) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (!s->prefilled) return fail(EMMAX_ERR_STATE, "no active sequences");
+    KCHK(launch_set_tokens(s->cur_tok, toks, s->cur_B, (hipStream_t)st));
+    return 0;
+}
+
+int emmax_generate(emmax_session* s, int max_new, int stop_on_eos, int32_t* out_ids, int32_t* out_lens, emmax_stream stream) {
+    if (!s || !out_ids || !out_lens) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (!s->prefilled) return fail(EMMAX_ERR_STATE, "generate before prefill");
+    if (max_new < 1 || max_new > s->max_out) return fail(EMMAX_ERR_INVALID, "max_new_tokens %d outside 1..%d", max_new, s->max_out);
+    hipStream_t st = (hipStream_t)stream;
+    const int B = s->cur_B;
+    KCHK(launch_set_int(s->max_new_d, max_new, st));
+    const bool use_graph = (max_new > 2) && ensure_graph(s, B, st) == 0;
+    const int CHK = 16;
+    int32_t* done_host = s->pinned;
+    bool pending = false;
+    for (int i = 1; i < max_new; ++i) {
+        if (use_graph) {
+            HIPCHK(hipGraphLaunch(s->graph_exec, st));
+        } else {
+            int r = run_decode_step(s, B, st);
+            if (r) return r;
+        }
+        if (stop_on_eos && (i % CHK) == 0) {
+            if (pending) {   // the previous read-back is certainly complete once its event fired
+                HIPCHK(hipEventSynchronize(s->ev));
+                bool all = true;
+                for (int b = 0; b < B; ++b) all = all && (done_host[b] != 0);
+                if (all) { pending = false; break; }
+            }
+            HIPCHK(hipMemcpyAsync(done_host, s->done, B * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipEventRecord(s->ev, st));
+            pending = true;
+        }
+    }
+    HIPCHK(hipMemcpy2DAsync(out_ids, (size_t)max_new * 4, s->out_ids, (size_t)s->max_out * 4, (size_t)max_new * 4, B,
+                            hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(out_lens, s->n_out, B * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int emmax_session_graph_active(emmax_session* s) { return s && s->graph_exec ? 1 : 0; }
+
+// ---- single-kernel entry points --------------------------------------------------------------------------------------
+int emmax_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const void* bias, int act,
+                  const void* scale, const void* residual, int ldr, int out_f32, emmax_stream st) {
+    GemmParams p = gp(A, lda, W, ldw, C, ldc, M, N, K);
+    p.bias = bias; p.act = act; p.scale = scale; p.residual = residual; p.ldr = ldr; p.out_f32 = out_f32;
+    int r = launch_gemm(p, (hipStream_t)st);
+    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_gemm: unsupported shape (K%%64, N%%128, ld%%8) or launch failure");
+    return 0;
+}
+int emmax_op_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, float eps, emmax_stream st) {
+    int r = launch_layernorm(x, y, w, b, rows, D, D, D, eps, (hipStream_t)st);
+    if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_layernorm: unsupported shape");
+    return 0;
+}
+int emmax_op_rmsnorm(const void* x, void* y, const void* w, int rows, int D, float eps, emmax_stream st) {
+    int r = launch_rmsnorm(x, y, w, rows, D, D, D, eps, (hipStream_t)st);
+    if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_rmsnorm: unsupported shape");
+    return 0;
+}
+int emmax_op_attention(const void* qkv, int ld_qkv, int q_off, int k_off, int v_off, void* out, int ld_out, const int32_t* cu, int B,
+                       int max_seqlen, int Hq, int Hkv, int head_dim, float scale, int causal, emmax_stream st) {
+    AttnParams a;
+    a.qkv = qkv; a.out = out; a.cu_seqlens = cu; a.ld_qkv = ld_qkv; a.q_off = q_off; a.k_off = k_off; a.v_off = v_off;
+    a.ld_out = ld_out; a.B = B; a.max_seqlen = max_seqlen; a.Hq = Hq; a.Hkv = Hkv; a.scale = scale; a.causal = causal;
+    int r = launch_attention(a, head_dim, (hipStream_t)st);
+    if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_attention: unsupported head_dim/strides");
+    return 0;
+}
+int emmax_op_gemv(const void* x, const void* W, void* y, int B, int N, int K, emmax_stream st) {
+    GemvParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.ldx = K; p.W = W; p.ldw = K; p.K = K; p.y = y; p.ldy = N; p.n_slots = N;
+    if (decode_gemv_init() != 0) return fail(EMMAX_ERR_HIP, "could not raise the dynamic LDS limit of the GEMV kernels");
+    int r = launch_decode_gemv(GEMV_PLAIN, p, B, (hipStream_t)st);
+    if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_gemv: unsupported shape (B<=8, K%%8)");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// norm.hip -- row normalisations (HBM-bound, one wave per row, 16-byte vector loads).
+//   LayerNorm (eps 1e-6, affine)  = timm `Block.norm1/norm2`
+//   RMSNorm                       = HF `LlamaRMSNorm.forward` (fp32 statistics, weight multiply after the normalise)
+// Statistics and the normalise are done in fp32 from the bf16 row; one rounding on store.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// D % 8 == 0, D <= 8 * 64 * MAXV
+template <int MAXV, bool RMS>
+__global__ __launch_bounds__(256) void emmax_rownorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                           const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
+                                                           int rows, int D, int ldx, int ldy, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = D >> 3;
+    const bf16_t* xr = x + (size_t)row * ldx;
+    u32x4_t v[MAXV];
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            v[i] = *(const u32x4_t*)(xr + c * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = bf_lo(v[i][j]), bb = bf_hi(v[i][j]);
+                s += a + bb;
+                ss += a * a + bb * bb;
+            }
+        }
+    }
+    float mean = 0.f, rstd;
+    if (RMS) {
+        ss = wave_sum(ss);
+        rstd = rsqrtf(ss / (float)D + eps);
+    } else {
+        s = wave_sum(s);
+        mean = s / (float)D;
+        // two-pass variance for accuracy (values are in registers)
+        float vs = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = bf_lo(v[i][j]) - mean, bb = bf_hi(v[i][j]) - mean;
+                    vs += a * a + bb * bb;
+                }
+            }
+        }
+        vs = wave_sum(vs);
+        rstd = rsqrtf(vs / (float)D + eps);
+    }
+    bf16_t* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            const u32x4_t wv = *(const u32x4_t*)(w + c * 8);
+            u32x4_t bv = {0u, 0u, 0u, 0u};
+            if (!RMS) bv = *(const u32x4_t*)(b + c * 8);
+            u32x4_t o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = (bf_lo(v[i][j]) - mean) * rstd, bb = (bf_hi(v[i][j]) - mean) * rstd;
+                if (RMS) {
+                    // HF: normalise in fp32, downcast to the activation dtype, then multiply by the weight
+                    a = bf2f(f2bf(a)) * bf_lo(wv[j]);
+                    bb = bf2f(f2bf(bb)) * bf_hi(wv[j]);
+                } else {
+                    a = a * bf_lo(wv[j]) + bf_lo(bv[j]);
+                    bb = bb * bf_hi(wv[j]) + bf_hi(bv[j]);
+                }
+                o[j] = pack_bf16x2(a, bb);
+            }
+            *(u32x4_t*)(yr + c * 8) = o;
+        }
+    }
+}
+
+}  // namespace
+
+static int launch_rownorm(bool rms, const void* x, void* y, const void* w, const void* b, int rows, int D, int ldx, int ldy,
+                          float eps, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    if (D % 8 != 0 || D > 8 * 64 * 16) return -1;
+    dim3 grid(cdiv(rows, 4)), block(256);
+    const int nv = cdiv(D / 8, 64);
+#define LAUNCH(MAXV)                                                                                                   \
+    do {                                                                                                               \
+        if (rms)                                                                                                       \
+            hipLaunchKernelGGL((emmax_rownorm_kernel<MAXV, true>), grid, block, 0, stream, (const bf16_t*)x, (bf16_t*)y, \
+                               (const bf16_t*)w, (const bf16_t*)b, rows, D, ldx, ldy, eps);                            \
+        else                                                                                                           \
+            hipLaunchKernelGGL((emmax_rownorm_kernel<MAXV, false>), grid, block, 0, stream, (const bf16_t*)x,          \
+                               (bf16_t*)y, (const bf16_t*)w, (const bf16_t*)b, rows, D, ldx, ldy, eps);                \
+    } while (0)
+    if (nv <= 1) LAUNCH(1);
+    else if (nv <= 2) LAUNCH(2);
+    else if (nv <= 4) LAUNCH(4);
+    else if (nv <= 8) LAUNCH(8);
+    else LAUNCH(16);
+#undef LAUNCH
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, int ldx, int ldy, float eps,
+                     hipStream_t stream) {
+    return launch_rownorm(false, x, y, w, b, rows, D, ldx, ldy, eps, stream);
+}
+int launch_rmsnorm(const void* x, void* y, const void* w, int rows, int D, int ldx, int ldy, float eps, hipStream_t stream) {
+    return launch_rownorm(true, x, y, w, nullptr, rows, D, ldx, ldy, eps, stream);
+}

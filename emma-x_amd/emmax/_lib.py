@@ -1,0 +1,114 @@
+"""
+_lib.py -- ctypes binding of libemmax_hip.so (the C ABI declared in include/emmax.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, an exception is raised.  The
+library is built in-tree by `__graft_entry__.build()` / `make -C emma-x_amd/csrc`.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libemmax_hip.so")
+
+_c_i32p = C.POINTER(C.c_int32)
+_c_i64p = C.POINTER(C.c_int64)
+_c_f32p = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+
+class EmmaxError(RuntimeError):
+    pass
+
+
+class TowerConfigC(C.Structure):
+    _fields_ = [
+        ("embed_dim", C.c_int32), ("depth", C.c_int32), ("num_heads", C.c_int32), ("mlp_hidden", C.c_int32),
+        ("has_cls", C.c_int32), ("n_reg", C.c_int32), ("layerscale", C.c_int32),
+        ("patch", C.c_int32), ("image_size", C.c_int32), ("take_index", C.c_int32),
+        ("ln_eps", C.c_float), ("mean", C.c_float * 3), ("std", C.c_float * 3),
+    ]
+
+
+class ConfigC(C.Structure):
+    _fields_ = [
+        ("tower", TowerConfigC * 2),
+        ("hidden", C.c_int32), ("inter", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32),
+        ("n_kv_heads", C.c_int32), ("head_dim", C.c_int32), ("vocab", C.c_int32),
+        ("rms_eps", C.c_float), ("rope_theta", C.c_float),
+        ("bos_id", C.c_int32), ("eos_id", C.c_int32), ("pad_id", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes): exactly the entry points of include/emmax.h
+SIGNATURES = {
+    "emmax_version": (C.c_char_p, []),
+    "emmax_last_error": (C.c_char_p, []),
+    "emmax_abi_version": (C.c_int, []),
+    "emmax_model_create": (C.c_int, [C.POINTER(ConfigC), C.POINTER(_vp)]),
+    "emmax_model_destroy": (None, [_vp]),
+    "emmax_model_bind_weight": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int, _c_i64p, C.c_int]),
+    "emmax_model_arena_bytes": (C.c_int64, [_vp]),
+    "emmax_model_finalize": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
+    "emmax_session_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _c_i64p, _c_i64p]),
+    "emmax_session_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp, C.c_int64, C.POINTER(_vp)]),
+    "emmax_session_destroy": (None, [_vp]),
+    "emmax_vision_encode": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
+    "emmax_vision_encode_pixels": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
+    "emmax_vision_features": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "emmax_prefill": (C.c_int, [_vp, _vp, _c_i32p, C.c_int, C.c_int, _vp, _vp]),
+    "emmax_prefill_logits": (C.c_int, [_vp, _vp, _vp]),
+    "emmax_last_logits": (C.c_int, [_vp, _vp, _vp]),
+    "emmax_decode_step": (C.c_int, [_vp, _vp]),
+    "emmax_set_current_tokens": (C.c_int, [_vp, _vp, _vp]),
+    "emmax_generate": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "emmax_op_gemm": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp,
+                                C.c_int, C.c_int, _vp]),
+    "emmax_op_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp]),
+    "emmax_op_rmsnorm": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp]),
+    "emmax_op_attention": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_float, C.c_int, _vp]),
+    "emmax_op_gemv": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libemmax_hip.so and attach the signatures; raises EmmaxError when the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise EmmaxError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C emma-x_amd/csrc`. There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.emmax_abi_version() != 1:
+        raise EmmaxError(f"ABI mismatch: library reports {lib.emmax_abi_version()}, host expects 1")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = load().emmax_last_error().decode("utf-8", "replace")
+        raise EmmaxError(f"{what or 'emmax call'} failed with status {status}: {msg}")
+
+
+def ptr(t) -> int:
+    """Device (or host) address of a torch tensor as an int for c_void_p arguments (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,181 @@
+"""
+engine.py -- thin Python owner of the libemmax_hip handles: device memory (torch tensors), weight binding, sessions.
+
+PyTorch is used for plumbing only (device allocations, the current HIP stream); every FLOP on the hot path happens in
+the hand-written gfx950 kernels behind the C ABI (include/emmax.h).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from .config import EmmaXConfig
+from .weights import param_shapes, validate_state_dict
+
+
+def _config_c(cfg: EmmaXConfig) -> _lib.ConfigC:
+    c = _lib.ConfigC()
+    for i, tw in enumerate(cfg.towers):
+        t = c.tower[i]
+        t.embed_dim, t.depth, t.num_heads, t.mlp_hidden = tw.embed_dim, tw.depth, tw.num_heads, tw.mlp_hidden
+        t.has_cls, t.n_reg, t.layerscale = int(tw.has_cls), tw.n_reg, int(tw.layerscale)
+        t.patch, t.image_size, t.take_index = tw.patch, tw.image_size, tw.take_index
+        t.ln_eps = tw.ln_eps
+        for j in range(3):
+            t.mean[j] = tw.mean[j]
+            t.std[j] = tw.std[j]
+    L = cfg.llm
+    c.hidden, c.inter, c.n_layers, c.n_heads, c.n_kv_heads, c.head_dim, c.vocab = (
+        L.hidden_size, L.intermediate_size, L.num_layers, L.num_heads, L.num_kv_heads, L.head_dim, L.vocab_size)
+    c.rms_eps, c.rope_theta = L.rms_eps, L.rope_theta
+    c.bos_id, c.eos_id, c.pad_id = cfg.bos_token_id, cfg.eos_token_id, cfg.pad_token_id
+    return c
+
+
+class EmmaxEngine:
+    """Model weights (re-laid-out into one device arena) + one session (workspace + paged KV cache)."""
+
+    def __init__(self, cfg: EmmaXConfig, state_dict: Dict[str, torch.Tensor], device: str = "cuda:0",
+                 max_batch: int = 1, max_prompt: int = 512, max_ctx: Optional[int] = None, free_state_dict: bool = False):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.EmmaxError("EmmaxEngine needs a HIP device (cuda:N); the product path has no CPU fallback")
+        validate_state_dict(state_dict, cfg)
+        torch.cuda.set_device(self.device)
+        self._model = C.c_void_p()
+        self._session = C.c_void_p()
+        cc = _config_c(cfg)
+        _lib.check(self.lib.emmax_model_create(C.byref(cc), C.byref(self._model)), "emmax_model_create")
+        # ---- bind (bf16, on device) and finalize into the arena ----
+        keep: List[torch.Tensor] = []
+        for key, shape, _ in param_shapes(cfg):
+            t = state_dict[key]
+            if t.device != self.device or t.dtype != torch.bfloat16 or not t.is_contiguous():
+                t = t.to(device=self.device, dtype=torch.bfloat16).contiguous()
+            keep.append(t)
+            shp = (C.c_int64 * t.ndim)(*t.shape)
+            _lib.check(self.lib.emmax_model_bind_weight(self._model, key.encode(), t.data_ptr(), 0, shp, t.ndim),
+                       f"bind {key}")
+            if free_state_dict:
+                state_dict[key] = None  # drop the caller's copy as soon as ours exists
+        nbytes = self.lib.emmax_model_arena_bytes(self._model)
+        self.arena = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        stream = _lib.current_stream()
+        _lib.check(self.lib.emmax_model_finalize(self._model, self.arena.data_ptr(), nbytes, stream), "emmax_model_finalize")
+        del keep
+        self.max_batch = self.max_prompt = self.max_ctx = 0
+        self.new_session(max_batch, max_prompt, max_ctx)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def new_session(self, max_batch: int, max_prompt: int, max_ctx: Optional[int] = None) -> None:
+        if self._session:
+            self.lib.emmax_session_destroy(self._session)
+            self._session = C.c_void_p()
+        np_ = self.cfg.n_patches
+        if max_ctx is None:
+            max_ctx = np_ + max_prompt + 512 + 1
+        ws, kv = C.c_int64(), C.c_int64()
+        _lib.check(self.lib.emmax_session_bytes(self._model, max_batch, max_prompt, max_ctx, C.byref(ws), C.byref(kv)),
+                   "emmax_session_bytes")
+        self.workspace = torch.empty(ws.value, dtype=torch.uint8, device=self.device)
+        self.kv = torch.empty(kv.value, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.emmax_session_create(self._model, max_batch, max_prompt, max_ctx, self.workspace.data_ptr(),
+                                                 ws.value, self.kv.data_ptr(), kv.value, C.byref(self._session)),
+                   "emmax_session_create")
+        self.max_batch, self.max_prompt, self.max_ctx = max_batch, max_prompt, max_ctx
+
+    def ensure_capacity(self, batch: int, prompt: int, max_new: int) -> None:
+        need_ctx = self.cfg.n_patches + prompt + max_new + 1
+        if batch > self.max_batch or prompt > self.max_prompt or need_ctx > self.max_ctx:
+            self.new_session(max(batch, self.max_batch), max(prompt, self.max_prompt), max(need_ctx, self.max_ctx))
+
+    def close(self) -> None:
+        if getattr(self, "_session", None):
+            self.lib.emmax_session_destroy(self._session)
+            self._session = C.c_void_p()
+        if getattr(self, "_model", None):
+            self.lib.emmax_model_destroy(self._model)
+            self._model = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def vision_encode(self, frames_u8: torch.Tensor) -> torch.Tensor:
+        """uint8 [B,224,224,3] on device -> bf16 [B,256,hidden] projected patch embeddings."""
+        assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.is_contiguous()
+        B = frames_u8.shape[0]
+        out = torch.empty(B, self.cfg.n_patches, self.cfg.llm.hidden_size, dtype=torch.bfloat16, device=self.device)
+        _lib.check(self.lib.emmax_vision_encode(self._session, frames_u8.data_ptr(), B, out.data_ptr(), _lib.current_stream()),
+                   "emmax_vision_encode")
+        return out
+
+    def vision_encode_pixels(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """bf16 [B,6,224,224] (PrismaticProcessor layout) -> bf16 [B,256,hidden]."""
+        pv = pixel_values.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        B = pv.shape[0]
+        out = torch.empty(B, self.cfg.n_patches, self.cfg.llm.hidden_size, dtype=torch.bfloat16, device=self.device)
+        _lib.check(self.lib.emmax_vision_encode_pixels(self._session, pv.data_ptr(), B, out.data_ptr(), _lib.current_stream()),
+                   "emmax_vision_encode_pixels")
+        return out
+
+    def vision_features(self, B: int) -> torch.Tensor:
+        out = torch.empty(B, self.cfg.n_patches, self.cfg.vision_dim, dtype=torch.bfloat16, device=self.device)
+        _lib.check(self.lib.emmax_vision_features(self._session, B, out.data_ptr(), _lib.current_stream()), "emmax_vision_features")
+        return out
+
+    def prefill(self, input_ids: Sequence[Sequence[int]], patch_embeds: torch.Tensor) -> List[int]:
+        """Ragged prompts (row b = list of ids starting with BOS). Returns per-row packed lengths S_b = 256 + P_b."""
+        B = len(input_ids)
+        lens = [len(r) for r in input_ids]
+        P_max = max(lens)
+        ids = torch.full((B, P_max), self.cfg.pad_token_id, dtype=torch.int32)
+        for b, r in enumerate(input_ids):
+            ids[b, : len(r)] = torch.as_tensor(list(r), dtype=torch.int32)
+        ids_d = ids.to(self.device)
+        lens_c = (C.c_int32 * B)(*lens)
+        pe = patch_embeds.contiguous()
+        assert pe.dtype == torch.bfloat16 and pe.shape[0] == B
+        _lib.check(self.lib.emmax_prefill(self._session, ids_d.data_ptr(), lens_c, B, P_max, pe.data_ptr(), _lib.current_stream()),
+                   "emmax_prefill")
+        self._last_S = [self.cfg.n_patches + n for n in lens]
+        self._last_B = B
+        return self._last_S
+
+    def prefill_logits(self) -> List[torch.Tensor]:
+        """f32 logits of every prefill position, one [S_b, vocab] tensor per row."""
+        total = sum(self._last_S)
+        out = torch.empty(total, self.cfg.llm.vocab_size, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.emmax_prefill_logits(self._session, out.data_ptr(), _lib.current_stream()), "emmax_prefill_logits")
+        return list(torch.split(out, self._last_S, dim=0))
+
+    def last_logits(self) -> torch.Tensor:
+        out = torch.empty(self._last_B, self.cfg.llm.vocab_size, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.emmax_last_logits(self._session, out.data_ptr(), _lib.current_stream()), "emmax_last_logits")
+        return out
+
+    def decode_step(self) -> None:
+        _lib.check(self.lib.emmax_decode_step(self._session, _lib.current_stream()), "emmax_decode_step")
+
+    def set_current_tokens(self, toks: Sequence[int]) -> None:
+        t = torch.as_tensor(list(toks), dtype=torch.int32).to(self.device)
+        _lib.check(self.lib.emmax_set_current_tokens(self._session, t.data_ptr(), _lib.current_stream()), "emmax_set_current_tokens")
+        torch.cuda.current_stream().synchronize()   # `t` must outlive the copy
+
+    def generate(self, max_new_tokens: int, stop_on_eos: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Greedy loop after prefill. Returns (ids int32 [B,max_new] padded with pad_id, lens int32 [B]) on device."""
+        B = self._last_B
+        out = torch.empty(B, max_new_tokens, dtype=torch.int32, device=self.device)
+        lens = torch.empty(B, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.emmax_generate(self._session, max_new_tokens, int(stop_on_eos), out.data_ptr(), lens.data_ptr(),
+                                           _lib.current_stream()), "emmax_generate")
+        return out, lens

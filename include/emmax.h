@@ -1,0 +1,146 @@
+/*
+ * emmax.h -- C ABI of libemmax_hip.so: the MI355X-native (gfx950) Emma-X VLA forward/generate hot path.
+ *
+ * The reference (declare-lab/Emma-X) has NO FFI/plugin ABI: its extension point is HuggingFace Auto-class registration
+ * of pure-Python nn.Modules (experiments/robot/openvla_utils.py:38-41).  This header is therefore the boundary a
+ * maintainer would bind from Python (ctypes) in place of the third-party math the reference calls:
+ *
+ *   emmax_vision_encode*   replaces PrismaticVisionBackbone.forward + PrismaticProjector.forward
+ *                          (prismatic/extern/hf/modeling_prismatic.py:114-123, 146-158; native twin
+ *                          prismatic/models/backbones/vision/dinosiglip_vit.py:142-147, prismatic/util/nn_utils.py:37-53)
+ *   emmax_prefill          replaces the multimodal branch of PrismaticForConditionalGeneration.forward
+ *                          (modeling_prismatic.py:362-415: embed, splice [BOS]+patches+text[1:], LlamaForCausalLM prefill)
+ *   emmax_decode_step      replaces the cached branch (modeling_prismatic.py:325-341) + one greedy step of
+ *                          transformers GenerationMixin.generate (invoked at modeling_prismatic.py:519,
+ *                          prismatic/models/vlms/prismatic.py:659-663)
+ *   emmax_generate         replaces the whole greedy loop (<= max_new_tokens, EOS stop) without a host sync per token
+ *   emmax_prefill_logits   replaces `forward(...).logits` (all positions), for API parity of `forward()`
+ *   emmax_op_*             single-kernel entry points, used by the parity tests
+ *
+ * Conventions: every function returns 0 on success or a negative emmax_status; emmax_last_error() gives the message of
+ * the last failure on the calling thread.  All pointers named *_dev are device pointers owned by the caller; the
+ * library never allocates device memory (the caller passes arenas sized by the *_bytes queries).  `stream` is a
+ * hipStream_t (NULL = default stream).  Handles are thread-compatible (one thread per handle at a time).  bf16 tensors
+ * are raw uint16_t bit patterns.  No torch types cross this boundary.
+ */
+#ifndef EMMAX_H
+#define EMMAX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMMAX_ABI_VERSION 1
+
+typedef enum emmax_status {
+    EMMAX_OK = 0,
+    EMMAX_ERR_INVALID = -1,     /* bad argument / shape / config outside the hot path          */
+    EMMAX_ERR_MISSING = -2,     /* finalize: a required weight was never bound                  */
+    EMMAX_ERR_NOMEM = -3,       /* arena / workspace too small                                  */
+    EMMAX_ERR_HIP = -4,         /* a HIP runtime call failed                                    */
+    EMMAX_ERR_STATE = -5        /* call order violated (e.g. decode before prefill)             */
+} emmax_status;
+
+typedef enum emmax_dtype { EMMAX_BF16 = 0, EMMAX_F32 = 1, EMMAX_U8 = 2, EMMAX_I32 = 3 } emmax_dtype;
+
+typedef void* emmax_stream;            /* hipStream_t */
+typedef struct emmax_model emmax_model;
+typedef struct emmax_session emmax_session;
+
+/* One timm ViT tower as the reference instantiates it (modeling_prismatic.py:78-101). */
+typedef struct emmax_tower_config {
+    int32_t embed_dim, depth, num_heads, mlp_hidden;
+    int32_t has_cls, n_reg, layerscale;
+    int32_t patch, image_size;
+    int32_t take_index;                /* block whose output is returned: depth-2 (modeling_prismatic.py:86,100) */
+    float ln_eps;
+    float mean[3], std[3];             /* per-tower normalisation (processing_prismatic.py:136-139)              */
+} emmax_tower_config;
+
+typedef struct emmax_config {
+    emmax_tower_config tower[2];       /* [0]=featurizer (DINOv2), [1]=fused_featurizer (SigLIP)                  */
+    int32_t hidden, inter, n_layers, n_heads, n_kv_heads, head_dim, vocab;
+    float rms_eps, rope_theta;
+    int32_t bos_id, eos_id, pad_id;
+} emmax_config;
+
+const char* emmax_version(void);
+const char* emmax_last_error(void);
+int emmax_abi_version(void);
+
+/* ---- model: weights ------------------------------------------------------------------------------------------------
+ * bind every tensor of the HF state dict (key names: vla-scripts/extern/convert_openvla_weights_to_hf.py:74-116) as a
+ * bf16 device pointer, then finalize(): all weights are re-laid-out into `arena` (kernel-native: fused QKV rows,
+ * 16-row interleaved gate/up, K/N padded to tile multiples, im2col-ordered patch-embed).  After finalize the bound
+ * pointers are no longer referenced and may be freed. */
+int emmax_model_create(const emmax_config* cfg, emmax_model** out);
+void emmax_model_destroy(emmax_model* m);
+int emmax_model_bind_weight(emmax_model* m, const char* hf_key, const void* ptr_dev, int dtype,
+                            const int64_t* shape, int ndim);
+int64_t emmax_model_arena_bytes(const emmax_model* m);
+int emmax_model_finalize(emmax_model* m, void* arena_dev, int64_t arena_bytes, emmax_stream stream);
+
+/* ---- session: activations workspace + paged KV cache for up to max_batch sequences of <= max_ctx tokens ------------ */
+int emmax_session_bytes(const emmax_model* m, int max_batch, int max_prompt, int max_ctx,
+                        int64_t* workspace_bytes, int64_t* kv_bytes);
+int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_ctx,
+                         void* workspace_dev, int64_t workspace_bytes, void* kv_dev, int64_t kv_bytes,
+                         emmax_session** out);
+void emmax_session_destroy(emmax_session* s);
+
+/* frames_u8_dev: uint8 [B,224,224,3] RGB (normalisation fused into the patch gather);  out: bf16 [B,256,hidden]. */
+int emmax_vision_encode(emmax_session* s, const uint8_t* frames_u8_dev, int B, void* patch_embeds_out_dev,
+                        emmax_stream stream);
+/* pixel_values_dev: bf16 [B,6,224,224] as PrismaticProcessor emits (already normalised per tower). */
+int emmax_vision_encode_pixels(emmax_session* s, const void* pixel_values_bf16_dev, int B, void* patch_embeds_out_dev,
+                               emmax_stream stream);
+/* raw concatenated tower features bf16 [B,256,D0+D1] of the last emmax_vision_encode* call (parity tests). */
+int emmax_vision_features(emmax_session* s, int B, void* feats_out_dev, emmax_stream stream);
+
+/* ids_dev: int32 [B,P_max] (row b uses the first lens_host[b] ids, ids[b][0] = BOS); patch_embeds: bf16 [B,256,hidden].
+ * Builds [BOS]+patches+text[1:] per row (no padding: rows are packed), runs the decoder stack, fills the KV cache and
+ * leaves the greedy first token of every row as the session's "current token". */
+int emmax_prefill(emmax_session* s, const int32_t* ids_dev, const int32_t* lens_host, int B, int P_max,
+                  const void* patch_embeds_dev, emmax_stream stream);
+/* f32 logits of every prefill position, packed rows [sum_b S_b, vocab] (S_b = 256 + lens[b]); valid after prefill. */
+int emmax_prefill_logits(emmax_session* s, float* logits_out_dev, emmax_stream stream);
+/* f32 last-position logits [B,vocab] of the most recent prefill/decode step (parity tests; costs one extra pass). */
+int emmax_last_logits(emmax_session* s, float* logits_out_dev, emmax_stream stream);
+
+/* One greedy step for all rows: consumes each row's current token, appends KV, leaves argmax as the new current token
+ * and records it in the session's output buffer.  Rows that already emitted EOS (or ran out of context) emit pad_id.
+ * Reads all step-varying state from device memory, so it is hipGraph-capturable. */
+int emmax_decode_step(emmax_session* s, emmax_stream stream);
+/* Overwrite the current token of every row (teacher forcing in tests): tokens_dev int32 [B]. */
+int emmax_set_current_tokens(emmax_session* s, const int32_t* tokens_dev, emmax_stream stream);
+/* Run up to max_new_tokens steps (including the token produced by prefill) as replays of a captured hipGraph of
+ * emmax_decode_step; stop early once all rows are done if stop_on_eos != 0.
+ * out_ids_dev int32 [B,max_new_tokens] (pad_id after a row's EOS), out_lens_dev int32 [B] (tokens incl. EOS). */
+int emmax_generate(emmax_session* s, int max_new_tokens, int stop_on_eos, int32_t* out_ids_dev, int32_t* out_lens_dev,
+                   emmax_stream stream);
+
+/* ---- single-kernel entry points (parity tests + micro-benchmarks) -------------------------------------------------- */
+/* C[M,N] = epilogue(A[M,K] @ W[N,K]^T): bf16 in, fp32 accumulate on MFMA.  K % 64 == 0, N % 128 == 0.
+ * bias/scale: bf16 [N] or NULL; residual: bf16 [M,ldr] or NULL; act: 0 none, 1 exact-erf GELU, 2 SwiGLU over
+ * 16-column interleaved (gate,up) groups (then C is [M,N/2]); out_f32: store fp32 instead of bf16. */
+int emmax_op_gemm(const void* A_dev, int lda, const void* W_dev, int ldw, void* C_dev, int ldc, int M, int N, int K,
+                  const void* bias_dev, int act, const void* scale_dev, const void* residual_dev, int ldr, int out_f32,
+                  emmax_stream stream);
+int emmax_op_layernorm(const void* x_dev, void* y_dev, const void* w_dev, const void* b_dev, int rows, int D, float eps,
+                       emmax_stream stream);
+int emmax_op_rmsnorm(const void* x_dev, void* y_dev, const void* w_dev, int rows, int D, float eps, emmax_stream stream);
+/* softmax(QK^T * scale [+causal]) V over a packed qkv buffer: token t of sequence b lives at row cu_seqlens[b]+t of
+ * qkv_dev (bf16, row stride ld_qkv elements); q head h at column q_off + h*head_dim, k/v head h/(Hq/Hkv) at k_off/v_off.
+ * out: bf16 rows of Hq*head_dim (row stride ld_out).  head_dim in {64,72,128}. */
+int emmax_op_attention(const void* qkv_dev, int ld_qkv, int q_off, int k_off, int v_off, void* out_dev, int ld_out,
+                       const int32_t* cu_seqlens_dev, int B, int max_seqlen, int Hq, int Hkv, int head_dim, float scale,
+                       int causal, emmax_stream stream);
+/* Decode-path weight-streaming GEMV: y[b,n] = sum_k x[b,k] W[n,k]  (bf16 in, fp32 accumulate, bf16 out), B <= 8. */
+int emmax_op_gemv(const void* x_dev, const void* W_dev, void* y_dev, int B, int N, int K, emmax_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMMAX_H */

@@ -1,0 +1,168 @@
+"""Per-kernel parity on a real MI355X: each HIP kernel (called through the C ABI) vs the CPU oracle's op in fp32 on the
+same bf16-rounded inputs.  Tolerances are bf16-output tolerances: |err| <= TOL * max|ref| with TOL = 1e-2 unless noted
+(one bf16 rounding is 2^-9 = 2e-3 relative; fp32 accumulation order adds ~1e-6)."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-2
+
+
+def _lib():
+    from emmax import _lib
+
+    return _lib, _lib.load()
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def relerr(got, ref):
+    ref = ref.float()
+    return ((got.float().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("M,N,K", [(261, 128, 64), (128, 256, 128), (300, 384, 640), (1, 128, 64), (517, 1152, 1024)])
+@pytest.mark.parametrize("variant", ["plain", "bias", "gelu", "scale_res", "f32"])
+def test_gemm(device, M, N, K, variant):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    bias = bf(torch.randn(N, generator=g)) if variant != "plain" else None
+    scale = bf(torch.rand(N, generator=g) + 0.5) if variant == "scale_res" else None
+    res = bf(torch.randn(M, N, generator=g)) if variant == "scale_res" else None
+    act = 1 if variant == "gelu" else 0
+    out_f32 = variant == "f32"
+    ref = A.float() @ W.float().t()
+    if bias is not None:
+        ref = ref + bias.float()
+    if act:
+        ref = F.gelu(ref)
+    if scale is not None:
+        ref = ref * scale.float() + res.float()
+    Ad, Wd = A.to(device), W.to(device)
+    Cd = torch.full((M, N), float("nan"), dtype=torch.float32 if out_f32 else torch.bfloat16, device=device)
+    bd = bias.to(device) if bias is not None else None
+    sd = scale.to(device) if scale is not None else None
+    rd = res.to(device) if res is not None else None
+    L.check(lib.emmax_op_gemm(Ad.data_ptr(), K, Wd.data_ptr(), K, Cd.data_ptr(), N, M, N, K, L.ptr(bd), act, L.ptr(sd), L.ptr(rd), N,
+                              int(out_f32), stream()), "gemm")
+    torch.cuda.synchronize()
+    assert torch.isfinite(Cd.float()).all()
+    assert relerr(Cd, ref) < (1e-4 if out_f32 else TOL)
+
+
+def test_gemm_swiglu(device):
+    L, lib = _lib()
+    M, inter, K = 200, 192, 128
+    g = torch.Generator().manual_seed(3)
+    A = bf(torch.randn(M, K, generator=g))
+    Wg = bf(torch.randn(inter, K, generator=g) * 0.1)
+    Wu = bf(torch.randn(inter, K, generator=g) * 0.1)
+    ref = F.silu(A.float() @ Wg.float().t()) * (A.float() @ Wu.float().t())
+    # 16-row interleave: [g0..15, u0..15, g16..31, u16..31, ...]
+    Wi = torch.stack([Wg.view(inter // 16, 16, K), Wu.view(inter // 16, 16, K)], dim=1).reshape(2 * inter, K).contiguous()
+    Ad, Wd = A.to(device), Wi.to(device)
+    Cd = torch.zeros(M, inter, dtype=torch.bfloat16, device=device)
+    L.check(lib.emmax_op_gemm(Ad.data_ptr(), K, Wd.data_ptr(), K, Cd.data_ptr(), inter, M, 2 * inter, K, None, 2, None, None, 0, 0,
+                              stream()), "gemm swiglu")
+    torch.cuda.synchronize()
+    assert relerr(Cd, ref) < TOL
+
+
+def test_gemm_rejects_bad_shapes(device):
+    L, lib = _lib()
+    x = torch.zeros(128, 128, dtype=torch.bfloat16, device=device)
+    assert lib.emmax_op_gemm(x.data_ptr(), 100, x.data_ptr(), 100, x.data_ptr(), 128, 128, 128, 100, None, 0, None, None, 0, 0, stream()) != 0
+    assert b"emmax_op_gemm" in lib.emmax_last_error()
+
+
+@pytest.mark.parametrize("rows,D", [(5, 128), (261, 1024), (256, 1152), (7, 144), (3, 4096)])
+def test_layernorm_rmsnorm(device, rows, D):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(rows + D)
+    x = bf(torch.randn(rows, D, generator=g) * 3 + 0.5)
+    w = bf(1 + 0.1 * torch.randn(D, generator=g))
+    b = bf(0.1 * torch.randn(D, generator=g))
+    xd, wd, bd = x.to(device), w.to(device), b.to(device)
+    y = torch.empty_like(xd)
+    L.check(lib.emmax_op_layernorm(xd.data_ptr(), y.data_ptr(), wd.data_ptr(), bd.data_ptr(), rows, D, 1e-6, stream()), "ln")
+    ref = F.layer_norm(x.float(), (D,), w.float(), b.float(), eps=1e-6)
+    assert relerr(y, ref) < TOL
+    from oracle import emmax_oracle as orc
+
+    L.check(lib.emmax_op_rmsnorm(xd.data_ptr(), y.data_ptr(), wd.data_ptr(), rows, D, 1e-5, stream()), "rms")
+    assert relerr(y, orc.rms_norm(x.float(), w.float(), 1e-5)) < TOL
+
+
+def _attn_ref(qkv, cu, Hq, Hkv, hd, q_off, k_off, v_off, scale, causal):
+    outs = []
+    for b in range(len(cu) - 1):
+        x = qkv[cu[b]:cu[b + 1]].float()
+        n = x.shape[0]
+        q = x[:, q_off:q_off + Hq * hd].view(n, Hq, hd).transpose(0, 1)
+        k = x[:, k_off:k_off + Hkv * hd].view(n, Hkv, hd).transpose(0, 1).repeat_interleave(Hq // Hkv, 0)
+        v = x[:, v_off:v_off + Hkv * hd].view(n, Hkv, hd).transpose(0, 1).repeat_interleave(Hq // Hkv, 0)
+        s = (q @ k.transpose(1, 2)) * scale
+        if causal:
+            s = s.masked_fill(torch.triu(torch.ones(n, n, dtype=torch.bool), 1), float("-inf"))
+        outs.append((s.softmax(-1) @ v).transpose(0, 1).reshape(n, Hq * hd))
+    return torch.cat(outs)
+
+
+@pytest.mark.parametrize("hd,Hq,Hkv,lens,causal", [
+    (64, 2, 2, [261], 0), (72, 2, 2, [256, 256], 0), (64, 16, 16, [261, 261], 0), (72, 16, 16, [256], 0),
+    (128, 2, 2, [300], 1), (128, 4, 2, [70, 1, 129, 64], 1), (128, 2, 2, [768], 1), (128, 2, 1, [5, 200], 1),
+])
+def test_attention(device, hd, Hq, Hkv, lens, causal):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(hd + sum(lens))
+    total = sum(lens)
+    qd, kvd = Hq * hd, Hkv * hd
+    ld = (qd + 2 * kvd + 127) // 128 * 128
+    qkv = bf(torch.randn(total, ld, generator=g))
+    cu = [0]
+    for n in lens:
+        cu.append(cu[-1] + n)
+    scale = hd ** -0.5
+    ref = _attn_ref(qkv, cu, Hq, Hkv, hd, 0, qd, qd + kvd, scale, causal)
+    qkv_d = qkv.to(device)
+    cu_d = torch.tensor(cu, dtype=torch.int32, device=device)
+    ld_out = (qd + 127) // 128 * 128
+    out = torch.zeros(total, ld_out, dtype=torch.bfloat16, device=device)
+    L.check(lib.emmax_op_attention(qkv_d.data_ptr(), ld, 0, qd, qd + kvd, out.data_ptr(), ld_out, cu_d.data_ptr(), len(lens), max(lens),
+                                   Hq, Hkv, hd, scale, causal, stream()), "attention")
+    torch.cuda.synchronize()
+    got = out[:, :qd]
+    assert torch.isfinite(got.float()).all()
+    assert relerr(got, ref) < TOL
+    if ld_out > qd:
+        assert (out[:, qd:] == 0).all(), "attention must not write the padding columns"
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("N,K", [(256, 256), (4096, 4096), (1000, 11008), (64, 688)])
+def test_gemv(device, B, N, K):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(B + N + K)
+    x = bf(torch.randn(B, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    ref = x.float() @ W.float().t()
+    xd, Wd = x.to(device), W.to(device)
+    y = torch.zeros(B, N, dtype=torch.bfloat16, device=device)
+    # a session is what normally raises the dynamic-LDS limit; do it here through a throw-away tiny engine
+    L.check(lib.emmax_op_gemv(xd.data_ptr(), Wd.data_ptr(), y.data_ptr(), B, N, K, stream()), "gemv")
+    torch.cuda.synchronize()
+    assert relerr(y, ref) < TOL
