@@ -480,11 +480,15 @@ __global__ __launch_bounds__(256) void emmax_decode_finish_kernel(FinishParams p
     if (tid == 0) {
         int tok = si[0];
         if (tok == 0x7fffffff) tok = p.pad_id;
-        const int was_done = p.done[b];
+        int was_done = p.done[b];
+        int n = p.n_out[b];
+        if (!p.is_prefill && !was_done && n >= *p.max_new_p) {   // token budget already spent before this step
+            was_done = 1;
+            p.done[b] = 1;
+        }
         if (!p.is_prefill && !was_done) p.ctx_len[b] += 1;   // the token consumed by this step now sits in the cache
         if (p.is_prefill)   // fresh sequence: clear the output row
             for (int i = 0; i < p.max_out; ++i) p.out_ids[(size_t)b * p.max_out + i] = p.pad_id;
-        int n = p.n_out[b];
         if (was_done) {
             tok = p.pad_id;
         } else {

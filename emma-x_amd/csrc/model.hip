@@ -412,6 +412,7 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
     }
     if (total > s->max_rows) return fail(EMMAX_ERR_NOMEM, "packed prefill rows %d exceed capacity %d", total, s->max_rows);
     KCHK(launch_prefill_state(ps, s->cu, s->ctx_len, s->done, s->n_out, st));
+    KCHK(launch_set_int(s->max_new_d, 0x7fffffff, st));   // no token budget until emmax_generate sets one
     s->cur_B = B; s->total_rows = total; s->max_seqlen = maxS;
 
     KCHK(launch_embed_splice(ids, P_max, s->cu, m->embed, patches, s->ph, B, maxS, np, m->H, m->vocab, st));
