@@ -25,11 +25,13 @@ enum { MODE_QKV = 0, MODE_RESID = 1, MODE_GATEUP = 2, MODE_LMHEAD = 3, MODE_PLAI
 
 __device__ __forceinline__ u32x4_t ld_nt(const u32x4_t* p) { return __builtin_nontemporal_load(p); }
 
+constexpr int PSTRIDE = 132;   // floats per attention split partial: 128 o + m + l + 2 pad (16-byte aligned rows)
+
 // ---------------------------------------------------------------------------------------------------------------------
 // GEMV.  Block = 256 threads = 4 waves; a wave owns RPW "row slots"; a slot is one output row (RESID/LMHEAD/PLAIN) or a
 // pair of rows (QKV: rows d and d+hd/2 of one head; GATEUP: gate row i and up row i).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int B, int RPW, int MODE, bool NORM>
+template <int B, int RPW, int MODE, bool NORM, bool XATTN = false>
 __global__ __launch_bounds__(256) void emmax_decode_gemv_kernel(GemvParams p) {
     constexpr int NR = (MODE == MODE_QKV || MODE == MODE_GATEUP) ? 2 * RPW : RPW;   // weight rows per wave
     constexpr int U = 8;   // 16-byte loads per row per outer iteration (8 * 64 lanes * 8 elems = 4096 elements)
@@ -68,6 +70,24 @@ __global__ __launch_bounds__(256) void emmax_decode_gemv_kernel(GemvParams p) {
 #pragma unroll
         for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
 
+    // ---- request the first batch of weights BEFORE the activation prologue: they do not depend on x, and the HBM
+    // latency of the stream's head then overlaps the norm reduction / staging instead of following it.  The loop below
+    // is rotated (compute chunk i, then request chunk i+1) so that ONE register buffer is live at any time. ----
+    const int KC = p.kc;   // elements per K phase (multiple of 8)
+    u32x4_t wr[NR][U];
+    auto issue_weights = [&](int kc0, int c0, int nch) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const u32x4_t* wrow = (const u32x4_t*)(W + (size_t)rows[r] * p.ldw + kc0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u * 64 + lane;
+                wr[r][u] = (c < nch) ? ld_nt(wrow + c) : (u32x4_t){0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    issue_weights(0, 0, min(KC, K) >> 3);
+
     // ---- RMSNorm statistics (prologue) ----
     float rstd[B];
     if (NORM) {
@@ -92,17 +112,39 @@ __global__ __launch_bounds__(256) void emmax_decode_gemv_kernel(GemvParams p) {
         for (int b = 0; b < B; ++b) rstd[b] = rsqrtf((red[0][b] + red[1][b] + red[2][b] + red[3][b]) / (float)K + p.eps);
     }
 
-    const int KC = p.kc;   // elements per K phase (multiple of 8)
-    for (int kc0 = 0; kc0 < K; kc0 += KC) {
-        const int kcn = min(KC, K - kc0);   // elements in this phase
-        const int nch = kcn >> 3;           // 16-byte chunks in this phase
-        if (kc0 > 0) __syncthreads();       // previous phase fully consumed
-        // ---- stage x[:, kc0 : kc0+kcn] into LDS (normalised if NORM) ----
+    // stage x[:, kc0 : kc0+kcn] into LDS (normalised if NORM, merged from the attention partials if XATTN)
+    auto stage_x = [&](int kc0, int nch) {
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             const u32x4_t* xr = (const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx + kc0);
             for (int c = tid; c < nch; c += 256) {
-                u32x4_t v = xr[c];
+                u32x4_t v;
+                if (XATTN) {
+                    // chunk cg = head (cg>>4), elements (cg&15)*8..+8 of the split partials
+                    const int cg = (kc0 >> 3) + c;
+                    const float* pp = p.attn_part + (size_t)(b * p.Hq + (cg >> 4)) * p.nsplit * PSTRIDE;
+                    const int d0 = (cg & 15) * 8;
+                    float M = -INFINITY;
+                    for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, pp[s * PSTRIDE + 128]);
+                    float den = 0.f, a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    for (int s = 0; s < p.nsplit; ++s) {
+                        const float ms = pp[s * PSTRIDE + 128];
+                        const float wgt = (ms == -INFINITY) ? 0.f : __expf(ms - M);
+                        den += pp[s * PSTRIDE + 129] * wgt;
+                        const f32x4_t o0 = *(const f32x4_t*)(pp + s * PSTRIDE + d0);
+                        const f32x4_t o1 = *(const f32x4_t*)(pp + s * PSTRIDE + d0 + 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            a8[j] += o0[j] * wgt;
+                            a8[4 + j] += o1[j] * wgt;
+                        }
+                    }
+                    const float inv = den > 0.f ? 1.0f / den : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = pack_bf16x2(a8[2 * j] * inv, a8[2 * j + 1] * inv);
+                } else {
+                    v = xr[c];
+                }
                 if (NORM) {
                     const u32x4_t wv = *((const u32x4_t*)((const bf16_t*)p.norm_w + kc0) + c);
 #pragma unroll
@@ -116,41 +158,48 @@ __global__ __launch_bounds__(256) void emmax_decode_gemv_kernel(GemvParams p) {
                 xs[b * (KC >> 3) + c] = v;
             }
         }
-        __syncthreads();
+    };
 
-        // ---- stream the weight rows of this wave over the phase ----
-        for (int c0 = 0; c0 < nch; c0 += 64 * U) {
-            u32x4_t wr[NR][U];
+    int kc0 = 0, c0 = 0;
+    int nch = min(KC, K) >> 3;   // 16-byte chunks in the current phase
+    stage_x(0, nch);
+    __syncthreads();
+    while (true) {
+        // ---- consume the chunk whose loads are in flight ----
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const u32x4_t* wrow = (const u32x4_t*)(W + (size_t)rows[r] * p.ldw + kc0);
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * 64 + lane;
+            if (c0 + u * 64 < nch) {   // wave-uniform
+                const int cc = (c < nch) ? c : 0;
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int c = c0 + u * 64 + lane;
-                    wr[r][u] = (c < nch) ? ld_nt(wrow + c) : (u32x4_t){0u, 0u, 0u, 0u};
-                }
-            }
+                for (int b = 0; b < B; ++b) {
+                    const u32x4_t xv = xs[b * (KC >> 3) + cc];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int c = c0 + u * 64 + lane;
-                if (c0 + u * 64 < nch) {   // wave-uniform
-                    const int cc = (c < nch) ? c : 0;
-#pragma unroll
-                    for (int b = 0; b < B; ++b) {
-                        const u32x4_t xv = xs[b * (KC >> 3) + cc];
-#pragma unroll
-                        for (int r = 0; r < NR; ++r) {
-                            float a = acc[r][b];
-                            a = dot2_bf16(wr[r][u][0], xv[0], a);
-                            a = dot2_bf16(wr[r][u][1], xv[1], a);
-                            a = dot2_bf16(wr[r][u][2], xv[2], a);
-                            a = dot2_bf16(wr[r][u][3], xv[3], a);
-                            acc[r][b] = a;
-                        }
+                    for (int r = 0; r < NR; ++r) {
+                        float a = acc[r][b];
+                        a = dot2_bf16(wr[r][u][0], xv[0], a);
+                        a = dot2_bf16(wr[r][u][1], xv[1], a);
+                        a = dot2_bf16(wr[r][u][2], xv[2], a);
+                        a = dot2_bf16(wr[r][u][3], xv[3], a);
+                        acc[r][b] = a;
                     }
                 }
             }
         }
+        // ---- advance; request the next chunk (then, at a phase boundary, restage x while those loads fly) ----
+        c0 += 64 * U;
+        if (c0 < nch) {
+            issue_weights(kc0, c0, nch);
+            continue;
+        }
+        kc0 += KC;
+        if (kc0 >= K) break;
+        c0 = 0;
+        nch = min(KC, K - kc0) >> 3;
+        issue_weights(kc0, 0, nch);
+        __syncthreads();   // every wave is done reading the previous phase from LDS
+        stage_x(kc0, nch);
+        __syncthreads();
     }
 
     // ---- wave reduction: every lane ends up with the full sums ----
@@ -271,16 +320,20 @@ __global__ __launch_bounds__(256) void emmax_decode_embed_kernel(const int32_t* 
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Split-KV decode attention over the paged cache.  grid (NSPLIT, Hkv, B), 256 threads.
-// part[((b*Hq + h)*NSPLIT + s) * (HD+2)] = { o[0..HD) un-normalised, m, l }
+// A 16-lane group owns one key at a time (lane = 16-byte chunk of the 128-wide row; 4 keys per wave load instruction,
+// fully coalesced) and keeps its own online-softmax state (m, l, o[8 per lane]); K and V of a whole chunk of keys are
+// requested before the first score is computed, so 2*KU 16-byte loads per lane are in flight.  The 16 group states of
+// the block are merged through shuffles + LDS, and the block writes one partial per (row, head, split):
+//   part[((b*Hq + h)*nsplit + s) * PSTRIDE] = { o[0..HD) un-normalised, m, l, pad }
+// The cross-split merge is fused into the staging prologue of the o-proj GEMV (XATTN).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int HD, int G>
 __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams p) {
     static_assert(HD == 128, "decode attention maps 16 lanes x 8 elements onto one 128-wide K/V row");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* sc = (float*)smem;                       // [G][kps] scores
-    __shared__ float red_m[4][G];
+    constexpr int KU = 6;    // keys per lane group per chunk  (block chunk = 16 * KU keys)
+    __shared__ int s_pages[64];
     __shared__ float red_o[4][G][HD];
-    __shared__ float red_l[4][G];
+    __shared__ float red_ml[4][G][2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kg = lane >> 4, ch = lane & 15;       // key group within the wave, 16-byte chunk within the row
@@ -292,17 +345,22 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
     const int k0 = split * kps;
     const int k1 = min(L, k0 + kps);
     const int Hq = p.Hkv * G;
-    float* part = p.part + ((size_t)(b * Hq + hk * G) * nsplit + split) * (HD + 2);
+    float* part = p.part + ((size_t)(b * Hq + hk * G) * nsplit + split) * PSTRIDE;
 
     if (k0 >= L) {   // empty split
-        for (int i = tid; i < G * (HD + 2); i += 256) {
-            const int gq = i / (HD + 2), j = i - gq * (HD + 2);
-            part[(size_t)gq * nsplit * (HD + 2) + j] = (j == HD) ? -INFINITY : 0.f;
+        for (int i = tid; i < G * PSTRIDE; i += 256) {
+            const int gq = i / PSTRIDE, j = i - gq * PSTRIDE;
+            part[(size_t)gq * nsplit * PSTRIDE + j] = (j == HD) ? -INFINITY : 0.f;
         }
         return;
     }
 
-    const int32_t* pt = p.page_table + (size_t)b * p.max_pages;
+    // page ids of this split -> LDS (removes the dependent global load in front of every K/V load)
+    const int pg0 = k0 / p.page;
+    const int npg = (k1 - 1) / p.page - pg0 + 1;
+    for (int i = tid; i < npg; i += 256)
+        if (i < 64) s_pages[i] = p.page_table[(size_t)b * p.max_pages + pg0 + i];
+
     const bf16_t* kc = (const bf16_t*)p.kcache;
     const bf16_t* vc = (const bf16_t*)p.vcache;
 
@@ -311,28 +369,36 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
 #pragma unroll
     for (int gq = 0; gq < G; ++gq)
         q[gq] = *(const u32x4_t*)((const bf16_t*)p.q + (size_t)b * p.ldq + (hk * G + gq) * HD + ch * 8);
+    __syncthreads();
 
-    // ---- phase A: scores ----
-    float mloc[G];
+    float m[G], l[G], o[G][8];
 #pragma unroll
-    for (int gq = 0; gq < G; ++gq) mloc[gq] = -INFINITY;
-    for (int kb = k0; kb < k1; kb += 32) {
-        u32x4_t kv[2];
-        int key[2];
+    for (int gq = 0; gq < G; ++gq) {
+        m[gq] = -INFINITY;
+        l[gq] = 0.f;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            key[u] = kb + u * 16 + wave * 4 + kg;
-            if (key[u] < k1) {
-                const int pg = pt[key[u] / p.page];
-                kv[u] = *(const u32x4_t*)(kc + (((size_t)pg * p.Hkv + hk) * p.page + key[u] % p.page) * HD + ch * 8);
-            } else {
-                kv[u] = (u32x4_t){0u, 0u, 0u, 0u};
-            }
+        for (int j = 0; j < 8; ++j) o[gq][j] = 0.f;
+    }
+
+    for (int kb = k0; kb < k1; kb += 16 * KU) {
+        u32x4_t kv[KU], vv[KU];
+        bool ok[KU];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int key = kb + u * 16 + wave * 4 + kg;
+            ok[u] = key < k1;
+            const int kk = ok[u] ? key : k0;
+            const int pg = s_pages[min(kk / p.page - pg0, 63)];
+            const size_t off = (((size_t)pg * p.Hkv + hk) * p.page + kk % p.page) * HD + ch * 8;
+            kv[u] = *(const u32x4_t*)(kc + off);
+            vv[u] = *(const u32x4_t*)(vc + off);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int gq = 0; gq < G; ++gq) {
+            float sc[KU];
+            float mc = -INFINITY;
 #pragma unroll
-            for (int gq = 0; gq < G; ++gq) {
+            for (int u = 0; u < KU; ++u) {
                 float s = 0.f;
                 s = dot2_bf16(kv[u][0], q[gq][0], s);
                 s = dot2_bf16(kv[u][1], q[gq][1], s);
@@ -342,108 +408,71 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
                 s += __shfl_xor(s, 2, 64);
                 s += __shfl_xor(s, 4, 64);
                 s += __shfl_xor(s, 8, 64);
-                s *= p.scale;
-                if (key[u] < k1) {
-                    if (ch == 0) sc[gq * kps + (key[u] - k0)] = s;
-                    mloc[gq] = fmaxf(mloc[gq], s);
+                s = ok[u] ? s * p.scale : -INFINITY;
+                sc[u] = s;
+                mc = fmaxf(mc, s);
+            }
+            const float mn = fmaxf(m[gq], mc);
+            const float msafe = (mn == -INFINITY) ? 0.f : mn;
+            const float alpha = __expf(m[gq] - msafe);
+            float ls = l[gq] * alpha;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[gq][j] *= alpha;
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const float pw = __expf(sc[u] - msafe);
+                ls += pw;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[gq][2 * j] += pw * bf_lo(vv[u][j]);
+                    o[gq][2 * j + 1] += pw * bf_hi(vv[u][j]);
                 }
             }
+            l[gq] = ls;
+            m[gq] = mn;
+        }
     }
-#pragma unroll
-    for (int gq = 0; gq < G; ++gq) {
-        const float m = wave_max(mloc[gq]);
-        if (lane == 0) red_m[wave][gq] = m;
-    }
-    __syncthreads();
-    float m[G];
-#pragma unroll
-    for (int gq = 0; gq < G; ++gq) m[gq] = fmaxf(fmaxf(red_m[0][gq], red_m[1][gq]), fmaxf(red_m[2][gq], red_m[3][gq]));
 
-    // ---- phase B: o = sum_k exp(s_k - m) V_k ----
-    float o[G][8], l[G];
+    // ---- merge the 4 key groups of the wave (lanes with equal ch), then the 4 waves through LDS ----
 #pragma unroll
     for (int gq = 0; gq < G; ++gq) {
-        l[gq] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[gq][j] = 0.f;
-    }
-    for (int kb = k0; kb < k1; kb += 32) {
-        u32x4_t vv[2];
-        int key[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            key[u] = kb + u * 16 + wave * 4 + kg;
-            if (key[u] < k1) {
-                const int pg = pt[key[u] / p.page];
-                vv[u] = *(const u32x4_t*)(vc + (((size_t)pg * p.Hkv + hk) * p.page + key[u] % p.page) * HD + ch * 8);
-            } else {
-                vv[u] = (u32x4_t){0u, 0u, 0u, 0u};
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            if (key[u] < k1) {
-#pragma unroll
-                for (int gq = 0; gq < G; ++gq) {
-                    const float pw = __expf(sc[gq * kps + (key[u] - k0)] - m[gq]);
-                    l[gq] += pw;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        o[gq][2 * j] += pw * bf_lo(vv[u][j]);
-                        o[gq][2 * j + 1] += pw * bf_hi(vv[u][j]);
-                    }
-                }
-            }
-    }
-    // reduce over the 4 key groups of the wave (lanes with equal ch), then over the 4 waves
-#pragma unroll
-    for (int gq = 0; gq < G; ++gq) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = o[gq][j];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            o[gq][j] = v;
-        }
-        float lv = l[gq];   // every lane of a key group added the same pw: count one lane per group
+        float mw = fmaxf(m[gq], __shfl_xor(m[gq], 16, 64));
+        mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
+        const float msafe = (mw == -INFINITY) ? 0.f : mw;
+        const float f = __expf(m[gq] - msafe);
+        // every lane of a 16-lane key group carries the same l: after the two exchanges each lane holds the wave sum
+        float lv = l[gq] * f;
         lv += __shfl_xor(lv, 16, 64);
         lv += __shfl_xor(lv, 32, 64);
-        if (kg == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) red_o[wave][gq][ch * 8 + j] = o[gq][j];
+        for (int j = 0; j < 8; ++j) {
+            float v = o[gq][j] * f;
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (kg == 0) red_o[wave][gq][ch * 8 + j] = v;
         }
-        if (lane == 0) red_l[wave][gq] = lv;
+        if (lane == 0) {
+            red_ml[wave][gq][0] = mw;
+            red_ml[wave][gq][1] = lv;
+        }
     }
     __syncthreads();
-    for (int i = tid; i < G * (HD + 2); i += 256) {
-        const int gq = i / (HD + 2), j = i - gq * (HD + 2);
-        float v;
-        if (j < HD)
-            v = red_o[0][gq][j] + red_o[1][gq][j] + red_o[2][gq][j] + red_o[3][gq][j];
-        else if (j == HD)
-            v = m[gq];
-        else
-            v = red_l[0][gq] + red_l[1][gq] + red_l[2][gq] + red_l[3][gq];
-        part[(size_t)gq * nsplit * (HD + 2) + j] = v;
+    for (int i = tid; i < G * PSTRIDE; i += 256) {
+        const int gq = i / PSTRIDE, j = i - gq * PSTRIDE;
+        const float M = fmaxf(fmaxf(red_ml[0][gq][0], red_ml[1][gq][0]), fmaxf(red_ml[2][gq][0], red_ml[3][gq][0]));
+        const float msafe = (M == -INFINITY) ? 0.f : M;
+        float v = 0.f;
+        if (j < HD) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red_o[w][gq][j] * __expf(red_ml[w][gq][0] - msafe);
+        } else if (j == HD) {
+            v = M;
+        } else if (j == HD + 1) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red_ml[w][gq][1] * __expf(red_ml[w][gq][0] - msafe);
+        }
+        part[(size_t)gq * nsplit * PSTRIDE + j] = v;
     }
-}
-
-// merge the split partials: out[b][h*HD + d] = sum_s o_s[d] e^{m_s - M} / sum_s l_s e^{m_s - M}
-template <int HD>
-__global__ __launch_bounds__(HD) void emmax_decode_attn_combine_kernel(const float* __restrict__ part, bf16_t* __restrict__ out,
-                                                                      int ldo, int Hq, int nsplit) {
-    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
-    const float* pp = part + (size_t)(b * Hq + h) * nsplit * (HD + 2);
-    float M = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pp[s * (HD + 2) + HD]);
-    float num = 0.f, den = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float ms = pp[s * (HD + 2) + HD];
-        const float w = (ms == -INFINITY) ? 0.f : __expf(ms - M);
-        num += pp[s * (HD + 2) + d] * w;
-        den += pp[s * (HD + 2) + HD + 1] * w;
-    }
-    out[(size_t)b * ldo + h * HD + d] = f2bf(den > 0.f ? num / den : 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -513,40 +542,42 @@ __global__ void emmax_set_tokens_kernel(int32_t* cur_tok, const int32_t* toks, i
 // ---------------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------------
-template <int B, int RPW, int MODE, bool NORM>
+template <int B, int RPW, int MODE, bool NORM, bool XATTN = false>
 static int launch_gemv_t(const GemvParams& p, hipStream_t stream) {
     const int slots_per_block = 4 * RPW;
     dim3 grid(cdiv(p.n_slots, slots_per_block)), block(256);
     const size_t smem = (size_t)B * p.kc * 2;
-    auto kern = emmax_decode_gemv_kernel<B, RPW, MODE, NORM>;
+    auto kern = emmax_decode_gemv_kernel<B, RPW, MODE, NORM, XATTN>;
     hipLaunchKernelGGL(kern, grid, block, smem, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-template <int MODE, bool NORM>
+// rows per wave: paired modes (QKV / GATEUP) hold 2*RPW weight rows x 8 loads in registers, so they drop to RPW = 1 once
+// the batch accumulators (B > 4) would push the kernel past 2 waves per SIMD
+template <int MODE, int B>
+struct RpwFor {
+    static constexpr int value = ((MODE == MODE_QKV || MODE == MODE_GATEUP) && B > 4) ? 1 : 2;
+};
+
+template <int MODE, bool NORM, bool XATTN = false>
 static int launch_gemv_mode(GemvParams p, int B, hipStream_t stream) {
     // K phase: keep B * kc * 2 bytes of activations under ~128 KiB of LDS
     const int cap = (128 * 1024 / 2 / B) & ~511;
     p.kc = p.K <= cap ? p.K : (cdiv(cdiv(p.K, cdiv(p.K, cap)), 512) * 512);
     if (NORM && p.kc != p.K) return -1;
     switch (B) {
-        case 1: return launch_gemv_t<1, 2, MODE, NORM>(p, stream);
-        case 2: return launch_gemv_t<2, 2, MODE, NORM>(p, stream);
-        case 3: return launch_gemv_t<3, 2, MODE, NORM>(p, stream);
-        case 4: return launch_gemv_t<4, 2, MODE, NORM>(p, stream);
-        case 5: return launch_gemv_t<5, 2, MODE, NORM>(p, stream);
-        case 6: return launch_gemv_t<6, 2, MODE, NORM>(p, stream);
-        case 7: return launch_gemv_t<7, 2, MODE, NORM>(p, stream);
-        case 8: return launch_gemv_t<8, 2, MODE, NORM>(p, stream);
+#define CASEB(BB) case BB: return launch_gemv_t<BB, RpwFor<MODE, BB>::value, MODE, NORM, XATTN>(p, stream)
+        CASEB(1); CASEB(2); CASEB(3); CASEB(4); CASEB(5); CASEB(6); CASEB(7); CASEB(8);
+#undef CASEB
         default: return -1;
     }
 }
 
-template <int MODE, bool NORM>
+template <int MODE, bool NORM, bool XATTN = false>
 static int gemv_init_mode() {
     const int lim = 160 * 1024 - 4096;
     hipError_t e = hipSuccess;
-#define SETB(BB) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_gemv_kernel<BB, 2, MODE, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
+#define SETB(BB) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_gemv_kernel<BB, RpwFor<MODE, BB>::value, MODE, NORM, XATTN>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
     SETB(1); SETB(2); SETB(3); SETB(4); SETB(5); SETB(6); SETB(7); SETB(8);
 #undef SETB
     return e == hipSuccess ? 0 : -4;
@@ -556,6 +587,7 @@ int decode_gemv_init() {
     if (done == 0) return 0;
     int r = gemv_init_mode<MODE_QKV, true>();
     if (!r) r = gemv_init_mode<MODE_RESID, false>();
+    if (!r) r = gemv_init_mode<MODE_RESID, false, true>();
     if (!r) r = gemv_init_mode<MODE_GATEUP, true>();
     if (!r) r = gemv_init_mode<MODE_LMHEAD, true>();
     if (!r) r = gemv_init_mode<MODE_PLAIN, false>();
@@ -567,7 +599,8 @@ int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream)
     if (p.K % 8 || p.ldw % 8 || p.ldx % 8) return -1;
     switch (mode) {
         case MODE_QKV: return launch_gemv_mode<MODE_QKV, true>(p, B, stream);
-        case MODE_RESID: return launch_gemv_mode<MODE_RESID, false>(p, B, stream);
+        case MODE_RESID:
+            return p.attn_part ? launch_gemv_mode<MODE_RESID, false, true>(p, B, stream) : launch_gemv_mode<MODE_RESID, false>(p, B, stream);
         case MODE_GATEUP: return launch_gemv_mode<MODE_GATEUP, true>(p, B, stream);
         case MODE_LMHEAD: return launch_gemv_mode<MODE_LMHEAD, true>(p, B, stream);
         case MODE_PLAIN: return launch_gemv_mode<MODE_PLAIN, false>(p, B, stream);
@@ -587,23 +620,17 @@ int decode_attn_nsplit(int B, int Hkv) {
     return ns;
 }
 
-int launch_decode_attn(const DecodeAttnParams& p, int B, int Hq, int head_dim, int nsplit, int max_ctx, void* out, int ldo,
-                       hipStream_t stream) {
+int launch_decode_attn(const DecodeAttnParams& p, int B, int Hq, int head_dim, int nsplit, hipStream_t stream) {
     if (head_dim != 128) return -1;
     const int G = Hq / p.Hkv;
-    int kps = cdiv(max_ctx + 1, nsplit);
-    kps = (kps + 15) & ~15;
-    const size_t smem = (size_t)G * kps * sizeof(float);
     dim3 grid(nsplit, p.Hkv, B), block(256);
     switch (G) {
-        case 1: hipLaunchKernelGGL((emmax_decode_attn_kernel<128, 1>), grid, block, smem, stream, p); break;
-        case 2: hipLaunchKernelGGL((emmax_decode_attn_kernel<128, 2>), grid, block, smem, stream, p); break;
-        case 4: hipLaunchKernelGGL((emmax_decode_attn_kernel<128, 4>), grid, block, smem, stream, p); break;
-        case 8: hipLaunchKernelGGL((emmax_decode_attn_kernel<128, 8>), grid, block, smem, stream, p); break;
+        case 1: hipLaunchKernelGGL((emmax_decode_attn_kernel<128, 1>), grid, block, 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((emmax_decode_attn_kernel<128, 2>), grid, block, 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((emmax_decode_attn_kernel<128, 4>), grid, block, 0, stream, p); break;
+        case 8: hipLaunchKernelGGL((emmax_decode_attn_kernel<128, 8>), grid, block, 0, stream, p); break;
         default: return -1;
     }
-    if (hipGetLastError() != hipSuccess) return -4;
-    hipLaunchKernelGGL(emmax_decode_attn_combine_kernel<128>, dim3(Hq, B), dim3(128), 0, stream, p.part, (bf16_t*)out, ldo, Hq, nsplit);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

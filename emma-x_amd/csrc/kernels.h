@@ -81,6 +81,9 @@ struct GemvParams {
     float* part_val;
     int32_t* part_idx;
     float* logits_out;      // optional f32 [B, n_slots]
+    // RESID with x = merged attention output: split partials f32 [B][Hq][nsplit][132] (null: x is a bf16 vector)
+    const float* attn_part;
+    int nsplit;
 };
 int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream);
 int decode_gemv_init();   // raise the dynamic-LDS limit of every GEMV instantiation (call once, outside graph capture)
@@ -92,13 +95,12 @@ struct DecodeAttnParams {
     const void* vcache;
     const int32_t* page_table;
     const int32_t* ctx_len;
-    float* part;            // f32 [B][Hq][nsplit][hd+2]
+    float* part;            // f32 [B][Hq][nsplit][132] = { o[128] un-normalised, m, l, pad }
     int ldq, Hkv, page, max_pages;
     float scale;
 };
 int decode_attn_nsplit(int B, int Hkv);
-int launch_decode_attn(const DecodeAttnParams& p, int B, int Hq, int head_dim, int nsplit, int max_ctx, void* out, int ldo,
-                       hipStream_t stream);
+int launch_decode_attn(const DecodeAttnParams& p, int B, int Hq, int head_dim, int nsplit, hipStream_t stream);
 
 struct FinishParams {
     const float* part_val;

@@ -231,6 +231,9 @@ struct emmax_session {
     hipStream_t graph_stream = nullptr;
     int graph_failed = 0;
     hipEvent_t ev = nullptr;
+    hipStream_t own_stream = nullptr;   // used by emmax_generate when the caller's stream is the (uncapturable) legacy stream
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    std::string graph_err;
 };
 
 struct SBump {
@@ -279,7 +282,7 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->dq = (bf16*)b.take((int64_t)Bd * m->q_dim * 2);
     s->datt = (bf16*)b.take((int64_t)Bd * m->q_dim * 2);
     s->dact = (bf16*)b.take((int64_t)Bd * m->inter_p * 2);
-    s->part = (float*)b.take((int64_t)Bd * m->cfg.n_heads * 16 * (m->cfg.head_dim + 2) * 4);
+    s->part = (float*)b.take((int64_t)Bd * m->cfg.n_heads * 16 * 132 * 4);
     s->n_lm_blocks = (m->vocab + 7) / 8;
     s->part_val = (float*)b.take((int64_t)s->n_lm_blocks * Bd * 4);
     s->part_idx = (int32_t*)b.take((int64_t)s->n_lm_blocks * Bd * 4);
@@ -448,47 +451,65 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
     return 0;
 }
 
-static int run_decode_step(emmax_session* s, int B, hipStream_t st) {
+enum { STAGE_QKV = 0, STAGE_ATTN = 1, STAGE_OPROJ = 2, STAGE_GATEUP = 3, STAGE_DOWN = 4, STAGE_LMHEAD = 5 };
+
+// one stage of decoder layer `li` (the unit the profiler times); the step is stages 0..4 of every layer + lm head
+static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStream_t st) {
     emmax_model* m = s->m;
     const auto& c = m->cfg;
-    KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st));
-    const int nsplit = decode_attn_nsplit(B, c.n_kv_heads);
-    for (int li = 0; li < c.n_layers; ++li) {
-        const LayerW& L = m->layers[li];
-        GemvParams p;
-        memset(&p, 0, sizeof(p));
-        p.x = s->dh; p.ldx = m->H; p.W = L.wqkv; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln1; p.eps = c.rms_eps;
-        p.y = s->dq; p.ldy = m->q_dim; p.n_slots = m->qkv_dim / 2;
-        p.head_dim = c.head_dim; p.Hq = c.n_heads; p.Hkv = c.n_kv_heads; p.page = PAGE; p.max_pages = s->max_pages;
-        p.ctx_len = s->ctx_len; p.page_table = s->page_table; p.cos_t = s->cos_t; p.sin_t = s->sin_t;
-        p.kcache = kcache_of(s, li); p.vcache = vcache_of(s, li);
-        KCHK(launch_decode_gemv(GEMV_QKV, p, B, st));
-
-        DecodeAttnParams a;
-        a.q = s->dq; a.ldq = m->q_dim; a.kcache = kcache_of(s, li); a.vcache = vcache_of(s, li);
-        a.page_table = s->page_table; a.ctx_len = s->ctx_len; a.part = s->part; a.Hkv = c.n_kv_heads; a.page = PAGE;
-        a.max_pages = s->max_pages; a.scale = 1.0f / sqrtf((float)c.head_dim);
-        KCHK(launch_decode_attn(a, B, c.n_heads, c.head_dim, nsplit, s->max_ctx, s->datt, m->q_dim, st));
-
-        memset(&p, 0, sizeof(p));
-        p.x = s->datt; p.ldx = m->q_dim; p.W = L.wo; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_slots = m->H;
-        KCHK(launch_decode_gemv(GEMV_RESID, p, B, st));
-
-        memset(&p, 0, sizeof(p));
-        p.x = s->dh; p.ldx = m->H; p.W = L.wgu; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln2; p.eps = c.rms_eps;
-        p.y = s->dact; p.ldy = m->inter_p; p.n_slots = m->inter_p;
-        KCHK(launch_decode_gemv(GEMV_GATEUP, p, B, st));
-
-        memset(&p, 0, sizeof(p));
-        p.x = s->dact; p.ldx = m->inter_p; p.W = L.wdown; p.ldw = m->inter_p; p.K = m->inter_p; p.y = s->dh; p.ldy = m->H; p.n_slots = m->H;
-        KCHK(launch_decode_gemv(GEMV_RESID, p, B, st));
+    const LayerW& L = m->layers[li];
+    GemvParams p;
+    memset(&p, 0, sizeof(p));
+    switch (stage) {
+        case STAGE_QKV:
+            p.x = s->dh; p.ldx = m->H; p.W = L.wqkv; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln1; p.eps = c.rms_eps;
+            p.y = s->dq; p.ldy = m->q_dim; p.n_slots = m->qkv_dim / 2;
+            p.head_dim = c.head_dim; p.Hq = c.n_heads; p.Hkv = c.n_kv_heads; p.page = PAGE; p.max_pages = s->max_pages;
+            p.ctx_len = s->ctx_len; p.page_table = s->page_table; p.cos_t = s->cos_t; p.sin_t = s->sin_t;
+            p.kcache = kcache_of(s, li); p.vcache = vcache_of(s, li);
+            KCHK(launch_decode_gemv(GEMV_QKV, p, B, st));
+            return 0;
+        case STAGE_ATTN: {
+            DecodeAttnParams a;
+            a.q = s->dq; a.ldq = m->q_dim; a.kcache = kcache_of(s, li); a.vcache = vcache_of(s, li);
+            a.page_table = s->page_table; a.ctx_len = s->ctx_len; a.part = s->part; a.Hkv = c.n_kv_heads; a.page = PAGE;
+            a.max_pages = s->max_pages; a.scale = 1.0f / sqrtf((float)c.head_dim);
+            KCHK(launch_decode_attn(a, B, c.n_heads, c.head_dim, decode_attn_nsplit(B, c.n_kv_heads), st));
+            return 0;
+        }
+        case STAGE_OPROJ:
+            p.x = s->datt; p.ldx = m->q_dim; p.W = L.wo; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_slots = m->H;
+            p.attn_part = s->part; p.nsplit = decode_attn_nsplit(B, c.n_kv_heads); p.Hq = c.n_heads;   // split merge fused into the staging
+            KCHK(launch_decode_gemv(GEMV_RESID, p, B, st));
+            return 0;
+        case STAGE_GATEUP:
+            p.x = s->dh; p.ldx = m->H; p.W = L.wgu; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln2; p.eps = c.rms_eps;
+            p.y = s->dact; p.ldy = m->inter_p; p.n_slots = m->inter_p;
+            KCHK(launch_decode_gemv(GEMV_GATEUP, p, B, st));
+            return 0;
+        case STAGE_DOWN:
+            p.x = s->dact; p.ldx = m->inter_p; p.W = L.wdown; p.ldw = m->inter_p; p.K = m->inter_p; p.y = s->dh; p.ldy = m->H; p.n_slots = m->H;
+            KCHK(launch_decode_gemv(GEMV_RESID, p, B, st));
+            return 0;
+        default:
+            return fail(EMMAX_ERR_INVALID, "unknown decode stage %d", stage);
     }
+}
+
+static int run_decode_step(emmax_session* s, int B, hipStream_t st) {
+    emmax_model* m = s->m;
+    KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st));
+    for (int li = 0; li < m->cfg.n_layers; ++li)
+        for (int stage = STAGE_QKV; stage <= STAGE_DOWN; ++stage) {
+            int r = run_decode_stage(s, B, li, stage, st);
+            if (r) return r;
+        }
     return run_lm_head_step(s, B, false, nullptr, true, st);
 }
 
 static void drop_graph(emmax_session* s) {
-    if (s->graph_exec) hipGraphExecDestroy(s->graph_exec);
-    if (s->graph) hipGraphDestroy(s->graph);
+    if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
     s->graph_exec = nullptr;
     s->graph = nullptr;
     s->graph_B = 0;
@@ -500,14 +521,20 @@ static int ensure_graph(emmax_session* s, int B, hipStream_t st) {
     if (s->graph_failed) return 1;
     // one eager step first would advance the state; capture does not execute, so just record
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) { s->graph_failed = 1; (void)hipGetLastError(); return 1; }
+    if (e != hipSuccess) { s->graph_failed = 1; s->graph_err = std::string("hipStreamBeginCapture: ") + hipGetErrorString(e); (void)hipGetLastError(); return 1; }
     int r = run_decode_step(s, B, st);
     hipGraph_t g = nullptr;
     e = hipStreamEndCapture(st, &g);
-    if (r != 0 || e != hipSuccess || !g) { s->graph_failed = 1; (void)hipGetLastError(); if (g) hipGraphDestroy(g); return 1; }
+    if (r != 0 || e != hipSuccess || !g) {
+        s->graph_failed = 1;
+        s->graph_err = r != 0 ? ("launch during capture: " + g_err) : (std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
+        if (g) (void)hipGraphDestroy(g);
+        return 1;
+    }
     hipGraphExec_t ge = nullptr;
     e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-    if (e != hipSuccess) { s->graph_failed = 1; (void)hipGetLastError(); hipGraphDestroy(g); return 1; }
+    if (e != hipSuccess) { s->graph_failed = 1; s->graph_err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); (void)hipGetLastError(); (void)hipGraphDestroy(g); return 1; }
     s->graph = g; s->graph_exec = ge; s->graph_B = B;
     return 0;
 }
@@ -672,6 +699,9 @@ int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_
     if (decode_gemv_init() != 0) return fail(EMMAX_ERR_HIP, "could not raise the dynamic LDS limit of the GEMV kernels");
     HIPCHK(hipHostMalloc((void**)&s->pinned, 4096 * 4, hipHostMallocDefault));
     HIPCHK(hipEventCreateWithFlags(&s->ev, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
+    HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
     // static page assignment: row b owns pages [b*max_pages, (b+1)*max_pages)
     {
         std::vector<int32_t> pt((size_t)max_batch * s->max_pages);
@@ -703,8 +733,11 @@ int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_
 void emmax_session_destroy(emmax_session* s) {
     if (!s) return;
     drop_graph(s);
-    if (s->pinned) hipHostFree(s->pinned);
-    if (s->ev) hipEventDestroy(s->ev);
+    if (s->pinned) (void)hipHostFree(s->pinned);
+    if (s->ev) (void)hipEventDestroy(s->ev);
+    if (s->ev_in) (void)hipEventDestroy(s->ev_in);
+    if (s->ev_out) (void)hipEventDestroy(s->ev_out);
+    if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     delete s;
 }
 
@@ -767,7 +800,15 @@ int emmax_generate(emmax_session* s, int max_new, int stop_on_eos, int32_t* out_
     if (!s || !out_ids || !out_lens) return fail(EMMAX_ERR_INVALID, "null argument");
     if (!s->prefilled) return fail(EMMAX_ERR_STATE, "generate before prefill");
     if (max_new < 1 || max_new > s->max_out) return fail(EMMAX_ERR_INVALID, "max_new_tokens %d outside 1..%d", max_new, s->max_out);
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t user = (hipStream_t)stream, st = user;
+    // the legacy / per-thread default streams cannot be captured: run the loop on the session's own stream, ordered
+    // after everything already queued on the caller's stream and before anything queued on it afterwards
+    const bool special = (uintptr_t)user <= 2;
+    if (special) {
+        st = s->own_stream;
+        HIPCHK(hipEventRecord(s->ev_in, user));
+        HIPCHK(hipStreamWaitEvent(st, s->ev_in, 0));
+    }
     const int B = s->cur_B;
     KCHK(launch_set_int(s->max_new_d, max_new, st));
     const bool use_graph = (max_new > 2) && ensure_graph(s, B, st) == 0;
@@ -796,10 +837,55 @@ int emmax_generate(emmax_session* s, int max_new, int stop_on_eos, int32_t* out_
     HIPCHK(hipMemcpy2DAsync(out_ids, (size_t)max_new * 4, s->out_ids, (size_t)s->max_out * 4, (size_t)max_new * 4, B,
                             hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(out_lens, s->n_out, B * 4, hipMemcpyDeviceToDevice, st));
+    if (special) {
+        HIPCHK(hipEventRecord(s->ev_out, st));
+        HIPCHK(hipStreamWaitEvent(user, s->ev_out, 0));
+    }
     return 0;
 }
 
-int emmax_session_graph_active(emmax_session* s) { return s && s->graph_exec ? 1 : 0; }
+int emmax_session_graph_active(emmax_session* s) {
+    if (s && !s->graph_exec && !s->graph_err.empty()) g_err = s->graph_err;   // why the capture was refused
+    return s && s->graph_exec ? 1 : 0;
+}
+
+int emmax_profile_decode_stage(emmax_session* s, int stage, int reps, float* avg_us, emmax_stream stream) {
+    if (!s || !avg_us || reps < 1) return fail(EMMAX_ERR_INVALID, "bad argument");
+    if (!s->prefilled) return fail(EMMAX_ERR_STATE, "profile needs an active (prefilled) session");
+    hipStream_t st = (hipStream_t)stream;
+    emmax_model* m = s->m;
+    const int B = s->cur_B, nl = m->cfg.n_layers;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    int launches = 0, r = 0;
+    // one untimed sweep (instruction cache, clocks), then `reps` timed sweeps over all layers: every launch streams a
+    // different layer's weights, so nothing is served from the 256 MiB Infinity Cache that a real step would not get
+    for (int pass = 0; pass < 2 && r == 0; ++pass) {
+        if (pass == 1) HIPCHK(hipEventRecord(e0, st));
+        const int n = pass == 0 ? 1 : reps;
+        for (int i = 0; i < n && r == 0; ++i) {
+            if (stage == STAGE_LMHEAD) {
+                r = run_lm_head_step(s, B, false, nullptr, false, st);
+                launches += pass;
+            } else {
+                for (int li = 0; li < nl && r == 0; ++li) {
+                    r = run_decode_stage(s, B, li, stage, st);
+                    launches += pass;
+                }
+            }
+        }
+    }
+    if (r) return r;
+    HIPCHK(hipEventRecord(e1, st));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_us = ms * 1000.0f / (float)launches;
+    return 0;
+}
 
 // ---- single-kernel entry points --------------------------------------------------------------------------------------
 int emmax_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const void* bias, int act,

@@ -1,0 +1,78 @@
+"""
+dist.py -- data-parallel sharding of camera frames over the GPUs of one node (one process per GPU).
+
+The reference's inference is strictly single-process / single-GPU (experiments/robot/openvla_utils.py:21,57); this is
+the extension of BASELINE config 3: every frame is an independent unit, each rank holds a full bf16 weight replica and a
+private KV cache, and the only exchange is ONE all_gather per batch of the results
+{actions f32 [b,7], token ids i32 [b,T], lengths i32 [b]} (~17 KB per rank) -- RCCL over xGMI on the GPU box
+(`backend="nccl"` is RCCL on ROCm), gloo in the CPU tests.  No tensor parallelism, no per-token communication.
+"""
+
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from torchrun's env; initialises the default group when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local
+
+
+def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of `n_items` for `rank`: the first (n % world) ranks get one extra item."""
+    q, r = divmod(n_items, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def gather_results(actions: torch.Tensor, ids: torch.Tensor, lens: torch.Tensor, counts: Optional[Sequence[int]] = None):
+    """One collective: every rank contributes its shard, every rank receives the whole batch in global order.
+
+    actions f32 [b,7], ids i32 [b,T], lens i32 [b] -> ([B,7], [B,T], [B]).  Shards may be ragged in b (`counts` =
+    per-rank shard sizes; default: all equal): rows are packed into one fixed-size i32 buffer per rank so a single
+    all_gather moves everything."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return actions, ids, lens
+    world = dist.get_world_size()
+    b, T = ids.shape
+    counts = list(counts) if counts is not None else [b] * world
+    bmax = max(counts)
+    width = 7 + T + 1
+    pack = torch.zeros(bmax, width, dtype=torch.int32, device=ids.device)
+    pack[:b, :7] = actions.to(torch.float32).contiguous().view(torch.int32)
+    pack[:b, 7:7 + T] = ids.to(torch.int32)
+    pack[:b, 7 + T] = lens.to(torch.int32)
+    out = torch.empty(world * bmax, width, dtype=torch.int32, device=ids.device)
+    dist.all_gather_into_tensor(out, pack)
+    out = out.view(world, bmax, width)
+    rows = torch.cat([out[r, : counts[r]] for r in range(world)], dim=0)
+    return rows[:, :7].contiguous().view(torch.float32), rows[:, 7:7 + T].contiguous(), rows[:, 7 + T].contiguous()
+
+
+def barrier() -> None:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(x: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -179,3 +179,13 @@ class EmmaxEngine:
         _lib.check(self.lib.emmax_generate(self._session, max_new_tokens, int(stop_on_eos), out.data_ptr(), lens.data_ptr(),
                                            _lib.current_stream()), "emmax_generate")
         return out, lens
+
+    def graph_active(self) -> bool:
+        return bool(self.lib.emmax_session_graph_active(self._session))
+
+    def profile_decode_stage(self, stage: int, reps: int = 3) -> float:
+        """Mean duration (microseconds) of one launch of decode stage `stage` (see include/emmax.h), HIP-event timed."""
+        us = C.c_float()
+        _lib.check(self.lib.emmax_profile_decode_stage(self._session, stage, reps, C.byref(us), _lib.current_stream()),
+                   "emmax_profile_decode_stage")
+        return float(us.value)

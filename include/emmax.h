@@ -121,6 +121,14 @@ int emmax_set_current_tokens(emmax_session* s, const int32_t* tokens_dev, emmax_
 int emmax_generate(emmax_session* s, int max_new_tokens, int stop_on_eos, int32_t* out_ids_dev, int32_t* out_lens_dev,
                    emmax_stream stream);
 
+/* 1 when emmax_generate is replaying a captured hipGraph of the step (0: eager launches). */
+int emmax_session_graph_active(emmax_session* s);
+/* Measurement hook (bench.py `roofline`): launch decode stage `stage` (0 qkv GEMV, 1 paged attention, 2 o-proj GEMV,
+ * 3 gate/up GEMV, 4 down GEMV: once per layer; 5 lm-head GEMV+argmax) `reps` sweeps on `stream`, bracketed by HIP
+ * events on that stream; returns the mean duration of one launch in microseconds.  Needs a prefilled session; the
+ * residual stream it leaves behind is garbage (run a new prefill afterwards). */
+int emmax_profile_decode_stage(emmax_session* s, int stage, int reps, float* avg_us_out, emmax_stream stream);
+
 /* ---- single-kernel entry points (parity tests + micro-benchmarks) -------------------------------------------------- */
 /* C[M,N] = epilogue(A[M,K] @ W[N,K]^T): bf16 in, fp32 accumulate on MFMA.  K % 64 == 0, N % 128 == 0.
  * bias/scale: bf16 [N] or NULL; residual: bf16 [M,ldr] or NULL; act: 0 none, 1 exact-erf GELU, 2 SwiGLU over
