@@ -96,7 +96,7 @@ class EmmaXImageProcessor:
         a = _to_uint8_hwc(img)
         size = self.cfg.towers[0].image_size
         a = self._resize(a, size)
-        x = torch.from_numpy(np.ascontiguousarray(a)).permute(2, 0, 1).to(torch.float32) / 255.0
+        x = torch.from_numpy(np.array(a, dtype=np.uint8, copy=True)).permute(2, 0, 1).to(torch.float32) / 255.0
         per_tower = []
         for mean, std in zip(self.means, self.stds):
             m = torch.tensor(mean, dtype=torch.float32).view(3, 1, 1)

@@ -1,0 +1,172 @@
+"""CPU: host-side logic of the product package (no device work): config/weight contracts, processor, planted chain,
+readers, error behaviour, and that the product path refuses to run without the HIP device."""
+
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from emmax.config import EmmaXConfig
+
+
+def test_7b_shapes_and_param_count():
+    from emmax.weights import param_shapes
+
+    cfg = EmmaXConfig.emma_x_7b()
+    shapes = {k: s for k, s, _ in param_shapes(cfg)}
+    assert shapes["language_model.lm_head.weight"] == (32064, 4096)
+    assert shapes["vision_backbone.featurizer.reg_token"] == (1, 4, 1024)
+    assert shapes["vision_backbone.fused_featurizer.blocks.26.mlp.fc1.weight"] == (4304, 1152)
+    assert shapes["vision_backbone.fused_featurizer.blocks.0.attn.qkv.weight"] == (3456, 1152)
+    assert shapes["projector.fc1.weight"] == (8704, 2176)
+    assert "vision_backbone.fused_featurizer.blocks.0.ls1.scale_factor" not in shapes
+    total = sum(math.prod(s) for s in shapes.values())
+    assert abs(total - 7.526e9) < 2e7
+    assert cfg.towers[0].take_index == 22 and cfg.towers[1].take_index == 25
+    assert cfg.towers[0].n_tokens == 261 and cfg.towers[1].n_tokens == 256 and cfg.towers[1].head_dim == 72
+    assert cfg.action_vocab_size == 32000 and cfg.projector_dims == (2176, 8704, 4096, 4096)
+
+
+def test_config_from_hf_dict_and_rejections(tmp_path):
+    d = {"vision_backbone_id": "dinosiglip-vit-so-224px", "llm_backbone_id": "llama2-7b-pure",
+         "text_config": {"hidden_size": 4096, "num_hidden_layers": 32, "num_attention_heads": 32, "rms_norm_eps": 1e-5,
+                         "vocab_size": 32064, "intermediate_size": 11008}, "n_action_bins": 256,
+         "norm_stats": {"bridge_orig": {"action": {"q01": [0] * 7, "q99": [1] * 7}}}}
+    cfg = EmmaXConfig.from_hf_dict(d)
+    assert cfg.llm.num_kv_heads == 32 and cfg.llm.head_dim == 128 and cfg.llm.rms_eps == 1e-5
+    with pytest.raises(ValueError):
+        EmmaXConfig.from_hf_dict({**d, "vision_backbone_id": "clip-vit-l-336px"})
+    with pytest.raises(ValueError):
+        EmmaXConfig.from_hf_dict({**d, "llm_backbone_id": "mistral-v0.1-7b-pure"})
+    (tmp_path / "config.json").write_text(json.dumps(d))
+    (tmp_path / "dataset_statistics.json").write_text(json.dumps({"x": {"action": {"q01": [0] * 7, "q99": [2] * 7}}}))
+    assert list(EmmaXConfig.from_pretrained(str(tmp_path)).norm_stats) == ["x"]
+
+
+def test_synthetic_weights_deterministic_and_planted_chain():
+    from emmax.weights import planted_chain, planted_start_token, planted_successor, synthetic_state_dict
+
+    cfg = EmmaXConfig.tiny()
+    a, b = synthetic_state_dict(cfg, seed=3), synthetic_state_dict(cfg, seed=3)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    c = synthetic_state_dict(cfg, seed=4)
+    assert not torch.equal(a["projector.fc1.weight"], c["projector.fc1.weight"])
+    succ = planted_successor(cfg)
+    start = planted_start_token(cfg, 5)
+    chain = planted_chain(cfg, start, 64)
+    assert chain[4] == 29871 and chain[-1] == cfg.eos_token_id and len(chain) == 5 + 8 + 1
+    assert all(31744 <= t < 32000 for t in chain[5:13]) and len(set(chain[5:13])) == 8
+    assert int(succ[1]) == 29871
+
+
+def test_safetensors_and_native_readers(tmp_path):
+    from safetensors.torch import save_file
+
+    from emmax.weights import (load_hf_state_dict, remap_native_state_dict, synthetic_state_dict, validate_state_dict)
+
+    cfg = EmmaXConfig.tiny()
+    sd = {k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(cfg, seed=1).items()}
+    keys = sorted(sd)
+    save_file({k: sd[k].contiguous() for k in keys[: len(keys) // 2]}, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file({k: sd[k].contiguous() for k in keys[len(keys) // 2:]}, str(tmp_path / "model-00002-of-00002.safetensors"))
+    back = load_hf_state_dict(str(tmp_path))
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+    validate_state_dict(back, cfg)
+    bad = dict(back)
+    bad.pop("projector.fc2.bias")
+    bad["projector.fc1.bias"] = torch.zeros(3)
+    with pytest.raises(ValueError) as e:
+        validate_state_dict(bad, cfg)
+    assert "missing projector.fc2.bias" in str(e.value) and "projector.fc1.bias" in str(e.value)
+    # native .pt layout -> HF keys (convert_openvla_weights_to_hf.py:84-116)
+    native = {"projector": {}, "llm_backbone": {}, "vision_backbone": {}}
+    for k, v in sd.items():
+        if k.startswith("projector."):
+            idx = {"fc1": "0", "fc2": "2", "fc3": "4"}[k.split(".")[1]]
+            native["projector"][f"projector.{idx}.{k.split('.')[2]}"] = v
+        elif k.startswith("language_model."):
+            native["llm_backbone"]["llm." + k[len("language_model."):]] = v
+        elif k.startswith("vision_backbone.featurizer."):
+            native["vision_backbone"]["dino_featurizer." + k[len("vision_backbone.featurizer."):].replace("scale_factor", "gamma")] = v
+        else:
+            native["vision_backbone"]["siglip_featurizer." + k[len("vision_backbone.fused_featurizer."):]] = v
+    again = remap_native_state_dict(native)
+    assert set(again) == set(sd) and all(torch.equal(again[k], sd[k]) for k in sd)
+
+
+def test_processor_matches_oracle_preprocessing():
+    from emmax.processing import EmmaXProcessor
+    from oracle import emmax_oracle as orc
+
+    cfg = EmmaXConfig.tiny()
+    proc = EmmaXProcessor.from_pretrained(cfg=cfg)
+    rng = np.random.default_rng(0)
+    frames = rng.integers(0, 256, size=(2, 224, 224, 3), dtype=np.uint8)
+    out = proc(["hello", "hellp"], [frames[0], frames[1]])
+    assert out["pixel_values"].shape == (2, 6, 224, 224) and out["pixel_values"].dtype == torch.float32
+    assert torch.equal(out["pixel_values"], orc.preprocess_frames(frames, cfg))
+    assert torch.equal(out["frames_u8"], torch.from_numpy(frames))
+    assert out["input_ids"][0, 0] == 1 and out["input_ids"].shape == out["attention_mask"].shape
+    moved = out.to("cpu", dtype=torch.bfloat16)
+    assert moved["pixel_values"].dtype == torch.bfloat16 and moved["input_ids"].dtype == torch.long
+    with pytest.raises(ValueError):
+        proc(["only one"], [frames[0], frames[1]])
+    prompt, img = proc.get_prompt("put the carrot on the plate", frames[0])
+    assert prompt == "In: What action should the robot take to achieve the instruction\nINSTRUCTION: \nput the carrot on the plate\nOut:"
+    # non-native resolution goes through PIL bicubic (torchvision's TVF.resize on PIL == PIL resize)
+    big = rng.integers(0, 256, size=(256, 256, 3), dtype=np.uint8)
+    assert proc.image_processor.preprocess(big)["pixel_values"].shape == (1, 6, 224, 224)
+
+
+def test_stub_tokenizer_roundtrip():
+    from emmax.tokenizer_stub import StubTokenizer
+
+    tok = StubTokenizer()
+    ids = tok("POLICIES:\nab", add_special_tokens=True).input_ids
+    assert ids[0] == 1 and ids[1] == 29871
+    assert tok.decode(ids, skip_special_tokens=True) == "POLICIES:\nab"
+    act = list(range(31744, 32000))
+    assert tok(tok.decode(act), add_special_tokens=False).input_ids[1:] == act
+    assert tok.decode([2, 32000, 5], skip_special_tokens=True) == tok.decode([5])
+
+
+def test_product_refuses_cpu_and_missing_extension(monkeypatch):
+    from emmax import _lib
+    from emmax.modeling import EmmaXForActionPrediction
+    from emmax.weights import synthetic_state_dict
+
+    cfg = EmmaXConfig.tiny()
+    m = EmmaXForActionPrediction(cfg, synthetic_state_dict(cfg, 0))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m.to("cpu")
+    with pytest.raises(RuntimeError, match="not on a HIP device"):
+        m.generate(torch.tensor([[1, 5]]), pixel_values=torch.zeros(1, 6, 224, 224))
+    with pytest.raises(NotImplementedError):
+        EmmaXForActionPrediction.from_pretrained("/nonexistent", load_in_8bit=True)
+    with pytest.raises(ValueError, match="unnorm_key"):
+        m._check_unnorm_key({"a": {}, "b": {}}, None)
+    assert m.get_action_dim("bridge_orig") == 7
+    # a missing shared library is a hard error, never a fallback
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libemmax_hip.so")
+    with pytest.raises(_lib.EmmaxError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_ids_level_action_extraction():
+    from emmax.modeling import EmmaXForActionPrediction
+    from oracle import emmax_oracle as orc
+
+    cfg = EmmaXConfig.tiny()
+    m = EmmaXForActionPrediction(cfg, None)
+    stats = cfg.norm_stats["bridge_orig"]["action"]
+    mv = list(range(31800, 31808))
+    pol = [31900, 31800, 31850, 31760, 31990, 31872, 31871, 31745]
+    row = [50, 60] + mv + [13, 29871] + pol + [2]
+    got = m.actions_from_ids(row, stats)
+    ref = orc.unnormalize_actions(orc.decode_token_ids_to_actions(np.array(pol[:7])), stats)
+    assert np.abs(got - ref).max() < 1e-6
+    assert np.array_equal(m.actions_from_ids([5, 6, 7], stats), np.zeros(7, dtype=np.float32))

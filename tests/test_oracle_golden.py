@@ -1,0 +1,134 @@
+"""CPU: the oracle (and the product's host-side mirrors) against the golden vectors generated from the REAL reference
+pieces by oracle/make_golden.py (HF LlamaForCausalLM, the reference's OpenVLAForActionPrediction through a stub-timm
+shim, ActionTokenizer, FusedMLPProjector, PurePromptBuilder, Solver).  This is what pins the oracle."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import emmax_oracle as orc
+
+
+def _npz(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def test_action_decode_known_answers():
+    g = _npz("action_decode.npz")
+    got = orc.decode_token_ids_to_actions(g["ids"])
+    assert np.array_equal(got, g["actions"])          # fp64 host math: bit-exact
+    assert np.array_equal(orc.bin_centers(), g["bin_centers"])
+    # SURVEY 8a known answers
+    for tid, val in [(31999, -0.99607843), (31998, -0.98823529), (31872, 0.0), (31871, 0.00784314), (31745, 0.99607843), (31744, 0.99607843), (5, 0.99607843)]:
+        assert abs(orc.decode_token_ids_to_actions(np.array([tid]))[0] - val) < 1e-8
+
+
+def test_product_action_tokenizer_matches_reference():
+    from emmax.actions import ActionTokenizer
+    from emmax.tokenizer_stub import StubTokenizer
+
+    g = _npz("action_decode.npz")
+    at = ActionTokenizer(StubTokenizer())
+    assert np.array_equal(at.decode_token_ids_to_actions(g["ids"]), g["actions"])
+    assert np.array_equal(at.encode_ids(g["cont"]), g["cont_token_ids"])
+    assert at.action_token_begin_idx == 32000 - 257 and at.vocab_size == 256
+    # text round trip through the stub tokenizer: encode -> decode ids -> bin centres of the same bins
+    txt = at(g["cont"][:7])
+    ids = at.tokenizer(txt, add_special_tokens=False).input_ids[1:]
+    assert ids == at.encode_ids(g["cont"][:7]).tolist()
+
+
+def test_projector_matches_reference_module():
+    g = _npz("projector.npz")
+    sd = {}
+    for native, hf in (("0", "fc1"), ("2", "fc2"), ("4", "fc3")):
+        sd[f"projector.{hf}.weight"] = torch.from_numpy(g[f"projector__{native}__weight"])
+        sd[f"projector.{hf}.bias"] = torch.from_numpy(g[f"projector__{native}__bias"])
+    y = orc.projector(torch.from_numpy(g["x"]), sd)
+    assert torch.allclose(y, torch.from_numpy(g["y"]), atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["mha", "gqa"])
+def test_llama_matches_hf(name):
+    from emmax.config import LlmConfig
+
+    g = _npz(f"llama_{name}.npz")
+    h, inter, nl, nh, nkv, hd, vocab = [int(x) for x in g["cfg"]]
+    lc = LlmConfig(hidden_size=h, intermediate_size=inter, num_layers=nl, num_heads=nh, num_kv_heads=nkv, head_dim=hd,
+                   vocab_size=vocab, rms_eps=1e-5, rope_theta=10000.0)
+    sd = {k.replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith("language_model")}
+    emb = torch.from_numpy(g["embeds"])
+    logits, cache = orc.llama_forward(emb, sd, lc, None)
+    assert torch.allclose(logits[0], torch.from_numpy(g["prefill_logits"]), atol=2e-5, rtol=1e-5)
+    ids = []
+    nxt = int(logits[0, -1].argmax())
+    for t in range(len(g["ids"])):
+        ids.append(nxt)
+        lg, cache = orc.llama_forward(orc.embed_tokens(torch.tensor([[nxt]]), sd), sd, lc, cache)
+        assert torch.allclose(lg[0, -1], torch.from_numpy(g["step_logits"][t]), atol=2e-5, rtol=1e-5)
+        nxt = int(lg[0, -1].argmax())
+    assert ids == g["ids"].tolist()      # token ids bit-exact vs HF greedy
+
+
+def test_wrapper_golden_splice_cache_predict_action():
+    """The reference wrapper's forward / generate / predict_action, reproduced by the oracle on the same weights."""
+    from emmax.config import EmmaXConfig
+    from emmax.weights import planted_chain, synthetic_state_dict
+
+    g = _npz("wrapper.npz")
+    cfg = EmmaXConfig.tiny()
+    sd = synthetic_state_dict(cfg, seed=int(g["seed"]), planted=True)
+    chk = float(sum(float(v.double().abs().sum()) for v in sd.values()))
+    assert abs(chk - float(g["weights_checksum"])) < 1e-6 * chk
+    prompt = g["prompt"].tolist()
+    pix = orc.preprocess_frames(g["frames"], cfg)
+    logits, _, _ = orc.vla_prefill_logits(torch.tensor([prompt]), pix, sd, cfg)
+    assert logits.shape[1] == len(prompt) + 256          # [BOS] + 256 patches + text[1:]
+    assert torch.allclose(logits[0, -1], torch.from_numpy(g["last_logits"]), atol=5e-4, rtol=1e-4)
+    assert np.array_equal(logits[0].argmax(-1).numpy(), g["logits_argmax"])
+    assert np.allclose(logits[0].double().sum(-1).numpy(), g["logits_rowsum"], rtol=1e-5, atol=1e-2)
+    gen = orc.greedy_generate(torch.tensor([prompt]), pix, sd, cfg, 20)
+    assert gen[0].tolist() == g["generated"].tolist()
+    assert gen[0, len(prompt):].tolist() == planted_chain(cfg, prompt[-1], 20)
+    # predict_action: append 29871, 7 new tokens, de-tokenise, un-normalise (modeling_prismatic.py:513-535)
+    pp = g["predict_prompt"].tolist() + [29871]
+    ids7 = orc.greedy_generate(torch.tensor([pp]), pix, sd, cfg, 7)[0].numpy()
+    act = orc.predict_action_tail(ids7, cfg.norm_stats["bridge_orig"]["action"])
+    assert np.allclose(act, g["action"], atol=1e-12)
+
+
+def test_prompts_match_reference_builder():
+    from emmax.prompting import PurePromptBuilder, bridge_task_label, build_prompt
+
+    cases = json.load(open(os.path.join(GOLDEN, "prompts.json")))
+    for c in cases:
+        assert orc.pure_prompt(c["message"]) == c["prompt"]
+        b = PurePromptBuilder("prismatic")
+        b.add_turn("human", c["message"])
+        assert b.get_prompt() == c["prompt"]
+        assert PurePromptBuilder("prismatic").get_potential_prompt(c["message"]) == c["potential"]
+    assert build_prompt(bridge_task_label("Put the pot next to the cans.")) == cases[0]["prompt"]
+    assert bridge_task_label("close the drawer", (48, 63)) == cases[3]["message"] == orc.bridge_task_prompt("close the drawer", (48, 63))
+
+
+def test_solver_matches_reference_class():
+    from emmax.actions import ActionTokenizer
+    from emmax.policy_parser import Solver
+    from emmax.tokenizer_stub import StubTokenizer
+
+    cases = json.load(open(os.path.join(GOLDEN, "solver.json")))
+    tok = StubTokenizer()
+    mine, oracle = Solver(ActionTokenizer(tok), verbose=False), orc.Solver(tok)
+    for c in cases:
+        for s in (mine, oracle):
+            pol, remain = s.extract_action_policies(c["text"])
+            req, mv = s.extract_movement_plan(c["text"])
+            assert pol == c["policies"] and remain == c["remain"] and req == c["require_unorm"]
+            assert np.allclose(np.asarray(mv, dtype=float), c["movement"])
+    # never raises, zeros on garbage (reference contract)
+    assert mine.extract_action_policies("POLICIES:")[0] == [[0] * 7]
+    assert mine.extract_movement_plan("")[1].tolist() == [-100] * 7
