@@ -28,75 +28,79 @@ __device__ __forceinline__ u32x4_t ld_nt(const u32x4_t* p) { return __builtin_no
 constexpr int PSTRIDE = 132;   // floats per attention split partial: 128 o + m + l + 2 pad (16-byte aligned rows)
 
 // ---------------------------------------------------------------------------------------------------------------------
-// GEMV.  Block = 256 threads = 4 waves; a wave owns RPW "row slots"; a slot is one output row (RESID/LMHEAD/PLAIN) or a
-// pair of rows (QKV: rows d and d+hd/2 of one head; GATEUP: gate row i and up row i).
+// GEMV.  Persistent blocks of 512 threads = 8 waves; block b owns a contiguous range of row GROUPS, its waves interleave
+// inside the range.  A group is 2 weight rows: (row d, row d+hd/2) of one head for QKV, (gate_i, up_i) for GATEUP, two
+// consecutive rows otherwise.  The activation prologue (RMSNorm / attention-split merge + staging into LDS) runs once
+// per block; a wave keeps 2 rows x 8 x 16 B of weights in flight, requests the head of its next group before reducing
+// the current one, and the very first request is issued before the prologue.  (tools/gemv_sweep.hip: this structure
+// streams 180 MB at ~6.1 TB/s, 97 % of a read-only kernel with the same access pattern.)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int B, int RPW, int MODE, bool NORM, bool XATTN = false>
-__global__ __launch_bounds__(256) void emmax_decode_gemv_kernel(GemvParams p) {
-    constexpr int NR = (MODE == MODE_QKV || MODE == MODE_GATEUP) ? 2 * RPW : RPW;   // weight rows per wave
-    constexpr int U = 8;   // 16-byte loads per row per outer iteration (8 * 64 lanes * 8 elems = 4096 elements)
+constexpr int GW = 8;   // waves per GEMV block
+
+// B <= 2: two resident blocks per CU (<= 128 VGPRs); larger batches keep more accumulators and run one block per CU
+template <int B, int MODE, bool NORM, bool XATTN = false>
+__global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_kernel(GemvParams p) {
+    constexpr int NR = 2;   // weight rows per group
+    constexpr int U = 8;    // 16-byte loads per row per chunk (8 * 64 lanes * 8 elems = 4096 elements)
+    constexpr int NT = GW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4_t* xs = (u32x4_t*)smem;   // [B][KC/8] 16-byte chunks
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bf16_t* __restrict__ W = (const bf16_t*)p.W;
     const int K = p.K;
-    const int slot0 = (blockIdx.x * 4 + wave) * RPW;   // first slot of this wave
+    const int KC = p.kc;   // elements per K phase (multiple of 8)
+    const bool multi_phase = KC < K;
 
-    // ---- weight row indices of this wave ----
-    int rows[NR];
-    bool slot_ok[RPW];
-#pragma unroll
-    for (int s = 0; s < RPW; ++s) {
-        const int slot = slot0 + s;
-        slot_ok[s] = slot < p.n_slots;
-        const int sl = slot_ok[s] ? slot : 0;
+    // contiguous share of the groups for this block
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int gq = p.n_groups / G, gr = p.n_groups % G;
+    const int g_lo = bid * gq + min(bid, gr), g_hi = g_lo + gq + (bid < gr ? 1 : 0);
+    const int rounds = (g_hi - g_lo + GW - 1) / GW;
+
+    auto group_rows = [&](int g, int& r0, int& r1) {
         if (MODE == MODE_QKV) {
             const int half = p.head_dim >> 1;
-            const int hb = sl / half, d = sl - hb * half;
-            rows[2 * s] = hb * p.head_dim + d;
-            rows[2 * s + 1] = hb * p.head_dim + d + half;
+            const int hb = g / half, d = g - hb * half;
+            r0 = hb * p.head_dim + d;
+            r1 = r0 + half;
         } else if (MODE == MODE_GATEUP) {
-            rows[2 * s] = (sl >> 4) * 32 + (sl & 15);
-            rows[2 * s + 1] = rows[2 * s] + 16;
+            r0 = (g >> 4) * 32 + (g & 15);
+            r1 = r0 + 16;
         } else {
-            rows[s] = sl;
-        }
-    }
-
-    float acc[NR][B];
-#pragma unroll
-    for (int r = 0; r < NR; ++r)
-#pragma unroll
-        for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
-
-    // ---- request the first batch of weights BEFORE the activation prologue: they do not depend on x, and the HBM
-    // latency of the stream's head then overlaps the norm reduction / staging instead of following it.  The loop below
-    // is rotated (compute chunk i, then request chunk i+1) so that ONE register buffer is live at any time. ----
-    const int KC = p.kc;   // elements per K phase (multiple of 8)
-    u32x4_t wr[NR][U];
-    auto issue_weights = [&](int kc0, int c0, int nch) {
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const u32x4_t* wrow = (const u32x4_t*)(W + (size_t)rows[r] * p.ldw + kc0);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int c = c0 + u * 64 + lane;
-                wr[r][u] = (c < nch) ? ld_nt(wrow + c) : (u32x4_t){0u, 0u, 0u, 0u};
-            }
+            r0 = 2 * g;
+            r1 = min(2 * g + 1, p.n_rows - 1);
         }
     };
-    issue_weights(0, 0, min(KC, K) >> 3);
 
-    // ---- RMSNorm statistics (prologue) ----
+    u32x4_t wr[NR][U];
+    auto issue_weights = [&](int g, int kc0, int c0, int nch) {
+        int r0, r1;
+        group_rows(g, r0, r1);
+        const u32x4_t* w0 = (const u32x4_t*)(W + (size_t)r0 * p.ldw + kc0);
+        const u32x4_t* w1 = (const u32x4_t*)(W + (size_t)r1 * p.ldw + kc0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * 64 + lane;
+            wr[0][u] = (c < nch) ? ld_nt(w0 + c) : (u32x4_t){0u, 0u, 0u, 0u};
+            wr[1][u] = (c < nch) ? ld_nt(w1 + c) : (u32x4_t){0u, 0u, 0u, 0u};
+        }
+    };
+
+    // ---- first request before the prologue: it does not depend on x ----
+    int g = g_lo + wave;
+    const int nch0 = min(KC, K) >> 3;
+    if (g < g_hi) issue_weights(g, 0, 0, nch0);
+
+    // ---- RMSNorm statistics ----
     float rstd[B];
     if (NORM) {
-        __shared__ float red[4][B];
+        __shared__ float red[GW][B];
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             float ss = 0.f;
             const u32x4_t* xr = (const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx);
-            for (int c = tid; c < (K >> 3); c += 256) {
+            for (int c = tid; c < (K >> 3); c += NT) {
                 const u32x4_t v = xr[c];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -109,15 +113,20 @@ __global__ __launch_bounds__(256) void emmax_decode_gemv_kernel(GemvParams p) {
         }
         __syncthreads();
 #pragma unroll
-        for (int b = 0; b < B; ++b) rstd[b] = rsqrtf((red[0][b] + red[1][b] + red[2][b] + red[3][b]) / (float)K + p.eps);
+        for (int b = 0; b < B; ++b) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < GW; ++w) t += red[w][b];
+            rstd[b] = rsqrtf(t / (float)K + p.eps);
+        }
     }
 
-    // stage x[:, kc0 : kc0+kcn] into LDS (normalised if NORM, merged from the attention partials if XATTN)
+    // stage x[:, kc0 : kc0 + 8*nch] into LDS (normalised if NORM, merged from the attention partials if XATTN)
     auto stage_x = [&](int kc0, int nch) {
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             const u32x4_t* xr = (const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx + kc0);
-            for (int c = tid; c < nch; c += 256) {
+            for (int c = tid; c < nch; c += NT) {
                 u32x4_t v;
                 if (XATTN) {
                     // chunk cg = head (cg>>4), elements (cg&15)*8..+8 of the split partials
@@ -159,90 +168,99 @@ __global__ __launch_bounds__(256) void emmax_decode_gemv_kernel(GemvParams p) {
             }
         }
     };
-
-    int kc0 = 0, c0 = 0;
-    int nch = min(KC, K) >> 3;   // 16-byte chunks in the current phase
-    stage_x(0, nch);
+    stage_x(0, nch0);
     __syncthreads();
-    while (true) {
-        // ---- consume the chunk whose loads are in flight ----
+
+    // LMHEAD: running best over this wave's rows
+    float best[B];
+    int besti[B];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int c = c0 + u * 64 + lane;
-            if (c0 + u * 64 < nch) {   // wave-uniform
-                const int cc = (c < nch) ? c : 0;
+    for (int b = 0; b < B; ++b) {
+        best[b] = -INFINITY;
+        besti[b] = 0x7fffffff;
+    }
+
+    for (int rd = 0; rd < rounds; ++rd, g += GW) {
+        const bool valid = g < g_hi;
+        float acc[NR][B];
 #pragma unroll
-                for (int b = 0; b < B; ++b) {
-                    const u32x4_t xv = xs[b * (KC >> 3) + cc];
+        for (int r = 0; r < NR; ++r)
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        float a = acc[r][b];
-                        a = dot2_bf16(wr[r][u][0], xv[0], a);
-                        a = dot2_bf16(wr[r][u][1], xv[1], a);
-                        a = dot2_bf16(wr[r][u][2], xv[2], a);
-                        a = dot2_bf16(wr[r][u][3], xv[3], a);
-                        acc[r][b] = a;
+            for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
+
+        for (int kc0 = 0; kc0 < K; kc0 += KC) {
+            const int nch = min(KC, K - kc0) >> 3;
+            if (multi_phase && (rd != 0 || kc0 != 0)) {   // restage x for this phase (block-uniform control flow)
+                if (valid) issue_weights(g, kc0, 0, nch);
+                __syncthreads();
+                stage_x(kc0, nch);
+                __syncthreads();
+            }
+            if (valid) {
+                for (int c0 = 0; c0 < nch; c0 += 64 * U) {
+                    if (c0 != 0) issue_weights(g, kc0, c0, nch);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int c = c0 + u * 64 + lane;
+                        if (c0 + u * 64 < nch) {   // wave-uniform
+                            const int cc = (c < nch) ? c : 0;
+#pragma unroll
+                            for (int b = 0; b < B; ++b) {
+                                const u32x4_t xv = xs[b * (KC >> 3) + cc];
+#pragma unroll
+                                for (int r = 0; r < NR; ++r) {
+                                    float a = acc[r][b];
+                                    a = dot2_bf16(wr[r][u][0], xv[0], a);
+                                    a = dot2_bf16(wr[r][u][1], xv[1], a);
+                                    a = dot2_bf16(wr[r][u][2], xv[2], a);
+                                    a = dot2_bf16(wr[r][u][3], xv[3], a);
+                                    acc[r][b] = a;
+                                }
+                            }
+                        }
                     }
                 }
             }
         }
-        // ---- advance; request the next chunk (then, at a phase boundary, restage x while those loads fly) ----
-        c0 += 64 * U;
-        if (c0 < nch) {
-            issue_weights(kc0, c0, nch);
-            continue;
-        }
-        kc0 += KC;
-        if (kc0 >= K) break;
-        c0 = 0;
-        nch = min(KC, K - kc0) >> 3;
-        issue_weights(kc0, 0, nch);
-        __syncthreads();   // every wave is done reading the previous phase from LDS
-        stage_x(kc0, nch);
-        __syncthreads();
-    }
+        // single phase: the next group's head goes out before this group's reduction / epilogue
+        if (!multi_phase && g + GW < g_hi) issue_weights(g + GW, 0, 0, nch0);
+        if (!valid) continue;
 
-    // ---- wave reduction: every lane ends up with the full sums ----
 #pragma unroll
-    for (int r = 0; r < NR; ++r)
+        for (int r = 0; r < NR; ++r)
 #pragma unroll
-        for (int b = 0; b < B; ++b) acc[r][b] = wave_sum(acc[r][b]);
+            for (int b = 0; b < B; ++b) acc[r][b] = wave_sum(acc[r][b]);
 
-    // ---- epilogues ----
-    if (MODE == MODE_PLAIN) {
-#pragma unroll
-        for (int s = 0; s < RPW; ++s)
+        int r0, r1;
+        group_rows(g, r0, r1);
+        if (MODE == MODE_PLAIN) {
 #pragma unroll
             for (int b = 0; b < B; ++b)
-                if (slot_ok[s] && lane == b) ((bf16_t*)p.y)[(size_t)b * p.ldy + rows[s]] = f2bf(acc[s][b]);
-    } else if (MODE == MODE_RESID) {
-#pragma unroll
-        for (int s = 0; s < RPW; ++s)
-#pragma unroll
-            for (int b = 0; b < B; ++b)
-                if (slot_ok[s] && lane == b) {
-                    bf16_t* hp = (bf16_t*)p.y + (size_t)b * p.ldy + rows[s];
-                    *hp = f2bf(bf2f(*hp) + acc[s][b]);
+                if (lane == b) {
+                    ((bf16_t*)p.y)[(size_t)b * p.ldy + r0] = f2bf(acc[0][b]);
+                    if (2 * g + 1 < p.n_rows) ((bf16_t*)p.y)[(size_t)b * p.ldy + r1] = f2bf(acc[1][b]);
                 }
-    } else if (MODE == MODE_GATEUP) {
-#pragma unroll
-        for (int s = 0; s < RPW; ++s)
+        } else if (MODE == MODE_RESID) {
 #pragma unroll
             for (int b = 0; b < B; ++b)
-                if (slot_ok[s] && lane == b)
-                    ((bf16_t*)p.y)[(size_t)b * p.ldy + slot0 + s] = f2bf(silu(acc[2 * s][b]) * acc[2 * s + 1][b]);
-    } else if (MODE == MODE_QKV) {
-        const int hd = p.head_dim, half = hd >> 1;
-#pragma unroll
-        for (int s = 0; s < RPW; ++s)
+                if (lane == b) {
+                    bf16_t* hp = (bf16_t*)p.y + (size_t)b * p.ldy;
+                    hp[r0] = f2bf(bf2f(hp[r0]) + acc[0][b]);
+                    if (2 * g + 1 < p.n_rows) hp[r1] = f2bf(bf2f(hp[r1]) + acc[1][b]);
+                }
+        } else if (MODE == MODE_GATEUP) {
 #pragma unroll
             for (int b = 0; b < B; ++b)
-                if (slot_ok[s] && lane == b) {
-                    const int slot = slot0 + s;
-                    const int hb = slot / half, d = slot - hb * half;
+                if (lane == b) ((bf16_t*)p.y)[(size_t)b * p.ldy + g] = f2bf(silu(acc[0][b]) * acc[1][b]);
+        } else if (MODE == MODE_QKV) {
+            const int hd = p.head_dim, half = hd >> 1;
+            const int hb = g / half, d = g - hb * half;
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+                if (lane == b) {
                     const int pos = p.ctx_len[b];
                     // linear outputs are bf16 activations in the reference; RoPE acts on those
-                    const float x0 = bf2f(f2bf(acc[2 * s][b])), x1 = bf2f(f2bf(acc[2 * s + 1][b]));
+                    const float x0 = bf2f(f2bf(acc[0][b])), x1 = bf2f(f2bf(acc[1][b]));
                     if (hb < p.Hq + p.Hkv) {
                         const float cs = p.cos_t[(size_t)pos * half + d], sn = p.sin_t[(size_t)pos * half + d];
                         const bf16_t y0 = f2bf(x0 * cs - x1 * sn), y1 = f2bf(x1 * cs + x0 * sn);
@@ -263,44 +281,50 @@ __global__ __launch_bounds__(256) void emmax_decode_gemv_kernel(GemvParams p) {
                         vc[d + half] = f2bf(x1);
                     }
                 }
-    } else if (MODE == MODE_LMHEAD) {
-        // per-wave best over its rows, then block best; first index wins ties (torch.argmax semantics)
-        __shared__ float bv[4][B];
-        __shared__ int bi[4][B];
+        } else if (MODE == MODE_LMHEAD) {
 #pragma unroll
-        for (int b = 0; b < B; ++b) {
-            float best = -INFINITY;
-            int besti = 0x7fffffff;
+            for (int b = 0; b < B; ++b) {
 #pragma unroll
-            for (int s = 0; s < RPW; ++s)
-                if (slot_ok[s]) {
-                    const float v = acc[s][b];
-                    if (v > best || (v == best && rows[s] < besti)) {
-                        best = v;
-                        besti = rows[s];
+                for (int r = 0; r < NR; ++r) {
+                    const int row = r == 0 ? r0 : r1;
+                    if (r == 1 && 2 * g + 1 >= p.n_rows) continue;
+                    const float v = acc[r][b];
+                    if (v > best[b] || (v == best[b] && row < besti[b])) {
+                        best[b] = v;
+                        besti[b] = row;
                     }
-                    if (p.logits_out && lane == 0) p.logits_out[(size_t)b * p.n_slots + rows[s]] = v;
+                    if (p.logits_out && lane == 0) p.logits_out[(size_t)b * p.n_rows + row] = v;
                 }
-            if (lane == 0) {
-                bv[wave][b] = best;
-                bi[wave][b] = besti;
+            }
+        }
+    }
+
+    if (MODE == MODE_LMHEAD) {
+        // block best; first index wins ties (torch.argmax semantics); one partial per block
+        __shared__ float bv[GW][B];
+        __shared__ int bi[GW][B];
+        if (lane == 0) {
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                bv[wave][b] = best[b];
+                bi[wave][b] = besti[b];
             }
         }
         __syncthreads();
         if (tid < B) {
-            float best = bv[0][tid];
-            int besti = bi[0][tid];
+            float v0 = bv[0][tid];
+            int i0 = bi[0][tid];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) {
+            for (int w = 1; w < GW; ++w) {
                 const float v = bv[w][tid];
                 const int ii = bi[w][tid];
-                if (v > best || (v == best && ii < besti)) {
-                    best = v;
-                    besti = ii;
+                if (v > v0 || (v == v0 && ii < i0)) {
+                    v0 = v;
+                    i0 = ii;
                 }
             }
-            p.part_val[(size_t)blockIdx.x * B + tid] = best;
-            p.part_idx[(size_t)blockIdx.x * B + tid] = besti;
+            p.part_val[(size_t)blockIdx.x * B + tid] = v0;
+            p.part_idx[(size_t)blockIdx.x * B + tid] = i0;
         }
     }
 }
@@ -542,22 +566,22 @@ __global__ void emmax_set_tokens_kernel(int32_t* cur_tok, const int32_t* toks, i
 // ---------------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------------
-template <int B, int RPW, int MODE, bool NORM, bool XATTN = false>
+// persistent grid: 2 blocks of 8 waves per CU when the staged activations allow it, never more blocks than work
+static int gemv_grid(int B, size_t smem, int n_groups) {
+    const int grid = (B > 2 || smem > 72 * 1024) ? 256 : 512;
+    return min(grid, cdiv(n_groups, GW));
+}
+int decode_lmhead_grid(int B, int K, int n_rows, int max_parts) { return min(gemv_grid(B, (size_t)B * K * 2, (n_rows + 1) / 2), max_parts); }
+
+template <int B, int MODE, bool NORM, bool XATTN = false>
 static int launch_gemv_t(const GemvParams& p, hipStream_t stream) {
-    const int slots_per_block = 4 * RPW;
-    dim3 grid(cdiv(p.n_slots, slots_per_block)), block(256);
     const size_t smem = (size_t)B * p.kc * 2;
-    auto kern = emmax_decode_gemv_kernel<B, RPW, MODE, NORM, XATTN>;
-    hipLaunchKernelGGL(kern, grid, block, smem, stream, p);
+    int grid = gemv_grid(B, smem, p.n_groups);
+    if (MODE == MODE_LMHEAD) grid = min(grid, p.max_parts);
+    auto kern = emmax_decode_gemv_kernel<B, MODE, NORM, XATTN>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(GW * 64), smem, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
-
-// rows per wave: paired modes (QKV / GATEUP) hold 2*RPW weight rows x 8 loads in registers, so they drop to RPW = 1 once
-// the batch accumulators (B > 4) would push the kernel past 2 waves per SIMD
-template <int MODE, int B>
-struct RpwFor {
-    static constexpr int value = ((MODE == MODE_QKV || MODE == MODE_GATEUP) && B > 4) ? 1 : 2;
-};
 
 template <int MODE, bool NORM, bool XATTN = false>
 static int launch_gemv_mode(GemvParams p, int B, hipStream_t stream) {
@@ -565,8 +589,11 @@ static int launch_gemv_mode(GemvParams p, int B, hipStream_t stream) {
     const int cap = (128 * 1024 / 2 / B) & ~511;
     p.kc = p.K <= cap ? p.K : (cdiv(cdiv(p.K, cdiv(p.K, cap)), 512) * 512);
     if (NORM && p.kc != p.K) return -1;
+    if (MODE == MODE_QKV) p.n_groups = p.n_rows / 2;
+    else if (MODE == MODE_GATEUP) p.n_groups = p.n_rows / 2;
+    else p.n_groups = (p.n_rows + 1) / 2;
     switch (B) {
-#define CASEB(BB) case BB: return launch_gemv_t<BB, RpwFor<MODE, BB>::value, MODE, NORM, XATTN>(p, stream)
+#define CASEB(BB) case BB: return launch_gemv_t<BB, MODE, NORM, XATTN>(p, stream)
         CASEB(1); CASEB(2); CASEB(3); CASEB(4); CASEB(5); CASEB(6); CASEB(7); CASEB(8);
 #undef CASEB
         default: return -1;
@@ -577,7 +604,7 @@ template <int MODE, bool NORM, bool XATTN = false>
 static int gemv_init_mode() {
     const int lim = 160 * 1024 - 4096;
     hipError_t e = hipSuccess;
-#define SETB(BB) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_gemv_kernel<BB, RpwFor<MODE, BB>::value, MODE, NORM, XATTN>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
+#define SETB(BB) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_gemv_kernel<BB, MODE, NORM, XATTN>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
     SETB(1); SETB(2); SETB(3); SETB(4); SETB(5); SETB(6); SETB(7); SETB(8);
 #undef SETB
     return e == hipSuccess ? 0 : -4;

@@ -66,7 +66,9 @@ struct GemvParams {
     void* y;                // output (mode dependent): q buffer / h (in place) / act / plain
     const void* norm_w;     // bf16 [K] RMSNorm weight (NORM modes)
     int K, ldw, ldx, ldy;
-    int n_slots;            // QKV: (Hq+2Hkv)*hd/2 pairs; GATEUP: inter pairs; else: rows
+    int n_rows;             // weight rows (QKV: (Hq+2Hkv)*hd; GATEUP: 2*inter_p interleaved; LMHEAD: vocab; else output rows)
+    int n_groups;           // 2-row groups (set by the launcher)
+    int max_parts;          // LMHEAD: capacity of part_val / part_idx in blocks
     int kc;                 // K phase length (set by the launcher)
     float eps;
     // QKV epilogue
@@ -80,12 +82,13 @@ struct GemvParams {
     // LMHEAD epilogue
     float* part_val;
     int32_t* part_idx;
-    float* logits_out;      // optional f32 [B, n_slots]
+    float* logits_out;      // optional f32 [B, n_rows]
     // RESID with x = merged attention output: split partials f32 [B][Hq][nsplit][132] (null: x is a bf16 vector)
     const float* attn_part;
     int nsplit;
 };
 int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream);
+int decode_lmhead_grid(int B, int K, int n_rows, int max_parts);   // blocks (= argmax partials) the lm-head launch uses
 int decode_gemv_init();   // raise the dynamic-LDS limit of every GEMV instantiation (call once, outside graph capture)
 int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, hipStream_t stream);
 

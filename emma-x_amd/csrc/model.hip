@@ -283,7 +283,7 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->datt = (bf16*)b.take((int64_t)Bd * m->q_dim * 2);
     s->dact = (bf16*)b.take((int64_t)Bd * m->inter_p * 2);
     s->part = (float*)b.take((int64_t)Bd * m->cfg.n_heads * 16 * 132 * 4);
-    s->n_lm_blocks = (m->vocab + 7) / 8;
+    s->n_lm_blocks = 512;   // persistent lm-head grid: one argmax partial per block
     s->part_val = (float*)b.take((int64_t)s->n_lm_blocks * Bd * 4);
     s->part_idx = (int32_t*)b.take((int64_t)s->n_lm_blocks * Bd * 4);
     s->logits = (float*)b.take((int64_t)Bd * m->vocab * 4);
@@ -377,12 +377,12 @@ static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* log
     GemvParams p;
     memset(&p, 0, sizeof(p));
     p.x = s->dh; p.ldx = m->H; p.W = m->lm_head; p.ldw = m->H; p.K = m->H; p.norm_w = m->final_norm; p.eps = m->cfg.rms_eps;
-    p.n_slots = m->vocab; p.part_val = s->part_val; p.part_idx = s->part_idx; p.logits_out = logits_out;
+    p.n_rows = m->vocab; p.max_parts = s->n_lm_blocks; p.part_val = s->part_val; p.part_idx = s->part_idx; p.logits_out = logits_out;
     KCHK(launch_decode_gemv(GEMV_LMHEAD, p, B, st));
     if (do_finish) {
         FinishParams f;
         memset(&f, 0, sizeof(f));
-        f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = s->n_lm_blocks; f.B = B;
+        f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = decode_lmhead_grid(B, m->H, m->vocab, s->n_lm_blocks); f.B = B;
         f.cur_tok = s->cur_tok; f.ctx_len = s->ctx_len; f.done = s->done; f.n_out = s->n_out; f.out_ids = s->out_ids;
         f.max_new_p = s->max_new_d; f.max_out = s->max_out; f.max_ctx = s->max_ctx;
         f.eos_id = m->cfg.eos_id; f.pad_id = m->cfg.pad_id; f.is_prefill = is_prefill ? 1 : 0;
@@ -463,7 +463,7 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
     switch (stage) {
         case STAGE_QKV:
             p.x = s->dh; p.ldx = m->H; p.W = L.wqkv; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln1; p.eps = c.rms_eps;
-            p.y = s->dq; p.ldy = m->q_dim; p.n_slots = m->qkv_dim / 2;
+            p.y = s->dq; p.ldy = m->q_dim; p.n_rows = m->qkv_dim;
             p.head_dim = c.head_dim; p.Hq = c.n_heads; p.Hkv = c.n_kv_heads; p.page = PAGE; p.max_pages = s->max_pages;
             p.ctx_len = s->ctx_len; p.page_table = s->page_table; p.cos_t = s->cos_t; p.sin_t = s->sin_t;
             p.kcache = kcache_of(s, li); p.vcache = vcache_of(s, li);
@@ -478,17 +478,17 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             return 0;
         }
         case STAGE_OPROJ:
-            p.x = s->datt; p.ldx = m->q_dim; p.W = L.wo; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_slots = m->H;
+            p.x = s->datt; p.ldx = m->q_dim; p.W = L.wo; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
             p.attn_part = s->part; p.nsplit = decode_attn_nsplit(B, c.n_kv_heads); p.Hq = c.n_heads;   // split merge fused into the staging
             KCHK(launch_decode_gemv(GEMV_RESID, p, B, st));
             return 0;
         case STAGE_GATEUP:
             p.x = s->dh; p.ldx = m->H; p.W = L.wgu; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln2; p.eps = c.rms_eps;
-            p.y = s->dact; p.ldy = m->inter_p; p.n_slots = m->inter_p;
+            p.y = s->dact; p.ldy = m->inter_p; p.n_rows = 2 * m->inter_p;
             KCHK(launch_decode_gemv(GEMV_GATEUP, p, B, st));
             return 0;
         case STAGE_DOWN:
-            p.x = s->dact; p.ldx = m->inter_p; p.W = L.wdown; p.ldw = m->inter_p; p.K = m->inter_p; p.y = s->dh; p.ldy = m->H; p.n_slots = m->H;
+            p.x = s->dact; p.ldx = m->inter_p; p.W = L.wdown; p.ldw = m->inter_p; p.K = m->inter_p; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
             KCHK(launch_decode_gemv(GEMV_RESID, p, B, st));
             return 0;
         default:
@@ -918,7 +918,7 @@ int emmax_op_attention(const void* qkv, int ld_qkv, int q_off, int k_off, int v_
 int emmax_op_gemv(const void* x, const void* W, void* y, int B, int N, int K, emmax_stream st) {
     GemvParams p;
     memset(&p, 0, sizeof(p));
-    p.x = x; p.ldx = K; p.W = W; p.ldw = K; p.K = K; p.y = y; p.ldy = N; p.n_slots = N;
+    p.x = x; p.ldx = K; p.W = W; p.ldw = K; p.K = K; p.y = y; p.ldy = N; p.n_rows = N;
     if (decode_gemv_init() != 0) return fail(EMMAX_ERR_HIP, "could not raise the dynamic LDS limit of the GEMV kernels");
     int r = launch_decode_gemv(GEMV_PLAIN, p, B, (hipStream_t)st);
     if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_gemv: unsupported shape (B<=8, K%%8)");

@@ -1,0 +1,349 @@
+// gemv_sweep.hip -- standalone micro-benchmark used to tune the decode weight-streaming GEMV (not part of the product).
+// Streams `NL` different [N,K] bf16 matrices (so nothing is served from the 256 MiB Infinity Cache) through kernel
+// variants and prints us/launch and GB/s.   Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemv_sweep.hip -o tools/bin/gemv_sweep
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int POLICY>
+__device__ __forceinline__ u32x4 ld(const u32x4* p) {
+    if (POLICY == 1) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+// ---- V0: static grid, one block = WAVES waves, each wave NR rows at a time, x in LDS -------------------------------
+template <int WAVES, int NR, int U, int POLICY, bool EARLY>
+__global__ __launch_bounds__(WAVES * 64) void k_static(const uint16_t* __restrict__ W, const uint16_t* __restrict__ x, float* __restrict__ y, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* xs = (u32x4*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = (blockIdx.x * WAVES + wave) * NR;
+    const int nch = K >> 3;
+    u32x4 wr[NR][U];
+    auto issue = [&](int c0) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int row = min(row0 + r, N - 1);
+            const u32x4* wrow = (const u32x4*)(W + (size_t)row * K);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u * 64 + lane;
+                wr[r][u] = c < nch ? ld<POLICY>(wrow + c) : (u32x4){0, 0, 0, 0};
+            }
+        }
+    };
+    if (EARLY) issue(0);
+    for (int c = tid; c < nch; c += WAVES * 64) xs[c] = ((const u32x4*)x)[c];
+    __syncthreads();
+    float acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = 0.f;
+    for (int c0 = 0; c0 < nch; c0 += 64 * U) {
+        if (!EARLY || c0 != 0) issue(c0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * 64 + lane;
+            if (c0 + u * 64 < nch) {
+                const u32x4 xv = xs[c < nch ? c : 0];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    float a = acc[r];
+                    a = dot2(wr[r][u][0], xv[0], a); a = dot2(wr[r][u][1], xv[1], a);
+                    a = dot2(wr[r][u][2], xv[2], a); a = dot2(wr[r][u][3], xv[3], a);
+                    acc[r] = a;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const float s = wave_sum(acc[r]);
+        if (lane == 0 && row0 + r < N) y[row0 + r] = s;
+    }
+}
+
+// ---- V1: persistent blocks, per-XCD dynamic queue of row groups ----------------------------------------------------
+// counters[8] (one per XCD) hand out groups of NR rows from that XCD's contiguous share of the rows.
+template <int WAVES, int NR, int U, int POLICY>
+__global__ __launch_bounds__(WAVES * 64) void k_queue(const uint16_t* __restrict__ W, const uint16_t* __restrict__ x, float* __restrict__ y, int N, int K,
+                                                      int* __restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* xs = (u32x4*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nch = K >> 3;
+    const int xcd = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | ((4 - 1) << 11)) & 7;
+    const int groups = (N + NR - 1) / NR;
+    const int gq = groups / 8, gr = groups % 8;
+    const int g_lo = xcd * gq + min(xcd, gr), g_hi = g_lo + gq + (xcd < gr ? 1 : 0);
+    int* ctr = counters + xcd * 16;   // 64-byte apart
+    auto fetch = [&]() {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(ctr, 1);
+        return __builtin_amdgcn_readfirstlane(v) + g_lo;
+    };
+    u32x4 wr[NR][U];
+    auto issue = [&](int g, int c0) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int row = min(g * NR + r, N - 1);
+            const u32x4* wrow = (const u32x4*)(W + (size_t)row * K);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u * 64 + lane;
+                wr[r][u] = c < nch ? ld<POLICY>(wrow + c) : (u32x4){0, 0, 0, 0};
+            }
+        }
+    };
+    int g = fetch();
+    if (g < g_hi) issue(g, 0);
+    for (int c = tid; c < nch; c += WAVES * 64) xs[c] = ((const u32x4*)x)[c];
+    __syncthreads();
+    while (g < g_hi) {
+        const int gnext = fetch();   // in flight while we compute
+        float acc[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[r] = 0.f;
+        for (int c0 = 0; c0 < nch; c0 += 64 * U) {
+            if (c0 != 0) issue(g, c0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u * 64 + lane;
+                if (c0 + u * 64 < nch) {
+                    const u32x4 xv = xs[c < nch ? c : 0];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        float a = acc[r];
+                        a = dot2(wr[r][u][0], xv[0], a); a = dot2(wr[r][u][1], xv[1], a);
+                        a = dot2(wr[r][u][2], xv[2], a); a = dot2(wr[r][u][3], xv[3], a);
+                        acc[r] = a;
+                    }
+                }
+            }
+        }
+        if (gnext < g_hi) issue(gnext, 0);   // next group's head is requested before the reduction of this one
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const float s = wave_sum(acc[r]);
+            if (lane == 0 && g * NR + r < N) y[g * NR + r] = s;
+        }
+        g = gnext;
+    }
+}
+
+// ---- V2: read-only ceiling for the same access pattern (no LDS, no dot) ---------------------------------------------
+template <int WAVES, int NR, int U, int POLICY>
+__global__ __launch_bounds__(WAVES * 64) void k_readonly(const uint16_t* __restrict__ W, float* __restrict__ y, int N, int K) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = (blockIdx.x * WAVES + wave) * NR;
+    const int nch = K >> 3;
+    uint32_t acc = 0;
+    for (int c0 = 0; c0 < nch; c0 += 64 * U) {
+        u32x4 wr[NR][U];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const u32x4* wrow = (const u32x4*)(W + (size_t)min(row0 + r, N - 1) * K);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u * 64 + lane;
+                wr[r][u] = c < nch ? ld<POLICY>(wrow + c) : (u32x4){0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc ^= wr[r][u][0] ^ wr[r][u][1] ^ wr[r][u][2] ^ wr[r][u][3];
+    }
+    if (acc == 0x12345678u) y[row0] = 1.f;
+}
+
+
+// ---- V3: persistent static: G blocks, block b owns a contiguous range of row groups, waves interleave inside it; optional
+// RMSNorm-style prologue (sum of squares over x + scaled staging) to price it -------------------------------------------------
+template <int WAVES, int NR, int U, bool NORM>
+__global__ __launch_bounds__(WAVES * 64) void k_persist(const uint16_t* __restrict__ W, const uint16_t* __restrict__ x, float* __restrict__ y, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* xs = (u32x4*)smem;
+    __shared__ float red[WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nch = K >> 3;
+    const int groups = (N + NR - 1) / NR;
+    const int G = gridDim.x;
+    const int q = groups / G, r = groups % G, b = blockIdx.x;
+    const int g_lo = b * q + min(b, r), g_hi = g_lo + q + (b < r ? 1 : 0);
+    u32x4 wr[NR][U];
+    auto issue = [&](int g, int c0) {
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            const int row = min(g * NR + rr, N - 1);
+            const u32x4* wrow = (const u32x4*)(W + (size_t)row * K);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u * 64 + lane;
+                wr[rr][u] = c < nch ? ld<1>(wrow + c) : (u32x4){0, 0, 0, 0};
+            }
+        }
+    };
+    int g = g_lo + wave;
+    if (g < g_hi) issue(g, 0);
+    float rstd = 1.f;
+    if (NORM) {
+        float ss = 0.f;
+        for (int c = tid; c < nch; c += WAVES * 64) {
+            const u32x4 v = ((const u32x4*)x)[c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = __uint_as_float(v[j] << 16), bb = __uint_as_float(v[j] & 0xffff0000u);
+                ss += a * a + bb * bb;
+            }
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) t += red[w];
+        rstd = rsqrtf(t / K + 1e-5f);
+    }
+    for (int c = tid; c < nch; c += WAVES * 64) {
+        u32x4 v = ((const u32x4*)x)[c];
+        if (NORM) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = __uint_as_float(v[j] << 16) * rstd, bb = __uint_as_float(v[j] & 0xffff0000u) * rstd;
+                v[j] = (__float_as_uint(a) >> 16) | (__float_as_uint(bb) & 0xffff0000u);
+            }
+        }
+        xs[c] = v;
+    }
+    __syncthreads();
+    while (g < g_hi) {
+        float acc[NR];
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) acc[rr] = 0.f;
+        for (int c0 = 0; c0 < nch; c0 += 64 * U) {
+            if (c0 != 0) issue(g, c0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u * 64 + lane;
+                if (c0 + u * 64 < nch) {
+                    const u32x4 xv = xs[c < nch ? c : 0];
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr) {
+                        float a = acc[rr];
+                        a = dot2(wr[rr][u][0], xv[0], a); a = dot2(wr[rr][u][1], xv[1], a);
+                        a = dot2(wr[rr][u][2], xv[2], a); a = dot2(wr[rr][u][3], xv[3], a);
+                        acc[rr] = a;
+                    }
+                }
+            }
+        }
+        const int gn = g + WAVES;
+        if (gn < g_hi) issue(gn, 0);   // next group's head in flight during the reduction
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            const float sres = wave_sum(acc[rr]);
+            if (lane == 0 && g * NR + rr < N) y[g * NR + rr] = sres;
+        }
+        g = gn;
+    }
+}
+
+struct Ctx {
+    std::vector<uint16_t*> W;
+    uint16_t* x;
+    float* y;
+    int* counters;
+    int N, K, NL;
+    hipStream_t st;
+};
+
+template <typename F>
+static void timeit(const char* name, Ctx& c, F launch, int reps = 5) {
+    for (int l = 0; l < c.NL; ++l) launch(l);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    CHECK(hipEventRecord(e0, c.st));
+    for (int r = 0; r < reps; ++r)
+        for (int l = 0; l < c.NL; ++l) launch(l);
+    CHECK(hipEventRecord(e1, c.st));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / (reps * c.NL);
+    printf("%-46s N=%6d K=%6d  %8.2f us  %8.1f GB/s\n", name, c.N, c.K, us, (double)c.N * c.K * 2 / us / 1e3);
+    fflush(stdout);
+}
+
+template <int WAVES, int NR, int U, int POLICY, bool EARLY>
+static void run_static(const char* name, Ctx& c) {
+    const int blocks = (c.N + WAVES * NR - 1) / (WAVES * NR);
+    timeit(name, c, [&](int l) { hipLaunchKernelGGL((k_static<WAVES, NR, U, POLICY, EARLY>), dim3(blocks), dim3(WAVES * 64), c.K * 2, c.st, c.W[l], c.x, c.y, c.N, c.K); });
+}
+template <int WAVES, int NR, int U, int POLICY>
+static void run_queue(const char* name, Ctx& c, int blocks) {
+    timeit(name, c, [&](int l) {
+        CHECK(hipMemsetAsync(c.counters, 0, 8 * 64, c.st));
+        hipLaunchKernelGGL((k_queue<WAVES, NR, U, POLICY>), dim3(blocks), dim3(WAVES * 64), c.K * 2, c.st, c.W[l], c.x, c.y, c.N, c.K, c.counters);
+    });
+}
+template <int WAVES, int NR, int U, int POLICY>
+static void run_ro(const char* name, Ctx& c) {
+    const int blocks = (c.N + WAVES * NR - 1) / (WAVES * NR);
+    timeit(name, c, [&](int l) { hipLaunchKernelGGL((k_readonly<WAVES, NR, U, POLICY>), dim3(blocks), dim3(WAVES * 64), 0, c.st, c.W[l], c.y, c.N, c.K); });
+}
+
+
+template <int WAVES, int NR, int U, bool NORM>
+static void run_persist(const char* name, Ctx& c, int blocks) {
+    timeit(name, c, [&](int l) { hipLaunchKernelGGL((k_persist<WAVES, NR, U, NORM>), dim3(blocks), dim3(WAVES * 64), c.K * 2, c.st, c.W[l], c.x, c.y, c.N, c.K); });
+}
+
+int main(int argc, char** argv) {
+    Ctx c;
+    c.NL = 24;
+    CHECK(hipStreamCreate(&c.st));
+    const int shapes[][2] = {{22016, 4096}, {12288, 4096}, {4096, 4096}, {4096, 11008}};
+    const size_t maxel = (size_t)22016 * 4096;
+    for (int l = 0; l < c.NL; ++l) {
+        uint16_t* p; CHECK(hipMalloc(&p, maxel * 2));
+        CHECK(hipMemset(p, 0x3c + (l & 3), maxel * 2));
+        c.W.push_back(p);
+    }
+    CHECK(hipMalloc(&c.x, 11008 * 2)); CHECK(hipMemset(c.x, 0x3c, 11008 * 2));
+    CHECK(hipMalloc(&c.y, 22016 * 4)); CHECK(hipMalloc(&c.counters, 8 * 64));
+    for (auto& s : shapes) {
+        c.N = s[0]; c.K = s[1];
+        printf("---- N=%d K=%d (%.1f MB) ----\n", c.N, c.K, (double)c.N * c.K * 2 / 1e6);
+        run_ro<4, 2, 8, 1>("readonly  w4 nr2 u8 nt", c);
+        run_static<4, 2, 8, 1, true>("static    w4 nr2 u8 nt early", c);
+        run_static<4, 4, 8, 1, true>("static    w4 nr4 u8 nt early", c);
+        run_persist<4, 2, 8, false>("persist   w4 nr2  256blk", c, 256);
+        run_persist<4, 2, 8, false>("persist   w4 nr2  512blk", c, 512);
+        run_persist<4, 2, 8, false>("persist   w4 nr2  768blk", c, 768);
+        run_persist<4, 2, 8, false>("persist   w4 nr2 1024blk", c, 1024);
+        run_persist<8, 2, 8, false>("persist   w8 nr2  256blk", c, 256);
+        run_persist<8, 2, 8, false>("persist   w8 nr2  512blk", c, 512);
+        run_persist<4, 4, 8, false>("persist   w4 nr4  512blk", c, 512);
+        run_persist<4, 2, 8, true>("persist   w4 nr2  512blk NORM", c, 512);
+        run_persist<4, 2, 8, true>("persist   w4 nr2 1024blk NORM", c, 1024);
+        run_persist<8, 2, 8, true>("persist   w8 nr2  256blk NORM", c, 256);
+        run_persist<8, 2, 8, true>("persist   w8 nr2  512blk NORM", c, 512);
+        run_persist<4, 4, 8, true>("persist   w4 nr4  512blk NORM", c, 512);
+        run_persist<16, 2, 8, true>("persist  w16 nr2  256blk NORM", c, 256);
+    }
+    return 0;
+}
