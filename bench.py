@@ -181,6 +181,13 @@ def main():
         }
         dom = "gateup_gemv"
         achieved = stage_bytes[dom] / (stage_us[dom] * 1e-6) / 1e9
+        # HBM traffic of the same kernel from PMC counters (separate rocprofv3 --pmc passes over tools/pmc_probe.py, B=1;
+        # FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); not collected during this run
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if B == 1 and not args.tiny and os.path.isfile(pmc_file):
+            with open(pmc_file) as f:
+                traffic = json.load(f)["stages"].get(dom, {}).get("hbm_bytes_per_launch")
         # whole decode step: algorithmic bytes / measured step time
         t_s = time.perf_counter()
         nsteps = 64
@@ -204,9 +211,10 @@ def main():
             "decode_step_hbm_gbs": round(step_gbs, 1), "decode_step_hbm_frac": round(step_gbs / HBM_PEAK_GBS, 4),
             "stage_us": {k: round(v, 2) for k, v in stage_us.items()},
             "stage_gbs": {k: round(stage_bytes[k] / (stage_us[k] * 1e-6) / 1e9, 1) for k in stage_names},
-            "roofline": {"kernel": "emmax_decode_gemv_kernel<B=%d,RPW=2,GATEUP,NORM> (gate/up GEMV + SiLU*mul)" % B, "bound": "hbm",
+            "roofline": {"kernel": "emmax_decode_gemv_kernel<B=%d,GATEUP,NORM> (gate/up GEMV + SiLU*mul)" % B, "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "bytes_per_launch": stage_bytes[dom], "us_per_launch": round(stage_us[dom], 2), "traffic": None},
+                         "bytes_per_launch": stage_bytes[dom], "us_per_launch": round(stage_us[dom], 2), "traffic": traffic,
+                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, offline)" if traffic else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, P, T)

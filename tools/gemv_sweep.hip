@@ -263,6 +263,59 @@ __global__ __launch_bounds__(WAVES * 64) void k_persist(const uint16_t* __restri
     }
 }
 
+// ---- V4: small-batch (B <= 16) decode GEMM on MFMA: a wave owns 16 weight rows (A operand, straight from HBM to VGPRs),
+// the batch is the 16-wide N side (B operand from LDS, zero padded); no cross-lane reduction at all ------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int WAVES, int U, int BATCH>
+__global__ __launch_bounds__(WAVES * 64) void k_mfma(const uint16_t* __restrict__ W, const uint16_t* __restrict__ x, float* __restrict__ y, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g4 = lane >> 4, i16 = lane & 15;
+    const int pitch = K * 2 + 16;                       // bytes per staged x row (odd number of 16-byte slots)
+    const int groups = N / 16, G = gridDim.x;
+    const int q = groups / G, r = groups % G, b = blockIdx.x;
+    const int g_lo = b * q + min(b, r), g_hi = g_lo + q + (b < r ? 1 : 0);
+    const int nk = K / 32;
+    u32x4 wr[U];
+    auto issue = [&](int g, int k0) {
+        const u32x4* wrow = (const u32x4*)(W + (size_t)(g * 16 + i16) * K) + g4;
+#pragma unroll
+        for (int u = 0; u < U; ++u) wr[u] = (k0 + u < nk) ? ld<1>(wrow + (size_t)(k0 + u) * 4) : (u32x4){0, 0, 0, 0};
+    };
+    int g = g_lo + wave;
+    if (g < g_hi) issue(g, 0);
+    // stage x (BATCH rows; rows >= BATCH are zero) with padded pitch
+    for (int c = tid; c < 16 * (K / 8); c += WAVES * 64) {
+        const int row = c / (K / 8), ch = c % (K / 8);
+        u32x4 v = {0, 0, 0, 0};
+        if (row < BATCH) v = ((const u32x4*)x)[ch];      // same vector for every batch row (bench only)
+        *(u32x4*)(smem + row * pitch + ch * 16) = v;
+    }
+    __syncthreads();
+    while (g < g_hi) {
+        f32x4 acc = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < nk; k0 += U) {
+            if (k0 != 0) issue(g, k0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (k0 + u < nk) {
+                    const bf16x8 xb = *(const bf16x8*)(smem + i16 * pitch + ((k0 + u) * 32 + g4 * 8) * 2);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[u]), xb, acc, 0, 0, 0);
+                }
+            }
+        }
+        const int gn = g + WAVES;
+        if (gn < g_hi) issue(gn, 0);
+        // D: row = 4*g4 + r (weight row), col = i16 (batch)
+        if (i16 < BATCH) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) y[(size_t)(g * 16 + 4 * g4 + rr)] = acc[rr];
+        }
+        g = gn;
+    }
+}
+
 struct Ctx {
     std::vector<uint16_t*> W;
     uint16_t* x;
@@ -312,6 +365,15 @@ static void run_persist(const char* name, Ctx& c, int blocks) {
     timeit(name, c, [&](int l) { hipLaunchKernelGGL((k_persist<WAVES, NR, U, NORM>), dim3(blocks), dim3(WAVES * 64), c.K * 2, c.st, c.W[l], c.x, c.y, c.N, c.K); });
 }
 
+template <int WAVES, int U, int BATCH>
+static void run_mfma(const char* name, Ctx& c, int blocks) {
+    const size_t smem = 16 * ((size_t)c.K * 2 + 16);
+    static bool set = false;
+    if (!set) { CHECK(hipFuncSetAttribute((const void*)k_mfma<WAVES, U, BATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); set = true; }
+    if (smem > 159 * 1024) { printf("%-46s skipped (LDS)\n", name); return; }
+    timeit(name, c, [&](int l) { hipLaunchKernelGGL((k_mfma<WAVES, U, BATCH>), dim3(blocks), dim3(WAVES * 64), smem, c.st, c.W[l], c.x, c.y, c.N, c.K); });
+}
+
 int main(int argc, char** argv) {
     Ctx c;
     c.NL = 24;
@@ -329,21 +391,13 @@ int main(int argc, char** argv) {
         c.N = s[0]; c.K = s[1];
         printf("---- N=%d K=%d (%.1f MB) ----\n", c.N, c.K, (double)c.N * c.K * 2 / 1e6);
         run_ro<4, 2, 8, 1>("readonly  w4 nr2 u8 nt", c);
-        run_static<4, 2, 8, 1, true>("static    w4 nr2 u8 nt early", c);
-        run_static<4, 4, 8, 1, true>("static    w4 nr4 u8 nt early", c);
-        run_persist<4, 2, 8, false>("persist   w4 nr2  256blk", c, 256);
-        run_persist<4, 2, 8, false>("persist   w4 nr2  512blk", c, 512);
-        run_persist<4, 2, 8, false>("persist   w4 nr2  768blk", c, 768);
-        run_persist<4, 2, 8, false>("persist   w4 nr2 1024blk", c, 1024);
-        run_persist<8, 2, 8, false>("persist   w8 nr2  256blk", c, 256);
-        run_persist<8, 2, 8, false>("persist   w8 nr2  512blk", c, 512);
-        run_persist<4, 4, 8, false>("persist   w4 nr4  512blk", c, 512);
-        run_persist<4, 2, 8, true>("persist   w4 nr2  512blk NORM", c, 512);
-        run_persist<4, 2, 8, true>("persist   w4 nr2 1024blk NORM", c, 1024);
-        run_persist<8, 2, 8, true>("persist   w8 nr2  256blk NORM", c, 256);
         run_persist<8, 2, 8, true>("persist   w8 nr2  512blk NORM", c, 512);
-        run_persist<4, 4, 8, true>("persist   w4 nr4  512blk NORM", c, 512);
-        run_persist<16, 2, 8, true>("persist  w16 nr2  256blk NORM", c, 256);
+        run_mfma<4, 8, 8>("mfma      w4 u8  256blk", c, 256);
+        run_mfma<8, 8, 8>("mfma      w8 u8  256blk", c, 256);
+        run_mfma<4, 16, 8>("mfma      w4 u16 256blk", c, 256);
+        run_mfma<8, 16, 8>("mfma      w8 u16 256blk", c, 256);
+        run_mfma<16, 8, 8>("mfma      w16 u8 256blk", c, 256);
+        run_mfma<16, 16, 8>("mfma      w16 u16 256blk", c, 256);
     }
     return 0;
 }
