@@ -73,24 +73,44 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
         }
     };
 
-    u32x4_t wr[NR][U];
-    auto issue_weights = [&](int g, int kc0, int c0, int nch) {
-        int r0, r1;
-        group_rows(g, r0, r1);
-        const u32x4_t* w0 = (const u32x4_t*)(W + (size_t)r0 * p.ldw + kc0);
-        const u32x4_t* w1 = (const u32x4_t*)(W + (size_t)r1 * p.ldw + kc0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int c = c0 + u * 64 + lane;
-            wr[0][u] = (c < nch) ? ld_nt(w0 + c) : (u32x4_t){0u, 0u, 0u, 0u};
-            wr[1][u] = (c < nch) ? ld_nt(w1 + c) : (u32x4_t){0u, 0u, 0u, 0u};
+    // The wave's work is a linear sequence of 8-step blocks: for every round (group) x K phase x 512-chunk block.
+    // A step = one 16-byte load per lane per row.  The producer cursor runs exactly one block ahead of the consumer:
+    // after step u of the current block is consumed, step u of the next block is requested into the same registers
+    // (rolling ring: ~16 loads per lane are in flight at every instant, across group and phase boundaries).
+    const int n_phase = (K + KC - 1) / KC;
+    struct Cursor { int rd, ph, blk; };
+    auto phase_nch = [&](int ph) { return min(KC, K - ph * KC) >> 3; };           // 16-byte chunks in a phase
+    auto phase_nblk = [&](int ph) { return (phase_nch(ph) + 64 * U - 1) / (64 * U); };
+    auto advance = [&](Cursor& c) {
+        if (++c.blk >= phase_nblk(c.ph)) {
+            c.blk = 0;
+            if (++c.ph >= n_phase) { c.ph = 0; ++c.rd; }
         }
     };
+    u32x4_t wr[NR][U];
+    const u32x4_t* w0p = nullptr;   // row pointers of the producer's current (group, phase)
+    const u32x4_t* w1p = nullptr;
+    auto producer_rows = [&](const Cursor& c) {
+        const int g = g_lo + c.rd * GW + wave;
+        int r0, r1;
+        group_rows(min(g, g_hi - 1), r0, r1);
+        w0p = (const u32x4_t*)(W + (size_t)r0 * p.ldw + c.ph * KC);
+        w1p = (const u32x4_t*)(W + (size_t)r1 * p.ldw + c.ph * KC);
+    };
+    auto issue_step = [&](const Cursor& c, int u, bool active) {
+        const int ch = c.blk * 64 * U + u * 64 + lane;
+        const bool ok = active && ch < phase_nch(c.ph);
+        wr[0][u] = ok ? ld_nt(w0p + ch) : (u32x4_t){0u, 0u, 0u, 0u};
+        wr[1][u] = ok ? ld_nt(w1p + ch) : (u32x4_t){0u, 0u, 0u, 0u};
+    };
 
-    // ---- first request before the prologue: it does not depend on x ----
-    int g = g_lo + wave;
-    const int nch0 = min(KC, K) >> 3;
-    if (g < g_hi) issue_weights(g, 0, 0, nch0);
+    // ---- first block requested before the prologue: it does not depend on x ----
+    Cursor P = {0, 0, 0}, Cc = {0, 0, 0};
+    const int my_rounds = (g_lo + wave < g_hi) ? (g_hi - g_lo - wave + GW - 1) / GW : 0;   // groups this wave really owns
+    producer_rows(P);
+#pragma unroll
+    for (int u = 0; u < U; ++u) issue_step(P, u, my_rounds > 0);
+    advance(P);
 
     // ---- RMSNorm statistics ----
     float rstd[B];
@@ -168,7 +188,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
             }
         }
     };
-    stage_x(0, nch0);
+    stage_x(0, phase_nch(0));
     __syncthreads();
 
     // LMHEAD: running best over this wave's rows
@@ -179,57 +199,59 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
         best[b] = -INFINITY;
         besti[b] = 0x7fffffff;
     }
+    float acc[NR][B];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
 
-    for (int rd = 0; rd < rounds; ++rd, g += GW) {
-        const bool valid = g < g_hi;
-        float acc[NR][B];
+    float red0[B], red1[B];
+    // every wave of the block walks the same number of rounds (block-uniform barriers in the multi-phase case)
+    while (Cc.rd < rounds) {
+        const bool valid = Cc.rd < my_rounds;
+        if (multi_phase && Cc.blk == 0 && (Cc.rd != 0 || Cc.ph != 0)) {   // new phase: restage x (loads keep flying)
+            __syncthreads();
+            stage_x(Cc.ph * KC, phase_nch(Cc.ph));
+            __syncthreads();
+        }
+        const bool p_active = P.rd < my_rounds;
+        if (P.blk == 0) producer_rows(P);
+        const int nch = phase_nch(Cc.ph);
 #pragma unroll
-        for (int r = 0; r < NR; ++r)
+        for (int u = 0; u < U; ++u) {
+            const int c = Cc.blk * 64 * U + u * 64 + lane;
+            if (valid && Cc.blk * 64 * U + u * 64 < nch) {   // wave-uniform
+                const int cc = (c < nch) ? c : 0;
 #pragma unroll
-            for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
-
-        for (int kc0 = 0; kc0 < K; kc0 += KC) {
-            const int nch = min(KC, K - kc0) >> 3;
-            if (multi_phase && (rd != 0 || kc0 != 0)) {   // restage x for this phase (block-uniform control flow)
-                if (valid) issue_weights(g, kc0, 0, nch);
-                __syncthreads();
-                stage_x(kc0, nch);
-                __syncthreads();
-            }
-            if (valid) {
-                for (int c0 = 0; c0 < nch; c0 += 64 * U) {
-                    if (c0 != 0) issue_weights(g, kc0, c0, nch);
+                for (int b = 0; b < B; ++b) {
+                    const u32x4_t xv = xs[b * (KC >> 3) + cc];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int c = c0 + u * 64 + lane;
-                        if (c0 + u * 64 < nch) {   // wave-uniform
-                            const int cc = (c < nch) ? c : 0;
-#pragma unroll
-                            for (int b = 0; b < B; ++b) {
-                                const u32x4_t xv = xs[b * (KC >> 3) + cc];
-#pragma unroll
-                                for (int r = 0; r < NR; ++r) {
-                                    float a = acc[r][b];
-                                    a = dot2_bf16(wr[r][u][0], xv[0], a);
-                                    a = dot2_bf16(wr[r][u][1], xv[1], a);
-                                    a = dot2_bf16(wr[r][u][2], xv[2], a);
-                                    a = dot2_bf16(wr[r][u][3], xv[3], a);
-                                    acc[r][b] = a;
-                                }
-                            }
-                        }
+                    for (int r = 0; r < NR; ++r) {
+                        float a = acc[r][b];
+                        a = dot2_bf16(wr[r][u][0], xv[0], a);
+                        a = dot2_bf16(wr[r][u][1], xv[1], a);
+                        a = dot2_bf16(wr[r][u][2], xv[2], a);
+                        a = dot2_bf16(wr[r][u][3], xv[3], a);
+                        acc[r][b] = a;
                     }
                 }
             }
+            issue_step(P, u, p_active);   // refill the register just consumed with the same step of the next block
         }
-        // single phase: the next group's head goes out before this group's reduction / epilogue
-        if (!multi_phase && g + GW < g_hi) issue_weights(g + GW, 0, 0, nch0);
-        if (!valid) continue;
+        const bool group_done = (Cc.ph == n_phase - 1) && (Cc.blk == phase_nblk(Cc.ph) - 1);
+        const int g = g_lo + Cc.rd * GW + wave;
+        advance(Cc);
+        advance(P);
+        if (!group_done || !valid) continue;
 
 #pragma unroll
         for (int r = 0; r < NR; ++r)
 #pragma unroll
-            for (int b = 0; b < B; ++b) acc[r][b] = wave_sum(acc[r][b]);
+            for (int b = 0; b < B; ++b) {
+                const float t = wave_sum(acc[r][b]);
+                acc[r][b] = 0.f;
+                if (r == 0) red0[b] = t; else red1[b] = t;
+            }
 
         int r0, r1;
         group_rows(g, r0, r1);
@@ -237,21 +259,21 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
 #pragma unroll
             for (int b = 0; b < B; ++b)
                 if (lane == b) {
-                    ((bf16_t*)p.y)[(size_t)b * p.ldy + r0] = f2bf(acc[0][b]);
-                    if (2 * g + 1 < p.n_rows) ((bf16_t*)p.y)[(size_t)b * p.ldy + r1] = f2bf(acc[1][b]);
+                    ((bf16_t*)p.y)[(size_t)b * p.ldy + r0] = f2bf(red0[b]);
+                    if (2 * g + 1 < p.n_rows) ((bf16_t*)p.y)[(size_t)b * p.ldy + r1] = f2bf(red1[b]);
                 }
         } else if (MODE == MODE_RESID) {
 #pragma unroll
             for (int b = 0; b < B; ++b)
                 if (lane == b) {
                     bf16_t* hp = (bf16_t*)p.y + (size_t)b * p.ldy;
-                    hp[r0] = f2bf(bf2f(hp[r0]) + acc[0][b]);
-                    if (2 * g + 1 < p.n_rows) hp[r1] = f2bf(bf2f(hp[r1]) + acc[1][b]);
+                    hp[r0] = f2bf(bf2f(hp[r0]) + red0[b]);
+                    if (2 * g + 1 < p.n_rows) hp[r1] = f2bf(bf2f(hp[r1]) + red1[b]);
                 }
         } else if (MODE == MODE_GATEUP) {
 #pragma unroll
             for (int b = 0; b < B; ++b)
-                if (lane == b) ((bf16_t*)p.y)[(size_t)b * p.ldy + g] = f2bf(silu(acc[0][b]) * acc[1][b]);
+                if (lane == b) ((bf16_t*)p.y)[(size_t)b * p.ldy + g] = f2bf(silu(red0[b]) * red1[b]);
         } else if (MODE == MODE_QKV) {
             const int hd = p.head_dim, half = hd >> 1;
             const int hb = g / half, d = g - hb * half;
@@ -260,7 +282,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
                 if (lane == b) {
                     const int pos = p.ctx_len[b];
                     // linear outputs are bf16 activations in the reference; RoPE acts on those
-                    const float x0 = bf2f(f2bf(acc[0][b])), x1 = bf2f(f2bf(acc[1][b]));
+                    const float x0 = bf2f(f2bf(red0[b])), x1 = bf2f(f2bf(red1[b]));
                     if (hb < p.Hq + p.Hkv) {
                         const float cs = p.cos_t[(size_t)pos * half + d], sn = p.sin_t[(size_t)pos * half + d];
                         const bf16_t y0 = f2bf(x0 * cs - x1 * sn), y1 = f2bf(x1 * cs + x0 * sn);
@@ -288,7 +310,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
                 for (int r = 0; r < NR; ++r) {
                     const int row = r == 0 ? r0 : r1;
                     if (r == 1 && 2 * g + 1 >= p.n_rows) continue;
-                    const float v = acc[r][b];
+                    const float v = r == 0 ? red0[b] : red1[b];
                     if (v > best[b] || (v == best[b] && row < besti[b])) {
                         best[b] = v;
                         besti[b] = row;
@@ -640,10 +662,11 @@ int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, i
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
+// splits of the KV range per (row, kv head): ~512 blocks in flight, at most 8 partials to merge
 int decode_attn_nsplit(int B, int Hkv) {
-    int ns = 256 / (B * Hkv);
+    int ns = 512 / (B * Hkv);
     if (ns < 1) ns = 1;
-    if (ns > 16) ns = 16;
+    if (ns > 8) ns = 8;
     return ns;
 }
 

@@ -1,0 +1,353 @@
+// decode_mfma.hip -- small-batch (3 <= B <= 8) decode projections on the matrix cores.
+//
+// At B >= 3 the per-lane dot-product GEMV of decode.hip stops being HBM-bound (B accumulators per row, B LDS reads per
+// weight chunk, B wave reductions per row), so the batch is treated as what it is: a [B,K] x [K,N] GEMM with a tiny M.
+// Weights are read from a second, MFMA-FRAGMENT-MAJOR copy built at finalize:
+//     fm[((n/16)*(K/32) + k/32) * 64 + lane] = 8 bf16 = W[16*(n/16) + (lane&15)][32*(k/32) + 8*(lane>>4) .. +8]
+// i.e. one wave load instruction = one contiguous 1 KiB tile = the A operand of one v_mfma_f32_16x16x32_bf16, straight
+// from HBM to VGPRs (nt), no LDS round trip, no cross-lane reduction (tools/gemv_sweep.hip: 5.7 TB/s at B=8 vs 4.3 TB/s
+// for MFMA over the row-major copy and 3.5 TB/s for the dot2 path).  The B activation rows (+1 zero row for the 16-B
+// padding columns) sit in LDS with an odd 16-byte-slot pitch and are the B operand.
+// A block (8 waves) owns one task (1 or 2 row tiles) at a time and splits K 8 ways; the partial tiles meet in LDS.
+// Same fused prologues / epilogues as the GEMV: RMSNorm, attention split merge | RoPE + paged K/V append, +residual,
+// SiLU*mul, greedy argmax.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+enum { MODE_QKV = 0, MODE_RESID = 1, MODE_GATEUP = 2, MODE_LMHEAD = 3, MODE_PLAIN = 4 };
+constexpr int PSTRIDE = 132;
+constexpr int GW = 8;
+__device__ __forceinline__ u32x4_t ld_nt(const u32x4_t* p) { return __builtin_nontemporal_load(p); }
+
+// row-major [N, ld] -> fragment-major tiles (N % 16 == 0, K % 32 == 0)
+__global__ __launch_bounds__(256) void emmax_repack_fm_kernel(const bf16_t* __restrict__ src, int ld, u32x4_t* __restrict__ dst, int N, int K) {
+    const size_t total = (size_t)N * K / 8;
+    for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < total; c += (size_t)gridDim.x * 256) {
+        const int lane = (int)(c & 63);
+        const size_t tile = c >> 6;
+        const int kt = (int)(tile % (K / 32)), nt = (int)(tile / (K / 32));
+        const int n = nt * 16 + (lane & 15), k = kt * 32 + (lane >> 4) * 8;
+        dst[c] = *(const u32x4_t*)(src + (size_t)n * ld + k);
+    }
+}
+
+template <int MODE, bool NORM, bool XATTN>
+__global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParams p) {
+    constexpr int TILES = (MODE == MODE_QKV || MODE == MODE_GATEUP) ? 2 : 1;
+    constexpr int U = 8;
+    constexpr int NT = GW * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int B = p.batch;
+    const int K = p.K, KC = p.kc;
+    const int pitch = KC * 2 + 16;                               // bytes per staged x row
+    float* red = (float*)(smem + (size_t)(B + 1) * pitch);      // [GW][TILES][4][64]
+    float* srstd = red + GW * TILES * 256;                      // [B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g4 = lane >> 4, c16 = lane & 15;
+    const int KT = K / 32;                                       // k-steps of the whole row
+    const int n_tasks = p.n_groups;
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int tq = n_tasks / G, tr = n_tasks % G;
+    const int t_lo = bid * tq + min(bid, tr), t_hi = t_lo + tq + (bid < tr ? 1 : 0);
+    const int n_phase = (K + KC - 1) / KC;
+    const u32x4_t* __restrict__ Wfm = (const u32x4_t*)p.W;
+
+    // tile index (16-row units) of tile tt of task t
+    auto tile_of = [&](int t, int tt) {
+        if (MODE == MODE_QKV) {
+            const int per_head = p.head_dim / 16, halfb = per_head / 2;     // 8 tiles per head, 4 low + 4 high
+            const int hb = t / halfb, db = t - hb * halfb;
+            return hb * per_head + db + tt * halfb;
+        }
+        return t * TILES + tt;
+    };
+    // this wave's k-step range inside phase ph
+    auto slice = [&](int ph, int& k_lo, int& k_n) {
+        const int kt0 = ph * (KC / 32), ktn = min(KC, K - ph * KC) / 32;
+        const int q = ktn / GW, r = ktn % GW;
+        k_lo = kt0 + wave * q + min(wave, r);
+        k_n = q + (wave < r ? 1 : 0);
+    };
+
+    u32x4_t wr[TILES][U];
+    auto issue = [&](int t, int k_lo, int k0, int k_n) {
+#pragma unroll
+        for (int tt = 0; tt < TILES; ++tt) {
+            const u32x4_t* wt = Wfm + ((size_t)tile_of(t, tt) * KT + k_lo) * 64 + lane;
+#pragma unroll
+            for (int u = 0; u < U; ++u) wr[tt][u] = (k0 + u < k_n) ? ld_nt(wt + (size_t)(k0 + u) * 64) : (u32x4_t){0u, 0u, 0u, 0u};
+        }
+    };
+
+    int kl0, kn0;
+    slice(0, kl0, kn0);
+    if (t_lo < t_hi) issue(t_lo, kl0, 0, kn0);   // head of the stream before the prologue
+
+    // ---- RMSNorm statistics ----
+    if (NORM) {
+        __shared__ float rsum[GW][EMMAX_MAX_DECODE_BATCH];
+        for (int b = 0; b < B; ++b) {
+            float ss = 0.f;
+            const u32x4_t* xr = (const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx);
+            for (int c = tid; c < (K >> 3); c += NT) {
+                const u32x4_t v = xr[c];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = bf_lo(v[j]), bb = bf_hi(v[j]);
+                    ss += a * a + bb * bb;
+                }
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) rsum[wave][b] = ss;
+        }
+        __syncthreads();
+        if (tid < B) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < GW; ++w) t += rsum[w][tid];
+            srstd[tid] = rsqrtf(t / (float)K + p.eps);
+        }
+        __syncthreads();
+    }
+
+    auto stage_x = [&](int ph) {
+        const int kc0 = ph * KC, nch = min(KC, K - kc0) >> 3;
+        for (int b = 0; b <= B; ++b) {
+            const u32x4_t* xr = (const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx + kc0);
+            const float rs = (NORM && b < B) ? srstd[b] : 1.f;
+            for (int c = tid; c < nch; c += NT) {
+                u32x4_t v = {0u, 0u, 0u, 0u};
+                if (b < B) {
+                    if (XATTN) {
+                        const int cg = (kc0 >> 3) + c;
+                        const float* pp = p.attn_part + (size_t)(b * p.Hq + (cg >> 4)) * p.nsplit * PSTRIDE;
+                        const int d0 = (cg & 15) * 8;
+                        float M = -INFINITY;
+                        for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, pp[s * PSTRIDE + 128]);
+                        float den = 0.f, a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        for (int s = 0; s < p.nsplit; ++s) {
+                            const float ms = pp[s * PSTRIDE + 128];
+                            const float wgt = (ms == -INFINITY) ? 0.f : __expf(ms - M);
+                            den += pp[s * PSTRIDE + 129] * wgt;
+                            const f32x4_t o0 = *(const f32x4_t*)(pp + s * PSTRIDE + d0);
+                            const f32x4_t o1 = *(const f32x4_t*)(pp + s * PSTRIDE + d0 + 4);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                a8[j] += o0[j] * wgt;
+                                a8[4 + j] += o1[j] * wgt;
+                            }
+                        }
+                        const float inv = den > 0.f ? 1.0f / den : 0.f;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = pack_bf16x2(a8[2 * j] * inv, a8[2 * j + 1] * inv);
+                    } else {
+                        v = xr[c];
+                    }
+                    if (NORM) {
+                        const u32x4_t wv = *((const u32x4_t*)((const bf16_t*)p.norm_w + kc0) + c);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float a = bf2f(f2bf(bf_lo(v[j]) * rs)) * bf_lo(wv[j]);
+                            const float bb = bf2f(f2bf(bf_hi(v[j]) * rs)) * bf_hi(wv[j]);
+                            v[j] = pack_bf16x2(a, bb);
+                        }
+                    }
+                }
+                *(u32x4_t*)(smem + (size_t)b * pitch + (size_t)c * 16) = v;
+            }
+        }
+    };
+    stage_x(0);
+    __syncthreads();
+
+    const int xrow = c16 < B ? c16 : B;   // padding columns of the 16-wide batch side read the zero row
+    // LMHEAD: per-thread running best of the (row slot, batch) it finalises
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+
+    for (int t = t_lo; t < t_hi; ++t) {
+        f32x4_t acc[TILES];
+#pragma unroll
+        for (int tt = 0; tt < TILES; ++tt) acc[tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int ph = 0; ph < n_phase; ++ph) {
+            int k_lo, k_n;
+            slice(ph, k_lo, k_n);
+            if (n_phase > 1 && (ph != 0 || t != t_lo)) {
+                issue(t, k_lo, 0, k_n);
+                __syncthreads();
+                stage_x(ph);
+                __syncthreads();
+            }
+            const unsigned char* xb = smem + (size_t)xrow * pitch + ((size_t)(k_lo - ph * (KC / 32)) * 32 + g4 * 8) * 2;
+            for (int k0 = 0; k0 < k_n; k0 += U) {
+                if (k0 != 0) issue(t, k_lo, k0, k_n);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (k0 + u < k_n) {
+                        const bf16x8_t xf = *(const bf16x8_t*)(xb + (size_t)(k0 + u) * 64);
+#pragma unroll
+                        for (int tt = 0; tt < TILES; ++tt)
+                            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wr[tt][u]), xf, acc[tt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (n_phase == 1 && t + 1 < t_hi) issue(t + 1, kl0, 0, kn0);   // next task's head flies during the reduction
+        // ---- cross-wave reduction: red[wave][tile][r][lane] ----
+#pragma unroll
+        for (int tt = 0; tt < TILES; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((wave * TILES + tt) * 4 + r) * 64 + lane] = acc[tt][r];
+        __syncthreads();
+        if (tid < 256) {
+            const int l = tid & 63, r = tid >> 6;
+            const int c = l & 15, row_in = 4 * (l >> 4) + r;       // batch column, row inside the tile
+            float v[TILES];
+#pragma unroll
+            for (int tt = 0; tt < TILES; ++tt) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < GW; ++w) s += red[((w * TILES + tt) * 4 + r) * 64 + l];
+                v[tt] = s;
+            }
+            if (c < B) {
+                if (MODE == MODE_PLAIN) {
+                    ((bf16_t*)p.y)[(size_t)c * p.ldy + t * 16 + row_in] = f2bf(v[0]);
+                } else if (MODE == MODE_RESID) {
+                    bf16_t* hp = (bf16_t*)p.y + (size_t)c * p.ldy + t * 16 + row_in;
+                    *hp = f2bf(bf2f(*hp) + v[0]);
+                } else if (MODE == MODE_GATEUP) {
+                    ((bf16_t*)p.y)[(size_t)c * p.ldy + t * 16 + row_in] = f2bf(silu(v[0]) * v[TILES - 1]);
+                } else if (MODE == MODE_QKV) {
+                    const int hd = p.head_dim, half = hd >> 1, halfb = hd / 32;
+                    const int hb = t / halfb, d = (t - hb * halfb) * 16 + row_in;
+                    const int pos = p.ctx_len[c];
+                    const float x0 = bf2f(f2bf(v[0])), x1 = bf2f(f2bf(v[TILES - 1]));
+                    if (hb < p.Hq + p.Hkv) {
+                        const float cs = p.cos_t[(size_t)pos * half + d], sn = p.sin_t[(size_t)pos * half + d];
+                        const bf16_t y0 = f2bf(x0 * cs - x1 * sn), y1 = f2bf(x1 * cs + x0 * sn);
+                        if (hb < p.Hq) {
+                            bf16_t* q = (bf16_t*)p.y + (size_t)c * p.ldy + hb * hd;
+                            q[d] = y0;
+                            q[d + half] = y1;
+                        } else {
+                            const int pg = p.page_table[(size_t)c * p.max_pages + pos / p.page];
+                            bf16_t* kc = (bf16_t*)p.kcache + (((size_t)pg * p.Hkv + (hb - p.Hq)) * p.page + pos % p.page) * hd;
+                            kc[d] = y0;
+                            kc[d + half] = y1;
+                        }
+                    } else {
+                        const int pg = p.page_table[(size_t)c * p.max_pages + pos / p.page];
+                        bf16_t* vc = (bf16_t*)p.vcache + (((size_t)pg * p.Hkv + (hb - p.Hq - p.Hkv)) * p.page + pos % p.page) * hd;
+                        vc[d] = f2bf(x0);
+                        vc[d + half] = f2bf(x1);
+                    }
+                } else if (MODE == MODE_LMHEAD) {
+                    const int row = t * 16 + row_in;
+                    if (row < p.n_rows) {
+                        if (v[0] > best || (v[0] == best && row < besti)) {
+                            best = v[0];
+                            besti = row;
+                        }
+                        if (p.logits_out) p.logits_out[(size_t)c * p.n_rows + row] = v[0];
+                    }
+                }
+            }
+        }
+        __syncthreads();   // red[] is reused by the next task
+    }
+
+    if (MODE == MODE_LMHEAD) {
+        float* bv = red;                      // [256]
+        int* bi = (int*)(red + 256);          // [256]
+        if (tid < 256) {
+            bv[tid] = best;
+            bi[tid] = besti;
+        }
+        __syncthreads();
+        if (tid < B) {   // the 16 (row slot) entries of batch column tid: l = g*16 + tid, r = 0..3
+            float v0 = -INFINITY;
+            int i0 = 0x7fffffff;
+            for (int g = 0; g < 4; ++g)
+                for (int r = 0; r < 4; ++r) {
+                    const int e = r * 64 + g * 16 + tid;
+                    const float v = bv[e];
+                    const int ii = bi[e];
+                    if (v > v0 || (v == v0 && ii < i0)) {
+                        v0 = v;
+                        i0 = ii;
+                    }
+                }
+            p.part_val[(size_t)blockIdx.x * B + tid] = v0;
+            p.part_idx[(size_t)blockIdx.x * B + tid] = i0;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_repack_fm(const void* src, int ld, void* dst, int N, int K, hipStream_t stream) {
+    if (N % 16 || K % 32 || ld % 8) return -1;
+    hipLaunchKernelGGL(emmax_repack_fm_kernel, dim3(2048), dim3(256), 0, stream, (const bf16_t*)src, ld, (u32x4_t*)dst, N, K);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+static size_t mfma_smem(int B, int kc, int tiles) { return (size_t)(B + 1) * (kc * 2 + 16) + (size_t)GW * tiles * 256 * 4 + 64; }
+
+// K phase length: multiple of 32, activations (B+1 rows) + reduction buffer within ~150 KiB
+static int mfma_kc(int B, int K, int tiles) {
+    const size_t budget = 150 * 1024 - (size_t)GW * tiles * 256 * 4 - 64;
+    int cap = (int)(budget / (B + 1) - 16) / 2;
+    cap &= ~31;
+    if (K <= cap) return K;
+    const int nph = cdiv(K, cap);
+    return cdiv(cdiv(K, nph), 32) * 32;
+}
+
+int decode_mfma_lmhead_grid(int n_rows, int max_parts) { return min(min(256, cdiv(n_rows, 16)), max_parts); }
+
+template <int MODE, bool NORM, bool XATTN>
+static int launch_mfma_t(GemvParams p, int B, hipStream_t stream) {
+    constexpr int TILES = (MODE == MODE_QKV || MODE == MODE_GATEUP) ? 2 : 1;
+    if (p.K % 32 || p.n_rows % (16 * TILES)) {
+        if (!(MODE == MODE_LMHEAD && p.n_rows % 16 == 0)) return -1;
+    }
+    p.batch = B;
+    p.kc = mfma_kc(B, p.K, TILES);
+    if (NORM && p.kc != p.K) return -1;
+    p.n_groups = p.n_rows / (16 * TILES);
+    int grid = min(256, p.n_groups);
+    if (MODE == MODE_LMHEAD) grid = min(grid, p.max_parts);
+    const size_t smem = mfma_smem(B, p.kc, TILES);
+    hipLaunchKernelGGL((emmax_decode_mfma_kernel<MODE, NORM, XATTN>), dim3(grid), dim3(GW * 64), smem, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_decode_mfma(int mode, const GemvParams& p, int B, hipStream_t stream) {
+    if (B < 1 || B > EMMAX_MAX_DECODE_BATCH) return -1;
+    switch (mode) {
+        case MODE_QKV: return launch_mfma_t<MODE_QKV, true, false>(p, B, stream);
+        case MODE_RESID:
+            return p.attn_part ? launch_mfma_t<MODE_RESID, false, true>(p, B, stream) : launch_mfma_t<MODE_RESID, false, false>(p, B, stream);
+        case MODE_GATEUP: return launch_mfma_t<MODE_GATEUP, true, false>(p, B, stream);
+        case MODE_LMHEAD: return launch_mfma_t<MODE_LMHEAD, true, false>(p, B, stream);
+        case MODE_PLAIN: return launch_mfma_t<MODE_PLAIN, false, false>(p, B, stream);
+        default: return -1;
+    }
+}
+
+int decode_mfma_init() {
+    static int done = -1;
+    if (done == 0) return 0;
+    const int lim = 160 * 1024 - 4096;
+    hipError_t e = hipSuccess;
+#define SET(M, N_, X) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_mfma_kernel<M, N_, X>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
+    SET(MODE_QKV, true, false); SET(MODE_RESID, false, true); SET(MODE_RESID, false, false); SET(MODE_GATEUP, true, false);
+    SET(MODE_LMHEAD, true, false); SET(MODE_PLAIN, false, false);
+#undef SET
+    done = (e == hipSuccess) ? 0 : -4;
+    return done;
+}

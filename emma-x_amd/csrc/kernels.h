@@ -70,6 +70,7 @@ struct GemvParams {
     int n_groups;           // 2-row groups (set by the launcher)
     int max_parts;          // LMHEAD: capacity of part_val / part_idx in blocks
     int kc;                 // K phase length (set by the launcher)
+    int batch;              // MFMA path: runtime batch (set by the launcher)
     float eps;
     // QKV epilogue
     int head_dim, Hq, Hkv, page, max_pages;
@@ -122,3 +123,10 @@ struct FinishParams {
 int launch_decode_finish(const FinishParams& p, hipStream_t stream);
 int launch_set_tokens(int32_t* cur_tok, const int32_t* toks, int B, hipStream_t stream);
 
+
+// ---- decode_mfma.hip: small-batch (B >= 3) projections on MFMA over the fragment-major weight copy ----
+int launch_repack_fm(const void* src, int ld, void* dst, int N, int K, hipStream_t stream);
+int launch_decode_mfma(int mode, const GemvParams& p, int B, hipStream_t stream);   // p.W = fragment-major copy
+int decode_mfma_lmhead_grid(int n_rows, int max_parts);
+int decode_mfma_init();
+#define EMMAX_MFMA_MIN_BATCH 3

@@ -68,6 +68,7 @@ struct TowerW {
 };
 struct LayerW {
     bf16 *ln1, *wqkv, *wo, *ln2, *wgu, *wdown;
+    bf16 *wqkv_fm, *wo_fm, *wgu_fm, *wdown_fm;   // MFMA-fragment-major copies for the B >= 3 decode path
 };
 
 struct emmax_model {
@@ -78,7 +79,7 @@ struct emmax_model {
     int H, inter, inter_p, q_dim, kv_dim, qkv_dim, vocab, vocab_p, V, Vp, P1, P1p;
     TowerW tw[2];
     bf16 *pj1_w, *pj1_b, *pj2_w, *pj2_b, *pj3_w, *pj3_b;
-    bf16 *embed, *final_norm, *lm_head;
+    bf16 *embed, *final_norm, *lm_head, *lm_head_fm;
     std::vector<LayerW> layers;
 };
 
@@ -179,9 +180,14 @@ static void plan_arena(emmax_model* m, Bump& b) {
         L.ln2 = b.take(m->H);
         L.wgu = b.take((int64_t)2 * m->inter_p * m->H);
         L.wdown = b.take((int64_t)m->H * m->inter_p);
+        L.wqkv_fm = b.take((int64_t)m->qkv_dim * m->H);
+        L.wo_fm = b.take((int64_t)m->H * m->q_dim);
+        L.wgu_fm = b.take((int64_t)2 * m->inter_p * m->H);
+        L.wdown_fm = b.take((int64_t)m->H * m->inter_p);
     }
     m->final_norm = b.take(m->H);
     m->lm_head = b.take((int64_t)m->vocab_p * m->H);
+    m->lm_head_fm = b.take((int64_t)m->vocab_p * m->H);
 }
 
 // copy a bound [rows, cols] bf16 matrix into dst (row pitch dst_ld elements) starting at dst row `row0`
@@ -369,6 +375,16 @@ static int run_vision(emmax_session* s, bool from_u8, const void* src, int B, vo
     return 0;
 }
 
+// B <= 2: per-lane dot-product GEMV over the row-major weights; B >= 3: MFMA over the fragment-major copy
+static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_fm, int B, hipStream_t st) {
+    if (B >= EMMAX_MFMA_MIN_BATCH) {
+        p.W = w_fm;
+        return launch_decode_mfma(mode, p, B, st);
+    }
+    p.W = w_rm;
+    return launch_decode_gemv(mode, p, B, st);
+}
+
 static bf16* kcache_of(emmax_session* s, int layer) { return s->kv + (size_t)layer * s->kv_layer_stride; }
 static bf16* vcache_of(emmax_session* s, int layer) { return s->kv + (size_t)layer * s->kv_layer_stride + s->kv_layer_stride / 2; }
 
@@ -376,13 +392,14 @@ static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* log
     emmax_model* m = s->m;
     GemvParams p;
     memset(&p, 0, sizeof(p));
-    p.x = s->dh; p.ldx = m->H; p.W = m->lm_head; p.ldw = m->H; p.K = m->H; p.norm_w = m->final_norm; p.eps = m->cfg.rms_eps;
+    p.x = s->dh; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = m->final_norm; p.eps = m->cfg.rms_eps;
     p.n_rows = m->vocab; p.max_parts = s->n_lm_blocks; p.part_val = s->part_val; p.part_idx = s->part_idx; p.logits_out = logits_out;
-    KCHK(launch_decode_gemv(GEMV_LMHEAD, p, B, st));
+    KCHK(launch_proj(GEMV_LMHEAD, p, m->lm_head, m->lm_head_fm, B, st));
     if (do_finish) {
         FinishParams f;
         memset(&f, 0, sizeof(f));
-        f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = decode_lmhead_grid(B, m->H, m->vocab, s->n_lm_blocks); f.B = B;
+        f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = B >= EMMAX_MFMA_MIN_BATCH ? decode_mfma_lmhead_grid(m->vocab, s->n_lm_blocks) : decode_lmhead_grid(B, m->H, m->vocab, s->n_lm_blocks);
+        f.B = B;
         f.cur_tok = s->cur_tok; f.ctx_len = s->ctx_len; f.done = s->done; f.n_out = s->n_out; f.out_ids = s->out_ids;
         f.max_new_p = s->max_new_d; f.max_out = s->max_out; f.max_ctx = s->max_ctx;
         f.eos_id = m->cfg.eos_id; f.pad_id = m->cfg.pad_id; f.is_prefill = is_prefill ? 1 : 0;
@@ -462,12 +479,12 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
     memset(&p, 0, sizeof(p));
     switch (stage) {
         case STAGE_QKV:
-            p.x = s->dh; p.ldx = m->H; p.W = L.wqkv; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln1; p.eps = c.rms_eps;
+            p.x = s->dh; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln1; p.eps = c.rms_eps;
             p.y = s->dq; p.ldy = m->q_dim; p.n_rows = m->qkv_dim;
             p.head_dim = c.head_dim; p.Hq = c.n_heads; p.Hkv = c.n_kv_heads; p.page = PAGE; p.max_pages = s->max_pages;
             p.ctx_len = s->ctx_len; p.page_table = s->page_table; p.cos_t = s->cos_t; p.sin_t = s->sin_t;
             p.kcache = kcache_of(s, li); p.vcache = vcache_of(s, li);
-            KCHK(launch_decode_gemv(GEMV_QKV, p, B, st));
+            KCHK(launch_proj(GEMV_QKV, p, L.wqkv, L.wqkv_fm, B, st));
             return 0;
         case STAGE_ATTN: {
             DecodeAttnParams a;
@@ -478,18 +495,18 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             return 0;
         }
         case STAGE_OPROJ:
-            p.x = s->datt; p.ldx = m->q_dim; p.W = L.wo; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
+            p.x = s->datt; p.ldx = m->q_dim; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
             p.attn_part = s->part; p.nsplit = decode_attn_nsplit(B, c.n_kv_heads); p.Hq = c.n_heads;   // split merge fused into the staging
-            KCHK(launch_decode_gemv(GEMV_RESID, p, B, st));
+            KCHK(launch_proj(GEMV_RESID, p, L.wo, L.wo_fm, B, st));
             return 0;
         case STAGE_GATEUP:
-            p.x = s->dh; p.ldx = m->H; p.W = L.wgu; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln2; p.eps = c.rms_eps;
+            p.x = s->dh; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln2; p.eps = c.rms_eps;
             p.y = s->dact; p.ldy = m->inter_p; p.n_rows = 2 * m->inter_p;
-            KCHK(launch_decode_gemv(GEMV_GATEUP, p, B, st));
+            KCHK(launch_proj(GEMV_GATEUP, p, L.wgu, L.wgu_fm, B, st));
             return 0;
         case STAGE_DOWN:
-            p.x = s->dact; p.ldx = m->inter_p; p.W = L.wdown; p.ldw = m->inter_p; p.K = m->inter_p; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
-            KCHK(launch_decode_gemv(GEMV_RESID, p, B, st));
+            p.x = s->dact; p.ldx = m->inter_p; p.ldw = m->inter_p; p.K = m->inter_p; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
+            KCHK(launch_proj(GEMV_RESID, p, L.wdown, L.wdown_fm, B, st));
             return 0;
         default:
             return fail(EMMAX_ERR_INVALID, "unknown decode stage %d", stage);
@@ -637,9 +654,14 @@ int emmax_model_finalize(emmax_model* m, void* arena, int64_t arena_bytes, emmax
             HIPCHK(hipMemcpy2DAsync((char*)L.wgu + grp, 2 * grp, iu->second.ptr, grp, grp, m->inter / 16, hipMemcpyDeviceToDevice, st));
         }
         PUT2(P + "mlp.down_proj.weight", m->H, m->inter, L.wdown, m->inter_p, 0);
+        KCHK(launch_repack_fm(L.wqkv, m->H, L.wqkv_fm, m->qkv_dim, m->H, st));
+        KCHK(launch_repack_fm(L.wo, m->q_dim, L.wo_fm, m->H, m->q_dim, st));
+        KCHK(launch_repack_fm(L.wgu, m->H, L.wgu_fm, 2 * m->inter_p, m->H, st));
+        KCHK(launch_repack_fm(L.wdown, m->inter_p, L.wdown_fm, m->H, m->inter_p, st));
     }
     PUT1("language_model.model.norm.weight", m->H, m->final_norm);
     PUT2("language_model.lm_head.weight", m->vocab, m->H, m->lm_head, m->H, 0);
+    KCHK(launch_repack_fm(m->lm_head, m->H, m->lm_head_fm, m->vocab_p, m->H, st));
 #undef PUT2
 #undef PUT1
     HIPCHK(hipStreamSynchronize(st));
@@ -684,6 +706,7 @@ int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_
         return fail(EMMAX_ERR_NOMEM, "session memory too small: workspace %lld/%lld, kv %lld/%lld", (long long)ws_bytes,
                     (long long)need_ws, (long long)kvb, (long long)need_kv);
     if (((uintptr_t)ws % 256) || ((uintptr_t)kv % 256)) return fail(EMMAX_ERR_INVALID, "workspace / kv must be 256-byte aligned");
+    if (decode_mfma_init() != 0) return fail(EMMAX_ERR_HIP, "could not raise the dynamic LDS limit of the MFMA decode kernels");
     emmax_session* s = new emmax_session();
     s->m = m;
     s->max_batch = max_batch; s->max_prompt = max_prompt; s->max_ctx = max_ctx;
@@ -922,6 +945,21 @@ int emmax_op_gemv(const void* x, const void* W, void* y, int B, int N, int K, em
     if (decode_gemv_init() != 0) return fail(EMMAX_ERR_HIP, "could not raise the dynamic LDS limit of the GEMV kernels");
     int r = launch_decode_gemv(GEMV_PLAIN, p, B, (hipStream_t)st);
     if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_gemv: unsupported shape (B<=8, K%%8)");
+    return 0;
+}
+
+int emmax_op_repack_fm(const void* W, int ld, void* W_fm, int N, int K, emmax_stream st) {
+    int r = launch_repack_fm(W, ld, W_fm, N, K, (hipStream_t)st);
+    if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_repack_fm: N %% 16, K %% 32, ld %% 8 required");
+    return 0;
+}
+int emmax_op_gemm_small(const void* x, const void* W_fm, void* y, int B, int N, int K, emmax_stream st) {
+    GemvParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.ldx = K; p.W = W_fm; p.ldw = K; p.K = K; p.y = y; p.ldy = N; p.n_rows = N;
+    if (decode_mfma_init() != 0) return fail(EMMAX_ERR_HIP, "could not raise the dynamic LDS limit of the MFMA decode kernels");
+    int r = launch_decode_mfma(GEMV_PLAIN, p, B, (hipStream_t)st);
+    if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_gemm_small: unsupported shape (1 <= B <= 8, N %% 16, K %% 32)");
     return 0;
 }
 

@@ -74,6 +74,8 @@ SIGNATURES = {
     "emmax_op_attention": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_float, C.c_int, _vp]),
     "emmax_op_gemv": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "emmax_op_repack_fm": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp]),
+    "emmax_op_gemm_small": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -73,7 +73,8 @@ int emmax_abi_version(void);
 /* ---- model: weights ------------------------------------------------------------------------------------------------
  * bind every tensor of the HF state dict (key names: vla-scripts/extern/convert_openvla_weights_to_hf.py:74-116) as a
  * bf16 device pointer, then finalize(): all weights are re-laid-out into `arena` (kernel-native: fused QKV rows,
- * 16-row interleaved gate/up, K/N padded to tile multiples, im2col-ordered patch-embed).  After finalize the bound
+ * 16-row interleaved gate/up, K/N padded to tile multiples, im2col-ordered patch-embed; plus an MFMA-fragment-major
+ * copy of the LLM projections for the batch >= 3 decode path).  After finalize the bound
  * pointers are no longer referenced and may be freed. */
 int emmax_model_create(const emmax_config* cfg, emmax_model** out);
 void emmax_model_destroy(emmax_model* m);
@@ -147,6 +148,11 @@ int emmax_op_attention(const void* qkv_dev, int ld_qkv, int q_off, int k_off, in
                        int causal, emmax_stream stream);
 /* Decode-path weight-streaming GEMV: y[b,n] = sum_k x[b,k] W[n,k]  (bf16 in, fp32 accumulate, bf16 out), B <= 8. */
 int emmax_op_gemv(const void* x_dev, const void* W_dev, void* y_dev, int B, int N, int K, emmax_stream stream);
+
+/* Small-batch decode projection on MFMA: y[b,n] = sum_k x[b,k] W[n,k], weights in the MFMA-fragment-major layout that
+ * emmax_op_repack_fm produces from a row-major [N,ld] matrix (N % 16 == 0, K % 32 == 0); 1 <= B <= 8. */
+int emmax_op_repack_fm(const void* W_dev, int ld, void* W_fm_out_dev, int N, int K, emmax_stream stream);
+int emmax_op_gemm_small(const void* x_dev, const void* W_fm_dev, void* y_dev, int B, int N, int K, emmax_stream stream);
 
 #ifdef __cplusplus
 }

@@ -166,3 +166,26 @@ def test_gemv(device, B, N, K):
     L.check(lib.emmax_op_gemv(xd.data_ptr(), Wd.data_ptr(), y.data_ptr(), B, N, K, stream()), "gemv")
     torch.cuda.synchronize()
     assert relerr(y, ref) < TOL
+
+
+@pytest.mark.parametrize("B", [1, 3, 4, 8])
+@pytest.mark.parametrize("N,K", [(256, 256), (4096, 4096), (1008, 11008), (64, 704), (32064, 256)])
+def test_gemm_small_mfma(device, B, N, K):
+    """Batch >= 3 decode projection: MFMA over the fragment-major weight copy (also exercised at B = 1 for the layout)."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(B * 3 + N + K)
+    x = bf(torch.randn(B, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    ref = x.float() @ W.float().t()
+    xd, Wd = x.to(device), W.to(device)
+    Wfm = torch.empty_like(Wd)
+    L.check(lib.emmax_op_repack_fm(Wd.data_ptr(), K, Wfm.data_ptr(), N, K, stream()), "repack")
+    # layout spot check: tile (nt, kt), lane -> W[16 nt + lane%16][32 kt + 8 (lane//16) : +8]
+    flat = Wfm.view(-1, 64, 8).cpu()
+    nt, kt, lane = (N // 16) - 1, (K // 32) - 1, 37
+    assert torch.equal(flat[nt * (K // 32) + kt, lane], W[16 * nt + lane % 16, 32 * kt + 8 * (lane // 16): 32 * kt + 8 * (lane // 16) + 8])
+    y = torch.full((B, N), float("nan"), dtype=torch.bfloat16, device=device)
+    L.check(lib.emmax_op_gemm_small(xd.data_ptr(), Wfm.data_ptr(), y.data_ptr(), B, N, K, stream()), "gemm_small")
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all()
+    assert relerr(y, ref) < TOL

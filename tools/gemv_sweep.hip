@@ -316,6 +316,135 @@ __global__ __launch_bounds__(WAVES * 64) void k_mfma(const uint16_t* __restrict_
     }
 }
 
+// ---- V5: MFMA small-batch GEMM, block = 8 waves splitting K of one task (TILES x 16 rows), LDS reduction ------------------
+template <int TILES, int U, int BATCH>
+__global__ __launch_bounds__(512) void k_mfma_ks(const uint16_t* __restrict__ W, const uint16_t* __restrict__ x, float* __restrict__ y, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int WAVES = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g4 = lane >> 4, i16 = lane & 15;
+    const int pitch = K * 2 + 16;
+    float* red = (float*)(smem + (BATCH + 1) * pitch);      // [WAVES][TILES][64][4]
+    const int tasks = N / (16 * TILES), G = gridDim.x;
+    const int q = tasks / G, r = tasks % G, b = blockIdx.x;
+    const int t_lo = b * q + min(b, r), t_hi = t_lo + q + (b < r ? 1 : 0);
+    const int ks = K / WAVES;                                // elements per wave slice (multiple of 32)
+    const int nk = ks / 32;
+    const int kbase = wave * ks;
+    u32x4 wr[TILES][U];
+    auto issue = [&](int t, int k0) {
+#pragma unroll
+        for (int tt = 0; tt < TILES; ++tt) {
+            const u32x4* wrow = (const u32x4*)(W + (size_t)((t * TILES + tt) * 16 + i16) * K + kbase) + g4;
+#pragma unroll
+            for (int u = 0; u < U; ++u) wr[tt][u] = (k0 + u < nk) ? ld<1>(wrow + (size_t)(k0 + u) * 4) : (u32x4){0, 0, 0, 0};
+        }
+    };
+    int t = t_lo;
+    if (t < t_hi) issue(t, 0);
+    for (int c = tid; c < (BATCH + 1) * (K / 8); c += 512) {
+        const int row = c / (K / 8), ch = c % (K / 8);
+        u32x4 v = {0, 0, 0, 0};
+        if (row < BATCH) v = ((const u32x4*)x)[ch];
+        *(u32x4*)(smem + row * pitch + ch * 16) = v;
+    }
+    __syncthreads();
+    const int xrow = i16 < BATCH ? i16 : BATCH;              // pad columns read the zero row
+    for (; t < t_hi; ++t) {
+        f32x4 acc[TILES];
+#pragma unroll
+        for (int tt = 0; tt < TILES; ++tt) acc[tt] = (f32x4){0, 0, 0, 0};
+        for (int k0 = 0; k0 < nk; k0 += U) {
+            if (k0 != 0) issue(t, k0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (k0 + u < nk) {
+                    const bf16x8 xb = *(const bf16x8*)(smem + xrow * pitch + (kbase + (k0 + u) * 32 + g4 * 8) * 2);
+#pragma unroll
+                    for (int tt = 0; tt < TILES; ++tt)
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[tt][u]), xb, acc[tt], 0, 0, 0);
+                }
+            }
+        }
+        if (t + 1 < t_hi) issue(t + 1, 0);
+#pragma unroll
+        for (int tt = 0; tt < TILES; ++tt) *(f32x4*)(red + ((wave * TILES + tt) * 64 + lane) * 4) = acc[tt];
+        __syncthreads();
+        for (int o = tid; o < TILES * 256; o += 512) {
+            const int tt = o >> 8, l = (o >> 2) & 63, rr = o & 3;
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) sum += red[((w * TILES + tt) * 64 + l) * 4 + rr];
+            if ((l & 15) < BATCH) y[(size_t)((t * TILES + tt) * 16 + 4 * (l >> 4) + rr)] = sum;
+        }
+        __syncthreads();
+    }
+}
+// ---- V6: as V5 but weights in MFMA-fragment-major tiles [N/16][K/32][64 lanes][8] (1 KiB contiguous per wave load) ------------------
+template <int TILES, int U, int BATCH>
+__global__ __launch_bounds__(512) void k_mfma_fm(const uint16_t* __restrict__ W, const uint16_t* __restrict__ x, float* __restrict__ y, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int WAVES = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g4 = lane >> 4, i16 = lane & 15;
+    const int pitch = K * 2 + 16;
+    float* red = (float*)(smem + (BATCH + 1) * pitch);      // [WAVES][TILES][64][4]
+    const int tasks = N / (16 * TILES), G = gridDim.x;
+    const int q = tasks / G, r = tasks % G, b = blockIdx.x;
+    const int t_lo = b * q + min(b, r), t_hi = t_lo + q + (b < r ? 1 : 0);
+    const int ks = K / WAVES;                                // elements per wave slice (multiple of 32)
+    const int nk = ks / 32;
+    const int kbase = wave * ks;
+    u32x4 wr[TILES][U];
+    auto issue = [&](int t, int k0) {
+#pragma unroll
+        for (int tt = 0; tt < TILES; ++tt) {
+            const u32x4* wt = (const u32x4*)W + ((size_t)(t * TILES + tt) * (K / 32) + kbase / 32) * 64 + lane;
+#pragma unroll
+            for (int u = 0; u < U; ++u) wr[tt][u] = (k0 + u < nk) ? ld<1>(wt + (size_t)(k0 + u) * 64) : (u32x4){0, 0, 0, 0};
+        }
+    };
+    int t = t_lo;
+    if (t < t_hi) issue(t, 0);
+    for (int c = tid; c < (BATCH + 1) * (K / 8); c += 512) {
+        const int row = c / (K / 8), ch = c % (K / 8);
+        u32x4 v = {0, 0, 0, 0};
+        if (row < BATCH) v = ((const u32x4*)x)[ch];
+        *(u32x4*)(smem + row * pitch + ch * 16) = v;
+    }
+    __syncthreads();
+    const int xrow = i16 < BATCH ? i16 : BATCH;              // pad columns read the zero row
+    for (; t < t_hi; ++t) {
+        f32x4 acc[TILES];
+#pragma unroll
+        for (int tt = 0; tt < TILES; ++tt) acc[tt] = (f32x4){0, 0, 0, 0};
+        for (int k0 = 0; k0 < nk; k0 += U) {
+            if (k0 != 0) issue(t, k0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (k0 + u < nk) {
+                    const bf16x8 xb = *(const bf16x8*)(smem + xrow * pitch + (kbase + (k0 + u) * 32 + g4 * 8) * 2);
+#pragma unroll
+                    for (int tt = 0; tt < TILES; ++tt)
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[tt][u]), xb, acc[tt], 0, 0, 0);
+                }
+            }
+        }
+        if (t + 1 < t_hi) issue(t + 1, 0);
+#pragma unroll
+        for (int tt = 0; tt < TILES; ++tt) *(f32x4*)(red + ((wave * TILES + tt) * 64 + lane) * 4) = acc[tt];
+        __syncthreads();
+        for (int o = tid; o < TILES * 256; o += 512) {
+            const int tt = o >> 8, l = (o >> 2) & 63, rr = o & 3;
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) sum += red[((w * TILES + tt) * 64 + l) * 4 + rr];
+            if ((l & 15) < BATCH) y[(size_t)((t * TILES + tt) * 16 + 4 * (l >> 4) + rr)] = sum;
+        }
+        __syncthreads();
+    }
+}
+
 struct Ctx {
     std::vector<uint16_t*> W;
     uint16_t* x;
@@ -374,6 +503,25 @@ static void run_mfma(const char* name, Ctx& c, int blocks) {
     timeit(name, c, [&](int l) { hipLaunchKernelGGL((k_mfma<WAVES, U, BATCH>), dim3(blocks), dim3(WAVES * 64), smem, c.st, c.W[l], c.x, c.y, c.N, c.K); });
 }
 
+template <int TILES, int U, int BATCH>
+static void run_mfma_ks(const char* name, Ctx& c, int blocks) {
+    const size_t smem = (BATCH + 1) * ((size_t)c.K * 2 + 16) + 8 * TILES * 64 * 16;
+    CHECK(hipFuncSetAttribute((const void*)k_mfma_ks<TILES, U, BATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    if (smem > 159 * 1024 || (c.K / 8) % 32) { printf("%-46s skipped\n", name); return; }
+    blocks = blocks < c.N / (16 * TILES) ? blocks : c.N / (16 * TILES);
+    timeit(name, c, [&](int l) { hipLaunchKernelGGL((k_mfma_ks<TILES, U, BATCH>), dim3(blocks), dim3(512), smem, c.st, c.W[l], c.x, c.y, c.N, c.K); });
+}
+
+template <int TILES, int U, int BATCH>
+static void run_mfma_fm(const char* name, Ctx& c, int blocks) {
+    const size_t smem = (BATCH + 1) * ((size_t)c.K * 2 + 16) + 8 * TILES * 64 * 16;
+    CHECK(hipFuncSetAttribute((const void*)k_mfma_fm<TILES, U, BATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    if (smem > 159 * 1024 || (c.K / 8) % 32) { printf("%-46s skipped\n", name); return; }
+    const int tasks = c.N / (16 * TILES);
+    if (blocks <= 0 || blocks > tasks) blocks = tasks;
+    timeit(name, c, [&](int l) { hipLaunchKernelGGL((k_mfma_fm<TILES, U, BATCH>), dim3(blocks), dim3(512), smem, c.st, c.W[l], c.x, c.y, c.N, c.K); });
+}
+
 int main(int argc, char** argv) {
     Ctx c;
     c.NL = 24;
@@ -392,12 +540,16 @@ int main(int argc, char** argv) {
         printf("---- N=%d K=%d (%.1f MB) ----\n", c.N, c.K, (double)c.N * c.K * 2 / 1e6);
         run_ro<4, 2, 8, 1>("readonly  w4 nr2 u8 nt", c);
         run_persist<8, 2, 8, true>("persist   w8 nr2  512blk NORM", c, 512);
-        run_mfma<4, 8, 8>("mfma      w4 u8  256blk", c, 256);
-        run_mfma<8, 8, 8>("mfma      w8 u8  256blk", c, 256);
-        run_mfma<4, 16, 8>("mfma      w4 u16 256blk", c, 256);
-        run_mfma<8, 16, 8>("mfma      w8 u16 256blk", c, 256);
-        run_mfma<16, 8, 8>("mfma      w16 u8 256blk", c, 256);
-        run_mfma<16, 16, 8>("mfma      w16 u16 256blk", c, 256);
+        run_mfma_ks<2, 8, 8>("mfma_ks   t2 u8  B8 512blk (row-major)", c, 512);
+        run_mfma_fm<2, 8, 8>("mfma_fm   t2 u8  B8 512blk", c, 512);
+        run_mfma_fm<2, 8, 8>("mfma_fm   t2 u8  B8 256blk", c, 256);
+        run_mfma_fm<2, 8, 8>("mfma_fm   t2 u8  B8 tasks", c, 0);
+        run_mfma_fm<2, 16, 8>("mfma_fm   t2 u16 B8 tasks", c, 0);
+        run_mfma_fm<1, 8, 8>("mfma_fm   t1 u8  B8 tasks", c, 0);
+        run_mfma_fm<1, 16, 8>("mfma_fm   t1 u16 B8 tasks", c, 0);
+        run_mfma_fm<1, 16, 8>("mfma_fm   t1 u16 B8 512blk", c, 512);
+        run_mfma_fm<2, 8, 1>("mfma_fm   t2 u8  B1 tasks", c, 0);
+        run_mfma_fm<1, 16, 4>("mfma_fm   t1 u16 B4 tasks", c, 0);
     }
     return 0;
 }

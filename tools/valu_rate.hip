@@ -1,0 +1,53 @@
+// valu_rate.hip -- instruction-rate probe for the decode GEMV inner loop candidates (not part of the product).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s\n", hipGetErrorString(e)); return 1; } } while (0)
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k(float* out, int iters, uint32_t seed) {
+    float a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3, a4 = 4, a5 = 5, a6 = 6, a7 = 7;
+    uint32_t w = seed + threadIdx.x, x = seed * 3 + 1;
+    f32x2 p0 = {1, 2}, p1 = {3, 4}, p2 = {5, 6}, p3 = {7, 8};
+    const f32x2 m = {__uint_as_float(0x3f800001u + seed), 1.0f}, c = {0.5f, 0.25f};
+    for (int i = 0; i < iters; ++i) {
+        if (KIND == 0) {   // v_dot2c_f32_bf16, 8 independent accumulators
+            bf16x2 ww = __builtin_bit_cast(bf16x2, w), xx = __builtin_bit_cast(bf16x2, x);
+            a0 = __builtin_amdgcn_fdot2_f32_bf16(ww, xx, a0, false); a1 = __builtin_amdgcn_fdot2_f32_bf16(ww, xx, a1, false);
+            a2 = __builtin_amdgcn_fdot2_f32_bf16(ww, xx, a2, false); a3 = __builtin_amdgcn_fdot2_f32_bf16(ww, xx, a3, false);
+            a4 = __builtin_amdgcn_fdot2_f32_bf16(ww, xx, a4, false); a5 = __builtin_amdgcn_fdot2_f32_bf16(ww, xx, a5, false);
+            a6 = __builtin_amdgcn_fdot2_f32_bf16(ww, xx, a6, false); a7 = __builtin_amdgcn_fdot2_f32_bf16(ww, xx, a7, false);
+        } else if (KIND == 1) {   // v_fma_f32
+            const float ww = __uint_as_float(w), xx = __uint_as_float(x);
+            a0 = fmaf(ww, xx, a0); a1 = fmaf(ww, xx, a1); a2 = fmaf(ww, xx, a2); a3 = fmaf(ww, xx, a3);
+            a4 = fmaf(ww, xx, a4); a5 = fmaf(ww, xx, a5); a6 = fmaf(ww, xx, a6); a7 = fmaf(ww, xx, a7);
+        } else {   // v_pk_fma_f32 (4 per iteration = 8 MACs)
+            p0 = __builtin_elementwise_fma(p0, m, c); p1 = __builtin_elementwise_fma(p1, m, c);
+            p2 = __builtin_elementwise_fma(p2, m, c); p3 = __builtin_elementwise_fma(p3, m, c);
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0[0] + p0[1] + p1[0] + p1[1] + p2[0] + p2[1] + p3[0] + p3[1];
+}
+
+int main() {
+    float* out; CHECK(hipMalloc(&out, 256 * 4 * 256 * 16));
+    const int iters = 20000, blocks = 256 * 8;
+    const char* names[] = {"v_dot2c_f32_bf16 (2 MAC/lane)", "v_fma_f32 (1 MAC/lane)", "v_pk_fma_f32 (2 MAC/lane)"};
+    for (int kind = 0; kind < 3; ++kind) {
+        hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        for (int rep = 0; rep < 2; ++rep) {
+            CHECK(hipEventRecord(e0));
+            if (kind == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, out, iters, 7u);
+            if (kind == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, out, iters, 7u);
+            if (kind == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, out, iters, 7u);
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        }
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double instr = (double)blocks * 4 /*waves*/ * iters * (kind == 2 ? 4 : 8);
+        const double per_simd = instr / (256.0 * 4);
+        printf("%-34s %8.3f ms  -> %.2f ns per wave-instruction per SIMD (~%.1f cycles @2.1GHz)\n", names[kind], ms, ms * 1e6 / per_simd, ms * 1e6 / per_simd * 2.1);
+    }
+    return 0;
+}
