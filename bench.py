@@ -128,6 +128,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    if os.environ.get("EMMAX_FORCE_DEVICE") is not None:   # test hook: several ranks on one GPU (with EMMAX_DIST_BACKEND=gloo)
+        local = int(os.environ["EMMAX_FORCE_DEVICE"])
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
     cfg = EmmaXConfig.tiny() if args.tiny else EmmaXConfig.emma_x_7b()

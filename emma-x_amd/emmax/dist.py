@@ -25,7 +25,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # EMMAX_DIST_BACKEND=gloo lets the multi-process control flow be exercised on a single-GPU box
+            backend = os.environ.get("EMMAX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, device_id=torch.device("cuda", local))
@@ -59,7 +60,12 @@ def gather_results(actions: torch.Tensor, ids: torch.Tensor, lens: torch.Tensor,
     pack[:b, 7:7 + T] = ids.to(torch.int32)
     pack[:b, 7 + T] = lens.to(torch.int32)
     out = torch.empty(world * bmax, width, dtype=torch.int32, device=ids.device)
-    dist.all_gather_into_tensor(out, pack)
+    if dist.get_backend() == "gloo" and pack.is_cuda:   # test hook only: gloo moves the 2 KB/row through the host
+        out_h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(out_h, pack.cpu())
+        out.copy_(out_h)
+    else:
+        dist.all_gather_into_tensor(out, pack)
     out = out.view(world, bmax, width)
     rows = torch.cat([out[r, : counts[r]] for r in range(world)], dim=0)
     return rows[:, :7].contiguous().view(torch.float32), rows[:, 7:7 + T].contiguous(), rows[:, 7 + T].contiguous()
@@ -73,6 +79,6 @@ def barrier() -> None:
 def max_over_ranks(x: float, device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return x
-    t = torch.tensor([x], dtype=torch.float64, device=device)
+    t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

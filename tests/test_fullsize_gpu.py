@@ -1,0 +1,97 @@
+"""Full-size (Emma-X-7B dims, BASELINE.json configs 2/3 shapes) checks on a real MI355X through size-independent
+properties -- the CPU oracle cannot run 7B in test time, so these use invariants instead of a reference run:
+
+  * known answer: with the margin-boosted (planted) 7B weights greedy decoding must emit the planted successor chain
+    (29871 -> 8 action tokens -> EOS) -- the same construction the tiny model is checked with against the oracle and
+    against the reference wrapper's golden;
+  * every row of a ragged batch == its bs=1 run (ids exact), across the dot2 (B<=2) and MFMA (B>=3) decode paths;
+  * hipGraph replay == eager stepping;  run-to-run determinism;
+  * the prefill's own last-position logits (MFMA GEMM path, fp32 out) == the decode-path lm-head on the same hidden
+    state (GEMV path) within bf16 tolerance, and both give the same argmax;
+  * action vector == de-tokenised planted ids within 1e-3."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big(device):
+    from emmax.config import EmmaXConfig
+    from emmax.modeling import EmmaXForActionPrediction
+
+    cfg = EmmaXConfig.emma_x_7b()
+    model = EmmaXForActionPrediction.from_synthetic(cfg, seed=0, device=device, planted=True, max_batch=4, max_prompt=512,
+                                                    max_ctx=256 + 512 + 64 + 1)
+    return cfg, model
+
+
+def _rows(cfg, lens, steps_to_prefix, seed=3):
+    from emmax.weights import planted_start_token
+
+    rng = np.random.default_rng(seed)
+    rows = []
+    for n, k in zip(lens, steps_to_prefix):
+        r = [1] + [int(x) for x in rng.integers(3, 31744, size=n - 1)]
+        r[-1] = planted_start_token(cfg, k)
+        rows.append(r)
+    frames = torch.from_numpy(rng.integers(0, 256, size=(len(lens), 224, 224, 3), dtype=np.uint8))
+    return frames, rows
+
+
+def test_fullsize_planted_known_answer_and_actions(device, big):
+    from emmax.actions import token_ids_to_actions, unnormalize
+    from emmax.weights import planted_chain
+
+    cfg, model = big
+    frames, rows = _rows(cfg, [512], [20])
+    acts, ids, lens = model.generate_actions_batch(frames.to(device), rows, max_new_tokens=48)
+    got = ids[0, : int(lens[0])].cpu().tolist()
+    want = planted_chain(cfg, rows[0][-1], 48)
+    assert got == want and got[-1] == cfg.eos_token_id and len(got) == 20 + 8 + 1
+    a_ids = [t for t in want if 31744 <= t < 32000][:7]
+    ref = unnormalize(token_ids_to_actions(np.array(a_ids), 32000, model.bin_centers), cfg.norm_stats["bridge_orig"]["action"])
+    assert np.abs(acts[0] - ref).max() <= 1e-3
+
+
+def test_fullsize_ragged_batch_equals_bs1_and_is_deterministic(device, big):
+    cfg, model = big
+    frames, rows = _rows(cfg, [512, 37, 300, 128], [5, 12, 30, 2], seed=11)
+    fr = frames.to(device)
+    _, ids_b, lens_b = model.generate_actions_batch(fr, rows, max_new_tokens=40)       # B=4: MFMA decode path
+    _, ids_b2, lens_b2 = model.generate_actions_batch(fr, rows, max_new_tokens=40)
+    assert torch.equal(ids_b, ids_b2) and torch.equal(lens_b, lens_b2)                 # run-to-run determinism
+    ids_b, lens_b = ids_b.cpu(), lens_b.cpu().tolist()
+    for b in range(4):
+        _, ids_1, lens_1 = model.generate_actions_batch(fr[b:b + 1].contiguous(), [rows[b]], max_new_tokens=40)   # dot2 path
+        assert lens_b[b] == int(lens_1[0])
+        assert ids_b[b, : lens_b[b]].tolist() == ids_1[0, : lens_b[b]].cpu().tolist()
+
+
+def test_fullsize_graph_equals_eager(device, big):
+    cfg, model = big
+    frames, rows = _rows(cfg, [200, 64], [25, 40], seed=5)
+    fr = frames.to(device)
+    T = 32
+    _, ids_g, lens_g = model.generate_actions_batch(fr, rows, max_new_tokens=T)
+    assert model.engine.graph_active()
+    model._prefill(rows, None, fr, max_new=T)
+    for _ in range(T - 1):
+        model.engine.decode_step()
+    ids_e, lens_e = model.engine.generate(T, True)
+    assert torch.equal(ids_g, ids_e) and torch.equal(lens_g, lens_e)
+
+
+def test_fullsize_prefill_logits_consistent_with_decode_head(device, big):
+    cfg, model = big
+    frames, rows = _rows(cfg, [96], [3], seed=9)
+    out = model.forward(input_ids=rows, frames_u8=frames.to(device))
+    full = out.logits[0]                                  # [S, vocab] from the MFMA GEMM (fp32 out)
+    assert full.shape == (256 + 96, cfg.llm.vocab_size)
+    last = model.engine.last_logits()[0]                  # lm-head GEMV on the gathered last row
+    err = (full[-1] - last).abs().max().item() / last.abs().max().item()
+    assert err < 1e-2
+    assert int(full[-1].argmax()) == int(last.argmax())
+    assert torch.isfinite(full).all()
