@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -237,6 +238,7 @@ struct emmax_session {
     hipStream_t graph_stream = nullptr;
     int graph_failed = 0;
     hipEvent_t ev = nullptr;
+    hipStream_t overlap_stream = nullptr;
     hipStream_t own_stream = nullptr;   // used by emmax_generate when the caller's stream is the (uncapturable) legacy stream
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     std::string graph_err;
@@ -516,6 +518,23 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
 static int run_decode_step(emmax_session* s, int B, hipStream_t st) {
     emmax_model* m = s->m;
     KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st));
+    // TIMING EXPERIMENT ONLY (results are wrong): alternate consecutive stages between two streams so that stage k+1 may
+    // overlap the drain of stage k; dependencies k-1 -> k+1 only.  Measures what a dependent-launch scheme could buy.
+    static const bool unsafe_overlap = getenv("EMMAX_UNSAFE_OVERLAP") != nullptr;
+    if (unsafe_overlap) {
+        hipStream_t sb = s->overlap_stream;
+        HIPCHK(hipEventRecord(s->ev_in, st));
+        HIPCHK(hipStreamWaitEvent(sb, s->ev_in, 0));
+        int k = 0;
+        for (int li = 0; li < m->cfg.n_layers; ++li)
+            for (int stage = STAGE_QKV; stage <= STAGE_DOWN; ++stage, ++k) {
+                int r = run_decode_stage(s, B, li, stage, (k & 1) ? sb : st);
+                if (r) return r;
+            }
+        HIPCHK(hipEventRecord(s->ev_out, sb));
+        HIPCHK(hipStreamWaitEvent(st, s->ev_out, 0));
+        return run_lm_head_step(s, B, false, nullptr, true, st);
+    }
     for (int li = 0; li < m->cfg.n_layers; ++li)
         for (int stage = STAGE_QKV; stage <= STAGE_DOWN; ++stage) {
             int r = run_decode_stage(s, B, li, stage, st);
@@ -725,6 +744,7 @@ int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_
     HIPCHK(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&s->overlap_stream, hipStreamNonBlocking));
     // static page assignment: row b owns pages [b*max_pages, (b+1)*max_pages)
     {
         std::vector<int32_t> pt((size_t)max_batch * s->max_pages);

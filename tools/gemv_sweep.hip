@@ -456,12 +456,13 @@ struct Ctx {
 
 template <typename F>
 static void timeit(const char* name, Ctx& c, F launch, int reps = 5) {
-    for (int l = 0; l < c.NL; ++l) launch(l);
+    static const bool same = getenv("SWEEP_SAME") != nullptr;
+    for (int l = 0; l < c.NL; ++l) launch(same ? 0 : l);
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     CHECK(hipEventRecord(e0, c.st));
     for (int r = 0; r < reps; ++r)
-        for (int l = 0; l < c.NL; ++l) launch(l);
+        for (int l = 0; l < c.NL; ++l) launch(same ? 0 : l);
     CHECK(hipEventRecord(e1, c.st));
     CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -539,17 +540,8 @@ int main(int argc, char** argv) {
         c.N = s[0]; c.K = s[1];
         printf("---- N=%d K=%d (%.1f MB) ----\n", c.N, c.K, (double)c.N * c.K * 2 / 1e6);
         run_ro<4, 2, 8, 1>("readonly  w4 nr2 u8 nt", c);
+        run_ro<4, 2, 8, 0>("readonly  w4 nr2 u8 plain", c);
         run_persist<8, 2, 8, true>("persist   w8 nr2  512blk NORM", c, 512);
-        run_mfma_ks<2, 8, 8>("mfma_ks   t2 u8  B8 512blk (row-major)", c, 512);
-        run_mfma_fm<2, 8, 8>("mfma_fm   t2 u8  B8 512blk", c, 512);
-        run_mfma_fm<2, 8, 8>("mfma_fm   t2 u8  B8 256blk", c, 256);
-        run_mfma_fm<2, 8, 8>("mfma_fm   t2 u8  B8 tasks", c, 0);
-        run_mfma_fm<2, 16, 8>("mfma_fm   t2 u16 B8 tasks", c, 0);
-        run_mfma_fm<1, 8, 8>("mfma_fm   t1 u8  B8 tasks", c, 0);
-        run_mfma_fm<1, 16, 8>("mfma_fm   t1 u16 B8 tasks", c, 0);
-        run_mfma_fm<1, 16, 8>("mfma_fm   t1 u16 B8 512blk", c, 512);
-        run_mfma_fm<2, 8, 1>("mfma_fm   t2 u8  B1 tasks", c, 0);
-        run_mfma_fm<1, 16, 4>("mfma_fm   t1 u16 B4 tasks", c, 0);
     }
     return 0;
 }
