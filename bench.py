@@ -207,7 +207,7 @@ def main():
             "config": {"workload": ("BASELINE configs[1]: Emma-X-7B bf16, %d frame(s)/GPU 224x224, %d-token prompt, greedy, %d new tokens "
                                     "(EOS disabled), random-init weights" % (B, P, T)) if not args.tiny else "TINY plumbing config (invalid as headline)",
                        "batch_per_gpu": B, "global_batch": B * world, "prompt_tokens": P, "new_tokens": T, "context": ctx + T,
-                       "parallelism": f"dp{world}", "hipgraph": eng.graph_active()},
+                       "parallelism": f"dp{world}", "hipgraph": eng.graph_active(), "chained_launch": eng.chain_active()},
             "p50_latency_ms": round(float(np.median(lat)) * 1e3, 2),
             "decode_ms_per_token": round(step_ms, 4), "decode_tokens_per_s": round(B * 1e3 / step_ms, 1),
             "decode_step_hbm_gbs": round(step_gbs, 1), "decode_step_hbm_frac": round(step_gbs / HBM_PEAK_GBS, 4),

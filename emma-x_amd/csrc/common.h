@@ -47,5 +47,54 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Chained launch: consecutive decode kernels run on two alternating streams, so kernel k+1 becomes resident and requests
+// its (x-independent) weights while kernel k drains; the DATA dependency k -> k+1 is enforced inside the kernel with the
+// placement-independent agent-scope release/acquire hand-off of cdna_hip_programming.md Guideline 16:
+//   producer block: every wave drains its stores -> barrier -> lane 0: release fence, drain, relaxed counter increment
+//   consumer block: lane 0 polls the counter relaxed (bounded), ONE acquire fence, barrier, then plain loads.
+// Stream order still serialises k and k+2, so at most two kernels are in flight and both fit the chip (grids <= 256
+// blocks, <= 128 VGPRs): the spinning consumer can never starve its producer.
+// ---------------------------------------------------------------------------------------------------------------------
+struct DepInfo {
+    unsigned int* wait_ctr;     // null: ordinary stream ordering, no in-kernel wait
+    unsigned int wait_count;    // blocks of the producer kernel
+    unsigned int* signal_ctr;   // null: nobody waits on this kernel
+    unsigned int* err;          // set to 1 when a wait gave up (bounded spin)
+};
+
+__device__ __forceinline__ void dep_wait(const DepInfo& d) {
+    if (d.wait_ctr) {
+        if (threadIdx.x == 0) {
+            // bounded: a legitimate wait lasts one producer kernel (tens of us); ~0.1 s of polling means the protocol
+            // is broken -> flag it (the host turns the flag into an error) and let every later wait fall through
+            unsigned int spins = 0;
+            if (__hip_atomic_load(d.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                while (__hip_atomic_load(d.wait_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < d.wait_count) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > (1u << 18)) {
+                        __hip_atomic_store(d.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void dep_signal(const DepInfo& d) {
+    if (d.signal_ctr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own stores
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler may drop the wait behind buffer_wbl2 (G16 pitfall 12)
+            __hip_atomic_fetch_add(d.signal_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t align_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
 #pragma unroll
     for (int u = 0; u < U; ++u) issue_step(P, u, my_rounds > 0);
     advance(P);
+    dep_wait(p.dep);   // everything below reads data of the previous kernel
 
     // ---- RMSNorm statistics ----
     float rstd[B];
@@ -349,19 +350,21 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
             p.part_idx[(size_t)blockIdx.x * B + tid] = i0;
         }
     }
+    dep_signal(p.dep);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // h[b] = E[cur_tok[b]]
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void emmax_decode_embed_kernel(const int32_t* __restrict__ cur_tok, const bf16_t* __restrict__ E,
-                                                                bf16_t* __restrict__ h, int hidden, int vocab) {
+                                                                bf16_t* __restrict__ h, int hidden, int vocab, DepInfo dep) {
     const int b = blockIdx.x;
     int id = cur_tok[b];
     id = min(max(id, 0), vocab - 1);
     const u32x4_t* s = (const u32x4_t*)(E + (size_t)id * hidden);
     u32x4_t* o = (u32x4_t*)(h + (size_t)b * hidden);
     for (int c = threadIdx.x; c < hidden / 8; c += blockDim.x) o[c] = s[c];
+    dep_signal(dep);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -398,8 +401,10 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
             const int gq = i / PSTRIDE, j = i - gq * PSTRIDE;
             part[(size_t)gq * nsplit * PSTRIDE + j] = (j == HD) ? -INFINITY : 0.f;
         }
+        dep_signal(p.dep);
         return;
     }
+    dep_wait(p.dep);   // q and the freshly appended K/V row come from the qkv kernel
 
     // page ids of this split -> LDS (removes the dependent global load in front of every K/V load)
     const int pg0 = k0 / p.page;
@@ -519,6 +524,7 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
         }
         part[(size_t)gq * nsplit * PSTRIDE + j] = v;
     }
+    dep_signal(p.dep);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -526,6 +532,7 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void emmax_decode_finish_kernel(FinishParams p) {
     const int b = blockIdx.x, tid = threadIdx.x;
+    dep_wait(p.dep);
     __shared__ float sv[256];
     __shared__ int si[256];
     float best = -INFINITY;
@@ -576,6 +583,7 @@ __global__ __launch_bounds__(256) void emmax_decode_finish_kernel(FinishParams p
         }
         p.cur_tok[b] = tok;
     }
+    dep_signal(p.dep);
 }
 
 __global__ void emmax_set_tokens_kernel(int32_t* cur_tok, const int32_t* toks, int B) {
@@ -589,24 +597,28 @@ __global__ void emmax_set_tokens_kernel(int32_t* cur_tok, const int32_t* toks, i
 // launchers
 // ---------------------------------------------------------------------------------------------------------------------
 // persistent grid: 2 blocks of 8 waves per CU when the staged activations allow it, never more blocks than work
-static int gemv_grid(int B, size_t smem, int n_groups) {
-    const int grid = (B > 2 || smem > 72 * 1024) ? 256 : 512;
+static int gemv_grid(int B, size_t smem, int n_groups, int max_grid = 0) {
+    int grid = (B > 2 || smem > 72 * 1024) ? 256 : 512;
+    if (max_grid > 0) grid = min(grid, max_grid);
     return min(grid, cdiv(n_groups, GW));
 }
-int decode_lmhead_grid(int B, int K, int n_rows, int max_parts) { return min(gemv_grid(B, (size_t)B * K * 2, (n_rows + 1) / 2), max_parts); }
+int decode_lmhead_grid(int B, int K, int n_rows, int max_parts, int max_grid) {
+    return min(gemv_grid(B, (size_t)B * K * 2, (n_rows + 1) / 2, max_grid), max_parts);
+}
 
 template <int B, int MODE, bool NORM, bool XATTN = false>
-static int launch_gemv_t(const GemvParams& p, hipStream_t stream) {
+static int launch_gemv_t(const GemvParams& p, hipStream_t stream, int* grid_out) {
     const size_t smem = (size_t)B * p.kc * 2;
-    int grid = gemv_grid(B, smem, p.n_groups);
+    int grid = gemv_grid(B, smem, p.n_groups, p.max_grid);
     if (MODE == MODE_LMHEAD) grid = min(grid, p.max_parts);
+    if (grid_out) *grid_out = grid;
     auto kern = emmax_decode_gemv_kernel<B, MODE, NORM, XATTN>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(GW * 64), smem, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
 template <int MODE, bool NORM, bool XATTN = false>
-static int launch_gemv_mode(GemvParams p, int B, hipStream_t stream) {
+static int launch_gemv_mode(GemvParams p, int B, hipStream_t stream, int* grid_out) {
     // K phase: keep B * kc * 2 bytes of activations under ~128 KiB of LDS
     const int cap = (128 * 1024 / 2 / B) & ~511;
     p.kc = p.K <= cap ? p.K : (cdiv(cdiv(p.K, cdiv(p.K, cap)), 512) * 512);
@@ -615,7 +627,7 @@ static int launch_gemv_mode(GemvParams p, int B, hipStream_t stream) {
     else if (MODE == MODE_GATEUP) p.n_groups = p.n_rows / 2;
     else p.n_groups = (p.n_rows + 1) / 2;
     switch (B) {
-#define CASEB(BB) case BB: return launch_gemv_t<BB, MODE, NORM, XATTN>(p, stream)
+#define CASEB(BB) case BB: return launch_gemv_t<BB, MODE, NORM, XATTN>(p, stream, grid_out)
         CASEB(1); CASEB(2); CASEB(3); CASEB(4); CASEB(5); CASEB(6); CASEB(7); CASEB(8);
 #undef CASEB
         default: return -1;
@@ -644,21 +656,22 @@ int decode_gemv_init() {
     return r;
 }
 
-int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream) {
+int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
     if (p.K % 8 || p.ldw % 8 || p.ldx % 8) return -1;
     switch (mode) {
-        case MODE_QKV: return launch_gemv_mode<MODE_QKV, true>(p, B, stream);
+        case MODE_QKV: return launch_gemv_mode<MODE_QKV, true>(p, B, stream, grid_out);
         case MODE_RESID:
-            return p.attn_part ? launch_gemv_mode<MODE_RESID, false, true>(p, B, stream) : launch_gemv_mode<MODE_RESID, false>(p, B, stream);
-        case MODE_GATEUP: return launch_gemv_mode<MODE_GATEUP, true>(p, B, stream);
-        case MODE_LMHEAD: return launch_gemv_mode<MODE_LMHEAD, true>(p, B, stream);
-        case MODE_PLAIN: return launch_gemv_mode<MODE_PLAIN, false>(p, B, stream);
+            return p.attn_part ? launch_gemv_mode<MODE_RESID, false, true>(p, B, stream, grid_out)
+                               : launch_gemv_mode<MODE_RESID, false>(p, B, stream, grid_out);
+        case MODE_GATEUP: return launch_gemv_mode<MODE_GATEUP, true>(p, B, stream, grid_out);
+        case MODE_LMHEAD: return launch_gemv_mode<MODE_LMHEAD, true>(p, B, stream, grid_out);
+        case MODE_PLAIN: return launch_gemv_mode<MODE_PLAIN, false>(p, B, stream, grid_out);
         default: return -1;
     }
 }
 
-int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, hipStream_t stream) {
-    hipLaunchKernelGGL(emmax_decode_embed_kernel, dim3(B), dim3(256), 0, stream, cur_tok, (const bf16_t*)E, (bf16_t*)h, hidden, vocab);
+int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, const DepInfo& dep, hipStream_t stream) {
+    hipLaunchKernelGGL(emmax_decode_embed_kernel, dim3(B), dim3(256), 0, stream, cur_tok, (const bf16_t*)E, (bf16_t*)h, hidden, vocab, dep);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

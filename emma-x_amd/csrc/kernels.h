@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "common.h"
+
 // ---- gemm.hip ----
 struct GemmParams {
     const void* A;         // bf16 [M, lda]
@@ -87,11 +89,13 @@ struct GemvParams {
     // RESID with x = merged attention output: split partials f32 [B][Hq][nsplit][132] (null: x is a bf16 vector)
     const float* attn_part;
     int nsplit;
+    int max_grid;           // 0: default persistent grid; chained launch caps it at 256 (two kernels co-resident)
+    DepInfo dep;            // chained-launch hand-off (all null: plain stream ordering)
 };
-int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream);
-int decode_lmhead_grid(int B, int K, int n_rows, int max_parts);   // blocks (= argmax partials) the lm-head launch uses
+int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
+int decode_lmhead_grid(int B, int K, int n_rows, int max_parts, int max_grid = 0);   // blocks (= argmax partials) the lm-head launch uses
 int decode_gemv_init();   // raise the dynamic-LDS limit of every GEMV instantiation (call once, outside graph capture)
-int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, hipStream_t stream);
+int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, const DepInfo& dep, hipStream_t stream);
 
 struct DecodeAttnParams {
     const void* q;          // bf16 [B, ldq] rotated queries
@@ -102,6 +106,7 @@ struct DecodeAttnParams {
     float* part;            // f32 [B][Hq][nsplit][132] = { o[128] un-normalised, m, l, pad }
     int ldq, Hkv, page, max_pages;
     float scale;
+    DepInfo dep;
 };
 int decode_attn_nsplit(int B, int Hkv);
 int launch_decode_attn(const DecodeAttnParams& p, int B, int Hq, int head_dim, int nsplit, hipStream_t stream);
@@ -119,6 +124,7 @@ struct FinishParams {
     int max_out, max_ctx;
     int eos_id, pad_id;
     int is_prefill;
+    DepInfo dep;
 };
 int launch_decode_finish(const FinishParams& p, hipStream_t stream);
 int launch_set_tokens(int32_t* cur_tok, const int32_t* toks, int B, hipStream_t stream);

@@ -234,11 +234,17 @@ struct emmax_session {
     int32_t* pinned = nullptr;  // small pinned host buffer for control uploads / done read-backs
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph2 = nullptr;             // chained launch: the second stream's half of the step
+    hipGraphExec_t graph_exec2 = nullptr;
+    hipStream_t graph_stream_cap = nullptr;  // stream the graphs were captured on
     int graph_B = 0;
     hipStream_t graph_stream = nullptr;
     int graph_failed = 0;
     hipEvent_t ev = nullptr;
-    hipStream_t overlap_stream = nullptr;
+    hipStream_t overlap_stream = nullptr;   // second stream of the chained launch
+    unsigned int* dep_ctr = nullptr;         // device: one completion counter per kernel of the step (+ error word at [511])
+    int chain = 1;                           // chained launch enabled (B <= 2 only); EMMAX_CHAIN=0 disables
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t own_stream = nullptr;   // used by emmax_generate when the caller's stream is the (uncapturable) legacy stream
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     std::string graph_err;
@@ -301,6 +307,7 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->n_out = (int32_t*)b.take(Bd * 4);
     s->out_ids = (int32_t*)b.take((int64_t)Bd * s->max_out * 4);
     s->max_new_d = (int32_t*)b.take(4);
+    s->dep_ctr = (unsigned int*)b.take(512 * 4);
     s->page_table = (int32_t*)b.take((int64_t)Bd * s->max_pages * 4);
     s->cos_t = (float*)b.take((int64_t)s->max_ctx * (m->cfg.head_dim / 2) * 4);
     s->sin_t = (float*)b.take((int64_t)s->max_ctx * (m->cfg.head_dim / 2) * 4);
@@ -378,34 +385,59 @@ static int run_vision(emmax_session* s, bool from_u8, const void* src, int B, vo
 }
 
 // B <= 2: per-lane dot-product GEMV over the row-major weights; B >= 3: MFMA over the fragment-major copy
-static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_fm, int B, hipStream_t st) {
+static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_fm, int B, hipStream_t st, int* grid_out = nullptr) {
     if (B >= EMMAX_MFMA_MIN_BATCH) {
         p.W = w_fm;
         return launch_decode_mfma(mode, p, B, st);
     }
     p.W = w_rm;
-    return launch_decode_gemv(mode, p, B, st);
+    return launch_decode_gemv(mode, p, B, st, grid_out);
 }
 
 static bf16* kcache_of(emmax_session* s, int layer) { return s->kv + (size_t)layer * s->kv_layer_stride; }
 static bf16* vcache_of(emmax_session* s, int layer) { return s->kv + (size_t)layer * s->kv_layer_stride + s->kv_layer_stride / 2; }
 
-static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st) {
+struct Chain;
+static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, Chain* ch = nullptr);
+
+// chained-launch bookkeeping: kernel k runs on stream[k & 1], waits for counter k-1 and bumps counter k
+struct Chain {
+    emmax_session* s;
+    hipStream_t st[2];
+    int k = 0, prev_grid = 0;
+    hipStream_t stream() const { return st[k & 1]; }
+    DepInfo dep() const {
+        DepInfo d;
+        d.wait_ctr = k > 0 ? s->dep_ctr + (k - 1) : nullptr;
+        d.wait_count = (unsigned)prev_grid;
+        d.signal_ctr = s->dep_ctr + k;
+        d.err = s->dep_ctr + 511;
+        return d;
+    }
+    void launched(int grid) { prev_grid = grid; ++k; }
+};
+
+static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, Chain* ch) {
     emmax_model* m = s->m;
     GemvParams p;
     memset(&p, 0, sizeof(p));
     p.x = s->dh; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = m->final_norm; p.eps = m->cfg.rms_eps;
     p.n_rows = m->vocab; p.max_parts = s->n_lm_blocks; p.part_val = s->part_val; p.part_idx = s->part_idx; p.logits_out = logits_out;
-    KCHK(launch_proj(GEMV_LMHEAD, p, m->lm_head, m->lm_head_fm, B, st));
+    int lm_grid = 0;
+    if (ch) { p.dep = ch->dep(); p.max_grid = 256; st = ch->stream(); }
+    KCHK(launch_proj(GEMV_LMHEAD, p, m->lm_head, m->lm_head_fm, B, st, &lm_grid));
+    if (ch) ch->launched(lm_grid);
     if (do_finish) {
         FinishParams f;
         memset(&f, 0, sizeof(f));
-        f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = B >= EMMAX_MFMA_MIN_BATCH ? decode_mfma_lmhead_grid(m->vocab, s->n_lm_blocks) : decode_lmhead_grid(B, m->H, m->vocab, s->n_lm_blocks);
+        f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = B >= EMMAX_MFMA_MIN_BATCH ? decode_mfma_lmhead_grid(m->vocab, s->n_lm_blocks) : decode_lmhead_grid(B, m->H, m->vocab, s->n_lm_blocks, ch ? 256 : 0);
         f.B = B;
         f.cur_tok = s->cur_tok; f.ctx_len = s->ctx_len; f.done = s->done; f.n_out = s->n_out; f.out_ids = s->out_ids;
         f.max_new_p = s->max_new_d; f.max_out = s->max_out; f.max_ctx = s->max_ctx;
         f.eos_id = m->cfg.eos_id; f.pad_id = m->cfg.pad_id; f.is_prefill = is_prefill ? 1 : 0;
+        if (ch) { f.dep = ch->dep(); st = ch->stream(); }
         KCHK(launch_decode_finish(f, st));
+        if (ch) ch->launched(B);
     }
     return 0;
 }
@@ -473,12 +505,15 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
 enum { STAGE_QKV = 0, STAGE_ATTN = 1, STAGE_OPROJ = 2, STAGE_GATEUP = 3, STAGE_DOWN = 4, STAGE_LMHEAD = 5 };
 
 // one stage of decoder layer `li` (the unit the profiler times); the step is stages 0..4 of every layer + lm head
-static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStream_t st) {
+static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStream_t st, Chain* ch = nullptr) {
     emmax_model* m = s->m;
     const auto& c = m->cfg;
     const LayerW& L = m->layers[li];
     GemvParams p;
     memset(&p, 0, sizeof(p));
+    int grid = 0;
+    if (ch) st = ch->stream();
+    auto arm = [&]() { if (ch) { p.dep = ch->dep(); p.max_grid = 256; } };
     switch (stage) {
         case STAGE_QKV:
             p.x = s->dh; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln1; p.eps = c.rms_eps;
@@ -486,55 +521,89 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             p.head_dim = c.head_dim; p.Hq = c.n_heads; p.Hkv = c.n_kv_heads; p.page = PAGE; p.max_pages = s->max_pages;
             p.ctx_len = s->ctx_len; p.page_table = s->page_table; p.cos_t = s->cos_t; p.sin_t = s->sin_t;
             p.kcache = kcache_of(s, li); p.vcache = vcache_of(s, li);
-            KCHK(launch_proj(GEMV_QKV, p, L.wqkv, L.wqkv_fm, B, st));
+            arm();
+            KCHK(launch_proj(GEMV_QKV, p, L.wqkv, L.wqkv_fm, B, st, &grid));
+            if (ch) ch->launched(grid);
             return 0;
         case STAGE_ATTN: {
             DecodeAttnParams a;
             a.q = s->dq; a.ldq = m->q_dim; a.kcache = kcache_of(s, li); a.vcache = vcache_of(s, li);
             a.page_table = s->page_table; a.ctx_len = s->ctx_len; a.part = s->part; a.Hkv = c.n_kv_heads; a.page = PAGE;
             a.max_pages = s->max_pages; a.scale = 1.0f / sqrtf((float)c.head_dim);
-            KCHK(launch_decode_attn(a, B, c.n_heads, c.head_dim, decode_attn_nsplit(B, c.n_kv_heads), st));
+            memset(&a.dep, 0, sizeof(a.dep));
+            if (ch) a.dep = ch->dep();
+            const int ns = decode_attn_nsplit(B, c.n_kv_heads);
+            KCHK(launch_decode_attn(a, B, c.n_heads, c.head_dim, ns, st));
+            if (ch) ch->launched(ns * c.n_kv_heads * B);
             return 0;
         }
         case STAGE_OPROJ:
             p.x = s->datt; p.ldx = m->q_dim; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
             p.attn_part = s->part; p.nsplit = decode_attn_nsplit(B, c.n_kv_heads); p.Hq = c.n_heads;   // split merge fused into the staging
-            KCHK(launch_proj(GEMV_RESID, p, L.wo, L.wo_fm, B, st));
+            arm();
+            KCHK(launch_proj(GEMV_RESID, p, L.wo, L.wo_fm, B, st, &grid));
+            if (ch) ch->launched(grid);
             return 0;
         case STAGE_GATEUP:
             p.x = s->dh; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln2; p.eps = c.rms_eps;
             p.y = s->dact; p.ldy = m->inter_p; p.n_rows = 2 * m->inter_p;
-            KCHK(launch_proj(GEMV_GATEUP, p, L.wgu, L.wgu_fm, B, st));
+            arm();
+            KCHK(launch_proj(GEMV_GATEUP, p, L.wgu, L.wgu_fm, B, st, &grid));
+            if (ch) ch->launched(grid);
             return 0;
         case STAGE_DOWN:
             p.x = s->dact; p.ldx = m->inter_p; p.ldw = m->inter_p; p.K = m->inter_p; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
-            KCHK(launch_proj(GEMV_RESID, p, L.wdown, L.wdown_fm, B, st));
+            arm();
+            KCHK(launch_proj(GEMV_RESID, p, L.wdown, L.wdown_fm, B, st, &grid));
+            if (ch) ch->launched(grid);
             return 0;
         default:
             return fail(EMMAX_ERR_INVALID, "unknown decode stage %d", stage);
     }
 }
 
+static bool chain_on(const emmax_session* s, int B) { return s->chain && B < EMMAX_MFMA_MIN_BATCH; }
+
+// chained launch (see common.h): the kernels of a step alternate between `st` and the session's second stream
+static int chain_step_begin(emmax_session* s, hipStream_t st) {
+    HIPCHK(hipMemsetAsync(s->dep_ctr, 0, 511 * 4, st));          // counters of this step (the error word survives)
+    HIPCHK(hipEventRecord(s->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(s->overlap_stream, s->ev_fork, 0));
+    return 0;
+}
+static int chain_step_kernels(emmax_session* s, int B, hipStream_t st) {
+    emmax_model* m = s->m;
+    Chain ch;
+    ch.s = s; ch.st[0] = st; ch.st[1] = s->overlap_stream;
+    KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, ch.dep(), ch.stream()));
+    ch.launched(B);
+    for (int li = 0; li < m->cfg.n_layers; ++li)
+        for (int stage = STAGE_QKV; stage <= STAGE_DOWN; ++stage) {
+            int r = run_decode_stage(s, B, li, stage, st, &ch);
+            if (r) return r;
+        }
+    int r = run_lm_head_step(s, B, false, nullptr, true, st, &ch);
+    if (r) return r;
+    if (ch.k >= 500) return fail(EMMAX_ERR_INVALID, "too many kernels per step for the chained launch (%d)", ch.k);
+    return 0;
+}
+static int chain_step_end(emmax_session* s, hipStream_t st) {
+    HIPCHK(hipEventRecord(s->ev_join, s->overlap_stream));
+    HIPCHK(hipStreamWaitEvent(st, s->ev_join, 0));
+    return 0;
+}
+
 static int run_decode_step(emmax_session* s, int B, hipStream_t st) {
     emmax_model* m = s->m;
-    KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st));
-    // TIMING EXPERIMENT ONLY (results are wrong): alternate consecutive stages between two streams so that stage k+1 may
-    // overlap the drain of stage k; dependencies k-1 -> k+1 only.  Measures what a dependent-launch scheme could buy.
-    static const bool unsafe_overlap = getenv("EMMAX_UNSAFE_OVERLAP") != nullptr;
-    if (unsafe_overlap) {
-        hipStream_t sb = s->overlap_stream;
-        HIPCHK(hipEventRecord(s->ev_in, st));
-        HIPCHK(hipStreamWaitEvent(sb, s->ev_in, 0));
-        int k = 0;
-        for (int li = 0; li < m->cfg.n_layers; ++li)
-            for (int stage = STAGE_QKV; stage <= STAGE_DOWN; ++stage, ++k) {
-                int r = run_decode_stage(s, B, li, stage, (k & 1) ? sb : st);
-                if (r) return r;
-            }
-        HIPCHK(hipEventRecord(s->ev_out, sb));
-        HIPCHK(hipStreamWaitEvent(st, s->ev_out, 0));
-        return run_lm_head_step(s, B, false, nullptr, true, st);
+    if (chain_on(s, B)) {
+        int r = chain_step_begin(s, st);
+        if (!r) r = chain_step_kernels(s, B, st);
+        if (!r) r = chain_step_end(s, st);
+        return r;
     }
+    DepInfo nodep;
+    memset(&nodep, 0, sizeof(nodep));
+    KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, nodep, st));
     for (int li = 0; li < m->cfg.n_layers; ++li)
         for (int stage = STAGE_QKV; stage <= STAGE_DOWN; ++stage) {
             int r = run_decode_stage(s, B, li, stage, st);
@@ -546,32 +615,53 @@ static int run_decode_step(emmax_session* s, int B, hipStream_t st) {
 static void drop_graph(emmax_session* s) {
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
     if (s->graph) (void)hipGraphDestroy(s->graph);
+    if (s->graph_exec2) (void)hipGraphExecDestroy(s->graph_exec2);
+    if (s->graph2) (void)hipGraphDestroy(s->graph2);
+    s->graph_exec2 = nullptr;
+    s->graph2 = nullptr;
     s->graph_exec = nullptr;
     s->graph = nullptr;
     s->graph_B = 0;
 }
 
+static int graph_fail(emmax_session* s, const std::string& why) {
+    s->graph_failed = 1;
+    s->graph_err = why;
+    (void)hipGetLastError();
+    return 1;
+}
+
+// Capture one decode step into a hipGraph (plain single-stream mode only).  The chained launch is NOT captured: its
+// in-kernel waits need the host's alternating submission order -- if the two streams happen to share a hardware queue,
+// a replayed graph would queue a whole stream's kernels ahead of their producers and dead-lock the waits, whereas eager
+// alternating launches degrade to plain sequential execution.  Eager launching costs ~0.6 ms of host time per 2.5 ms
+// step, fully overlapped with the GPU.
 static int ensure_graph(emmax_session* s, int B, hipStream_t st) {
-    if (s->graph_exec && s->graph_B == B) return 0;
+    if (chain_on(s, B)) return 1;
+    if (s->graph_exec && s->graph_B == B && s->graph_stream_cap == st) return 0;
     drop_graph(s);
     if (s->graph_failed) return 1;
-    // one eager step first would advance the state; capture does not execute, so just record
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) { s->graph_failed = 1; s->graph_err = std::string("hipStreamBeginCapture: ") + hipGetErrorString(e); (void)hipGetLastError(); return 1; }
-    int r = run_decode_step(s, B, st);
+    if (e != hipSuccess) return graph_fail(s, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e));
+    const int r = run_decode_step(s, B, st);
     hipGraph_t g = nullptr;
     e = hipStreamEndCapture(st, &g);
     if (r != 0 || e != hipSuccess || !g) {
-        s->graph_failed = 1;
-        s->graph_err = r != 0 ? ("launch during capture: " + g_err) : (std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-        (void)hipGetLastError();
         if (g) (void)hipGraphDestroy(g);
-        return 1;
+        return graph_fail(s, r != 0 ? ("launch during capture: " + g_err) : (std::string("hipStreamEndCapture: ") + hipGetErrorString(e)));
     }
     hipGraphExec_t ge = nullptr;
     e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-    if (e != hipSuccess) { s->graph_failed = 1; s->graph_err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); (void)hipGetLastError(); (void)hipGraphDestroy(g); return 1; }
-    s->graph = g; s->graph_exec = ge; s->graph_B = B;
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return graph_fail(s, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    }
+    s->graph = g; s->graph_exec = ge; s->graph_B = B; s->graph_stream_cap = st;
+    return 0;
+}
+
+static int launch_graph_step(emmax_session* s, int B, hipStream_t st) {
+    HIPCHK(hipGraphLaunch(s->graph_exec, st));
     return 0;
 }
 
@@ -745,6 +835,9 @@ int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_
     HIPCHK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&s->overlap_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+    s->chain = !(getenv("EMMAX_CHAIN") && atoi(getenv("EMMAX_CHAIN")) == 0);
     // static page assignment: row b owns pages [b*max_pages, (b+1)*max_pages)
     {
         std::vector<int32_t> pt((size_t)max_batch * s->max_pages);
@@ -781,6 +874,9 @@ void emmax_session_destroy(emmax_session* s) {
     if (s->ev_in) (void)hipEventDestroy(s->ev_in);
     if (s->ev_out) (void)hipEventDestroy(s->ev_out);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
+    if (s->overlap_stream) (void)hipStreamDestroy(s->overlap_stream);
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     delete s;
 }
 
@@ -860,7 +956,8 @@ int emmax_generate(emmax_session* s, int max_new, int stop_on_eos, int32_t* out_
     bool pending = false;
     for (int i = 1; i < max_new; ++i) {
         if (use_graph) {
-            HIPCHK(hipGraphLaunch(s->graph_exec, st));
+            int r = launch_graph_step(s, B, st);
+            if (r) return r;
         } else {
             int r = run_decode_step(s, B, st);
             if (r) return r;
@@ -880,12 +977,19 @@ int emmax_generate(emmax_session* s, int max_new, int stop_on_eos, int32_t* out_
     HIPCHK(hipMemcpy2DAsync(out_ids, (size_t)max_new * 4, s->out_ids, (size_t)s->max_out * 4, (size_t)max_new * 4, B,
                             hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(out_lens, s->n_out, B * 4, hipMemcpyDeviceToDevice, st));
+    if (s->chain && B < EMMAX_MFMA_MIN_BATCH) {   // a bounded dependency wait that gave up is an error, never a silent wrong answer
+        HIPCHK(hipMemcpyAsync(s->pinned + 1024, s->dep_ctr + 511, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (s->pinned[1024] != 0) return fail(EMMAX_ERR_HIP, "chained launch: a dependency wait timed out (results invalid)");
+    }
     if (special) {
         HIPCHK(hipEventRecord(s->ev_out, st));
         HIPCHK(hipStreamWaitEvent(user, s->ev_out, 0));
     }
     return 0;
 }
+
+int emmax_session_chain_active(emmax_session* s) { return s && s->prefilled && chain_on(s, s->cur_B) ? 1 : 0; }
 
 int emmax_session_graph_active(emmax_session* s) {
     if (s && !s->graph_exec && !s->graph_err.empty()) g_err = s->graph_err;   // why the capture was refused

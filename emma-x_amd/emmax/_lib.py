@@ -66,6 +66,7 @@ SIGNATURES = {
     "emmax_set_current_tokens": (C.c_int, [_vp, _vp, _vp]),
     "emmax_generate": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "emmax_session_graph_active": (C.c_int, [_vp]),
+    "emmax_session_chain_active": (C.c_int, [_vp]),
     "emmax_profile_decode_stage": (C.c_int, [_vp, C.c_int, C.c_int, _c_f32p, _vp]),
     "emmax_op_gemm": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp,
                                 C.c_int, C.c_int, _vp]),

@@ -183,6 +183,9 @@ class EmmaxEngine:
     def graph_active(self) -> bool:
         return bool(self.lib.emmax_session_graph_active(self._session))
 
+    def chain_active(self) -> bool:
+        return bool(self.lib.emmax_session_chain_active(self._session))
+
     def profile_decode_stage(self, stage: int, reps: int = 3) -> float:
         """Mean duration (microseconds) of one launch of decode stage `stage` (see include/emmax.h), HIP-event timed."""
         us = C.c_float()

@@ -124,6 +124,8 @@ int emmax_generate(emmax_session* s, int max_new_tokens, int stop_on_eos, int32_
 
 /* 1 when emmax_generate is replaying a captured hipGraph of the step (0: eager launches). */
 int emmax_session_graph_active(emmax_session* s);
+/* 1 when the decode steps of the active batch run as a chained two-stream launch (batch <= 2). */
+int emmax_session_chain_active(emmax_session* s);
 /* Measurement hook (bench.py `roofline`): launch decode stage `stage` (0 qkv GEMV, 1 paged attention, 2 o-proj GEMV,
  * 3 gate/up GEMV, 4 down GEMV: once per layer; 5 lm-head GEMV+argmax) `reps` sweeps on `stream`, bracketed by HIP
  * events on that stream; returns the mean duration of one launch in microseconds.  Needs a prefilled session; the

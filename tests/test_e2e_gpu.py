@@ -245,3 +245,30 @@ def test_graph_replay_equals_eager(device, tiny_planted):
     torch.cuda.synchronize()
     assert lens_g.cpu().tolist() == lens_e.cpu().tolist()
     assert ids_g.cpu().tolist() == ids_e.cpu().tolist()
+
+
+def test_chained_launch_equals_sequential(device, tiny_random, monkeypatch):
+    """The two-stream chained launch (in-kernel release/acquire hand-off between consecutive decode kernels) must give
+    bit-identical logits to plain single-stream ordering, step after step (a stale hand-off would show up here)."""
+    cfg, model, _ = tiny_random
+    eng = model.engine
+    frames, rows = _inputs(cfg, 2, [9, 21], seed=21)
+    fr = torch.from_numpy(frames).to(device)
+
+    def run(chain):
+        monkeypatch.setenv("EMMAX_CHAIN", "1" if chain else "0")
+        eng.new_session(eng.max_batch, eng.max_prompt, eng.max_ctx)     # the switch is read at session creation
+        model._prefill(rows, None, fr, max_new=40)
+        outs = []
+        for _ in range(24):
+            outs.append(eng.last_logits().clone())
+            eng.decode_step()
+        _, ids, lens = model.generate_actions_batch(fr, rows, max_new_tokens=24, stop_on_eos=False)
+        return torch.stack(outs), ids.clone(), lens.clone()
+
+    a, ids_a, lens_a = run(True)
+    b, ids_b, lens_b = run(False)
+    assert torch.equal(a, b)
+    assert torch.equal(ids_a, ids_b) and torch.equal(lens_a, lens_b)
+    monkeypatch.setenv("EMMAX_CHAIN", "1")
+    eng.new_session(eng.max_batch, eng.max_prompt, eng.max_ctx)
