@@ -57,21 +57,23 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x));
 // blocks, <= 128 VGPRs): the spinning consumer can never starve its producer.
 // ---------------------------------------------------------------------------------------------------------------------
 struct DepInfo {
-    unsigned int* wait_ctr;     // null: ordinary stream ordering, no in-kernel wait
-    unsigned int wait_count;    // blocks of the producer kernel
-    unsigned int* signal_ctr;   // null: nobody waits on this kernel
+    unsigned int* wait_flag;    // null: ordinary stream ordering, no in-kernel wait.  Polled word: != 0 once the producer is done
+    unsigned int* signal_ctr;   // null: nobody waits on this kernel.  Arrival counter of THIS kernel's blocks ...
+    unsigned int* signal_flag;  // ... and the flag its last-arriving block raises (a different 64-byte line than the counter,
+                                // so the consumer's pollers never contend with the producers' atomics)
+    unsigned int n_blocks;      // blocks of this kernel (the last arriver sees n_blocks - 1)
     unsigned int* err;          // set to 1 when a wait gave up (bounded spin)
 };
 
 __device__ __forceinline__ void dep_wait(const DepInfo& d) {
-    if (d.wait_ctr) {
+    if (d.wait_flag) {
         if (threadIdx.x == 0) {
             // bounded: a legitimate wait lasts one producer kernel (tens of us); ~0.1 s of polling means the protocol
             // is broken -> flag it (the host turns the flag into an error) and let every later wait fall through
             unsigned int spins = 0;
             if (__hip_atomic_load(d.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                while (__hip_atomic_load(d.wait_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < d.wait_count) {
-                    __builtin_amdgcn_s_sleep(4);
+                while (__hip_atomic_load(d.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    __builtin_amdgcn_s_sleep(8);
                     if (++spins > (1u << 18)) {
                         __hip_atomic_store(d.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
@@ -91,7 +93,8 @@ __device__ __forceinline__ void dep_signal(const DepInfo& d) {
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler may drop the wait behind buffer_wbl2 (G16 pitfall 12)
-            __hip_atomic_fetch_add(d.signal_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int prev = __hip_atomic_fetch_add(d.signal_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == d.n_blocks - 1u) __hip_atomic_store(d.signal_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

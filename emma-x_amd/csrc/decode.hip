@@ -612,8 +612,10 @@ static int launch_gemv_t(const GemvParams& p, hipStream_t stream, int* grid_out)
     int grid = gemv_grid(B, smem, p.n_groups, p.max_grid);
     if (MODE == MODE_LMHEAD) grid = min(grid, p.max_parts);
     if (grid_out) *grid_out = grid;
+    GemvParams q = p;
+    q.dep.n_blocks = (unsigned)grid;
     auto kern = emmax_decode_gemv_kernel<B, MODE, NORM, XATTN>;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(GW * 64), smem, stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(GW * 64), smem, stream, q);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
@@ -670,7 +672,9 @@ int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream,
     }
 }
 
-int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, const DepInfo& dep, hipStream_t stream) {
+int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, const DepInfo& dep_in, hipStream_t stream) {
+    DepInfo dep = dep_in;
+    dep.n_blocks = (unsigned)B;
     hipLaunchKernelGGL(emmax_decode_embed_kernel, dim3(B), dim3(256), 0, stream, cur_tok, (const bf16_t*)E, (bf16_t*)h, hidden, vocab, dep);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
@@ -683,8 +687,10 @@ int decode_attn_nsplit(int B, int Hkv) {
     return ns;
 }
 
-int launch_decode_attn(const DecodeAttnParams& p, int B, int Hq, int head_dim, int nsplit, hipStream_t stream) {
+int launch_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_dim, int nsplit, hipStream_t stream) {
     if (head_dim != 128) return -1;
+    DecodeAttnParams p = p_in;
+    p.dep.n_blocks = (unsigned)(nsplit * p.Hkv * B);
     const int G = Hq / p.Hkv;
     dim3 grid(nsplit, p.Hkv, B), block(256);
     switch (G) {
@@ -697,7 +703,9 @@ int launch_decode_attn(const DecodeAttnParams& p, int B, int Hq, int head_dim, i
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-int launch_decode_finish(const FinishParams& p, hipStream_t stream) {
+int launch_decode_finish(const FinishParams& p_in, hipStream_t stream) {
+    FinishParams p = p_in;
+    p.dep.n_blocks = (unsigned)p.B;
     hipLaunchKernelGGL(emmax_decode_finish_kernel, dim3(p.B), dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }

@@ -243,7 +243,8 @@ struct emmax_session {
     hipEvent_t ev = nullptr;
     hipStream_t overlap_stream = nullptr;   // second stream of the chained launch
     unsigned int* dep_ctr = nullptr;         // device: one completion counter per kernel of the step (+ error word at [511])
-    int chain = 1;                           // chained launch enabled (B <= 2 only); EMMAX_CHAIN=0 disables
+    int chain = 0;                           // chained launch (B <= 2 only), experimental: EMMAX_CHAIN=1 enables
+    int chain_graph = 0;                     // EMMAX_CHAIN_GRAPH=1: replay the chained step as two per-stream graphs
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t own_stream = nullptr;   // used by emmax_generate when the caller's stream is the (uncapturable) legacy stream
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -307,7 +308,7 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->n_out = (int32_t*)b.take(Bd * 4);
     s->out_ids = (int32_t*)b.take((int64_t)Bd * s->max_out * 4);
     s->max_new_d = (int32_t*)b.take(4);
-    s->dep_ctr = (unsigned int*)b.take(512 * 4);
+    s->dep_ctr = (unsigned int*)b.take((256 * 32 + 16) * 4);
     s->page_table = (int32_t*)b.take((int64_t)Bd * s->max_pages * 4);
     s->cos_t = (float*)b.take((int64_t)s->max_ctx * (m->cfg.head_dim / 2) * 4);
     s->sin_t = (float*)b.take((int64_t)s->max_ctx * (m->cfg.head_dim / 2) * 4);
@@ -397,6 +398,8 @@ static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_
 static bf16* kcache_of(emmax_session* s, int layer) { return s->kv + (size_t)layer * s->kv_layer_stride; }
 static bf16* vcache_of(emmax_session* s, int layer) { return s->kv + (size_t)layer * s->kv_layer_stride + s->kv_layer_stride / 2; }
 
+constexpr int DEP_MAX_KERNELS = 256;
+constexpr int DEP_WORDS = DEP_MAX_KERNELS * 32 + 16;
 struct Chain;
 static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, Chain* ch = nullptr);
 
@@ -404,17 +407,19 @@ static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* log
 struct Chain {
     emmax_session* s;
     hipStream_t st[2];
-    int k = 0, prev_grid = 0;
+    int k = 0;
     hipStream_t stream() const { return st[k & 1]; }
-    DepInfo dep() const {
+    // kernel k: arrival counter at word 32k, done flag at word 32k+16 (separate 64-byte lines); error word at the end
+    DepInfo dep() const {   // n_blocks is filled in by the launcher, which knows its grid
         DepInfo d;
-        d.wait_ctr = k > 0 ? s->dep_ctr + (k - 1) : nullptr;
-        d.wait_count = (unsigned)prev_grid;
-        d.signal_ctr = s->dep_ctr + k;
-        d.err = s->dep_ctr + 511;
+        d.wait_flag = k > 0 ? s->dep_ctr + 32 * (k - 1) + 16 : nullptr;
+        d.signal_ctr = s->dep_ctr + 32 * k;
+        d.signal_flag = s->dep_ctr + 32 * k + 16;
+        d.n_blocks = 0;
+        d.err = s->dep_ctr + DEP_WORDS - 1;
         return d;
     }
-    void launched(int grid) { prev_grid = grid; ++k; }
+    void launched() { ++k; }
 };
 
 static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, Chain* ch) {
@@ -426,7 +431,7 @@ static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* log
     int lm_grid = 0;
     if (ch) { p.dep = ch->dep(); p.max_grid = 256; st = ch->stream(); }
     KCHK(launch_proj(GEMV_LMHEAD, p, m->lm_head, m->lm_head_fm, B, st, &lm_grid));
-    if (ch) ch->launched(lm_grid);
+    if (ch) ch->launched();
     if (do_finish) {
         FinishParams f;
         memset(&f, 0, sizeof(f));
@@ -437,7 +442,7 @@ static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* log
         f.eos_id = m->cfg.eos_id; f.pad_id = m->cfg.pad_id; f.is_prefill = is_prefill ? 1 : 0;
         if (ch) { f.dep = ch->dep(); st = ch->stream(); }
         KCHK(launch_decode_finish(f, st));
-        if (ch) ch->launched(B);
+        if (ch) ch->launched();
     }
     return 0;
 }
@@ -523,7 +528,7 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             p.kcache = kcache_of(s, li); p.vcache = vcache_of(s, li);
             arm();
             KCHK(launch_proj(GEMV_QKV, p, L.wqkv, L.wqkv_fm, B, st, &grid));
-            if (ch) ch->launched(grid);
+            if (ch) ch->launched();
             return 0;
         case STAGE_ATTN: {
             DecodeAttnParams a;
@@ -534,7 +539,7 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             if (ch) a.dep = ch->dep();
             const int ns = decode_attn_nsplit(B, c.n_kv_heads);
             KCHK(launch_decode_attn(a, B, c.n_heads, c.head_dim, ns, st));
-            if (ch) ch->launched(ns * c.n_kv_heads * B);
+            if (ch) ch->launched();
             return 0;
         }
         case STAGE_OPROJ:
@@ -542,20 +547,20 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             p.attn_part = s->part; p.nsplit = decode_attn_nsplit(B, c.n_kv_heads); p.Hq = c.n_heads;   // split merge fused into the staging
             arm();
             KCHK(launch_proj(GEMV_RESID, p, L.wo, L.wo_fm, B, st, &grid));
-            if (ch) ch->launched(grid);
+            if (ch) ch->launched();
             return 0;
         case STAGE_GATEUP:
             p.x = s->dh; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln2; p.eps = c.rms_eps;
             p.y = s->dact; p.ldy = m->inter_p; p.n_rows = 2 * m->inter_p;
             arm();
             KCHK(launch_proj(GEMV_GATEUP, p, L.wgu, L.wgu_fm, B, st, &grid));
-            if (ch) ch->launched(grid);
+            if (ch) ch->launched();
             return 0;
         case STAGE_DOWN:
             p.x = s->dact; p.ldx = m->inter_p; p.ldw = m->inter_p; p.K = m->inter_p; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
             arm();
             KCHK(launch_proj(GEMV_RESID, p, L.wdown, L.wdown_fm, B, st, &grid));
-            if (ch) ch->launched(grid);
+            if (ch) ch->launched();
             return 0;
         default:
             return fail(EMMAX_ERR_INVALID, "unknown decode stage %d", stage);
@@ -566,7 +571,7 @@ static bool chain_on(const emmax_session* s, int B) { return s->chain && B < EMM
 
 // chained launch (see common.h): the kernels of a step alternate between `st` and the session's second stream
 static int chain_step_begin(emmax_session* s, hipStream_t st) {
-    HIPCHK(hipMemsetAsync(s->dep_ctr, 0, 511 * 4, st));          // counters of this step (the error word survives)
+    HIPCHK(hipMemsetAsync(s->dep_ctr, 0, (DEP_WORDS - 1) * 4, st));          // counters of this step (the error word survives)
     HIPCHK(hipEventRecord(s->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(s->overlap_stream, s->ev_fork, 0));
     return 0;
@@ -576,7 +581,7 @@ static int chain_step_kernels(emmax_session* s, int B, hipStream_t st) {
     Chain ch;
     ch.s = s; ch.st[0] = st; ch.st[1] = s->overlap_stream;
     KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, ch.dep(), ch.stream()));
-    ch.launched(B);
+    ch.launched();
     for (int li = 0; li < m->cfg.n_layers; ++li)
         for (int stage = STAGE_QKV; stage <= STAGE_DOWN; ++stage) {
             int r = run_decode_stage(s, B, li, stage, st, &ch);
@@ -584,7 +589,7 @@ static int chain_step_kernels(emmax_session* s, int B, hipStream_t st) {
         }
     int r = run_lm_head_step(s, B, false, nullptr, true, st, &ch);
     if (r) return r;
-    if (ch.k >= 500) return fail(EMMAX_ERR_INVALID, "too many kernels per step for the chained launch (%d)", ch.k);
+    if (ch.k >= DEP_MAX_KERNELS) return fail(EMMAX_ERR_INVALID, "too many kernels per step for the chained launch (%d)", ch.k);
     return 0;
 }
 static int chain_step_end(emmax_session* s, hipStream_t st) {
@@ -637,30 +642,53 @@ static int graph_fail(emmax_session* s, const std::string& why) {
 // alternating launches degrade to plain sequential execution.  Eager launching costs ~0.6 ms of host time per 2.5 ms
 // step, fully overlapped with the GPU.
 static int ensure_graph(emmax_session* s, int B, hipStream_t st) {
-    if (chain_on(s, B)) return 1;
+    const bool chain = chain_on(s, B);
+    if (chain && !s->chain_graph) return 1;
     if (s->graph_exec && s->graph_B == B && s->graph_stream_cap == st) return 0;
     drop_graph(s);
     if (s->graph_failed) return 1;
+    hipStream_t sb = s->overlap_stream;
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) return graph_fail(s, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e));
-    const int r = run_decode_step(s, B, st);
-    hipGraph_t g = nullptr;
-    e = hipStreamEndCapture(st, &g);
-    if (r != 0 || e != hipSuccess || !g) {
-        if (g) (void)hipGraphDestroy(g);
-        return graph_fail(s, r != 0 ? ("launch during capture: " + g_err) : (std::string("hipStreamEndCapture: ") + hipGetErrorString(e)));
+    if (chain) {   // two LINEAR graphs, one per stream; memset + fork/join stay outside (launch_graph_step)
+        e = hipStreamBeginCapture(sb, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) {
+            hipGraph_t tmp = nullptr;
+            (void)hipStreamEndCapture(st, &tmp);
+            if (tmp) (void)hipGraphDestroy(tmp);
+            return graph_fail(s, std::string("hipStreamBeginCapture(second stream): ") + hipGetErrorString(e));
+        }
     }
-    hipGraphExec_t ge = nullptr;
+    const int r = chain ? chain_step_kernels(s, B, st) : run_decode_step(s, B, st);
+    hipGraph_t g = nullptr, g2 = nullptr;
+    e = hipStreamEndCapture(st, &g);
+    hipError_t e2 = chain ? hipStreamEndCapture(sb, &g2) : hipSuccess;
+    if (r != 0 || e != hipSuccess || e2 != hipSuccess || !g || (chain && !g2)) {
+        if (g) (void)hipGraphDestroy(g);
+        if (g2) (void)hipGraphDestroy(g2);
+        return graph_fail(s, r != 0 ? ("launch during capture: " + g_err) : (std::string("hipStreamEndCapture: ") + hipGetErrorString(e != hipSuccess ? e : e2)));
+    }
+    hipGraphExec_t ge = nullptr, ge2 = nullptr;
     e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    if (e == hipSuccess && chain) e = hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0);
     if (e != hipSuccess) {
+        if (ge) (void)hipGraphExecDestroy(ge);
         (void)hipGraphDestroy(g);
+        if (g2) (void)hipGraphDestroy(g2);
         return graph_fail(s, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
     }
-    s->graph = g; s->graph_exec = ge; s->graph_B = B; s->graph_stream_cap = st;
+    s->graph = g; s->graph_exec = ge; s->graph2 = g2; s->graph_exec2 = ge2; s->graph_B = B; s->graph_stream_cap = st;
     return 0;
 }
 
 static int launch_graph_step(emmax_session* s, int B, hipStream_t st) {
+    if (chain_on(s, B)) {
+        int r = chain_step_begin(s, st);
+        if (r) return r;
+        HIPCHK(hipGraphLaunch(s->graph_exec, st));
+        HIPCHK(hipGraphLaunch(s->graph_exec2, s->overlap_stream));
+        return chain_step_end(s, st);
+    }
     HIPCHK(hipGraphLaunch(s->graph_exec, st));
     return 0;
 }
@@ -834,10 +862,20 @@ int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_
     HIPCHK(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&s->overlap_stream, hipStreamNonBlocking));
+    {   // a different priority class gives the second stream its own hardware queue
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&s->overlap_stream, hipStreamNonBlocking, hi) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(hipStreamCreateWithFlags(&s->overlap_stream, hipStreamNonBlocking));
+        }
+    }
+    s->chain_graph = getenv("EMMAX_CHAIN_GRAPH") && atoi(getenv("EMMAX_CHAIN_GRAPH")) != 0;
     HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
-    s->chain = !(getenv("EMMAX_CHAIN") && atoi(getenv("EMMAX_CHAIN")) == 0);
+    // OFF by default: measured 5.3 ms/token vs 3.1 ms for plain stream ordering -- an all-to-all in-kernel hand-off costs
+    // ~13 us under streaming load (MI355X_MICROARCH.md "fanin"), far more than the ~1.5 us kernel boundary it replaces.
+    s->chain = getenv("EMMAX_CHAIN") && atoi(getenv("EMMAX_CHAIN")) != 0;
     // static page assignment: row b owns pages [b*max_pages, (b+1)*max_pages)
     {
         std::vector<int32_t> pt((size_t)max_batch * s->max_pages);
@@ -978,7 +1016,7 @@ int emmax_generate(emmax_session* s, int max_new, int stop_on_eos, int32_t* out_
                             hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(out_lens, s->n_out, B * 4, hipMemcpyDeviceToDevice, st));
     if (s->chain && B < EMMAX_MFMA_MIN_BATCH) {   // a bounded dependency wait that gave up is an error, never a silent wrong answer
-        HIPCHK(hipMemcpyAsync(s->pinned + 1024, s->dep_ctr + 511, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(s->pinned + 1024, s->dep_ctr + DEP_WORDS - 1, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (s->pinned[1024] != 0) return fail(EMMAX_ERR_HIP, "chained launch: a dependency wait timed out (results invalid)");
     }

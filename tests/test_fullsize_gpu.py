@@ -116,5 +116,5 @@ def test_fullsize_chained_launch_equals_sequential(device, big, monkeypatch):
     ia, la, ga = run(True)
     ib, lb, gb = run(False)
     assert torch.equal(ia, ib) and torch.equal(la, lb) and torch.equal(ga, gb)
-    monkeypatch.setenv("EMMAX_CHAIN", "1")
+    monkeypatch.delenv("EMMAX_CHAIN")
     eng.new_session(eng.max_batch, eng.max_prompt, eng.max_ctx)
