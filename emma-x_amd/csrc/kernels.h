@@ -58,6 +58,8 @@ int launch_embed_splice(const int32_t* ids, int P_max, const int32_t* cu, const 
 int launch_rope_kv_write(void* qkv, int ld, int q_off, int k_off, int v_off, const int32_t* cu, int B, int total_rows,
                          const float* cos_t, const float* sin_t, void* kcache, void* vcache, const int32_t* page_table,
                          int max_pages, int Hq, int Hkv, int hd, int page, hipStream_t stream);
+int launch_resize_bicubic_u8(const uint8_t* src, int B, int H, int W, uint8_t* dst, int OH, int OW, uint8_t* tmp, const int32_t* bounds_h,
+                             const int32_t* kk_h, int ksize_h, const int32_t* bounds_v, const int32_t* kk_v, int ksize_v, hipStream_t stream);
 int launch_gather_last_rows(const void* in, void* out, const int32_t* cu, int B, int D, hipStream_t stream);
 
 // ---- decode.hip ----

@@ -135,6 +135,37 @@ __global__ __launch_bounds__(256) void emmax_gather_last_rows_kernel(const bf16_
     for (int c = threadIdx.x; c < D / 8; c += blockDim.x) o[c] = s[c];
 }
 
+// One separable pass of Pillow's antialiased bicubic resize on uint8 RGB (22-bit fixed-point taps, round-half-up, clip):
+// AXIS 1: [B,H,W,3] -> [B,H,out_n,3] (horizontal);  AXIS 0: [B,H,W,3] -> [B,out_n,W,3] (vertical).
+// bounds[o] = (first input index, taps), kk[o*ksize + t] = tap t.  Bit-exact with PIL.Image.resize(BICUBIC), which is what
+// torchvision's TVF.resize does for the PIL images of processing_prismatic.py:136.
+template <int AXIS>
+__global__ __launch_bounds__(256) void emmax_resize_pass_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int B, int H,
+                                                               int W, int out_n, const int32_t* __restrict__ bounds,
+                                                               const int32_t* __restrict__ kk, int ksize) {
+    const int OH = AXIS == 0 ? out_n : H, OW = AXIS == 1 ? out_n : W;
+    const size_t total = (size_t)B * OH * OW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int ox = (int)(i % OW), oy = (int)((i / OW) % OH), b = (int)(i / ((size_t)OW * OH));
+        const int o = AXIS == 0 ? oy : ox;
+        const int lo = bounds[2 * o], n = bounds[2 * o + 1];
+        const int32_t* k = kk + (size_t)o * ksize;
+        int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+        for (int t = 0; t < n; ++t) {
+            const int sy = AXIS == 0 ? lo + t : oy, sx = AXIS == 1 ? lo + t : ox;
+            const uint8_t* px = src + (((size_t)b * H + sy) * W + sx) * 3;
+            const int w = k[t];
+            a0 += (int)px[0] * w;
+            a1 += (int)px[1] * w;
+            a2 += (int)px[2] * w;
+        }
+        uint8_t* q = dst + (((size_t)b * OH + oy) * OW + ox) * 3;
+        q[0] = (uint8_t)min(max(a0 >> 22, 0), 255);
+        q[1] = (uint8_t)min(max(a1 >> 22, 0), 255);
+        q[2] = (uint8_t)min(max(a2 >> 22, 0), 255);
+    }
+}
+
 // device-side (re)initialisation of the per-sequence state at prefill: cu_seqlens, ctx_len, done, n_out.
 // Values travel as kernel arguments, so there is no host staging buffer to race with.
 __global__ void emmax_prefill_state_kernel(PrefillState st, int32_t* cu, int32_t* ctx_len, int32_t* done, int32_t* n_out) {
@@ -160,6 +191,29 @@ int launch_prefill_state(const PrefillState& st, int32_t* cu, int32_t* ctx_len, 
 }
 int launch_set_int(int32_t* p, int32_t v, hipStream_t stream) {
     hipLaunchKernelGGL(emmax_set_int_kernel, dim3(1), dim3(1), 0, stream, p, v);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_resize_bicubic_u8(const uint8_t* src, int B, int H, int W, uint8_t* dst, int OH, int OW, uint8_t* tmp, const int32_t* bounds_h,
+                             const int32_t* kk_h, int ksize_h, const int32_t* bounds_v, const int32_t* kk_v, int ksize_v, hipStream_t stream) {
+    // Pillow's order: horizontal first (into tmp [B,H,OW,3]), then vertical
+    const uint8_t* cur = src;
+    int curW = W;
+    if (W != OW) {
+        uint8_t* out = (H != OH) ? tmp : dst;
+        const size_t total = (size_t)B * H * OW;
+        hipLaunchKernelGGL(emmax_resize_pass_kernel<1>, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0, stream, cur, out, B, H, W,
+                           OW, bounds_h, kk_h, ksize_h);
+        cur = out;
+        curW = OW;
+    }
+    if (H != OH) {
+        const size_t total = (size_t)B * OH * curW;
+        hipLaunchKernelGGL(emmax_resize_pass_kernel<0>, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0, stream, cur, dst, B, H, curW,
+                           OH, bounds_v, kk_v, ksize_v);
+    } else if (W == OW) {
+        if (hipMemcpyAsync(dst, src, (size_t)B * H * W * 3, hipMemcpyDeviceToDevice, stream) != hipSuccess) return -4;
+    }
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -1110,6 +1110,16 @@ int emmax_op_gemv(const void* x, const void* W, void* y, int B, int N, int K, em
     return 0;
 }
 
+int emmax_op_resize_bicubic_u8(const uint8_t* src, int B, int H, int W, uint8_t* dst, int OH, int OW, uint8_t* tmp,
+                               const int32_t* bounds_h, const int32_t* kk_h, int ksize_h, const int32_t* bounds_v, const int32_t* kk_v,
+                               int ksize_v, emmax_stream st) {
+    if (!src || !dst || B < 1 || H < 1 || W < 1 || OH < 1 || OW < 1) return fail(EMMAX_ERR_INVALID, "emmax_op_resize_bicubic_u8: bad argument");
+    if ((W != OW && (!bounds_h || !kk_h)) || (H != OH && (!bounds_v || !kk_v)) || (W != OW && H != OH && !tmp))
+        return fail(EMMAX_ERR_INVALID, "emmax_op_resize_bicubic_u8: missing tables / scratch");
+    int r = launch_resize_bicubic_u8(src, B, H, W, dst, OH, OW, tmp, bounds_h, kk_h, ksize_h, bounds_v, kk_v, ksize_v, (hipStream_t)st);
+    if (r) return fail(EMMAX_ERR_HIP, "emmax_op_resize_bicubic_u8: launch failed");
+    return 0;
+}
 int emmax_op_repack_fm(const void* W, int ld, void* W_fm, int N, int K, emmax_stream st) {
     int r = launch_repack_fm(W, ld, W_fm, N, K, (hipStream_t)st);
     if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_repack_fm: N %% 16, K %% 32, ld %% 8 required");

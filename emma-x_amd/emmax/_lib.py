@@ -75,6 +75,7 @@ SIGNATURES = {
     "emmax_op_attention": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_float, C.c_int, _vp]),
     "emmax_op_gemv": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "emmax_op_resize_bicubic_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "emmax_op_repack_fm": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp]),
     "emmax_op_gemm_small": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
 }

@@ -146,6 +146,11 @@ class EmmaXConfig:
         L.vocab_size = tc.get("vocab_size", L.vocab_size)
         L.rms_eps = tc.get("rms_norm_eps", L.rms_eps)
         L.rope_theta = tc.get("rope_theta", L.rope_theta)
+        L.max_position = d.get("llm_max_length", L.max_position)
+        for tw, ov in zip(cfg.towers, d.get("emmax_tower_overrides") or []):   # synthetic tiny checkpoints only
+            for k in ("embed_dim", "depth", "num_heads", "mlp_hidden"):
+                if k in ov:
+                    setattr(tw, k, int(ov[k]))
         cfg.n_action_bins = d.get("n_action_bins", 256)
         cfg.pad_to_multiple_of = d.get("pad_to_multiple_of", 64)
         cfg.pad_token_id = d.get("pad_token_id", 32000)

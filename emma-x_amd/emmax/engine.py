@@ -113,10 +113,35 @@ class EmmaxEngine:
     def vision_encode(self, frames_u8: torch.Tensor) -> torch.Tensor:
         """uint8 [B,224,224,3] on device -> bf16 [B,256,hidden] projected patch embeddings."""
         assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.is_contiguous()
+        frames_u8 = self.resize_frames(frames_u8)   # no-op at the native 224x224
         B = frames_u8.shape[0]
         out = torch.empty(B, self.cfg.n_patches, self.cfg.llm.hidden_size, dtype=torch.bfloat16, device=self.device)
         _lib.check(self.lib.emmax_vision_encode(self._session, frames_u8.data_ptr(), B, out.data_ptr(), _lib.current_stream()),
                    "emmax_vision_encode")
+        return out
+
+    def resize_frames(self, frames_u8: torch.Tensor, size: Optional[int] = None) -> torch.Tensor:
+        """uint8 [B,H,W,3] on device -> uint8 [B,size,size,3], bit-exact with PIL.Image.resize(BICUBIC) (resize-naive)."""
+        from .resize import bicubic_coeffs
+
+        size = size or self.cfg.towers[0].image_size
+        B, H, W, _ = frames_u8.shape
+        if H == size and W == size:
+            return frames_u8
+        assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.is_contiguous()
+        key = (H, W, size)
+        if not hasattr(self, "_resize_tables"):
+            self._resize_tables = {}
+        if key not in self._resize_tables:
+            bh, kh, nh = bicubic_coeffs(W, size)
+            bv, kv, nv = bicubic_coeffs(H, size)
+            self._resize_tables[key] = tuple(torch.from_numpy(a.copy()).to(self.device) for a in (bh, kh, bv, kv)) + (nh, nv)
+        bh, kh, bv, kv, nh, nv = self._resize_tables[key]
+        out = torch.empty(B, size, size, 3, dtype=torch.uint8, device=self.device)
+        tmp = torch.empty(B, H, size, 3, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.emmax_op_resize_bicubic_u8(frames_u8.data_ptr(), B, H, W, out.data_ptr(), size, size, tmp.data_ptr(),
+                                                       bh.data_ptr(), kh.data_ptr(), nh, bv.data_ptr(), kv.data_ptr(), nv,
+                                                       _lib.current_stream()), "emmax_op_resize_bicubic_u8")
         return out
 
     def vision_encode_pixels(self, pixel_values: torch.Tensor) -> torch.Tensor:

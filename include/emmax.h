@@ -151,6 +151,14 @@ int emmax_op_attention(const void* qkv_dev, int ld_qkv, int q_off, int k_off, in
 /* Decode-path weight-streaming GEMV: y[b,n] = sum_k x[b,k] W[n,k]  (bf16 in, fp32 accumulate, bf16 out), B <= 8. */
 int emmax_op_gemv(const void* x_dev, const void* W_dev, void* y_dev, int B, int N, int K, emmax_stream stream);
 
+/* Pillow-exact antialiased bicubic resize of uint8 RGB frames [B,H,W,3] -> [B,OH,OW,3] on the device (the `resize-naive`
+ * transform of processing_prismatic.py:136 for non-224 cameras).  bounds_* int32 [out,2] = (first input index, taps),
+ * kk_* int32 [out,ksize] = 22-bit fixed-point taps as Pillow's precompute_coeffs/normalize_coeffs_8bpc produce them
+ * (emmax/resize.py builds them); tmp: uint8 [B,H,OW,3] scratch, needed when both axes change. */
+int emmax_op_resize_bicubic_u8(const uint8_t* src_dev, int B, int H, int W, uint8_t* dst_dev, int OH, int OW, uint8_t* tmp_dev,
+                               const int32_t* bounds_h_dev, const int32_t* kk_h_dev, int ksize_h, const int32_t* bounds_v_dev,
+                               const int32_t* kk_v_dev, int ksize_v, emmax_stream stream);
+
 /* Small-batch decode projection on MFMA: y[b,n] = sum_k x[b,k] W[n,k], weights in the MFMA-fragment-major layout that
  * emmax_op_repack_fm produces from a row-major [N,ld] matrix (N % 16 == 0, K % 32 == 0); 1 <= B <= 8. */
 int emmax_op_repack_fm(const void* W_dev, int ld, void* W_fm_out_dev, int N, int K, emmax_stream stream);

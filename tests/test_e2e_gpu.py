@@ -273,3 +273,39 @@ def test_chained_launch_equals_sequential(device, tiny_random, monkeypatch):
     assert torch.equal(ids_a, ids_b) and torch.equal(lens_a, lens_b)
     monkeypatch.delenv("EMMAX_CHAIN")
     eng.new_session(eng.max_batch, eng.max_prompt, eng.max_ctx)
+
+
+def test_checkpoint_ingest_and_caller_shims(device, tmp_path):
+    """HF-format directory (config.json + sharded safetensors + dataset_statistics.json) -> from_pretrained -> the
+    reference's caller functions (experiments/robot/openvla_utils.py get_vla_action / get_seq_action)."""
+    import sys
+
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    from tools.make_synthetic_checkpoint import write_checkpoint
+
+    from emmax.callers import get_seq_action, get_vla_action
+    from emmax.config import EmmaXConfig
+    from emmax.modeling import EmmaXForActionPrediction
+    from emmax.processing import EmmaXProcessor
+    from emmax.weights import synthetic_state_dict
+
+    cfg = EmmaXConfig.tiny()
+    ck = str(tmp_path / "ckpt")
+    write_checkpoint(ck, cfg, seed=5, planted=True, shards=3, tiny_towers=True)
+    vla = EmmaXForActionPrediction.from_pretrained(ck, torch_dtype=torch.bfloat16, trust_remote_code=True).to(device)
+    assert vla.config.llm.hidden_size == cfg.llm.hidden_size and vla.config.towers[1].mlp_hidden == cfg.towers[1].mlp_hidden
+    assert list(vla.norm_stats) == ["bridge_orig"]
+    proc = EmmaXProcessor.from_pretrained(ck)
+    rng = np.random.default_rng(8)
+    obs = {"full_image": rng.integers(0, 256, size=(224, 224, 3), dtype=np.uint8)}
+    # reference model built directly from the same synthetic weights must agree exactly
+    direct = EmmaXForActionPrediction(cfg, {k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(cfg, seed=5, planted=True).items()}).to(device)
+    a1 = get_vla_action(vla, proc, "openvla", obs, "Put the carrot on the plate", "bridge_orig")
+    a2 = get_vla_action(direct, proc, "openvla", obs, "Put the carrot on the plate", "bridge_orig")
+    assert a1.shape == (7,) and np.array_equal(a1, a2)
+    acts, text = get_seq_action(vla, proc, "openvla", obs, "What action should the robot take to achieve the instruction\nINSTRUCTION: \nput it down\n", "bridge_orig", "act")
+    acts2, text2 = get_seq_action(direct, proc, "openvla", obs, "What action should the robot take to achieve the instruction\nINSTRUCTION: \nput it down\n", "bridge_orig", "act")
+    assert text == text2 and len(acts) == len(acts2) and all(np.array_equal(x, y) for x, y in zip(acts, acts2))
+    with pytest.raises(NotImplementedError):
+        get_vla_action(vla, proc, "openvla", obs, "x", "bridge_orig", center_crop=True)

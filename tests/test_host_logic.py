@@ -170,3 +170,17 @@ def test_ids_level_action_extraction():
     ref = orc.unnormalize_actions(orc.decode_token_ids_to_actions(np.array(pol[:7])), stats)
     assert np.abs(got - ref).max() < 1e-6
     assert np.array_equal(m.actions_from_ids([5, 6, 7], stats), np.zeros(7, dtype=np.float32))
+
+
+def test_bicubic_tables_match_pillow():
+    """The coefficient restatement (emmax/resize.py) against the installed Pillow, incl. the robot's 256 -> 224."""
+    from PIL import Image
+
+    from emmax.resize import bicubic_coeffs, resize_u8_reference
+
+    rng = np.random.default_rng(0)
+    for h, w in [(256, 256), (480, 640), (224, 300), (100, 180)]:
+        a = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        assert np.array_equal(resize_u8_reference(a, 224, 224), np.asarray(Image.fromarray(a).resize((224, 224), Image.BICUBIC)))
+    b, k, n = bicubic_coeffs(256, 224)
+    assert n == 7 and b.shape == (224, 2) and abs(int(k[100].sum()) - (1 << 22)) <= 4

@@ -189,3 +189,27 @@ def test_gemm_small_mfma(device, B, N, K):
     torch.cuda.synchronize()
     assert torch.isfinite(y.float()).all()
     assert relerr(y, ref) < TOL
+
+
+@pytest.mark.parametrize("H,W", [(256, 256), (480, 640), (224, 300), (100, 180), (500, 224)])
+def test_device_resize_matches_pillow(device, H, W):
+    """Device-side resize-naive == PIL.Image.resize((224,224), BICUBIC) bit for bit (uint8)."""
+    from PIL import Image
+
+    from emmax.config import EmmaXConfig
+    from emmax.resize import bicubic_coeffs
+
+    L, lib = _lib()
+    rng = np.random.default_rng(H * 7 + W)
+    frames = rng.integers(0, 256, size=(2, H, W, 3), dtype=np.uint8)
+    ref = np.stack([np.asarray(Image.fromarray(f).resize((224, 224), Image.BICUBIC)) for f in frames])
+    src = torch.from_numpy(frames).to(device)
+    dst = torch.zeros(2, 224, 224, 3, dtype=torch.uint8, device=device)
+    tmp = torch.zeros(2, H, 224, 3, dtype=torch.uint8, device=device)
+    bh, kh, nh = bicubic_coeffs(W, 224)
+    bv, kv, nv = bicubic_coeffs(H, 224)
+    t = [torch.from_numpy(a.copy()).to(device) for a in (bh, kh, bv, kv)]
+    L.check(lib.emmax_op_resize_bicubic_u8(src.data_ptr(), 2, H, W, dst.data_ptr(), 224, 224, tmp.data_ptr(), t[0].data_ptr(), t[1].data_ptr(), nh,
+                                           t[2].data_ptr(), t[3].data_ptr(), nv, stream()), "resize")
+    torch.cuda.synchronize()
+    assert np.array_equal(dst.cpu().numpy(), ref)
