@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=512)
     ap.add_argument("--tiny", action="store_true", help="tiny config (plumbing check only; NOT a valid headline number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE config 5: fp8-e4m3 decode weights (NOT the bf16 headline)")
     args = ap.parse_args()
 
     from emmax import dist as edist
@@ -133,6 +134,9 @@ def main():
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
     cfg = EmmaXConfig.tiny() if args.tiny else EmmaXConfig.emma_x_7b()
+    if args.fp8:
+        cfg.decode_weight_dtype = "fp8"
+    wbytes = 1 if args.fp8 else 2   # bytes per decode weight
     B, P, T = args.batch_per_gpu, args.prompt_tokens, args.new_tokens
     model = EmmaXForActionPrediction.from_synthetic(cfg, seed=0, device=dev, max_batch=B, max_prompt=P,
                                                     max_ctx=cfg.n_patches + P + T + 1)
@@ -174,12 +178,12 @@ def main():
         inter_p = (L.intermediate_size + 63) // 64 * 64
         ctx = cfg.n_patches + P
         stage_bytes = {
-            "qkv_gemv": (qd + 2 * kvd) * L.hidden_size * 2,
+            "qkv_gemv": (qd + 2 * kvd) * L.hidden_size * wbytes,
             "paged_attn": B * 2 * ctx * kvd * 2,
-            "oproj_gemv": L.hidden_size * qd * 2,
-            "gateup_gemv": 2 * inter_p * L.hidden_size * 2,
-            "down_gemv": L.hidden_size * inter_p * 2,
-            "lmhead_argmax": L.vocab_size * L.hidden_size * 2,
+            "oproj_gemv": L.hidden_size * qd * wbytes,
+            "gateup_gemv": 2 * inter_p * L.hidden_size * wbytes,
+            "down_gemv": L.hidden_size * inter_p * wbytes,
+            "lmhead_argmax": L.vocab_size * L.hidden_size * wbytes,
         }
         dom = "gateup_gemv"
         achieved = stage_bytes[dom] / (stage_us[dom] * 1e-6) / 1e9
@@ -187,7 +191,7 @@ def main():
         # FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); not collected during this run
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if B == 1 and not args.tiny and os.path.isfile(pmc_file):
+        if B == 1 and not args.tiny and not args.fp8 and os.path.isfile(pmc_file):
             with open(pmc_file) as f:
                 traffic = json.load(f)["stages"].get(dom, {}).get("hbm_bytes_per_launch")
         # whole decode step: algorithmic bytes / measured step time
@@ -197,14 +201,14 @@ def main():
         torch.cuda.synchronize()
         step_ms = (time.perf_counter() - t_s) / nsteps * 1e3
         w_llm = (L.num_layers * ((qd + 2 * kvd) * L.hidden_size + L.hidden_size * qd + 3 * L.intermediate_size * L.hidden_size
-                                 + 2 * L.hidden_size) + L.hidden_size + L.vocab_size * L.hidden_size) * 2
+                                 + 2 * L.hidden_size) + L.hidden_size + L.vocab_size * L.hidden_size) * wbytes
         kv_bytes = L.num_layers * B * 2 * (ctx + nsteps // 2) * kvd * 2
         step_gbs = (w_llm + kv_bytes) / (step_ms * 1e-3) / 1e9
         out = {
             "metric": "actions/sec", "value": round(actions_per_s, 4), "unit": "actions/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: Emma-X-7B bf16, %d frame(s)/GPU 224x224, %d-token prompt, greedy, %d new tokens "
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not args.fp8 else "bf16 activations / fp8-e4m3 decode weights", "data": "synthetic",
+            "config": {"workload": ("BASELINE configs[4] (fp8 decode weights): " if args.fp8 else "") + ("BASELINE configs[1]: Emma-X-7B bf16, %d frame(s)/GPU 224x224, %d-token prompt, greedy, %d new tokens "
                                     "(EOS disabled), random-init weights" % (B, P, T)) if not args.tiny else "TINY plumbing config (invalid as headline)",
                        "batch_per_gpu": B, "global_batch": B * world, "prompt_tokens": P, "new_tokens": T, "context": ctx + T,
                        "parallelism": f"dp{world}", "hipgraph": eng.graph_active(), "chained_launch": eng.chain_active()},
@@ -213,7 +217,7 @@ def main():
             "decode_step_hbm_gbs": round(step_gbs, 1), "decode_step_hbm_frac": round(step_gbs / HBM_PEAK_GBS, 4),
             "stage_us": {k: round(v, 2) for k, v in stage_us.items()},
             "stage_gbs": {k: round(stage_bytes[k] / (stage_us[k] * 1e-6) / 1e9, 1) for k in stage_names},
-            "roofline": {"kernel": "emmax_decode_gemv_kernel<B=%d,GATEUP,NORM> (gate/up GEMV + SiLU*mul)" % B, "bound": "hbm",
+            "roofline": {"kernel": ("emmax_decode_gemv_kernel<B=%d,GATEUP,NORM>" % B if (B <= 2 and not args.fp8) else "emmax_decode_mfma_kernel<GATEUP,NORM%s> (B=%d)" % (",FP8" if args.fp8 else "", B)) + " (gate/up projection + SiLU*mul)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "bytes_per_launch": stage_bytes[dom], "us_per_launch": round(stage_us[dom], 2), "traffic": traffic,
                          "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, offline)" if traffic else None},

@@ -33,7 +33,57 @@ __global__ __launch_bounds__(256) void emmax_repack_fm_kernel(const bf16_t* __re
     }
 }
 
-template <int MODE, bool NORM, bool XATTN>
+// row-major bf16 [N, ld] -> fp8 e4m3 (OCP) fragment-major tiles + one fp32 scale per row (amax / 448).
+//   fm8[((n/16)*(K/64) + k/64) * 64 + lane] = 16 bytes: W8[row][64*(k/64) + 8g .. +8] ++ W8[row][64*(k/64) + 32 + 8g .. +8]
+//   with row = 16*(n/16) + (lane & 15), g = lane >> 4: one 16-byte load feeds two v_mfma_f32_16x16x32_bf16 k-steps.
+// One block per row.  N % 16 == 0, K % 64 == 0.
+__global__ __launch_bounds__(256) void emmax_quant_fm8_kernel(const bf16_t* __restrict__ src, int ld, uint8_t* __restrict__ dst,
+                                                             float* __restrict__ scales, int N, int K) {
+    const int n = blockIdx.x, tid = threadIdx.x;
+    __shared__ float red[4];
+    const bf16_t* row = src + (size_t)n * ld;
+    float amax = 0.f;
+    for (int c = tid; c < K / 8; c += 256) {
+        const u32x4_t v = *(const u32x4_t*)(row + c * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(bf_lo(v[j])), fabsf(bf_hi(v[j]))));
+    }
+    amax = wave_max(amax);
+    if ((tid & 63) == 0) red[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (tid == 0) scales[n] = scale;
+    const int nt = n >> 4, i16 = n & 15, KT2 = K / 64;
+    for (int c = tid; c < K / 8; c += 256) {       // one 8-element (8-byte) group per thread
+        const u32x4_t v = *(const u32x4_t*)(row + c * 8);
+        const int k = c * 8, kt2 = k >> 6, kin = k & 63, half = kin >> 5, g = (kin & 31) >> 3;
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[0]) / scale, bf_hi(v[0]) / scale, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[1]) / scale, bf_hi(v[1]) / scale, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[2]) / scale, bf_hi(v[2]) / scale, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[3]) / scale, bf_hi(v[3]) / scale, hi, true);
+        u32x2_t w = {(uint32_t)lo, (uint32_t)hi};
+        *(u32x2_t*)(dst + (((size_t)nt * KT2 + kt2) * 64 + g * 16 + i16) * 16 + half * 8) = w;
+    }
+}
+
+// 8 fp8 e4m3 (two dwords) -> 8 bf16 (exact: e4m3 fits bf16)
+__device__ __forceinline__ bf16x8_t fp8x8_to_bf16x8(uint32_t a, uint32_t b) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    const f32x2_t f0 = __builtin_amdgcn_cvt_pk_f32_fp8(a, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(a, true);
+    const f32x2_t f2 = __builtin_amdgcn_cvt_pk_f32_fp8(b, false), f3 = __builtin_amdgcn_cvt_pk_f32_fp8(b, true);
+    u32x4_t r;
+    r[0] = (__float_as_uint(f0[0]) >> 16) | (__float_as_uint(f0[1]) & 0xffff0000u);
+    r[1] = (__float_as_uint(f1[0]) >> 16) | (__float_as_uint(f1[1]) & 0xffff0000u);
+    r[2] = (__float_as_uint(f2[0]) >> 16) | (__float_as_uint(f2[1]) & 0xffff0000u);
+    r[3] = (__float_as_uint(f3[0]) >> 16) | (__float_as_uint(f3[1]) & 0xffff0000u);
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+
+// FP8: weights are the fp8 fragment-major copy (1 KiB tile = 16 rows x 64 k), de-quantised to bf16 in registers
+// (exact), per-row scale applied to the fp32 result; activations stay bf16.  A "k-step" is then 64 elements.
+template <int MODE, bool NORM, bool XATTN, bool FP8 = false>
 __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParams p) {
     constexpr int TILES = (MODE == MODE_QKV || MODE == MODE_GATEUP) ? 2 : 1;
     constexpr int U = 8;
@@ -47,7 +97,8 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, c16 = lane & 15;
-    const int KT = K / 32;                                       // k-steps of the whole row
+    constexpr int KS = FP8 ? 64 : 32;                            // elements per k-step (one 16-byte load per lane)
+    const int KT = K / KS;                                       // k-steps of the whole row
     const int n_tasks = p.n_groups;
     const int G = gridDim.x, bid = blockIdx.x;
     const int tq = n_tasks / G, tr = n_tasks % G;
@@ -66,7 +117,7 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
     };
     // this wave's k-step range inside phase ph
     auto slice = [&](int ph, int& k_lo, int& k_n) {
-        const int kt0 = ph * (KC / 32), ktn = min(KC, K - ph * KC) / 32;
+        const int kt0 = ph * (KC / KS), ktn = min(KC, K - ph * KC) / KS;
         const int q = ktn / GW, r = ktn % GW;
         k_lo = kt0 + wave * q + min(wave, r);
         k_n = q + (wave < r ? 1 : 0);
@@ -181,16 +232,25 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
                 stage_x(ph);
                 __syncthreads();
             }
-            const unsigned char* xb = smem + (size_t)xrow * pitch + ((size_t)(k_lo - ph * (KC / 32)) * 32 + g4 * 8) * 2;
+            const unsigned char* xb = smem + (size_t)xrow * pitch + ((size_t)(k_lo - ph * (KC / KS)) * KS + g4 * 8) * 2;
             for (int k0 = 0; k0 < k_n; k0 += U) {
                 if (k0 != 0) issue(t, k_lo, k0, k_n);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (k0 + u < k_n) {
-                        const bf16x8_t xf = *(const bf16x8_t*)(xb + (size_t)(k0 + u) * 64);
+                        const bf16x8_t xf = *(const bf16x8_t*)(xb + (size_t)(k0 + u) * (KS * 2));
+                        if (FP8) {
+                            const bf16x8_t xf2 = *(const bf16x8_t*)(xb + (size_t)(k0 + u) * (KS * 2) + 64);
 #pragma unroll
-                        for (int tt = 0; tt < TILES; ++tt)
-                            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wr[tt][u]), xf, acc[tt], 0, 0, 0);
+                            for (int tt = 0; tt < TILES; ++tt) {
+                                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(wr[tt][u][0], wr[tt][u][1]), xf, acc[tt], 0, 0, 0);
+                                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(wr[tt][u][2], wr[tt][u][3]), xf2, acc[tt], 0, 0, 0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int tt = 0; tt < TILES; ++tt)
+                                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wr[tt][u]), xf, acc[tt], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -211,6 +271,7 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
                 float s = 0.f;
 #pragma unroll
                 for (int w = 0; w < GW; ++w) s += red[((w * TILES + tt) * 4 + r) * 64 + l];
+                if (FP8) s *= p.wscale[tile_of(t, tt) * 16 + row_in];
                 v[tt] = s;
             }
             if (c < B) {
@@ -298,45 +359,57 @@ int launch_repack_fm(const void* src, int ld, void* dst, int N, int K, hipStream
 static size_t mfma_smem(int B, int kc, int tiles) { return (size_t)(B + 1) * (kc * 2 + 16) + (size_t)GW * tiles * 256 * 4 + 64; }
 
 // K phase length: multiple of 32, activations (B+1 rows) + reduction buffer within ~150 KiB
-static int mfma_kc(int B, int K, int tiles) {
+static int mfma_kc(int B, int K, int tiles, int kstep) {
     const size_t budget = 150 * 1024 - (size_t)GW * tiles * 256 * 4 - 64;
     int cap = (int)(budget / (B + 1) - 16) / 2;
-    cap &= ~31;
+    cap = cap / kstep * kstep;
     if (K <= cap) return K;
     const int nph = cdiv(K, cap);
-    return cdiv(cdiv(K, nph), 32) * 32;
+    return cdiv(cdiv(K, nph), kstep) * kstep;
 }
 
 int decode_mfma_lmhead_grid(int n_rows, int max_parts) { return min(min(256, cdiv(n_rows, 16)), max_parts); }
 
-template <int MODE, bool NORM, bool XATTN>
+template <int MODE, bool NORM, bool XATTN, bool FP8>
 static int launch_mfma_t(GemvParams p, int B, hipStream_t stream) {
     constexpr int TILES = (MODE == MODE_QKV || MODE == MODE_GATEUP) ? 2 : 1;
-    if (p.K % 32 || p.n_rows % (16 * TILES)) {
+    if (FP8 && !p.wscale) return -1;
+    if (p.K % (FP8 ? 64 : 32) || p.n_rows % (16 * TILES)) {
         if (!(MODE == MODE_LMHEAD && p.n_rows % 16 == 0)) return -1;
     }
     p.batch = B;
-    p.kc = mfma_kc(B, p.K, TILES);
+    p.kc = mfma_kc(B, p.K, TILES, FP8 ? 64 : 32);
     if (NORM && p.kc != p.K) return -1;
     p.n_groups = p.n_rows / (16 * TILES);
     int grid = min(256, p.n_groups);
     if (MODE == MODE_LMHEAD) grid = min(grid, p.max_parts);
     const size_t smem = mfma_smem(B, p.kc, TILES);
-    hipLaunchKernelGGL((emmax_decode_mfma_kernel<MODE, NORM, XATTN>), dim3(grid), dim3(GW * 64), smem, stream, p);
+    hipLaunchKernelGGL((emmax_decode_mfma_kernel<MODE, NORM, XATTN, FP8>), dim3(grid), dim3(GW * 64), smem, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+template <bool FP8>
+static int launch_mfma_mode(int mode, const GemvParams& p, int B, hipStream_t stream) {
+    switch (mode) {
+        case MODE_QKV: return launch_mfma_t<MODE_QKV, true, false, FP8>(p, B, stream);
+        case MODE_RESID:
+            return p.attn_part ? launch_mfma_t<MODE_RESID, false, true, FP8>(p, B, stream) : launch_mfma_t<MODE_RESID, false, false, FP8>(p, B, stream);
+        case MODE_GATEUP: return launch_mfma_t<MODE_GATEUP, true, false, FP8>(p, B, stream);
+        case MODE_LMHEAD: return launch_mfma_t<MODE_LMHEAD, true, false, FP8>(p, B, stream);
+        case MODE_PLAIN: return launch_mfma_t<MODE_PLAIN, false, false, FP8>(p, B, stream);
+        default: return -1;
+    }
 }
 
 int launch_decode_mfma(int mode, const GemvParams& p, int B, hipStream_t stream) {
     if (B < 1 || B > EMMAX_MAX_DECODE_BATCH) return -1;
-    switch (mode) {
-        case MODE_QKV: return launch_mfma_t<MODE_QKV, true, false>(p, B, stream);
-        case MODE_RESID:
-            return p.attn_part ? launch_mfma_t<MODE_RESID, false, true>(p, B, stream) : launch_mfma_t<MODE_RESID, false, false>(p, B, stream);
-        case MODE_GATEUP: return launch_mfma_t<MODE_GATEUP, true, false>(p, B, stream);
-        case MODE_LMHEAD: return launch_mfma_t<MODE_LMHEAD, true, false>(p, B, stream);
-        case MODE_PLAIN: return launch_mfma_t<MODE_PLAIN, false, false>(p, B, stream);
-        default: return -1;
-    }
+    return p.wscale ? launch_mfma_mode<true>(mode, p, B, stream) : launch_mfma_mode<false>(mode, p, B, stream);
+}
+
+int launch_quant_fm8(const void* src, int ld, void* dst, float* scales, int N, int K, hipStream_t stream) {
+    if (N % 16 || K % 64 || ld % 8) return -1;
+    hipLaunchKernelGGL(emmax_quant_fm8_kernel, dim3(N), dim3(256), 0, stream, (const bf16_t*)src, ld, (uint8_t*)dst, scales, N, K);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
 int decode_mfma_init() {
@@ -344,7 +417,9 @@ int decode_mfma_init() {
     if (done == 0) return 0;
     const int lim = 160 * 1024 - 4096;
     hipError_t e = hipSuccess;
-#define SET(M, N_, X) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_mfma_kernel<M, N_, X>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
+#define SET(M, N_, X)                                                                                                          \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_mfma_kernel<M, N_, X, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim); \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_mfma_kernel<M, N_, X, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
     SET(MODE_QKV, true, false); SET(MODE_RESID, false, true); SET(MODE_RESID, false, false); SET(MODE_GATEUP, true, false);
     SET(MODE_LMHEAD, true, false); SET(MODE_PLAIN, false, false);
 #undef SET

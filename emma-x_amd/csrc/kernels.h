@@ -91,6 +91,7 @@ struct GemvParams {
     // RESID with x = merged attention output: split partials f32 [B][Hq][nsplit][132] (null: x is a bf16 vector)
     const float* attn_part;
     int nsplit;
+    const float* wscale;    // MFMA path: per-row fp32 scales when W is the fp8 fragment-major copy (null: bf16 copy)
     int max_grid;           // 0: default persistent grid; chained launch caps it at 256 (two kernels co-resident)
     DepInfo dep;            // chained-launch hand-off (all null: plain stream ordering)
 };
@@ -134,6 +135,7 @@ int launch_set_tokens(int32_t* cur_tok, const int32_t* toks, int B, hipStream_t 
 
 // ---- decode_mfma.hip: small-batch (B >= 3) projections on MFMA over the fragment-major weight copy ----
 int launch_repack_fm(const void* src, int ld, void* dst, int N, int K, hipStream_t stream);
+int launch_quant_fm8(const void* src, int ld, void* dst, float* scales, int N, int K, hipStream_t stream);   // fp8 e4m3 + per-row scale
 int launch_decode_mfma(int mode, const GemvParams& p, int B, hipStream_t stream);   // p.W = fragment-major copy
 int decode_mfma_lmhead_grid(int n_rows, int max_parts);
 int decode_mfma_init();

@@ -69,7 +69,8 @@ struct TowerW {
 };
 struct LayerW {
     bf16 *ln1, *wqkv, *wo, *ln2, *wgu, *wdown;
-    bf16 *wqkv_fm, *wo_fm, *wgu_fm, *wdown_fm;   // MFMA-fragment-major copies for the B >= 3 decode path
+    bf16 *wqkv_fm, *wo_fm, *wgu_fm, *wdown_fm;   // MFMA-fragment-major copies for the B >= 3 decode path (fp8 mode: e4m3 tiles)
+    float *wqkv_sc, *wo_sc, *wgu_sc, *wdown_sc;  // fp8 mode: per-row scales (null otherwise)
 };
 
 struct emmax_model {
@@ -81,6 +82,8 @@ struct emmax_model {
     TowerW tw[2];
     bf16 *pj1_w, *pj1_b, *pj2_w, *pj2_b, *pj3_w, *pj3_b;
     bf16 *embed, *final_norm, *lm_head, *lm_head_fm;
+    float* lm_head_sc = nullptr;
+    bool fp8 = false;
     std::vector<LayerW> layers;
 };
 
@@ -103,6 +106,7 @@ static int check_config(const emmax_config& c) {
     if (G != 1 && G != 2 && G != 4 && G != 8) return fail(EMMAX_ERR_INVALID, "GQA group %d unsupported (1,2,4,8)", G);
     if (c.inter % 16) return fail(EMMAX_ERR_INVALID, "LLM intermediate size must be a multiple of 16");
     if (c.vocab % 8) return fail(EMMAX_ERR_INVALID, "vocab must be a multiple of 8");
+    if (c.decode_fp8 && (c.hidden % 64 || (c.n_heads * c.head_dim) % 64)) return fail(EMMAX_ERR_INVALID, "fp8 decode needs K % 64 == 0");
     return 0;
 }
 
@@ -137,6 +141,7 @@ static void derive(emmax_model* m) {
         T.blk.resize(T.n_blocks);
     }
     m->layers.resize(c.n_layers);
+    m->fp8 = c.decode_fp8 != 0;
 }
 
 // Arena plan.  `base == nullptr` only sizes.  Every tensor is 256-byte aligned.
@@ -181,14 +186,23 @@ static void plan_arena(emmax_model* m, Bump& b) {
         L.ln2 = b.take(m->H);
         L.wgu = b.take((int64_t)2 * m->inter_p * m->H);
         L.wdown = b.take((int64_t)m->H * m->inter_p);
-        L.wqkv_fm = b.take((int64_t)m->qkv_dim * m->H);
-        L.wo_fm = b.take((int64_t)m->H * m->q_dim);
-        L.wgu_fm = b.take((int64_t)2 * m->inter_p * m->H);
-        L.wdown_fm = b.take((int64_t)m->H * m->inter_p);
+        const int d = m->fp8 ? 2 : 1;   // fp8 tiles take half the bytes
+        L.wqkv_fm = b.take((int64_t)m->qkv_dim * m->H / d);
+        L.wo_fm = b.take((int64_t)m->H * m->q_dim / d);
+        L.wgu_fm = b.take((int64_t)2 * m->inter_p * m->H / d);
+        L.wdown_fm = b.take((int64_t)m->H * m->inter_p / d);
+        L.wqkv_sc = L.wo_sc = L.wgu_sc = L.wdown_sc = nullptr;
+        if (m->fp8) {
+            L.wqkv_sc = (float*)b.take(2 * (int64_t)m->qkv_dim);
+            L.wo_sc = (float*)b.take(2 * (int64_t)m->H);
+            L.wgu_sc = (float*)b.take(4 * (int64_t)m->inter_p);
+            L.wdown_sc = (float*)b.take(2 * (int64_t)m->H);
+        }
     }
     m->final_norm = b.take(m->H);
     m->lm_head = b.take((int64_t)m->vocab_p * m->H);
-    m->lm_head_fm = b.take((int64_t)m->vocab_p * m->H);
+    m->lm_head_fm = b.take((int64_t)m->vocab_p * m->H / (m->fp8 ? 2 : 1));
+    if (m->fp8) m->lm_head_sc = (float*)b.take(2 * (int64_t)m->vocab_p);
 }
 
 // copy a bound [rows, cols] bf16 matrix into dst (row pitch dst_ld elements) starting at dst row `row0`
@@ -386,9 +400,11 @@ static int run_vision(emmax_session* s, bool from_u8, const void* src, int B, vo
 }
 
 // B <= 2: per-lane dot-product GEMV over the row-major weights; B >= 3: MFMA over the fragment-major copy
-static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_fm, int B, hipStream_t st, int* grid_out = nullptr) {
-    if (B >= EMMAX_MFMA_MIN_BATCH) {
+static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_fm, int B, hipStream_t st, int* grid_out = nullptr,
+                       const float* w_scale = nullptr) {
+    if (B >= EMMAX_MFMA_MIN_BATCH || w_scale) {   // fp8 weights exist only as fragment-major tiles: every batch goes MFMA
         p.W = w_fm;
+        p.wscale = w_scale;
         return launch_decode_mfma(mode, p, B, st);
     }
     p.W = w_rm;
@@ -430,12 +446,12 @@ static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* log
     p.n_rows = m->vocab; p.max_parts = s->n_lm_blocks; p.part_val = s->part_val; p.part_idx = s->part_idx; p.logits_out = logits_out;
     int lm_grid = 0;
     if (ch) { p.dep = ch->dep(); p.max_grid = 256; st = ch->stream(); }
-    KCHK(launch_proj(GEMV_LMHEAD, p, m->lm_head, m->lm_head_fm, B, st, &lm_grid));
+    KCHK(launch_proj(GEMV_LMHEAD, p, m->lm_head, m->lm_head_fm, B, st, &lm_grid, m->lm_head_sc));
     if (ch) ch->launched();
     if (do_finish) {
         FinishParams f;
         memset(&f, 0, sizeof(f));
-        f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = B >= EMMAX_MFMA_MIN_BATCH ? decode_mfma_lmhead_grid(m->vocab, s->n_lm_blocks) : decode_lmhead_grid(B, m->H, m->vocab, s->n_lm_blocks, ch ? 256 : 0);
+        f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = (B >= EMMAX_MFMA_MIN_BATCH || m->fp8) ? decode_mfma_lmhead_grid(m->vocab, s->n_lm_blocks) : decode_lmhead_grid(B, m->H, m->vocab, s->n_lm_blocks, ch ? 256 : 0);
         f.B = B;
         f.cur_tok = s->cur_tok; f.ctx_len = s->ctx_len; f.done = s->done; f.n_out = s->n_out; f.out_ids = s->out_ids;
         f.max_new_p = s->max_new_d; f.max_out = s->max_out; f.max_ctx = s->max_ctx;
@@ -527,7 +543,7 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             p.ctx_len = s->ctx_len; p.page_table = s->page_table; p.cos_t = s->cos_t; p.sin_t = s->sin_t;
             p.kcache = kcache_of(s, li); p.vcache = vcache_of(s, li);
             arm();
-            KCHK(launch_proj(GEMV_QKV, p, L.wqkv, L.wqkv_fm, B, st, &grid));
+            KCHK(launch_proj(GEMV_QKV, p, L.wqkv, L.wqkv_fm, B, st, &grid, L.wqkv_sc));
             if (ch) ch->launched();
             return 0;
         case STAGE_ATTN: {
@@ -546,20 +562,20 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             p.x = s->datt; p.ldx = m->q_dim; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
             p.attn_part = s->part; p.nsplit = decode_attn_nsplit(B, c.n_kv_heads); p.Hq = c.n_heads;   // split merge fused into the staging
             arm();
-            KCHK(launch_proj(GEMV_RESID, p, L.wo, L.wo_fm, B, st, &grid));
+            KCHK(launch_proj(GEMV_RESID, p, L.wo, L.wo_fm, B, st, &grid, L.wo_sc));
             if (ch) ch->launched();
             return 0;
         case STAGE_GATEUP:
             p.x = s->dh; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln2; p.eps = c.rms_eps;
             p.y = s->dact; p.ldy = m->inter_p; p.n_rows = 2 * m->inter_p;
             arm();
-            KCHK(launch_proj(GEMV_GATEUP, p, L.wgu, L.wgu_fm, B, st, &grid));
+            KCHK(launch_proj(GEMV_GATEUP, p, L.wgu, L.wgu_fm, B, st, &grid, L.wgu_sc));
             if (ch) ch->launched();
             return 0;
         case STAGE_DOWN:
             p.x = s->dact; p.ldx = m->inter_p; p.ldw = m->inter_p; p.K = m->inter_p; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
             arm();
-            KCHK(launch_proj(GEMV_RESID, p, L.wdown, L.wdown_fm, B, st, &grid));
+            KCHK(launch_proj(GEMV_RESID, p, L.wdown, L.wdown_fm, B, st, &grid, L.wdown_sc));
             if (ch) ch->launched();
             return 0;
         default:
@@ -567,7 +583,7 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
     }
 }
 
-static bool chain_on(const emmax_session* s, int B) { return s->chain && B < EMMAX_MFMA_MIN_BATCH; }
+static bool chain_on(const emmax_session* s, int B) { return s->chain && B < EMMAX_MFMA_MIN_BATCH && !s->m->fp8; }
 
 // chained launch (see common.h): the kernels of a step alternate between `st` and the session's second stream
 static int chain_step_begin(emmax_session* s, hipStream_t st) {
@@ -791,14 +807,22 @@ int emmax_model_finalize(emmax_model* m, void* arena, int64_t arena_bytes, emmax
             HIPCHK(hipMemcpy2DAsync((char*)L.wgu + grp, 2 * grp, iu->second.ptr, grp, grp, m->inter / 16, hipMemcpyDeviceToDevice, st));
         }
         PUT2(P + "mlp.down_proj.weight", m->H, m->inter, L.wdown, m->inter_p, 0);
-        KCHK(launch_repack_fm(L.wqkv, m->H, L.wqkv_fm, m->qkv_dim, m->H, st));
-        KCHK(launch_repack_fm(L.wo, m->q_dim, L.wo_fm, m->H, m->q_dim, st));
-        KCHK(launch_repack_fm(L.wgu, m->H, L.wgu_fm, 2 * m->inter_p, m->H, st));
-        KCHK(launch_repack_fm(L.wdown, m->inter_p, L.wdown_fm, m->H, m->inter_p, st));
+        if (m->fp8) {
+            KCHK(launch_quant_fm8(L.wqkv, m->H, L.wqkv_fm, L.wqkv_sc, m->qkv_dim, m->H, st));
+            KCHK(launch_quant_fm8(L.wo, m->q_dim, L.wo_fm, L.wo_sc, m->H, m->q_dim, st));
+            KCHK(launch_quant_fm8(L.wgu, m->H, L.wgu_fm, L.wgu_sc, 2 * m->inter_p, m->H, st));
+            KCHK(launch_quant_fm8(L.wdown, m->inter_p, L.wdown_fm, L.wdown_sc, m->H, m->inter_p, st));
+        } else {
+            KCHK(launch_repack_fm(L.wqkv, m->H, L.wqkv_fm, m->qkv_dim, m->H, st));
+            KCHK(launch_repack_fm(L.wo, m->q_dim, L.wo_fm, m->H, m->q_dim, st));
+            KCHK(launch_repack_fm(L.wgu, m->H, L.wgu_fm, 2 * m->inter_p, m->H, st));
+            KCHK(launch_repack_fm(L.wdown, m->inter_p, L.wdown_fm, m->H, m->inter_p, st));
+        }
     }
     PUT1("language_model.model.norm.weight", m->H, m->final_norm);
     PUT2("language_model.lm_head.weight", m->vocab, m->H, m->lm_head, m->H, 0);
-    KCHK(launch_repack_fm(m->lm_head, m->H, m->lm_head_fm, m->vocab_p, m->H, st));
+    if (m->fp8) KCHK(launch_quant_fm8(m->lm_head, m->H, m->lm_head_fm, m->lm_head_sc, m->vocab_p, m->H, st));
+    else KCHK(launch_repack_fm(m->lm_head, m->H, m->lm_head_fm, m->vocab_p, m->H, st));
 #undef PUT2
 #undef PUT1
     HIPCHK(hipStreamSynchronize(st));
@@ -1118,6 +1142,21 @@ int emmax_op_resize_bicubic_u8(const uint8_t* src, int B, int H, int W, uint8_t*
         return fail(EMMAX_ERR_INVALID, "emmax_op_resize_bicubic_u8: missing tables / scratch");
     int r = launch_resize_bicubic_u8(src, B, H, W, dst, OH, OW, tmp, bounds_h, kk_h, ksize_h, bounds_v, kk_v, ksize_v, (hipStream_t)st);
     if (r) return fail(EMMAX_ERR_HIP, "emmax_op_resize_bicubic_u8: launch failed");
+    return 0;
+}
+int emmax_op_quant_fm8(const void* W, int ld, void* W8, float* scales, int N, int K, emmax_stream st) {
+    int r = launch_quant_fm8(W, ld, W8, scales, N, K, (hipStream_t)st);
+    if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_quant_fm8: N %% 16, K %% 64, ld %% 8 required");
+    return 0;
+}
+int emmax_op_gemm_small_fp8(const void* x, const void* W8, const float* scales, void* y, int B, int N, int K, emmax_stream st) {
+    GemvParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.ldx = K; p.W = W8; p.ldw = K; p.K = K; p.y = y; p.ldy = N; p.n_rows = N; p.wscale = scales;
+    if (!scales) return fail(EMMAX_ERR_INVALID, "emmax_op_gemm_small_fp8: scales required");
+    if (decode_mfma_init() != 0) return fail(EMMAX_ERR_HIP, "could not raise the dynamic LDS limit of the MFMA decode kernels");
+    int r = launch_decode_mfma(GEMV_PLAIN, p, B, (hipStream_t)st);
+    if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_gemm_small_fp8: unsupported shape (1 <= B <= 8, N %% 16, K %% 64)");
     return 0;
 }
 int emmax_op_repack_fm(const void* W, int ld, void* W_fm, int N, int K, emmax_stream st) {

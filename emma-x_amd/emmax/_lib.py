@@ -39,7 +39,7 @@ class ConfigC(C.Structure):
         ("hidden", C.c_int32), ("inter", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32),
         ("n_kv_heads", C.c_int32), ("head_dim", C.c_int32), ("vocab", C.c_int32),
         ("rms_eps", C.c_float), ("rope_theta", C.c_float),
-        ("bos_id", C.c_int32), ("eos_id", C.c_int32), ("pad_id", C.c_int32),
+        ("bos_id", C.c_int32), ("eos_id", C.c_int32), ("pad_id", C.c_int32), ("decode_fp8", C.c_int32),
     ]
 
 
@@ -76,6 +76,8 @@ SIGNATURES = {
                                      C.c_int, C.c_int, C.c_float, C.c_int, _vp]),
     "emmax_op_gemv": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "emmax_op_resize_bicubic_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
+    "emmax_op_quant_fm8": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "emmax_op_gemm_small_fp8": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "emmax_op_repack_fm": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp]),
     "emmax_op_gemm_small": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
 }

@@ -85,6 +85,8 @@ class EmmaXConfig:
     llm_backbone_id: str = "llama2-7b-pure"
     arch_specifier: str = "no-align+fused-gelu-mlp"
     image_resize_strategy: str = "resize-naive"
+    # MI355X extension (BASELINE config 5): "fp8" streams an e4m3 per-row-scaled copy of the LLM projections in decode
+    decode_weight_dtype: str = "bf16"
 
     # --- derived ---
     @property

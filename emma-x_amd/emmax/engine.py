@@ -33,6 +33,7 @@ def _config_c(cfg: EmmaXConfig) -> _lib.ConfigC:
         L.hidden_size, L.intermediate_size, L.num_layers, L.num_heads, L.num_kv_heads, L.head_dim, L.vocab_size)
     c.rms_eps, c.rope_theta = L.rms_eps, L.rope_theta
     c.bos_id, c.eos_id, c.pad_id = cfg.bos_token_id, cfg.eos_token_id, cfg.pad_token_id
+    c.decode_fp8 = 1 if getattr(cfg, "decode_weight_dtype", "bf16") == "fp8" else 0
     return c
 
 

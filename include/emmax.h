@@ -64,6 +64,8 @@ typedef struct emmax_config {
     int32_t hidden, inter, n_layers, n_heads, n_kv_heads, head_dim, vocab;
     float rms_eps, rope_theta;
     int32_t bos_id, eos_id, pad_id;
+    int32_t decode_fp8;                /* 1: the decode projections stream an fp8-e4m3 (per-row scale) weight copy, de-quantised
+                                          in registers (BASELINE config 5); 0: bf16 weights (the headline path)     */
 } emmax_config;
 
 const char* emmax_version(void);
@@ -161,6 +163,11 @@ int emmax_op_resize_bicubic_u8(const uint8_t* src_dev, int B, int H, int W, uint
 
 /* Small-batch decode projection on MFMA: y[b,n] = sum_k x[b,k] W[n,k], weights in the MFMA-fragment-major layout that
  * emmax_op_repack_fm produces from a row-major [N,ld] matrix (N % 16 == 0, K % 32 == 0); 1 <= B <= 8. */
+/* fp8 variant: quantise a row-major bf16 [N,ld] matrix to e4m3 fragment-major tiles + fp32 per-row scales (N % 16, K % 64),
+ * and the matching small-batch projection (activations bf16, weights de-quantised in registers). */
+int emmax_op_quant_fm8(const void* W_dev, int ld, void* W8_fm_out_dev, float* scales_out_dev, int N, int K, emmax_stream stream);
+int emmax_op_gemm_small_fp8(const void* x_dev, const void* W8_fm_dev, const float* scales_dev, void* y_dev, int B, int N, int K,
+                            emmax_stream stream);
 int emmax_op_repack_fm(const void* W_dev, int ld, void* W_fm_out_dev, int N, int K, emmax_stream stream);
 int emmax_op_gemm_small(const void* x_dev, const void* W_fm_dev, void* y_dev, int B, int N, int K, emmax_stream stream);
 

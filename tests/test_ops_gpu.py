@@ -213,3 +213,33 @@ def test_device_resize_matches_pillow(device, H, W):
                                            t[2].data_ptr(), t[3].data_ptr(), nv, stream()), "resize")
     torch.cuda.synchronize()
     assert np.array_equal(dst.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("B", [1, 4, 8])
+@pytest.mark.parametrize("N,K", [(256, 256), (4096, 4096), (1008, 11008), (64, 704)])
+def test_fp8_weight_projection(device, B, N, K):
+    """fp8-e4m3 weight copy (per-row scale, fragment-major) de-quantised in registers: the device quantiser must agree
+    with torch.float8_e4m3fn (OCP) bit for bit, and the projection with an fp32 matmul over the de-quantised weights."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(B * 5 + N + K)
+    x = bf(torch.randn(B, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    W[3, 5] = 0.7   # an outlier that sets the row scale
+    scale_ref = W.float().abs().amax(dim=1).clamp_min(1e-30) / 448.0
+    Wq_ref = (W.float() / scale_ref[:, None]).to(torch.float8_e4m3fn)
+    Wd, xd = W.to(device), x.to(device)
+    W8 = torch.empty(N * K, dtype=torch.uint8, device=device)
+    sc = torch.empty(N, dtype=torch.float32, device=device)
+    L.check(lib.emmax_op_quant_fm8(Wd.data_ptr(), K, W8.data_ptr(), sc.data_ptr(), N, K, stream()), "quant")
+    torch.cuda.synchronize()
+    assert torch.allclose(sc.cpu(), scale_ref, rtol=1e-6, atol=0)
+    # undo the fragment-major layout: tile (nt, kt2) lane (g, i) bytes [0:8] = k 8g.., [8:16] = k 32+8g..
+    t = W8.cpu().view(N // 16, K // 64, 4, 16, 2, 8)            # nt, kt2, g, i, half, j
+    back = t.permute(0, 3, 1, 4, 2, 5).reshape(N, K)              # (nt, i) x (kt2, half, g, j)
+    diff = (back != Wq_ref.view(torch.uint8))
+    assert not diff.any(), f"{int(diff.sum())} of {diff.numel()} fp8 codes differ from torch.float8_e4m3fn"
+    ref = x.float() @ (Wq_ref.float() * scale_ref[:, None]).t()
+    y = torch.full((B, N), float("nan"), dtype=torch.bfloat16, device=device)
+    L.check(lib.emmax_op_gemm_small_fp8(xd.data_ptr(), W8.data_ptr(), sc.data_ptr(), y.data_ptr(), B, N, K, stream()), "gemm fp8")
+    torch.cuda.synchronize()
+    assert relerr(y, ref) < TOL
