@@ -16,6 +16,8 @@
 // Attention: split-KV over the paged cache (16 lanes per key row, 4 keys per wave load), fp32 two-pass softmax inside
 // a split, log-sum-exp merge of the splits in a tiny combine kernel.
 // All step-varying state (positions, current tokens, done flags) is read from device memory -> hipGraph-capturable.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -681,6 +683,8 @@ int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, i
 
 // splits of the KV range per (row, kv head): ~512 blocks in flight, at most 8 partials to merge
 int decode_attn_nsplit(int B, int Hkv) {
+    static const int forced = getenv("EMMAX_ATTN_NSPLIT") ? atoi(getenv("EMMAX_ATTN_NSPLIT")) : 0;   // tuning hook
+    if (forced > 0) return forced > 16 ? 16 : forced;
     int ns = 512 / (B * Hkv);
     if (ns < 1) ns = 1;
     if (ns > 8) ns = 8;

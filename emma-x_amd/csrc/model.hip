@@ -463,6 +463,7 @@ static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* log
     return 0;
 }
 
+// patches == nullptr: language-only forward (no patch rows are spliced in; modeling_prismatic.py:343-359)
 static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens, int B, int P_max, const void* patches,
                        hipStream_t st) {
     emmax_model* m = s->m;
@@ -470,7 +471,7 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
     if (!m->finalized) return fail(EMMAX_ERR_STATE, "model not finalized");
     if (B <= 0 || B > s->max_batch || B > EMMAX_MAX_DECODE_BATCH)
         return fail(EMMAX_ERR_INVALID, "prefill batch %d outside 1..min(max_batch=%d, %d)", B, s->max_batch, EMMAX_MAX_DECODE_BATCH);
-    const int np = m->tw[0].n_patches;
+    const int np = patches ? m->tw[0].n_patches : 0;
     s->S.assign(B, 0);
     int total = 0, maxS = 0;
     PrefillState ps;
@@ -964,6 +965,11 @@ int emmax_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens, int
     const void* pe = patches ? patches : s->patch_embeds;
     if (!patches && s->vision_B != B) return fail(EMMAX_ERR_STATE, "no patch embeddings for batch %d (call emmax_vision_encode first)", B);
     return run_prefill(s, ids, lens, B, P_max, pe, (hipStream_t)st);
+}
+
+int emmax_prefill_text(emmax_session* s, const int32_t* ids, const int32_t* lens, int B, int P_max, emmax_stream st) {
+    if (!s || !ids || !lens) return fail(EMMAX_ERR_INVALID, "null argument");
+    return run_prefill(s, ids, lens, B, P_max, nullptr, (hipStream_t)st);
 }
 
 int emmax_prefill_logits(emmax_session* s, float* out, emmax_stream stream) {

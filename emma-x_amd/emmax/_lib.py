@@ -60,6 +60,7 @@ SIGNATURES = {
     "emmax_vision_encode_pixels": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     "emmax_vision_features": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "emmax_prefill": (C.c_int, [_vp, _vp, _c_i32p, C.c_int, C.c_int, _vp, _vp]),
+    "emmax_prefill_text": (C.c_int, [_vp, _vp, _c_i32p, C.c_int, C.c_int, _vp]),
     "emmax_prefill_logits": (C.c_int, [_vp, _vp, _vp]),
     "emmax_last_logits": (C.c_int, [_vp, _vp, _vp]),
     "emmax_decode_step": (C.c_int, [_vp, _vp]),

@@ -82,3 +82,31 @@ def max_over_ranks(x: float, device) -> float:
     t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def generate_actions_dp(model, frames_u8: torch.Tensor, prompt_rows, max_new_tokens: int = 512, stop_on_eos: bool = True,
+                        tokenizer=None):
+    """Data-parallel `generate_actions_batch` (BASELINE config 3): every rank passes the SAME global batch (frames uint8
+    [B,H,W,3], B prompts); rank r computes its contiguous shard on its own GPU (sub-batches of <= 8 rows) and one
+    all_gather returns (actions f32 [B,7], ids i32 [B,T], lens i32 [B]) in global order on every rank."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    Btot = frames_u8.shape[0]
+    lo, hi = shard_bounds(Btot, rank, world)
+    counts = [shard_bounds(Btot, r, world)[1] - shard_bounds(Btot, r, world)[0] for r in range(world)]
+    dev = model.device
+    acts_l, ids_l, lens_l = [], [], []
+    for s0 in range(lo, hi, 8):
+        s1 = min(hi, s0 + 8)
+        a, i, n = model.generate_actions_batch(frames_u8[s0:s1].to(dev).contiguous(), prompt_rows[s0:s1], max_new_tokens,
+                                               stop_on_eos, tokenizer)
+        acts_l.append(torch.from_numpy(a).to(dev))
+        ids_l.append(i)
+        lens_l.append(n)
+    if acts_l:
+        acts, ids, lens = torch.cat(acts_l), torch.cat(ids_l), torch.cat(lens_l)
+    else:   # more ranks than frames
+        acts = torch.zeros(0, 7, dtype=torch.float32, device=dev)
+        ids = torch.zeros(0, max_new_tokens, dtype=torch.int32, device=dev)
+        lens = torch.zeros(0, dtype=torch.int32, device=dev)
+    return gather_results(acts, ids, lens, counts)

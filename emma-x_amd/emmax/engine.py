@@ -169,6 +169,12 @@ class EmmaxEngine:
             ids[b, : len(r)] = torch.as_tensor(list(r), dtype=torch.int32)
         ids_d = ids.to(self.device)
         lens_c = (C.c_int32 * B)(*lens)
+        if patch_embeds is None:   # language-only forward
+            _lib.check(self.lib.emmax_prefill_text(self._session, ids_d.data_ptr(), lens_c, B, P_max, _lib.current_stream()),
+                       "emmax_prefill_text")
+            self._last_S = list(lens)
+            self._last_B = B
+            return self._last_S
         pe = patch_embeds.contiguous()
         assert pe.dtype == torch.bfloat16 and pe.shape[0] == B
         _lib.check(self.lib.emmax_prefill(self._session, ids_d.data_ptr(), lens_c, B, P_max, pe.data_ptr(), _lib.current_stream()),

@@ -211,7 +211,14 @@ class EmmaXForActionPrediction:
         if input_ids is not None and isinstance(input_ids, torch.Tensor) and input_ids.shape[-1] == 1:
             assert past_key_values is not None, "You must provide `past_key_values` during cached generation!"
         if pixel_values is None and frames_u8 is None:
-            raise NotImplementedError("language-only forward is outside the VLA hot path (pixel_values required)")
+            # unimodal forward (modeling_prismatic.py:343-359): text only, no patch rows
+            assert past_key_values is None, "Unexpected key `past_key_values` provided during language-only forward!"
+            eng.ensure_capacity(len(rows), max(len(r) for r in rows), 1)
+            eng.prefill(rows, None)
+            per_row = eng.prefill_logits()
+            same = len({t.shape[0] for t in per_row}) == 1
+            return EmmaXCausalLMOutputWithPast(logits=torch.stack(per_row) if same else per_row,
+                                               past_key_values=KVHandle(eng, eng._last_S) if use_cache else None)
         patches = self._prefill(rows, pixel_values, frames_u8)
         per_row = eng.prefill_logits()
         same = len({t.shape[0] for t in per_row}) == 1

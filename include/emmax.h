@@ -107,6 +107,8 @@ int emmax_vision_features(emmax_session* s, int B, void* feats_out_dev, emmax_st
  * leaves the greedy first token of every row as the session's "current token". */
 int emmax_prefill(emmax_session* s, const int32_t* ids_dev, const int32_t* lens_host, int B, int P_max,
                   const void* patch_embeds_dev, emmax_stream stream);
+/* Language-only prefill (no image): the `pixel_values is None` branch of forward (modeling_prismatic.py:343-359). */
+int emmax_prefill_text(emmax_session* s, const int32_t* ids_dev, const int32_t* lens_host, int B, int P_max, emmax_stream stream);
 /* f32 logits of every prefill position, packed rows [sum_b S_b, vocab] (S_b = 256 + lens[b]); valid after prefill. */
 int emmax_prefill_logits(emmax_session* s, float* logits_out_dev, emmax_stream stream);
 /* f32 last-position logits [B,vocab] of the most recent prefill/decode step (parity tests; costs one extra pass). */

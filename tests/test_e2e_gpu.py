@@ -351,3 +351,32 @@ def test_fp8_weight_decode_vs_bf16(device):
         _, ids, lens = p8.generate_actions_batch(torch.from_numpy(fr2).to(device), rows2, max_new_tokens=32)
         for b in range(Bn):
             assert ids[b, : int(lens[b])].cpu().tolist() == planted_chain(cfg, rows2[b][-1], 32)
+
+
+def test_language_only_forward_matches_oracle(device, tiny_random):
+    """Unimodal branch of forward (pixel_values is None, modeling_prismatic.py:343-359) vs the oracle's decoder."""
+    from oracle import emmax_oracle as orc
+
+    cfg, model, sd_ref = tiny_random
+    rows = [[1, 50, 600, 7000, 31000, 12, 13], [1, 99, 98, 97]]
+    out = model.forward(input_ids=rows)
+    for b, r in enumerate(rows):
+        ref, _ = orc.llama_forward(orc.embed_tokens(torch.tensor([r]), sd_ref), sd_ref, cfg.llm, None)
+        assert out.logits[b].shape == ref[0].shape
+        assert rel(out.logits[b], ref[0]) < FEAT_TOL
+
+
+def test_generate_actions_dp_single_process(device, tiny_planted):
+    """emmax.dist.generate_actions_dp without a process group == generate_actions_batch, incl. sub-batching of > 8 rows."""
+    from emmax.dist import generate_actions_dp
+    from emmax.weights import planted_start_token
+
+    cfg, model, _ = tiny_planted
+    frames, rows = _inputs(cfg, 10, 9, seed=61)
+    for b in range(10):
+        rows[b][-1] = planted_start_token(cfg, 1 + b % 5)
+    fr = torch.from_numpy(frames)
+    a, i, n = generate_actions_dp(model, fr, rows, max_new_tokens=20)
+    assert a.shape == (10, 7) and i.shape == (10, 20) and n.shape == (10,)
+    a1, i1, n1 = model.generate_actions_batch(fr[3:4].to(device).contiguous(), [rows[3]], max_new_tokens=20)
+    assert torch.equal(i[3], i1[0]) and int(n[3]) == int(n1[0]) and np.abs(a[3].cpu().numpy() - a1[0]).max() == 0
