@@ -99,5 +99,75 @@ __device__ __forceinline__ void dep_signal(const DepInfo& d) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Split-KV attention partials: per (row, head, split) EMMAX_PSTRIDE floats = { o[0..128) un-normalised, m, l, 2 pad }.
+// attn_merge_chunk merges the NS partials of one head for the 8 output elements d0..d0+8 and returns them as 8 bf16.
+// Branch-free with every load issued before the first use (one L2 round trip for the scalars, one for the vectors):
+// the merge sits on the critical path of every o-proj launch.
+// ---------------------------------------------------------------------------------------------------------------------
+#define EMMAX_PSTRIDE 132
+template <int NS, int GMAX = 4>   // GMAX: vector loads (pairs) in flight per group -- the register budget of the caller
+__device__ __forceinline__ u32x4_t attn_merge_chunk(const float* __restrict__ pp, int d0) {
+    float ms[NS], dn[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        ms[s] = pp[s * EMMAX_PSTRIDE + 128];
+        dn[s] = pp[s * EMMAX_PSTRIDE + 129];
+    }
+    constexpr int GS = NS < GMAX ? NS : GMAX;
+    float M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) M = fmaxf(M, ms[s]);
+    float den = 0.f, a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s0 = 0; s0 < NS; s0 += GS) {
+        f32x4_t o0[GS], o1[GS];
+#pragma unroll
+        for (int s = 0; s < GS; ++s) {
+            o0[s] = *(const f32x4_t*)(pp + (s0 + s) * EMMAX_PSTRIDE + d0);
+            o1[s] = *(const f32x4_t*)(pp + (s0 + s) * EMMAX_PSTRIDE + d0 + 4);
+        }
+#pragma unroll
+        for (int s = 0; s < GS; ++s) {
+            const float wgt = (ms[s0 + s] == -INFINITY) ? 0.f : __expf(ms[s0 + s] - M);
+            den += dn[s0 + s] * wgt;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a8[j] += o0[s][j] * wgt;
+                a8[4 + j] += o1[s][j] * wgt;
+            }
+        }
+    }
+    const float inv = den > 0.f ? 1.0f / den : 0.f;
+    u32x4_t v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = pack_bf16x2(a8[2 * j] * inv, a8[2 * j + 1] * inv);
+    return v;
+}
+// generic split count, small register footprint (the dot2 GEMV keeps its 16-load weight ring live across the prologue
+// and must stay under 128 VGPRs)
+__device__ __forceinline__ u32x4_t attn_merge_chunk_loop(const float* __restrict__ pp, int d0, int nsplit) {
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pp[s * EMMAX_PSTRIDE + 128]);
+    float den = 0.f, a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsplit; ++s) {
+        const float m = pp[s * EMMAX_PSTRIDE + 128];
+        const float wgt = (m == -INFINITY) ? 0.f : __expf(m - M);
+        den += pp[s * EMMAX_PSTRIDE + 129] * wgt;
+        const f32x4_t o0 = *(const f32x4_t*)(pp + s * EMMAX_PSTRIDE + d0);
+        const f32x4_t o1 = *(const f32x4_t*)(pp + s * EMMAX_PSTRIDE + d0 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a8[j] += o0[j] * wgt;
+            a8[4 + j] += o1[j] * wgt;
+        }
+    }
+    const float inv = den > 0.f ? 1.0f / den : 0.f;
+    u32x4_t v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = pack_bf16x2(a8[2 * j] * inv, a8[2 * j + 1] * inv);
+    return v;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t align_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }

@@ -27,7 +27,7 @@ enum { MODE_QKV = 0, MODE_RESID = 1, MODE_GATEUP = 2, MODE_LMHEAD = 3, MODE_PLAI
 
 __device__ __forceinline__ u32x4_t ld_nt(const u32x4_t* p) { return __builtin_nontemporal_load(p); }
 
-constexpr int PSTRIDE = 132;   // floats per attention split partial: 128 o + m + l + 2 pad (16-byte aligned rows)
+constexpr int PSTRIDE = EMMAX_PSTRIDE;   // floats per attention split partial: 128 o + m + l + 2 pad (16-byte aligned rows)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // GEMV.  Persistent blocks of 512 threads = 8 waves; block b owns a contiguous range of row GROUPS, its waves interleave
@@ -117,7 +117,48 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
 
     // ---- RMSNorm statistics ----
     float rstd[B];
-    if (NORM) {
+    // single-pass prologue: when the whole row fits one 16-byte chunk per thread, x and the norm weight are read ONCE
+    // (both loads issued together), the statistics come from registers and the normalised row goes straight to LDS --
+    // one L2 round trip instead of two on the critical path of every qkv / gate-up / lm-head launch
+    const bool one_pass = NORM && !XATTN && !multi_phase && (K >> 3) <= NT;
+    if (one_pass) {
+        __shared__ float red1p[GW][B];
+        const bool mine = tid < (K >> 3);
+        u32x4_t xv[B];
+        const u32x4_t wv = mine ? *((const u32x4_t*)p.norm_w + tid) : (u32x4_t){0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+            xv[b] = mine ? *((const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx) + tid) : (u32x4_t){0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = bf_lo(xv[b][j]), bb = bf_hi(xv[b][j]);
+                ss += a * a + bb * bb;
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) red1p[wave][b] = ss;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < GW; ++w) t += red1p[w][b];
+            rstd[b] = rsqrtf(t / (float)K + p.eps);
+            if (mine) {
+                u32x4_t v = xv[b];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = bf2f(f2bf(bf_lo(v[j]) * rstd[b])) * bf_lo(wv[j]);
+                    const float bb = bf2f(f2bf(bf_hi(v[j]) * rstd[b])) * bf_hi(wv[j]);
+                    v[j] = pack_bf16x2(a, bb);
+                }
+                xs[b * (KC >> 3) + tid] = v;
+            }
+        }
+    } else if (NORM) {
         __shared__ float red[GW][B];
 #pragma unroll
         for (int b = 0; b < B; ++b) {
@@ -155,25 +196,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
                     // chunk cg = head (cg>>4), elements (cg&15)*8..+8 of the split partials
                     const int cg = (kc0 >> 3) + c;
                     const float* pp = p.attn_part + (size_t)(b * p.Hq + (cg >> 4)) * p.nsplit * PSTRIDE;
-                    const int d0 = (cg & 15) * 8;
-                    float M = -INFINITY;
-                    for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, pp[s * PSTRIDE + 128]);
-                    float den = 0.f, a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    for (int s = 0; s < p.nsplit; ++s) {
-                        const float ms = pp[s * PSTRIDE + 128];
-                        const float wgt = (ms == -INFINITY) ? 0.f : __expf(ms - M);
-                        den += pp[s * PSTRIDE + 129] * wgt;
-                        const f32x4_t o0 = *(const f32x4_t*)(pp + s * PSTRIDE + d0);
-                        const f32x4_t o1 = *(const f32x4_t*)(pp + s * PSTRIDE + d0 + 4);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            a8[j] += o0[j] * wgt;
-                            a8[4 + j] += o1[j] * wgt;
-                        }
-                    }
-                    const float inv = den > 0.f ? 1.0f / den : 0.f;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = pack_bf16x2(a8[2 * j] * inv, a8[2 * j + 1] * inv);
+                    v = attn_merge_chunk_loop(pp, (cg & 15) * 8, p.nsplit);
                 } else {
                     v = xr[c];
                 }
@@ -191,7 +214,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
             }
         }
     };
-    stage_x(0, phase_nch(0));
+    if (!one_pass) stage_x(0, phase_nch(0));
     __syncthreads();
 
     // LMHEAD: running best over this wave's rows
@@ -612,6 +635,22 @@ template <int B, int MODE, bool NORM, bool XATTN = false>
 static int launch_gemv_t(const GemvParams& p, hipStream_t stream, int* grid_out) {
     const size_t smem = (size_t)B * p.kc * 2;
     int grid = gemv_grid(B, smem, p.n_groups, p.max_grid);
+    {   // tuning hook: EMMAX_GEMV_GRID="qkv,resid,gateup,lmhead,plain" (0 = default) overrides the persistent grid per mode
+        static int forced[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        static bool parsed = false;
+        if (!parsed) {
+            parsed = true;
+            if (const char* e = getenv("EMMAX_GEMV_GRID")) {
+                int i = 0;
+                while (*e && i < 8) {
+                    forced[i++] = atoi(e);
+                    while (*e && *e != ',') ++e;
+                    if (*e == ',') ++e;
+                }
+            }
+        }
+        if (forced[MODE] > 0 && p.max_grid == 0) grid = min(forced[MODE], cdiv(p.n_groups, GW));
+    }
     if (MODE == MODE_LMHEAD) grid = min(grid, p.max_parts);
     if (grid_out) *grid_out = grid;
     GemvParams q = p;
@@ -688,6 +727,7 @@ int decode_attn_nsplit(int B, int Hkv) {
     int ns = 512 / (B * Hkv);
     if (ns < 1) ns = 1;
     if (ns > 8) ns = 8;
+    while (ns & (ns - 1)) ns &= ns - 1;   // power of two: the o-proj prologue merges with a branch-free unrolled loop
     return ns;
 }
 

@@ -17,7 +17,7 @@
 namespace {
 
 enum { MODE_QKV = 0, MODE_RESID = 1, MODE_GATEUP = 2, MODE_LMHEAD = 3, MODE_PLAIN = 4 };
-constexpr int PSTRIDE = 132;
+constexpr int PSTRIDE = EMMAX_PSTRIDE;
 constexpr int GW = 8;
 __device__ __forceinline__ u32x4_t ld_nt(const u32x4_t* p) { return __builtin_nontemporal_load(p); }
 
@@ -81,6 +81,23 @@ __device__ __forceinline__ bf16x8_t fp8x8_to_bf16x8(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(bf16x8_t, r);
 }
 
+// o-proj prologue: merge the NS split partials of head (cg >> 4) for every batch row, two rows per iteration so the loads
+// of both are in flight together; dst = LDS address of chunk c of row 0
+template <int NS>
+__device__ __forceinline__ void stage_attn_rows(const float* __restrict__ attn_part, unsigned char* dst, int pitch, int B, int Hq, int cg) {
+    const float* pp0 = attn_part + (size_t)(cg >> 4) * NS * PSTRIDE;
+    const size_t row = (size_t)Hq * NS * PSTRIDE;
+    const int d0 = (cg & 15) * 8;
+    int b = 0;
+    for (; b + 1 < B; b += 2) {
+        const u32x4_t v0 = attn_merge_chunk<NS>(pp0 + (size_t)b * row, d0);
+        const u32x4_t v1 = attn_merge_chunk<NS>(pp0 + (size_t)(b + 1) * row, d0);
+        *(u32x4_t*)(dst + (size_t)b * pitch) = v0;
+        *(u32x4_t*)(dst + (size_t)(b + 1) * pitch) = v1;
+    }
+    if (b < B) *(u32x4_t*)(dst + (size_t)b * pitch) = attn_merge_chunk<NS>(pp0 + (size_t)b * row, d0);
+}
+
 // FP8: weights are the fp8 fragment-major copy (1 KiB tile = 16 rows x 64 k), de-quantised to bf16 in registers
 // (exact), per-row scale applied to the fp32 result; activations stay bf16.  A "k-step" is then 64 elements.
 template <int MODE, bool NORM, bool XATTN, bool FP8 = false>
@@ -123,22 +140,92 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
         k_n = q + (wave < r ? 1 : 0);
     };
 
-    u32x4_t wr[TILES][U];
-    auto issue = [&](int t, int k_lo, int k0, int k_n) {
-#pragma unroll
-        for (int tt = 0; tt < TILES; ++tt) {
-            const u32x4_t* wt = Wfm + ((size_t)tile_of(t, tt) * KT + k_lo) * 64 + lane;
-#pragma unroll
-            for (int u = 0; u < U; ++u) wr[tt][u] = (k0 + u < k_n) ? ld_nt(wt + (size_t)(k0 + u) * 64) : (u32x4_t){0u, 0u, 0u, 0u};
+    // The wave's work is a linear sequence of U-step blocks: for every task x K phase x block of its k-slice.  The producer
+    // cursor runs exactly one block ahead of the consumer: right after the MFMAs of step u are issued, step u of the next
+    // block is requested into the same registers (rolling ring, TILES*U KiB in flight per wave at every instant, across
+    // task and phase boundaries and underneath the block barriers of the reduction).
+    struct Cursor { int t, ph, kb; };
+    // block-uniform trip count: the longest k-slice of the phase
+    auto nkb_of = [&](int ph) {
+        const int ktn = min(KC, K - ph * KC) / KS;
+        return (ktn / GW + (ktn % GW ? 1 : 0) + U - 1) / U;
+    };
+    auto advance = [&](Cursor& c) {
+        if (++c.kb >= nkb_of(c.ph)) {
+            c.kb = 0;
+            if (++c.ph >= n_phase) { c.ph = 0; ++c.t; }
         }
     };
+    u32x4_t wr[TILES][U];
+    const u32x4_t* wbase[TILES];   // producer: tile base + slice start of its current (task, phase)
+    int p_n = 0;                   // producer: k-steps in its slice
+    auto producer_setup = [&](const Cursor& c) {
+        int k_lo;
+        slice(c.ph, k_lo, p_n);
+        const int t = min(c.t, t_hi - 1);
+#pragma unroll
+        for (int tt = 0; tt < TILES; ++tt) wbase[tt] = Wfm + ((size_t)tile_of(t, tt) * KT + k_lo) * 64 + lane;
+    };
+    auto issue_step = [&](const Cursor& c, int u) {
+        const int k = c.kb * U + u;
+        const bool ok = c.t < t_hi && k < p_n;
+#pragma unroll
+        for (int tt = 0; tt < TILES; ++tt) wr[tt][u] = ok ? ld_nt(wbase[tt] + (size_t)k * 64) : (u32x4_t){0u, 0u, 0u, 0u};
+    };
 
-    int kl0, kn0;
-    slice(0, kl0, kn0);
-    if (t_lo < t_hi) issue(t_lo, kl0, 0, kn0);   // head of the stream before the prologue
+    Cursor P = {t_lo, 0, 0}, C = {t_lo, 0, 0};
+    if (t_lo < t_hi) {   // head of the stream before the prologue
+        producer_setup(P);
+#pragma unroll
+        for (int u = 0; u < U; ++u) issue_step(P, u);
+        advance(P);
+    }
 
-    // ---- RMSNorm statistics ----
-    if (NORM) {
+    // ---- prologue: x (B rows + one zero row) into LDS.  Every variant issues all of a thread's loads before the first
+    // use: B sequential L2 round trips (one per row) used to cost 12-16 us of every launch at B = 8 ----
+    // one pass (norm'd projections, K/8 <= 512): thread c keeps chunk c of every row in registers, the statistics come
+    // from those registers and the normalised rows go straight to LDS
+    const bool one_pass = NORM && !XATTN && n_phase == 1 && (K >> 3) <= NT;
+    if (one_pass) {
+        __shared__ float rsum1[GW][EMMAX_MAX_DECODE_BATCH];
+        const bool mine = tid < (K >> 3);
+        u32x4_t xv[EMMAX_MAX_DECODE_BATCH];
+        const u32x4_t wv = mine ? *((const u32x4_t*)p.norm_w + tid) : (u32x4_t){0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b)
+            xv[b] = (mine && b < B) ? *((const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx) + tid) : (u32x4_t){0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b) {
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = bf_lo(xv[b][j]), bb = bf_hi(xv[b][j]);
+                ss += a * a + bb * bb;
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) rsum1[wave][b] = ss;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b) {
+            if (b < B && mine) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < GW; ++w) t += rsum1[w][b];
+                const float rs = rsqrtf(t / (float)K + p.eps);
+                u32x4_t v = xv[b];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // HF LlamaRMSNorm: fp32 normalise -> downcast -> * weight (-> downcast)
+                    const float a = bf2f(f2bf(bf_lo(v[j]) * rs)) * bf_lo(wv[j]);
+                    const float bb = bf2f(f2bf(bf_hi(v[j]) * rs)) * bf_hi(wv[j]);
+                    v[j] = pack_bf16x2(a, bb);
+                }
+                *(u32x4_t*)(smem + (size_t)b * pitch + (size_t)tid * 16) = v;
+            }
+        }
+        if (mine) *(u32x4_t*)(smem + (size_t)B * pitch + (size_t)tid * 16) = (u32x4_t){0u, 0u, 0u, 0u};
+    } else if (NORM) {
         __shared__ float rsum[GW][EMMAX_MAX_DECODE_BATCH];
         for (int b = 0; b < B; ++b) {
             float ss = 0.f;
@@ -166,52 +253,53 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
 
     auto stage_x = [&](int ph) {
         const int kc0 = ph * KC, nch = min(KC, K - kc0) >> 3;
-        for (int b = 0; b <= B; ++b) {
-            const u32x4_t* xr = (const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx + kc0);
-            const float rs = (NORM && b < B) ? srstd[b] : 1.f;
+        if (XATTN) {
+            // x = merged attention split partials; chunk cg = head (cg >> 4), elements (cg & 15) * 8 .. +8
             for (int c = tid; c < nch; c += NT) {
-                u32x4_t v = {0u, 0u, 0u, 0u};
-                if (b < B) {
-                    if (XATTN) {
-                        const int cg = (kc0 >> 3) + c;
-                        const float* pp = p.attn_part + (size_t)(b * p.Hq + (cg >> 4)) * p.nsplit * PSTRIDE;
-                        const int d0 = (cg & 15) * 8;
-                        float M = -INFINITY;
-                        for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, pp[s * PSTRIDE + 128]);
-                        float den = 0.f, a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        for (int s = 0; s < p.nsplit; ++s) {
-                            const float ms = pp[s * PSTRIDE + 128];
-                            const float wgt = (ms == -INFINITY) ? 0.f : __expf(ms - M);
-                            den += pp[s * PSTRIDE + 129] * wgt;
-                            const f32x4_t o0 = *(const f32x4_t*)(pp + s * PSTRIDE + d0);
-                            const f32x4_t o1 = *(const f32x4_t*)(pp + s * PSTRIDE + d0 + 4);
+                const int cg = (kc0 >> 3) + c;
+                unsigned char* dst = smem + (size_t)c * 16;
+                switch (p.nsplit) {
+                    case 1: stage_attn_rows<1>(p.attn_part, dst, pitch, B, p.Hq, cg); break;
+                    case 2: stage_attn_rows<2>(p.attn_part, dst, pitch, B, p.Hq, cg); break;
+                    case 4: stage_attn_rows<4>(p.attn_part, dst, pitch, B, p.Hq, cg); break;
+                    case 8: stage_attn_rows<8>(p.attn_part, dst, pitch, B, p.Hq, cg); break;
+                    default:
+                        for (int b = 0; b < B; ++b)
+                            *(u32x4_t*)(dst + (size_t)b * pitch) =
+                                attn_merge_chunk_loop(p.attn_part + (size_t)(b * p.Hq + (cg >> 4)) * p.nsplit * PSTRIDE, (cg & 15) * 8, p.nsplit);
+                }
+                *(u32x4_t*)(dst + (size_t)B * pitch) = (u32x4_t){0u, 0u, 0u, 0u};
+            }
+        } else {
+            // flattened (row, chunk) space, four loads in flight per thread
+            const int total = (B + 1) * nch;
+            for (int i0 = tid; i0 < total; i0 += 4 * NT) {
+                u32x4_t v[4];
+                int off[4];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                a8[j] += o0[j] * wgt;
-                                a8[4 + j] += o1[j] * wgt;
-                            }
-                        }
-                        const float inv = den > 0.f ? 1.0f / den : 0.f;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = pack_bf16x2(a8[2 * j] * inv, a8[2 * j + 1] * inv);
-                    } else {
-                        v = xr[c];
-                    }
-                    if (NORM) {
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + j * NT;
+                    const int b = i / nch, c = i - b * nch;
+                    off[j] = i < total ? (int)(b * pitch + c * 16) : -1;
+                    v[j] = (i < total && b < B) ? *((const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx + kc0) + c) : (u32x4_t){0u, 0u, 0u, 0u};
+                    if (NORM && i < total && b < B) {
                         const u32x4_t wv = *((const u32x4_t*)((const bf16_t*)p.norm_w + kc0) + c);
+                        const float rs = srstd[b];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float a = bf2f(f2bf(bf_lo(v[j]) * rs)) * bf_lo(wv[j]);
-                            const float bb = bf2f(f2bf(bf_hi(v[j]) * rs)) * bf_hi(wv[j]);
-                            v[j] = pack_bf16x2(a, bb);
+                        for (int q = 0; q < 4; ++q) {
+                            const float a = bf2f(f2bf(bf_lo(v[j][q]) * rs)) * bf_lo(wv[q]);
+                            const float bb = bf2f(f2bf(bf_hi(v[j][q]) * rs)) * bf_hi(wv[q]);
+                            v[j][q] = pack_bf16x2(a, bb);
                         }
                     }
                 }
-                *(u32x4_t*)(smem + (size_t)b * pitch + (size_t)c * 16) = v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (off[j] >= 0) *(u32x4_t*)(smem + off[j]) = v[j];
             }
         }
     };
-    stage_x(0);
+    if (!one_pass) stage_x(0);
     __syncthreads();
 
     const int xrow = c16 < B ? c16 : B;   // padding columns of the 16-wide batch side read the zero row
@@ -219,48 +307,56 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
     float best = -INFINITY;
     int besti = 0x7fffffff;
 
-    for (int t = t_lo; t < t_hi; ++t) {
-        f32x4_t acc[TILES];
+    f32x4_t acc[TILES];
 #pragma unroll
-        for (int tt = 0; tt < TILES; ++tt) acc[tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        for (int ph = 0; ph < n_phase; ++ph) {
-            int k_lo, k_n;
-            slice(ph, k_lo, k_n);
-            if (n_phase > 1 && (ph != 0 || t != t_lo)) {
-                issue(t, k_lo, 0, k_n);
-                __syncthreads();
-                stage_x(ph);
-                __syncthreads();
-            }
-            const unsigned char* xb = smem + (size_t)xrow * pitch + ((size_t)(k_lo - ph * (KC / KS)) * KS + g4 * 8) * 2;
-            for (int k0 = 0; k0 < k_n; k0 += U) {
-                if (k0 != 0) issue(t, k_lo, k0, k_n);
+    for (int tt = 0; tt < TILES; ++tt) acc[tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    int c_n = 0;
+    const unsigned char* xb = smem;
+    while (C.t < t_hi) {
+        if (n_phase > 1 && C.kb == 0 && (C.ph != 0 || C.t != t_lo)) {   // new phase: restage x (the ring keeps flying)
+            __syncthreads();
+            stage_x(C.ph);
+            __syncthreads();
+        }
+        if (C.kb == 0) {
+            int k_lo;
+            slice(C.ph, k_lo, c_n);
+            xb = smem + (size_t)xrow * pitch + ((size_t)(k_lo - C.ph * (KC / KS)) * KS + g4 * 8) * 2;
+        }
+        if (P.kb == 0 && P.t < t_hi) producer_setup(P);
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (k0 + u < k_n) {
-                        const bf16x8_t xf = *(const bf16x8_t*)(xb + (size_t)(k0 + u) * (KS * 2));
-                        if (FP8) {
-                            const bf16x8_t xf2 = *(const bf16x8_t*)(xb + (size_t)(k0 + u) * (KS * 2) + 64);
+        for (int u = 0; u < U; ++u) {
+            const int k = C.kb * U + u;
+            if (k < c_n) {   // wave-uniform
+                const bf16x8_t xf = *(const bf16x8_t*)(xb + (size_t)k * (KS * 2));
+                if (FP8) {
+                    const bf16x8_t xf2 = *(const bf16x8_t*)(xb + (size_t)k * (KS * 2) + 64);
 #pragma unroll
-                            for (int tt = 0; tt < TILES; ++tt) {
-                                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(wr[tt][u][0], wr[tt][u][1]), xf, acc[tt], 0, 0, 0);
-                                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(wr[tt][u][2], wr[tt][u][3]), xf2, acc[tt], 0, 0, 0);
-                            }
-                        } else {
-#pragma unroll
-                            for (int tt = 0; tt < TILES; ++tt)
-                                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wr[tt][u]), xf, acc[tt], 0, 0, 0);
-                        }
+                    for (int tt = 0; tt < TILES; ++tt) {
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(wr[tt][u][0], wr[tt][u][1]), xf, acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(wr[tt][u][2], wr[tt][u][3]), xf2, acc[tt], 0, 0, 0);
                     }
+                } else {
+#pragma unroll
+                    for (int tt = 0; tt < TILES; ++tt)
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wr[tt][u]), xf, acc[tt], 0, 0, 0);
                 }
             }
+            issue_step(P, u);   // refill the registers just consumed with the same step of the next block
         }
-        if (n_phase == 1 && t + 1 < t_hi) issue(t + 1, kl0, 0, kn0);   // next task's head flies during the reduction
+        const bool task_done = (C.ph == n_phase - 1) && (C.kb == nkb_of(C.ph) - 1);
+        const int t = C.t;
+        advance(C);
+        advance(P);
+        if (!task_done) continue;
+
         // ---- cross-wave reduction: red[wave][tile][r][lane] ----
 #pragma unroll
         for (int tt = 0; tt < TILES; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[((wave * TILES + tt) * 4 + r) * 64 + lane] = acc[tt][r];
+#pragma unroll
+        for (int tt = 0; tt < TILES; ++tt) acc[tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         __syncthreads();
         if (tid < 256) {
             const int l = tid & 63, r = tid >> 6;

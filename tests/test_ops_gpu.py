@@ -153,7 +153,8 @@ def test_attention(device, hd, Hq, Hkv, lens, causal):
 
 
 @pytest.mark.parametrize("B", [1, 2, 3, 5, 8])
-@pytest.mark.parametrize("N,K", [(256, 256), (4096, 4096), (1000, 11008), (64, 688)])
+# (4096, 11008): the down-projection shape; (999, 8712): odd row count, K not a multiple of the 4096-element step
+@pytest.mark.parametrize("N,K", [(256, 256), (4096, 4096), (1000, 11008), (64, 688), (4096, 11008), (999, 8712)])
 def test_gemv(device, B, N, K):
     L, lib = _lib()
     g = torch.Generator().manual_seed(B + N + K)
