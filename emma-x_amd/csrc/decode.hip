@@ -404,8 +404,9 @@ __global__ __launch_bounds__(256) void emmax_decode_embed_kernel(const int32_t* 
 template <int HD, int G>
 __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams p) {
     static_assert(HD == 128, "decode attention maps 16 lanes x 8 elements onto one 128-wide K/V row");
-    constexpr int KU = 6;    // keys per lane group per chunk  (block chunk = 16 * KU keys)
-    __shared__ int s_pages[64];
+    constexpr int KU = G <= 2 ? 4 : 2;    // keys per lane group per chunk (block chunk = 16 * KU keys), two chunks in flight
+    constexpr int SP = 512;  // page ids kept in LDS; longer tables fall back to the global table
+    __shared__ int s_pages[SP];
     __shared__ float red_o[4][G][HD];
     __shared__ float red_ml[4][G][2];
 
@@ -413,6 +414,15 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
     const int kg = lane >> 4, ch = lane & 15;       // key group within the wave, 16-byte chunk within the row
     const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
     const int nsplit = gridDim.x;
+    dep_wait(p.dep);   // q, ctx_len and the freshly appended K/V row come from the kernels before
+    // one L2 round trip for everything that does not depend on the context length: the row's whole page table -> LDS
+    // (no dependent global load in front of the K/V loads), q, and the length itself
+    for (int i = tid; i < min(p.max_pages, SP); i += 256) s_pages[i] = p.page_table[(size_t)b * p.max_pages + i];
+    // q (already rotated, bf16) for the G heads of this kv head: lane holds elements ch*8 .. +8
+    u32x4_t q[G];
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq)
+        q[gq] = *(const u32x4_t*)((const bf16_t*)p.q + (size_t)b * p.ldq + (hk * G + gq) * HD + ch * 8);
     const int L = p.ctx_len[b] + 1;                 // keys including the one appended by the qkv kernel of this step
     int kps = (L + nsplit - 1) / nsplit;
     kps = (kps + 15) & ~15;
@@ -429,22 +439,10 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
         dep_signal(p.dep);
         return;
     }
-    dep_wait(p.dep);   // q and the freshly appended K/V row come from the qkv kernel
-
-    // page ids of this split -> LDS (removes the dependent global load in front of every K/V load)
-    const int pg0 = k0 / p.page;
-    const int npg = (k1 - 1) / p.page - pg0 + 1;
-    for (int i = tid; i < npg; i += 256)
-        if (i < 64) s_pages[i] = p.page_table[(size_t)b * p.max_pages + pg0 + i];
 
     const bf16_t* kc = (const bf16_t*)p.kcache;
     const bf16_t* vc = (const bf16_t*)p.vcache;
 
-    // q (already rotated, bf16) for the G heads of this kv head: lane holds elements ch*8 .. +8
-    u32x4_t q[G];
-#pragma unroll
-    for (int gq = 0; gq < G; ++gq)
-        q[gq] = *(const u32x4_t*)((const bf16_t*)p.q + (size_t)b * p.ldq + (hk * G + gq) * HD + ch * 8);
     __syncthreads();
 
     float m[G], l[G], o[G][8];
@@ -456,19 +454,23 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
         for (int j = 0; j < 8; ++j) o[gq][j] = 0.f;
     }
 
-    for (int kb = k0; kb < k1; kb += 16 * KU) {
-        u32x4_t kv[KU], vv[KU];
-        bool ok[KU];
+    // software pipeline: two register chunk buffers; the loads of chunk i+1 are issued before the scores of chunk i are
+    // computed, so every wave has K/V requests in flight at all times (a 1/8 split of a 1K context is two chunks: both
+    // are requested up front)
+    auto load_chunk = [&](int kb, u32x4_t (&kv)[KU], u32x4_t (&vv)[KU], bool (&ok)[KU]) {
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int key = kb + u * 16 + wave * 4 + kg;
             ok[u] = key < k1;
             const int kk = ok[u] ? key : k0;
-            const int pg = s_pages[min(kk / p.page - pg0, 63)];
+            const int pi = kk / p.page;
+            const int pg = pi < SP ? s_pages[pi] : p.page_table[(size_t)b * p.max_pages + pi];
             const size_t off = (((size_t)pg * p.Hkv + hk) * p.page + kk % p.page) * HD + ch * 8;
             kv[u] = *(const u32x4_t*)(kc + off);
             vv[u] = *(const u32x4_t*)(vc + off);
         }
+    };
+    auto consume_chunk = [&](const u32x4_t (&kv)[KU], const u32x4_t (&vv)[KU], const bool (&ok)[KU]) {
 #pragma unroll
         for (int gq = 0; gq < G; ++gq) {
             float sc[KU];
@@ -506,6 +508,18 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
             }
             l[gq] = ls;
             m[gq] = mn;
+        }
+    };
+    {
+        u32x4_t kvA[KU], vvA[KU], kvB[KU], vvB[KU];
+        bool okA[KU], okB[KU];
+        load_chunk(k0, kvA, vvA, okA);
+        for (int kb = k0; kb < k1; kb += 2 * 16 * KU) {
+            const bool hasB = kb + 16 * KU < k1;          // block-uniform
+            if (hasB) load_chunk(kb + 16 * KU, kvB, vvB, okB);
+            consume_chunk(kvA, vvA, okA);
+            if (kb + 2 * 16 * KU < k1) load_chunk(kb + 2 * 16 * KU, kvA, vvA, okA);
+            if (hasB) consume_chunk(kvB, vvB, okB);
         }
     }
 
