@@ -1,0 +1,185 @@
+// gemm256.hip -- the large-problem variant of the bf16 MFMA GEMM (same contract and epilogues as gemm.hip):
+//   C[M,N] = epi(A[M,K] . W[N,K]^T)    A, W bf16 row-major (K contiguous), fp32 accumulate.
+// Used when the problem has enough 256x256 tiles to fill the chip a few times over (ViT at batch >= 64, projector,
+// LLaMA prefill at batch >= 4); small problems stay on the 128x128 kernel of gemm.hip, whose finer tiles fill 256 CUs.
+//
+// Tiling: 256x256x64 block tile, 512 threads = 8 waves as 2(M) x 4(N), each wave 128x64 = 8x4 v_mfma_f32_16x16x32_bf16
+// tiles (128 accumulator registers), one block per CU.
+// Staging: HBM -> LDS directly with global_load_lds_dwordx4 (no staging registers, no ds_write pass), two LDS stages of
+// 64 KiB (A 32 KiB + B 32 KiB): the DMA of K-tile t+1 is issued before the MFMAs of K-tile t and drained (vmcnt(0)) at
+// the single barrier that ends the K step.
+// LDS image: operand tile = [256 rows][8 chunks of 16 B], rows 128 B apart.  A wave-level DMA writes 1 KiB = 8 whole
+// rows in lane order, so the image itself is linear; the bank-conflict swizzle is applied to the SOURCE address instead:
+// physical chunk c of row r holds logical chunk c ^ ((r >> 1) & 7).  A ds_read_b128 fragment read (16 lanes = 16 rows at
+// one logical chunk) then touches 16 distinct 16-byte slots of the 256-byte bank row.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int OP_BYTES = BM * BK * 2;        // 32 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * OP_BYTES;    // A + B
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES;  // two stages: 128 KiB
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(512) void emmax_gemm256_bf16_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int g = lane >> 4, li = lane & 15;
+
+    // XCD-aware tile order: block ids go round-robin over the 8 XCDs; give each XCD a contiguous run of tiles that walks M
+    // fastest, so the blocks resident in one XCD share a W panel (and neighbouring A panels) in that XCD's L2.
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid % tiles_m, tn = bid / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- DMA sources: wave w fills slabs 4w .. 4w+3 (8 rows each) of both operand tiles ----
+    const unsigned char* srcA[4];
+    const unsigned char* srcB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + (lane >> 3);
+        const int lch = (lane & 7) ^ ((row >> 1) & 7);                      // logical chunk landing in physical chunk lane&7
+        const int gm = min(m0 + row, p.M - 1), gn = min(n0 + row, p.N - 1);  // edge tiles re-read the last row (never stored)
+        srcA[j] = (const unsigned char*)((const bf16_t*)p.A + (size_t)gm * p.lda + lch * 8);
+        srcB[j] = (const unsigned char*)((const bf16_t*)p.W + (size_t)gn * p.ldw + lch * 8);
+    }
+    auto issue = [&](int kt, int stage) {
+        unsigned char* dst = smem + stage * STAGE_BYTES + wave * 4096;
+        const size_t koff = (size_t)kt * (BK * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(srcA[j] + koff, dst + j * 1024);
+            glds16(srcB[j] + koff, dst + OP_BYTES + j * 1024);
+        }
+    };
+
+    // ---- fragment read offsets: row base + swizzled chunk; (row >> 1) & 7 == (li >> 1) & 7 for every tile row ----
+    const int swz = (li >> 1) & 7;
+    const int c0 = (g ^ swz) << 4;            // k half 0: logical chunk g;  half 1: logical chunk 4 + g == c0 ^ 64
+    const int offA = (wm * 128 + li) * 128, offB = OP_BYTES + (wn * 64 + li) * 128;
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);   // lands during the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int cc = kk ? (c0 ^ 64) : c0;
+            bf16x8_t fa[8], fb[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = *(const bf16x8_t*)(st + offA + i * 2048 + cc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8_t*)(st + offB + j * 2048 + cc);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage has landed ...
+        __syncthreads();                                    // ... and everybody is done reading this one
+    }
+
+    // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg ----
+    const bf16_t* bias = (const bf16_t*)p.bias;
+    const bf16_t* scale = (const bf16_t*)p.scale;
+    const bf16_t* res = (const bf16_t*)p.residual;
+    const int n_ok = min(p.N, p.N_store);
+    if (ACT == 2) {
+        // SwiGLU: 16-column groups alternate (gate, up); output column = (col/32)*16 + col%16.
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const int col = n0 + wn * 64 + j * 16 + li;
+                const int ocol = (col >> 5) * 16 + (col & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm * 128 + i * 16 + g * 4 + r;
+                    if (row < p.M && col < p.N) {
+                        const float v = silu(acc[i][j][r]) * acc[i][j + 1][r];
+                        ((bf16_t*)p.C)[(size_t)row * p.ldc + ocol] = f2bf(v);
+                    }
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + li;
+        const bool col_ok = col < n_ok;
+        const float bv = (bias && col_ok) ? bf2f(bias[col]) : 0.f;
+        const float sv = (scale && col_ok) ? bf2f(scale[col]) : 1.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 128 + i * 16 + g * 4 + r;
+                if (row < p.M && col_ok) {
+                    float v = acc[i][j][r] + bv;
+                    if (ACT == 1) v = gelu_erf(v);
+                    v *= sv;
+                    if (res) v += bf2f(res[(size_t)row * p.ldr + col]);
+                    if (OUT_F32)
+                        ((float*)p.C)[(size_t)row * p.ldc + col] = v;
+                    else
+                        ((bf16_t*)p.C)[(size_t)row * p.ldc + col] = f2bf(v);
+                }
+            }
+    }
+}
+
+template <int ACT, bool OUT_F32>
+int launch_t(const GemmParams& p, int tiles, hipStream_t stream) {
+    auto kern = emmax_gemm256_bf16_kernel<ACT, OUT_F32>;
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) != hipSuccess) return -4;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), SMEM_BYTES, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+}  // namespace
+
+// number of 256x256 tiles of the problem
+int gemm256_tiles(const GemmParams& p) { return cdiv(p.M, BM) * cdiv(p.N, BN); }
+
+int launch_gemm256(const GemmParams& p, hipStream_t stream) {
+    if (p.M <= 0) return 0;
+    if (p.K % BK != 0 || p.N % 128 != 0 || p.K <= 0 || p.N <= 0) return -1;
+    if ((p.lda % 8) || (p.ldw % 8)) return -1;
+    const int tiles = gemm256_tiles(p);
+    if (p.act == 2) {
+        if (p.out_f32) return -1;
+        return launch_t<2, false>(p, tiles, stream);
+    }
+    if (p.act == 1) return p.out_f32 ? launch_t<1, true>(p, tiles, stream) : launch_t<1, false>(p, tiles, stream);
+    return p.out_f32 ? launch_t<0, true>(p, tiles, stream) : launch_t<0, false>(p, tiles, stream);
+}

@@ -20,7 +20,9 @@ struct GemmParams {
     int act;               // 0 none, 1 gelu(erf), 2 swiglu over 16-col interleaved (gate,up)
     int out_f32;
 };
-int launch_gemm(const GemmParams& p, hipStream_t stream);
+int launch_gemm(const GemmParams& p, hipStream_t stream);       // picks the 128x128 or the 256x256 tile kernel
+int launch_gemm256(const GemmParams& p, hipStream_t stream);    // gemm256.hip: 256x256x64 tiles, direct-to-LDS staging
+int gemm256_tiles(const GemmParams& p);
 
 // ---- norm.hip ----
 int launch_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, int ldx, int ldy, float eps,

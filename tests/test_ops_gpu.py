@@ -25,7 +25,7 @@ def bf(x):
 
 
 def relerr(got, ref):
-    ref = ref.float()
+    ref = ref.float().cpu()
     return ((got.float().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item()
 
 
@@ -80,6 +80,45 @@ def test_gemm_swiglu(device):
                               stream()), "gemm swiglu")
     torch.cuda.synchronize()
     assert relerr(Cd, ref) < TOL
+
+
+@pytest.mark.parametrize("variant", ["plain", "gelu", "scale_res", "f32", "swiglu"])
+def test_gemm_big_tile(device, variant):
+    """>= 512 tiles of 256x256 route to the direct-to-LDS 256x256x64 kernel (gemm256.hip): ragged M (4100 = 16 tiles + 4
+    rows), N = 65 * 128 (the last tile column is half empty), every epilogue; reference = fp32 matmul on the same device."""
+    L, lib = _lib()
+    M, N, K = 4100, 8320, 192
+    g = torch.Generator().manual_seed(11)
+    A = bf(torch.randn(M, K, generator=g)).to(device)
+    W = bf(torch.randn(N, K, generator=g) * 0.05).to(device)
+    ref = A.float() @ W.float().t()
+    if variant == "swiglu":
+        inter = N // 2
+        Wg, Wu = W[:inter], W[inter:]
+        ref = F.silu(A.float() @ Wg.float().t()) * (A.float() @ Wu.float().t())
+        Wi = torch.stack([Wg.view(inter // 16, 16, K), Wu.view(inter // 16, 16, K)], dim=1).reshape(N, K).contiguous()
+        Cd = torch.full((M, inter), float("nan"), dtype=torch.bfloat16, device=device)
+        L.check(lib.emmax_op_gemm(A.data_ptr(), K, Wi.data_ptr(), K, Cd.data_ptr(), inter, M, N, K, None, 2, None, None, 0, 0, stream()), "gemm")
+        torch.cuda.synchronize()
+        assert torch.isfinite(Cd.float()).all()
+        assert relerr(Cd, ref) < TOL
+        return
+    bias = bf(torch.randn(N, generator=g)).to(device) if variant != "plain" else None
+    scale = bf(torch.rand(N, generator=g) + 0.5).to(device) if variant == "scale_res" else None
+    res = bf(torch.randn(M, N, generator=g)).to(device) if variant == "scale_res" else None
+    if bias is not None:
+        ref = ref + bias.float()
+    if variant == "gelu":
+        ref = F.gelu(ref)
+    if scale is not None:
+        ref = ref * scale.float() + res.float()
+    out_f32 = variant == "f32"
+    Cd = torch.full((M, N), float("nan"), dtype=torch.float32 if out_f32 else torch.bfloat16, device=device)
+    L.check(lib.emmax_op_gemm(A.data_ptr(), K, W.data_ptr(), K, Cd.data_ptr(), N, M, N, K, L.ptr(bias), int(variant == "gelu"),
+                              L.ptr(scale), L.ptr(res), N, int(out_f32), stream()), "gemm")
+    torch.cuda.synchronize()
+    assert torch.isfinite(Cd.float()).all()
+    assert relerr(Cd, ref) < (1e-4 if out_f32 else TOL)
 
 
 def test_gemm_rejects_bad_shapes(device):

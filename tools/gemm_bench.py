@@ -1,0 +1,59 @@
+"""GEMM micro-benchmark through the C ABI (emmax_op_gemm) on the shapes of the dense stages (not the headline bench):
+ViT B=256 (DINOv2 261 tok, SigLIP 256 tok), projector, LLaMA prefill S=768 at B=1 and B=8.  Random normal operands."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "emma-x_amd")]
+import torch
+
+from emmax import _lib as L
+
+SHAPES = [
+    # name, M, N, K, act
+    ("dino qkv", 261 * 256, 3072, 1024, 0), ("dino proj", 261 * 256, 1024, 1024, 0),
+    ("dino fc1", 261 * 256, 4096, 1024, 1), ("dino fc2", 261 * 256, 1024, 4096, 0),
+    ("siglip qkv", 256 * 256, 3456, 1152, 0), ("siglip proj", 256 * 256, 1152, 1152, 0),
+    ("siglip fc1", 256 * 256, 4352, 1152, 1), ("siglip fc2", 256 * 256, 1152, 4352, 0),
+    ("proj fc1", 256 * 256, 8704, 2176, 1), ("proj fc2", 256 * 256, 4096, 8704, 1),
+    ("llama qkv B8", 768 * 8, 12288, 4096, 0), ("llama o B8", 768 * 8, 4096, 4096, 0),
+    ("llama gateup B8", 768 * 8, 22016, 4096, 2), ("llama down B8", 768 * 8, 4096, 11008, 0),
+    ("llama qkv B1", 768, 12288, 4096, 0), ("llama o B1", 768, 4096, 4096, 0),
+    ("llama gateup B1", 768, 22016, 4096, 2), ("llama down B1", 768, 4096, 11008, 0),
+    ("square 4096", 4096, 4096, 4096, 0), ("square 8192", 8192, 8192, 8192, 0),
+]
+
+
+def main():
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for name, M, N, K, act in SHAPES:
+        A = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
+        W = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
+        C = torch.empty(M, N // 2 if act == 2 else N, dtype=torch.bfloat16, device=dev)
+
+        def run():
+            L.check(lib.emmax_op_gemm(A.data_ptr(), K, W.data_ptr(), K, C.data_ptr(), C.shape[1], M, N, K, None, act, None, None, 0, 0, st), "gemm")
+
+        run()
+        torch.cuda.synchronize()
+        reps = 5
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        tf = 2.0 * M * N * K / ms / 1e9
+        out[name] = {"ms": round(ms, 4), "tflops": round(tf, 1)}
+        print(f"{name:18s} M={M:6d} N={N:6d} K={K:6d} act={act}  {ms:8.4f} ms  {tf:7.1f} TF/s", flush=True)
+        del A, W, C
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
