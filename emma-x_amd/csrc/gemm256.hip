@@ -3,15 +3,26 @@
 // Used when the problem has enough 256x256 tiles to fill the chip a few times over (ViT at batch >= 64, projector,
 // LLaMA prefill at batch >= 4); small problems stay on the 128x128 kernel of gemm.hip, whose finer tiles fill 256 CUs.
 //
-// Tiling: 256x256x64 block tile, 512 threads = 8 waves as 2(M) x 4(N), each wave 128x64 = 8x4 v_mfma_f32_16x16x32_bf16
+// Tiling: 256x256x64 block tile; 512 threads = 8 waves as 2(M) x 4(N), each wave 128x64 = 8x4 v_mfma_f32_16x16x32_bf16
 // tiles (128 accumulator registers), one block per CU.
 // Staging: HBM -> LDS directly with global_load_lds_dwordx4 (no staging registers, no ds_write pass), two LDS stages of
-// 64 KiB (A 32 KiB + B 32 KiB): the DMA of K-tile t+1 is issued before the MFMAs of K-tile t and drained (vmcnt(0)) at
-// the single barrier that ends the K step.
-// LDS image: operand tile = [256 rows][8 chunks of 16 B], rows 128 B apart.  A wave-level DMA writes 1 KiB = 8 whole
-// rows in lane order, so the image itself is linear; the bank-conflict swizzle is applied to the SOURCE address instead:
+// 64 KiB (A 32 KiB + B 32 KiB): the DMA of K step t+1 is issued before the MFMAs of K step t and drained (vmcnt(0)) at the
+// single barrier that ends the step.  (A ring of four 32-deep stages with counted vmcnt was measured 15 % slower: twice the
+// barriers for the same MFMA work.)
+// Fragments: ds_read_b128 two row tiles ahead of the MFMAs that consume them (A through a 4-slot register ring, the B
+// fragments of the second k half during the first), pinned with sched_group_barrier -- left alone, the scheduler sinks
+// every read to just above its first use.
+// LDS image: operand tile = [256 rows][8 chunks of 16 B], rows 128 B apart.  A wave-level DMA writes 1 KiB = 8 whole rows
+// in lane order, so the image itself is linear; the bank-conflict swizzle is applied to the SOURCE address instead:
 // physical chunk c of row r holds logical chunk c ^ ((r >> 1) & 7).  A ds_read_b128 fragment read (16 lanes = 16 rows at
 // one logical chunk) then touches 16 distinct 16-byte slots of the 256-byte bank row.
+// MFMA operands are swapped (W fragment first): the accumulator of a lane then holds 4 CONSECUTIVE output columns of one
+// output row, and the epilogue stores 8 bytes per lane instead of four 2-byte scatters.
+// Tile order: block ids go round-robin over the 8 XCDs; each XCD gets a contiguous run of tiles, walked in bands of 4 tile
+// columns (column fastest), so the ~32 blocks resident in one XCD form an 8 x 4 patch that shares 8 A panels and 4 W
+// panels in that XCD's 4 MiB L2 instead of streaming 32 different A panels through it.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -21,6 +32,7 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int OP_BYTES = BM * BK * 2;        // 32 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * OP_BYTES;    // A + B
 constexpr int SMEM_BYTES = 2 * STAGE_BYTES;  // two stages: 128 KiB
+constexpr int BAND = 4;                      // tile columns per band of the tile order
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -36,8 +48,7 @@ __global__ __launch_bounds__(512) void emmax_gemm256_bf16_kernel(GemmParams p) {
     const int wm = wave >> 2, wn = wave & 3;
     const int g = lane >> 4, li = lane & 15;
 
-    // XCD-aware tile order: block ids go round-robin over the 8 XCDs; give each XCD a contiguous run of tiles that walks M
-    // fastest, so the blocks resident in one XCD share a W panel (and neighbouring A panels) in that XCD's L2.
+    // XCD-contiguous run index, then banded order (see header)
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int nwg = tiles_m * tiles_n;
     int bid = blockIdx.x;
@@ -45,7 +56,9 @@ __global__ __launch_bounds__(512) void emmax_gemm256_bf16_kernel(GemmParams p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid % tiles_m, tn = bid / tiles_m;
+    const int band = bid / (BAND * tiles_m), in_band = bid - band * (BAND * tiles_m);
+    const int bw = min(BAND, tiles_n - band * BAND);
+    const int tm = in_band / bw, tn = band * BAND + (in_band - tm * bw);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- DMA sources: wave w fills slabs 4w .. 4w+3 (8 rows each) of both operand tiles ----
@@ -59,8 +72,8 @@ __global__ __launch_bounds__(512) void emmax_gemm256_bf16_kernel(GemmParams p) {
         srcA[j] = (const unsigned char*)((const bf16_t*)p.A + (size_t)gm * p.lda + lch * 8);
         srcB[j] = (const unsigned char*)((const bf16_t*)p.W + (size_t)gn * p.ldw + lch * 8);
     }
-    auto issue = [&](int kt, int stage) {
-        unsigned char* dst = smem + stage * STAGE_BYTES + wave * 4096;
+    auto issue = [&](int kt) {
+        unsigned char* dst = smem + (kt & 1) * STAGE_BYTES + wave * 4096;
         const size_t koff = (size_t)kt * (BK * 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -69,10 +82,13 @@ __global__ __launch_bounds__(512) void emmax_gemm256_bf16_kernel(GemmParams p) {
         }
     };
 
-    // ---- fragment read offsets: row base + swizzled chunk; (row >> 1) & 7 == (li >> 1) & 7 for every tile row ----
+    // ---- fragment read offsets: row base + swizzled chunk; (row >> 1) & 7 == (li >> 1) & 7 for every 16-row tile ----
     const int swz = (li >> 1) & 7;
     const int c0 = (g ^ swz) << 4;            // k half 0: logical chunk g;  half 1: logical chunk 4 + g == c0 ^ 64
     const int offA = (wm * 128 + li) * 128, offB = OP_BYTES + (wn * 64 + li) * 128;
+    // position s = kk * 8 + i of the K step: k half kk, row tile i
+    auto ldA = [&](const unsigned char* st, int s_) { return *(const bf16x8_t*)(st + offA + (s_ & 7) * 2048 + ((s_ >> 3) ? (c0 ^ 64) : c0)); };
+    auto ldB = [&](const unsigned char* st, int kk, int j) { return *(const bf16x8_t*)(st + offB + j * 2048 + (kk ? (c0 ^ 64) : c0)); };
 
     f32x4_t acc[8][4];
 #pragma unroll
@@ -81,76 +97,119 @@ __global__ __launch_bounds__(512) void emmax_gemm256_bf16_kernel(GemmParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
-    issue(0, 0);
+    issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);   // lands during the MFMAs below
+        if (kt + 1 < nk) issue(kt + 1);   // lands during the MFMAs below
+        bf16x8_t fb[2][4], fa[4];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int cc = kk ? (c0 ^ 64) : c0;
-            bf16x8_t fa[8], fb[4];
+        for (int j = 0; j < 4; ++j) fb[0][j] = ldB(st, 0, j);
+        fa[0] = ldA(st, 0);
+        fa[1] = ldA(st, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) fa[i] = *(const bf16x8_t*)(st + offA + i * 2048 + cc);
+        for (int s_ = 0; s_ < 16; ++s_) {
+            const int kk = s_ >> 3, i = s_ & 7;
+            if (s_ + 2 < 16) fa[(s_ + 2) & 3] = ldA(st, s_ + 2);
+            if (s_ < 4) fb[1][s_] = ldB(st, 1, s_);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8_t*)(st + offB + j * 2048 + cc);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[s_ & 3], acc[i][j], 0, 0, 0);
+            if (s_ < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            else if (s_ + 2 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage has landed ...
         __syncthreads();                                    // ... and everybody is done reading this one
     }
 
-    // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg ----
+    // ---- epilogue.  Swapped-operand C/D layout: lane (g, li) holds output row m = li of the row tile and the four
+    // consecutive columns n = 4 g + r (r = register) of the column tile ----
     const bf16_t* bias = (const bf16_t*)p.bias;
     const bf16_t* scale = (const bf16_t*)p.scale;
     const bf16_t* res = (const bf16_t*)p.residual;
     const int n_ok = min(p.N, p.N_store);
     if (ACT == 2) {
         // SwiGLU: 16-column groups alternate (gate, up); output column = (col/32)*16 + col%16.
+        const bool vec = (p.ldc & 3) == 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i) {
+            const int row = m0 + wm * 128 + i * 16 + li;
 #pragma unroll
             for (int j = 0; j < 4; j += 2) {
-                const int col = n0 + wn * 64 + j * 16 + li;
+                const int col = n0 + wn * 64 + j * 16 + g * 4;
                 const int ocol = (col >> 5) * 16 + (col & 15);
+                if (row < p.M && col < p.N) {
+                    float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = m0 + wm * 128 + i * 16 + g * 4 + r;
-                    if (row < p.M && col < p.N) {
-                        const float v = silu(acc[i][j][r]) * acc[i][j + 1][r];
-                        ((bf16_t*)p.C)[(size_t)row * p.ldc + ocol] = f2bf(v);
+                    for (int r = 0; r < 4; ++r) v[r] = silu(acc[i][j][r]) * acc[i][j + 1][r];
+                    bf16_t* dst = (bf16_t*)p.C + (size_t)row * p.ldc + ocol;
+                    if (vec) {
+                        *(u32x2_t*)dst = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dst[r] = f2bf(v[r]);
                     }
                 }
             }
+        }
         return;
     }
+    const bool vec_c = (p.ldc & 3) == 0, vec_r = (p.ldr & 3) == 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wn * 64 + j * 16 + li;
-        const bool col_ok = col < n_ok;
-        const float bv = (bias && col_ok) ? bf2f(bias[col]) : 0.f;
-        const float sv = (scale && col_ok) ? bf2f(scale[col]) : 1.f;
+        const int col = n0 + wn * 64 + j * 16 + g * 4;
+        float bv[4], sv[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int r = 0; r < 4; ++r) {
+            bv[r] = (bias && col + r < n_ok) ? bf2f(bias[col + r]) : 0.f;
+            sv[r] = (scale && col + r < n_ok) ? bf2f(scale[col + r]) : 1.f;
+        }
+        const bool full = col + 3 < n_ok;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = m0 + wm * 128 + i * 16 + li;
+            if (row >= p.M || col >= n_ok) continue;
+            float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 128 + i * 16 + g * 4 + r;
-                if (row < p.M && col_ok) {
-                    float v = acc[i][j][r] + bv;
-                    if (ACT == 1) v = gelu_erf(v);
-                    v *= sv;
-                    if (res) v += bf2f(res[(size_t)row * p.ldr + col]);
-                    if (OUT_F32)
-                        ((float*)p.C)[(size_t)row * p.ldc + col] = v;
-                    else
-                        ((bf16_t*)p.C)[(size_t)row * p.ldc + col] = f2bf(v);
+                v[r] = acc[i][j][r] + bv[r];
+                if (ACT == 1) v[r] = gelu_erf(v[r]);
+                v[r] *= sv[r];
+            }
+            if (res) {
+                const bf16_t* rp = res + (size_t)row * p.ldr + col;
+                if (full && vec_r) {
+                    const u32x2_t rv = *(const u32x2_t*)rp;
+                    v[0] += bf_lo(rv[0]); v[1] += bf_hi(rv[0]); v[2] += bf_lo(rv[1]); v[3] += bf_hi(rv[1]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col + r < n_ok) v[r] += bf2f(rp[r]);
                 }
             }
+            if (OUT_F32) {
+                float* dst = (float*)p.C + (size_t)row * p.ldc + col;
+                if (full && vec_c) {
+                    *(f32x4_t*)dst = (f32x4_t){v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col + r < n_ok) dst[r] = v[r];
+                }
+            } else {
+                bf16_t* dst = (bf16_t*)p.C + (size_t)row * p.ldc + col;
+                if (full && vec_c) {
+                    *(u32x2_t*)dst = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col + r < n_ok) dst[r] = f2bf(v[r]);
+                }
+            }
+        }
     }
 }
 
