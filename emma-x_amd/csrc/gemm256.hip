@@ -39,92 +39,91 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// bf16 epilogue through LDS: a wave parks 64 rows of its 128 x 64 (SwiGLU: 128 x 32) result in a private 8 KiB LDS window
+// (16-byte chunks XOR-swizzled with the row, so both the 8-byte writes in accumulator layout and the 16-byte reads in row
+// layout are conflict-free) and stores it back as WHOLE rows: 16 bytes per lane, 128 (64) contiguous bytes per row.
+// Measured on the store path alone: 8-byte accumulator-layout stores (32-byte runs) sustain 2.6 TB/s chip-wide against the
+// 6.4 TB/s of a plain fill -- the epilogue of a K = 1024 tile was a third of its time.
+template <int ACT>
+__device__ __forceinline__ void gemm256_epilogue_staged(const GemmParams& p, const f32x4_t (&acc)[8][4], int m0, int n0, int wm, int wn, int g,
+                                                        int li, int lane, unsigned char* wl) {
+    constexpr int WC = (ACT == 2) ? 32 : 64;   // output columns of this wave
+    constexpr int CH = WC / 8;                  // 16-byte chunks per staged row
+    constexpr int NG = WC / 16;                 // 16-column output groups
+    const bf16_t* bias = (const bf16_t*)p.bias;
+    const bf16_t* scale = (const bf16_t*)p.scale;
+    const bf16_t* res = (const bf16_t*)p.residual;
+    const int n_ok = (ACT == 2) ? p.N / 2 : min(p.N, p.N_store);
+    const int ocol0 = (ACT == 2) ? ((n0 + wn * 64) >> 1) : (n0 + wn * 64);
+    const bool vec_r = (p.ldr & 3) == 0;
+    float bv[NG][4], sv[NG][4];
+#pragma unroll
+    for (int jo = 0; jo < NG; ++jo)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = ocol0 + jo * 16 + g * 4 + r;
+            bv[jo][r] = (ACT != 2 && bias && col < n_ok) ? bf2f(bias[col]) : 0.f;
+            sv[jo][r] = (ACT != 2 && scale && col < n_ok) ? bf2f(scale[col]) : 1.f;
+        }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = 4 * h + ii, rl = ii * 16 + li;          // row inside the 64-row window
+            const int row = m0 + wm * 128 + i * 16 + li;
+#pragma unroll
+            for (int jo = 0; jo < NG; ++jo) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (ACT == 2) {
+                        v[r] = silu(acc[i][2 * jo][r]) * acc[i][2 * jo + 1][r];
+                    } else {
+                        v[r] = acc[i][jo][r] + bv[jo][r];
+                        if (ACT == 1) v[r] = gelu_erf(v[r]);
+                        v[r] *= sv[jo][r];
+                    }
+                }
+                if (ACT != 2 && res && row < p.M) {
+                    const int col = ocol0 + jo * 16 + g * 4;
+                    const bf16_t* rp = res + (size_t)row * p.ldr + col;
+                    if (col + 3 < n_ok && vec_r) {
+                        const u32x2_t rv = *(const u32x2_t*)rp;
+                        v[0] += bf_lo(rv[0]); v[1] += bf_hi(rv[0]); v[2] += bf_lo(rv[1]); v[3] += bf_hi(rv[1]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col + r < n_ok) v[r] += bf2f(rp[r]);
+                    }
+                }
+                const int c = jo * 2 + (g >> 1);                  // 16-byte chunk of the row, half g & 1
+                *(u32x2_t*)(wl + rl * (WC * 2) + ((c ^ (rl & (CH - 1))) << 4) + (g & 1) * 8) =
+                    (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+        }
+        // whole rows back out: lane -> (row, chunk); LDS executes a wave's accesses in order, no barrier needed
+#pragma unroll
+        for (int itr = 0; itr < CH; ++itr) {
+            const int idx = itr * 64 + lane;
+            const int rr = idx / CH, cl = idx % CH;
+            const u32x4_t val = *(const u32x4_t*)(wl + rr * (WC * 2) + ((cl ^ (rr & (CH - 1))) << 4));
+            const int row = m0 + wm * 128 + h * 64 + rr, col = ocol0 + cl * 8;
+            if (row < p.M) {
+                bf16_t* dst = (bf16_t*)p.C + (size_t)row * p.ldc + col;
+                if (col + 7 < n_ok) {
+                    *(u32x4_t*)dst = val;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (col + e < n_ok) dst[e] = (bf16_t)((val[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                }
+            }
+        }
+    }
+}
+
 template <int ACT, bool OUT_F32>
-__global__ __launch_bounds__(512) void emmax_gemm256_bf16_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int g = lane >> 4, li = lane & 15;
-
-    // XCD-contiguous run index, then banded order (see header)
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int band = bid / (BAND * tiles_m), in_band = bid - band * (BAND * tiles_m);
-    const int bw = min(BAND, tiles_n - band * BAND);
-    const int tm = in_band / bw, tn = band * BAND + (in_band - tm * bw);
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    // ---- DMA sources: wave w fills slabs 4w .. 4w+3 (8 rows each) of both operand tiles ----
-    const unsigned char* srcA[4];
-    const unsigned char* srcB[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = (wave * 4 + j) * 8 + (lane >> 3);
-        const int lch = (lane & 7) ^ ((row >> 1) & 7);                      // logical chunk landing in physical chunk lane&7
-        const int gm = min(m0 + row, p.M - 1), gn = min(n0 + row, p.N - 1);  // edge tiles re-read the last row (never stored)
-        srcA[j] = (const unsigned char*)((const bf16_t*)p.A + (size_t)gm * p.lda + lch * 8);
-        srcB[j] = (const unsigned char*)((const bf16_t*)p.W + (size_t)gn * p.ldw + lch * 8);
-    }
-    auto issue = [&](int kt) {
-        unsigned char* dst = smem + (kt & 1) * STAGE_BYTES + wave * 4096;
-        const size_t koff = (size_t)kt * (BK * 2);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            glds16(srcA[j] + koff, dst + j * 1024);
-            glds16(srcB[j] + koff, dst + OP_BYTES + j * 1024);
-        }
-    };
-
-    // ---- fragment read offsets: row base + swizzled chunk; (row >> 1) & 7 == (li >> 1) & 7 for every 16-row tile ----
-    const int swz = (li >> 1) & 7;
-    const int c0 = (g ^ swz) << 4;            // k half 0: logical chunk g;  half 1: logical chunk 4 + g == c0 ^ 64
-    const int offA = (wm * 128 + li) * 128, offB = OP_BYTES + (wn * 64 + li) * 128;
-    // position s = kk * 8 + i of the K step: k half kk, row tile i
-    auto ldA = [&](const unsigned char* st, int s_) { return *(const bf16x8_t*)(st + offA + (s_ & 7) * 2048 + ((s_ >> 3) ? (c0 ^ 64) : c0)); };
-    auto ldB = [&](const unsigned char* st, int kk, int j) { return *(const bf16x8_t*)(st + offB + j * 2048 + (kk ? (c0 ^ 64) : c0)); };
-
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / BK;
-    issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
-        if (kt + 1 < nk) issue(kt + 1);   // lands during the MFMAs below
-        bf16x8_t fb[2][4], fa[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[0][j] = ldB(st, 0, j);
-        fa[0] = ldA(st, 0);
-        fa[1] = ldA(st, 1);
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-        for (int s_ = 0; s_ < 16; ++s_) {
-            const int kk = s_ >> 3, i = s_ & 7;
-            if (s_ + 2 < 16) fa[(s_ + 2) & 3] = ldA(st, s_ + 2);
-            if (s_ < 4) fb[1][s_] = ldB(st, 1, s_);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[s_ & 3], acc[i][j], 0, 0, 0);
-            if (s_ < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            else if (s_ + 2 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage has landed ...
-        __syncthreads();                                    // ... and everybody is done reading this one
-    }
-
+__device__ __forceinline__ void gemm256_epilogue(const GemmParams& p, const f32x4_t (&acc)[8][4], int m0, int n0, int wm, int wn, int g, int li) {
     // ---- epilogue.  Swapped-operand C/D layout: lane (g, li) holds output row m = li of the row tile and the four
     // consecutive columns n = 4 g + r (r = register) of the column tile ----
     const bf16_t* bias = (const bf16_t*)p.bias;
@@ -214,6 +213,126 @@ __global__ __launch_bounds__(512) void emmax_gemm256_bf16_kernel(GemmParams p) {
 }
 
 template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(512) void emmax_gemm256_bf16_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int g = lane >> 4, li = lane & 15;
+
+    // ---- persistent tile loop.  Block b lives on XCD b & 7 (round-robin dispatch); that XCD owns a contiguous run of the
+    // banded tile order and its gridDim/8 blocks walk it side by side ----
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+    const int rq = nwg >> 3, rr = nwg & 7;
+    const int run0 = xcd < rr ? xcd * (rq + 1) : rr * (rq + 1) + (xcd - rr) * rq, run_n = rq + (xcd < rr ? 1 : 0);
+    auto tile_origin = [&](int it, int& m0, int& n0) {
+        const int bid = run0 + it;
+        const int band = bid / (BAND * tiles_m), in_band = bid - band * (BAND * tiles_m);
+        const int bw = min(BAND, tiles_n - band * BAND);
+        const int tm = in_band / bw, tn = band * BAND + (in_band - tm * bw);
+        m0 = tm * BM;
+        n0 = tn * BN;
+    };
+
+    // ---- DMA sources: wave w fills slabs 4w .. 4w+3 (8 rows each) of both operand tiles ----
+    const unsigned char* srcA[4];
+    const unsigned char* srcB[4];
+    auto set_sources = [&](int m0, int n0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (wave * 4 + j) * 8 + (lane >> 3);
+            const int lch = (lane & 7) ^ ((row >> 1) & 7);                      // logical chunk landing in physical chunk lane&7
+            const int gm = min(m0 + row, p.M - 1), gn = min(n0 + row, p.N - 1);  // edge tiles re-read the last row (never stored)
+            srcA[j] = (const unsigned char*)((const bf16_t*)p.A + (size_t)gm * p.lda + lch * 8);
+            srcB[j] = (const unsigned char*)((const bf16_t*)p.W + (size_t)gn * p.ldw + lch * 8);
+        }
+    };
+    auto issue = [&](int kt) {
+        unsigned char* dst = smem + (kt & 1) * STAGE_BYTES + wave * 4096;
+        const size_t koff = (size_t)kt * (BK * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(srcA[j] + koff, dst + j * 1024);
+            glds16(srcB[j] + koff, dst + OP_BYTES + j * 1024);
+        }
+    };
+
+    // ---- fragment read offsets: row base + swizzled chunk; (row >> 1) & 7 == (li >> 1) & 7 for every 16-row tile ----
+    const int swz = (li >> 1) & 7;
+    const int c0 = (g ^ swz) << 4;            // k half 0: logical chunk g;  half 1: logical chunk 4 + g == c0 ^ 64
+    const int offA = (wm * 128 + li) * 128, offB = OP_BYTES + (wn * 64 + li) * 128;
+    // position s = kk * 8 + i of the K step: k half kk, row tile i
+    auto ldA = [&](const unsigned char* st, int s_) { return *(const bf16x8_t*)(st + offA + (s_ & 7) * 2048 + ((s_ >> 3) ? (c0 ^ 64) : c0)); };
+    auto ldB = [&](const unsigned char* st, int kk, int j) { return *(const bf16x8_t*)(st + offB + j * 2048 + (kk ? (c0 ^ 64) : c0)); };
+
+    const bool staged_ok = (p.ldc & 7) == 0 && (((size_t)p.C) & 15) == 0 && !(p.dbg & 8);   // 16-byte row-layout stores possible
+    const int nk = (p.dbg & 4) ? 1 : p.K / BK;   // dbg 4: one K step per tile (store path alone)
+    int it = blockIdx.x >> 3;
+    if (it >= run_n) return;
+    int ntrace = 0;
+    int m0, n0;
+    tile_origin(it, m0, n0);
+    set_sources(m0, n0);
+    issue(0);
+    while (true) {
+        f32x4_t acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K step 0 has landed (and the previous tile's stores retired)
+        __syncthreads();
+        if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[ntrace++] = wall_clock64();
+        for (int kt = 0; kt < nk; ++kt) {
+            const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
+            if (kt + 1 < nk && !((p.dbg & 1) && kt > 0)) issue(kt + 1);   // lands during the MFMAs below
+            bf16x8_t fb[2][4], fa[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[0][j] = ldB(st, 0, j);
+            fa[0] = ldA(st, 0);
+            fa[1] = ldA(st, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+            for (int s_ = 0; s_ < 16; ++s_) {
+                const int kk = s_ >> 3, i = s_ & 7;
+                if (s_ + 2 < 16) fa[(s_ + 2) & 3] = ldA(st, s_ + 2);
+                if (s_ < 4) fb[1][s_] = ldB(st, 1, s_);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[s_ & 3], acc[i][j], 0, 0, 0);
+                if (s_ < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                else if (s_ + 2 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage has landed ...
+            __syncthreads();                                    // ... and everybody is done reading this one
+        }
+        // the next tile's first K step is requested BEFORE this tile's epilogue: its HBM/L2 latency (and the block
+        // re-launch a one-tile-per-block grid would pay) hides under the stores
+        if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[ntrace++] = wall_clock64();
+        const int cm0 = m0, cn0 = n0;
+        it += per_xcd;
+        const bool more = it < run_n;
+        if (more) {
+            tile_origin(it, m0, n0);
+            set_sources(m0, n0);
+            issue(0);
+        }
+        if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[ntrace++] = wall_clock64();
+        if (!(p.dbg & 2)) {
+            // stage 1 is free between the last K step of this tile and the second DMA of the next one
+            if (!OUT_F32 && staged_ok) gemm256_epilogue_staged<ACT>(p, acc, cm0, cn0, wm, wn, g, li, lane, smem + STAGE_BYTES + wave * 8192);
+            else gemm256_epilogue<ACT, OUT_F32>(p, acc, cm0, cn0, wm, wn, g, li);
+        }
+        if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[ntrace++] = wall_clock64();
+        if (!more) break;
+    }
+}
+
+template <int ACT, bool OUT_F32>
 int launch_t(const GemmParams& p, int tiles, hipStream_t stream) {
     auto kern = emmax_gemm256_bf16_kernel<ACT, OUT_F32>;
     static bool attr_done = false;   // per instantiation
@@ -221,7 +340,7 @@ int launch_t(const GemmParams& p, int tiles, hipStream_t stream) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) != hipSuccess) return -4;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), SMEM_BYTES, stream, p);
+    hipLaunchKernelGGL(kern, dim3(tiles < 256 ? (tiles + 7) / 8 * 8 : 256), dim3(512), SMEM_BYTES, stream, p);   // persistent: 32 blocks per XCD
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -19,6 +19,8 @@ struct GemmParams {
     int N_store;           // columns >= N_store are not written
     int act;               // 0 none, 1 gelu(erf), 2 swiglu over 16-col interleaved (gate,up)
     int out_f32;
+    int dbg;               // tools only: 1 = skip the operand DMA after K step 1 (LDS + MFMA time alone), 2 = skip the stores
+    long long* trace;      // tools only (tools/gemm_trace.hip): block 0 writes wall_clock64() stamps per tile phase; null in the product
 };
 int launch_gemm(const GemmParams& p, hipStream_t stream);       // picks the 128x128 or the 256x256 tile kernel
 int launch_gemm256(const GemmParams& p, hipStream_t stream);    // gemm256.hip: 256x256x64 tiles, direct-to-LDS staging

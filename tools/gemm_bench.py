@@ -26,6 +26,9 @@ SHAPES = [
 
 
 def main():
+    global SHAPES
+    if len(sys.argv) > 1:   # custom shapes: "M,N,K,act;M,N,K,act;..."
+        SHAPES = [(f"custom{i}",) + tuple(int(v) for v in t.split(",")) for i, t in enumerate(sys.argv[1].split(";"))]
     lib = L.load()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
