@@ -150,9 +150,13 @@ __global__ __launch_bounds__(256) void emmax_gemm_bf16_kernel(GemmParams p) {
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0) return 0;
     {
-        // enough 256x256 tiles to fill the 256 CUs at least twice -> the big-tile kernel (EMMAX_GEMM256=0/1 forces a path)
+        // The 256x256 kernel runs one tile per CU at ~1.3x the per-CU rate of this one: it wins whenever its last (or
+        // only) round keeps >= 70 % of the 256 CUs busy, and from 112 tiles up when there is a single round (measured
+        // cross-over on the prefill shapes, tools/gemm_bench.py).  EMMAX_GEMM256=0/1 forces a path.
         static const int force = getenv("EMMAX_GEMM256") ? atoi(getenv("EMMAX_GEMM256")) : -1;
-        if (force == 1 || (force != 0 && gemm256_tiles(p) >= 512)) return launch_gemm256(p, stream);
+        const int t = gemm256_tiles(p);
+        const bool big = t <= 256 ? t >= 112 : 10 * t >= 7 * 256 * cdiv(t, 256);
+        if (force == 1 || (force != 0 && big)) return launch_gemm256(p, stream);
     }
     if (p.K % BK != 0 || p.N % BN != 0 || p.K <= 0 || p.N <= 0) return -1;
     if ((p.lda % 8) || (p.ldw % 8)) return -1;
