@@ -11,7 +11,9 @@
 // barriers for the same MFMA work.)
 // Fragments: ds_read_b128 two row tiles ahead of the MFMAs that consume them (A through a 4-slot register ring, the B
 // fragments of the second k half during the first), pinned with sched_group_barrier -- left alone, the scheduler sinks
-// every read to just above its first use.
+// every read to just above its first use.  (With a global_load_lds in flight hipcc models the LDS counter as unordered and
+// emits lgkmcnt(0) for every wait; inline-asm reads with hand-counted lgkmcnt(N) were tried and measured neutral, +-4 %:
+// the loop is bound by LDS and L2->LDS bandwidth, not by read latency.)
 // LDS image: operand tile = [256 rows][8 chunks of 16 B], rows 128 B apart.  A wave-level DMA writes 1 KiB = 8 whole rows
 // in lane order, so the image itself is linear; the bank-conflict swizzle is applied to the SOURCE address instead:
 // physical chunk c of row r holds logical chunk c ^ ((r >> 1) & 7).  A ds_read_b128 fragment read (16 lanes = 16 rows at
