@@ -603,7 +603,8 @@ __global__ __launch_bounds__(256) void emmax_decode_finish_kernel(FinishParams p
         if (tok == 0x7fffffff) tok = p.pad_id;
         int was_done = p.done[b];
         int n = p.n_out[b];
-        if (!p.is_prefill && !was_done && n >= *p.max_new_p) {   // token budget already spent before this step
+        const int budget_n = p.max_new_p[b];
+        if (!p.is_prefill && !was_done && n >= budget_n) {   // token budget already spent before this step
             was_done = 1;
             p.done[b] = 1;
         }
@@ -617,8 +618,27 @@ __global__ __launch_bounds__(256) void emmax_decode_finish_kernel(FinishParams p
             n += 1;
             p.n_out[b] = n;
             // stop on EOS, on the token budget, or when the next append would overflow the cache
-            const bool budget = !p.is_prefill && n >= *p.max_new_p;
-            if (tok == p.eos_id || budget || p.ctx_len[b] + 1 >= p.max_ctx) p.done[b] = 1;
+            const bool budget = !p.is_prefill && n >= budget_n;
+            // early exit: n_after tokens after the trigger id sequence (e.g. "POLICIES:" + the 8 action-line tokens)
+            bool stop = false;
+            const int n_trig = p.stop_cfg[0];
+            if (n_trig > 0) {
+                int aft = p.stop_after[b];
+                if (aft >= 0) {
+                    aft += 1;
+                } else {
+                    int mp = p.stop_m[b];
+                    mp = (tok == p.stop_ids[mp]) ? mp + 1 : ((tok == p.stop_ids[0]) ? 1 : 0);   // single-restart matcher
+                    if (mp == n_trig) {
+                        aft = 0;
+                        mp = 0;
+                    }
+                    p.stop_m[b] = mp;
+                }
+                p.stop_after[b] = aft;
+                stop = aft >= 0 && aft >= p.stop_cfg[1];
+            }
+            if (tok == p.eos_id || budget || stop || p.ctx_len[b] + 1 >= p.max_ctx) p.done[b] = 1;
         }
         p.cur_tok[b] = tok;
     }

@@ -51,12 +51,17 @@ int launch_assemble_tokens(const void* pe, const void* pos, const void* cls, con
 int launch_copy_rows(const void* in, int ld_in, void* out, int B, int rows_in, int r_off, int rows_out, int D, int ld_out,
                      int col_off, hipStream_t stream);
 #define EMMAX_MAX_DECODE_BATCH 8
+#define EMMAX_MAX_STOP_IDS 16
 struct PrefillState {
     int B;
     int S[EMMAX_MAX_DECODE_BATCH];
 };
-int launch_prefill_state(const PrefillState& st, int32_t* cu, int32_t* ctx_len, int32_t* done, int32_t* n_out, hipStream_t stream);
+// per-row decode state of B fresh sequences (pointers already offset to the first row / slot)
+int launch_prefill_state(const PrefillState& st, int32_t* cu, int32_t* ctx_len, int32_t* done, int32_t* n_out, int32_t* max_new,
+                         int32_t* stop_m, int32_t* stop_after, hipStream_t stream);
 int launch_set_int(int32_t* p, int32_t v, hipStream_t stream);
+int launch_set_ints(int32_t* p, int n, int32_t v, hipStream_t stream);
+int launch_slots_idle(int n, int32_t* cur_tok, int32_t* ctx_len, int32_t* done, int32_t* n_out, int32_t pad_id, hipStream_t stream);
 int launch_embed_splice(const int32_t* ids, int P_max, const int32_t* cu, const void* E, const void* patches, void* h, int B,
                         int max_seqlen, int n_patches, int hidden, int vocab, hipStream_t stream);
 int launch_rope_kv_write(void* qkv, int ld, int q_off, int k_off, int v_off, const int32_t* cu, int B, int total_rows,
@@ -127,7 +132,13 @@ struct FinishParams {
     int32_t* done;
     int32_t* n_out;
     int32_t* out_ids;
-    const int32_t* max_new_p;   // device int: token budget of the running generate() call
+    const int32_t* max_new_p;   // device int[B]: per-row token budget
+    // early exit (emmax_session_set_stop): stop_cfg = {n_trigger, n_after}; a row is done n_after tokens after it emitted
+    // the trigger id sequence.  stop_m[b] = trigger ids matched so far, stop_after[b] = tokens since the match (-1: none yet)
+    const int32_t* stop_ids;
+    const int32_t* stop_cfg;
+    int32_t* stop_m;
+    int32_t* stop_after;
     int max_out, max_ctx;
     int eos_id, pad_id;
     int is_prefill;

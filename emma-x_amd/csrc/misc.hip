@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void emmax_resize_pass_kernel(const uint8_t* _
 
 // device-side (re)initialisation of the per-sequence state at prefill: cu_seqlens, ctx_len, done, n_out.
 // Values travel as kernel arguments, so there is no host staging buffer to race with.
-__global__ void emmax_prefill_state_kernel(PrefillState st, int32_t* cu, int32_t* ctx_len, int32_t* done, int32_t* n_out) {
+__global__ void emmax_prefill_state_kernel(PrefillState st, int32_t* cu, int32_t* ctx_len, int32_t* done, int32_t* n_out, int32_t* max_new,
+                                           int32_t* stop_m, int32_t* stop_after) {
     if (threadIdx.x == 0) {
         int acc = 0;
         cu[0] = 0;
@@ -178,15 +179,42 @@ __global__ void emmax_prefill_state_kernel(PrefillState st, int32_t* cu, int32_t
             ctx_len[b] = st.S[b];
             done[b] = 0;
             n_out[b] = 0;
+            max_new[b] = 0x7fffffff;   // no token budget until a generate / slot call sets one
+            stop_m[b] = 0;
+            stop_after[b] = -1;
         }
     }
 }
 __global__ void emmax_set_int_kernel(int32_t* p, int32_t v) { *p = v; }
+__global__ void emmax_set_ints_kernel(int32_t* p, int n, int32_t v) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = v;
+}
+// idle request slots: nothing to decode, empty context (their share of a batched step costs no K/V traffic)
+__global__ void emmax_slots_idle_kernel(int n, int32_t* cur_tok, int32_t* ctx_len, int32_t* done, int32_t* n_out, int32_t pad_id) {
+    const int b = threadIdx.x;
+    if (b < n) {
+        cur_tok[b] = pad_id;
+        ctx_len[b] = 0;
+        done[b] = 1;
+        n_out[b] = 0;
+    }
+}
 
 }  // namespace
 
-int launch_prefill_state(const PrefillState& st, int32_t* cu, int32_t* ctx_len, int32_t* done, int32_t* n_out, hipStream_t stream) {
-    hipLaunchKernelGGL(emmax_prefill_state_kernel, dim3(1), dim3(64), 0, stream, st, cu, ctx_len, done, n_out);
+int launch_prefill_state(const PrefillState& st, int32_t* cu, int32_t* ctx_len, int32_t* done, int32_t* n_out, int32_t* max_new,
+                         int32_t* stop_m, int32_t* stop_after, hipStream_t stream) {
+    hipLaunchKernelGGL(emmax_prefill_state_kernel, dim3(1), dim3(64), 0, stream, st, cu, ctx_len, done, n_out, max_new, stop_m, stop_after);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+int launch_set_ints(int32_t* p, int n, int32_t v, hipStream_t stream) {
+    if (n < 1 || n > 64) return -1;
+    hipLaunchKernelGGL(emmax_set_ints_kernel, dim3(1), dim3(64), 0, stream, p, n, v);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+int launch_slots_idle(int n, int32_t* cur_tok, int32_t* ctx_len, int32_t* done, int32_t* n_out, int32_t pad_id, hipStream_t stream) {
+    if (n < 1 || n > 64) return -1;
+    hipLaunchKernelGGL(emmax_slots_idle_kernel, dim3(1), dim3(64), 0, stream, n, cur_tok, ctx_len, done, n_out, pad_id);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 int launch_set_int(int32_t* p, int32_t v, hipStream_t stream) {

@@ -235,7 +235,9 @@ struct emmax_session {
     // decode
     bf16 *dh, *dq, *datt, *dact;
     float *part, *part_val, *logits;
-    int32_t *part_idx, *cur_tok, *ctx_len, *done, *n_out, *out_ids, *max_new_d, *page_table;
+    int32_t *part_idx, *cur_tok, *ctx_len, *done, *n_out, *out_ids, *max_new_d /* [max_batch] */, *page_table;
+    int32_t *stop_ids /* [EMMAX_MAX_STOP_IDS] */, *stop_cfg /* {n_trigger, n_after} */, *stop_m, *stop_after;
+    bool slots_open = false;    // slot serving mode: rows are independent request slots (emmax_slots_open)
     float *cos_t, *sin_t;
     int n_lm_blocks;
     // kv
@@ -321,7 +323,11 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->done = (int32_t*)b.take(Bd * 4);
     s->n_out = (int32_t*)b.take(Bd * 4);
     s->out_ids = (int32_t*)b.take((int64_t)Bd * s->max_out * 4);
-    s->max_new_d = (int32_t*)b.take(4);
+    s->max_new_d = (int32_t*)b.take(Bd * 4);
+    s->stop_ids = (int32_t*)b.take(EMMAX_MAX_STOP_IDS * 4);
+    s->stop_cfg = (int32_t*)b.take(2 * 4);
+    s->stop_m = (int32_t*)b.take(Bd * 4);
+    s->stop_after = (int32_t*)b.take(Bd * 4);
     s->dep_ctr = (unsigned int*)b.take((256 * 32 + 16) * 4);
     s->page_table = (int32_t*)b.take((int64_t)Bd * s->max_pages * 4);
     s->cos_t = (float*)b.take((int64_t)s->max_ctx * (m->cfg.head_dim / 2) * 4);
@@ -417,7 +423,8 @@ static bf16* vcache_of(emmax_session* s, int layer) { return s->kv + (size_t)lay
 constexpr int DEP_MAX_KERNELS = 256;
 constexpr int DEP_WORDS = DEP_MAX_KERNELS * 32 + 16;
 struct Chain;
-static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, Chain* ch = nullptr);
+static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, Chain* ch = nullptr,
+                            int slot0 = 0);
 
 // chained-launch bookkeeping: kernel k runs on stream[k & 1], waits for counter k-1 and bumps counter k
 struct Chain {
@@ -438,11 +445,12 @@ struct Chain {
     void launched() { ++k; }
 };
 
-static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, Chain* ch) {
+// slot0: first row of the B rows this call covers (slot prefill: one row in the middle of a live batch)
+static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, Chain* ch, int slot0) {
     emmax_model* m = s->m;
     GemvParams p;
     memset(&p, 0, sizeof(p));
-    p.x = s->dh; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = m->final_norm; p.eps = m->cfg.rms_eps;
+    p.x = s->dh + (size_t)slot0 * m->H; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = m->final_norm; p.eps = m->cfg.rms_eps;
     p.n_rows = m->vocab; p.max_parts = s->n_lm_blocks; p.part_val = s->part_val; p.part_idx = s->part_idx; p.logits_out = logits_out;
     int lm_grid = 0;
     if (ch) { p.dep = ch->dep(); p.max_grid = 256; st = ch->stream(); }
@@ -453,8 +461,10 @@ static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* log
         memset(&f, 0, sizeof(f));
         f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = (B >= EMMAX_MFMA_MIN_BATCH || m->fp8) ? decode_mfma_lmhead_grid(m->vocab, s->n_lm_blocks) : decode_lmhead_grid(B, m->H, m->vocab, s->n_lm_blocks, ch ? 256 : 0);
         f.B = B;
-        f.cur_tok = s->cur_tok; f.ctx_len = s->ctx_len; f.done = s->done; f.n_out = s->n_out; f.out_ids = s->out_ids;
-        f.max_new_p = s->max_new_d; f.max_out = s->max_out; f.max_ctx = s->max_ctx;
+        f.cur_tok = s->cur_tok + slot0; f.ctx_len = s->ctx_len + slot0; f.done = s->done + slot0; f.n_out = s->n_out + slot0;
+        f.out_ids = s->out_ids + (size_t)slot0 * s->max_out;
+        f.max_new_p = s->max_new_d + slot0; f.max_out = s->max_out; f.max_ctx = s->max_ctx;
+        f.stop_ids = s->stop_ids; f.stop_cfg = s->stop_cfg; f.stop_m = s->stop_m + slot0; f.stop_after = s->stop_after + slot0;
         f.eos_id = m->cfg.eos_id; f.pad_id = m->cfg.pad_id; f.is_prefill = is_prefill ? 1 : 0;
         if (ch) { f.dep = ch->dep(); st = ch->stream(); }
         KCHK(launch_decode_finish(f, st));
@@ -464,15 +474,25 @@ static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* log
 }
 
 // patches == nullptr: language-only forward (no patch rows are spliced in; modeling_prismatic.py:343-359)
+// slot0 >= 0: slot serving -- the B (= 1) rows land in rows slot0.. of the live decode batch, whose other rows are untouched
 static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens, int B, int P_max, const void* patches,
-                       hipStream_t st) {
+                       hipStream_t st, int slot0 = -1) {
     emmax_model* m = s->m;
     const auto& c = m->cfg;
     if (!m->finalized) return fail(EMMAX_ERR_STATE, "model not finalized");
     if (B <= 0 || B > s->max_batch || B > EMMAX_MAX_DECODE_BATCH)
         return fail(EMMAX_ERR_INVALID, "prefill batch %d outside 1..min(max_batch=%d, %d)", B, s->max_batch, EMMAX_MAX_DECODE_BATCH);
     const int np = patches ? m->tw[0].n_patches : 0;
-    s->S.assign(B, 0);
+    const bool slot_mode = slot0 >= 0;
+    const int r0 = slot_mode ? slot0 : 0;
+    if (slot_mode) {
+        if (!s->slots_open) return fail(EMMAX_ERR_STATE, "slot prefill before emmax_slots_open");
+        if (r0 + B > s->cur_B) return fail(EMMAX_ERR_INVALID, "slot %d outside the %d open slots", r0, s->cur_B);
+        if ((int)s->S.size() < s->cur_B) s->S.resize(s->cur_B, 0);
+    } else {
+        s->S.assign(B, 0);
+        s->slots_open = false;
+    }
     int total = 0, maxS = 0;
     PrefillState ps;
     ps.B = B;
@@ -481,15 +501,15 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
             return fail(EMMAX_ERR_INVALID, "row %d: prompt length %d outside 1..min(P_max=%d, max_prompt=%d)", b, lens[b], P_max, s->max_prompt);
         const int Sb = np + lens[b];
         if (Sb + 1 > s->max_ctx) return fail(EMMAX_ERR_NOMEM, "row %d: %d prompt+patch tokens do not fit max_ctx %d", b, Sb, s->max_ctx);
-        s->S[b] = Sb;
+        s->S[r0 + b] = Sb;
         ps.S[b] = Sb;
         total += Sb;
         maxS = std::max(maxS, Sb);
     }
     if (total > s->max_rows) return fail(EMMAX_ERR_NOMEM, "packed prefill rows %d exceed capacity %d", total, s->max_rows);
-    KCHK(launch_prefill_state(ps, s->cu, s->ctx_len, s->done, s->n_out, st));
-    KCHK(launch_set_int(s->max_new_d, 0x7fffffff, st));   // no token budget until emmax_generate sets one
-    s->cur_B = B; s->total_rows = total; s->max_seqlen = maxS;
+    KCHK(launch_prefill_state(ps, s->cu, s->ctx_len + r0, s->done + r0, s->n_out + r0, s->max_new_d + r0, s->stop_m + r0, s->stop_after + r0, st));
+    if (!slot_mode) s->cur_B = B;
+    s->total_rows = total; s->max_seqlen = maxS;
 
     KCHK(launch_embed_splice(ids, P_max, s->cu, m->embed, patches, s->ph, B, maxS, np, m->H, m->vocab, st));
     for (int li = 0; li < c.n_layers; ++li) {
@@ -498,8 +518,8 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
         GemmParams g = gp(s->pxn, m->H, L.wqkv, m->H, s->pqkv, m->qkv_dim, total, m->qkv_dim, m->H);
         KCHK(launch_gemm(g, st));
         KCHK(launch_rope_kv_write(s->pqkv, m->qkv_dim, 0, m->q_dim, m->q_dim + m->kv_dim, s->cu, B, total, s->cos_t, s->sin_t,
-                                  kcache_of(s, li), vcache_of(s, li), s->page_table, s->max_pages, c.n_heads, c.n_kv_heads,
-                                  c.head_dim, PAGE, st));
+                                  kcache_of(s, li), vcache_of(s, li), s->page_table + (size_t)r0 * s->max_pages, s->max_pages, c.n_heads,
+                                  c.n_kv_heads, c.head_dim, PAGE, st));
         AttnParams a;
         a.qkv = s->pqkv; a.out = s->patt; a.cu_seqlens = s->cu;
         a.ld_qkv = m->qkv_dim; a.q_off = 0; a.k_off = m->q_dim; a.v_off = m->q_dim + m->kv_dim; a.ld_out = m->q_dim;
@@ -517,8 +537,8 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
         g.residual = s->ph; g.ldr = m->H;
         KCHK(launch_gemm(g, st));
     }
-    KCHK(launch_gather_last_rows(s->ph, s->dh, s->cu, B, m->H, st));
-    int r = run_lm_head_step(s, B, true, nullptr, true, st);
+    KCHK(launch_gather_last_rows(s->ph, s->dh + (size_t)r0 * m->H, s->cu, B, m->H, st));
+    int r = run_lm_head_step(s, B, true, nullptr, true, st, nullptr, r0);
     if (r) return r;
     s->prefilled = true;
     return 0;
@@ -1017,7 +1037,7 @@ int emmax_generate(emmax_session* s, int max_new, int stop_on_eos, int32_t* out_
         HIPCHK(hipStreamWaitEvent(st, s->ev_in, 0));
     }
     const int B = s->cur_B;
-    KCHK(launch_set_int(s->max_new_d, max_new, st));
+    KCHK(launch_set_ints(s->max_new_d, B, max_new, st));
     const bool use_graph = (max_new > 2) && ensure_graph(s, B, st) == 0;
     const int CHK = 16;
     int32_t* done_host = s->pinned;
@@ -1055,6 +1075,123 @@ int emmax_generate(emmax_session* s, int max_new, int stop_on_eos, int32_t* out_
         HIPCHK(hipStreamWaitEvent(user, s->ev_out, 0));
     }
     return 0;
+}
+
+// ---- early exit + slot serving (continuous batching) ----------------------------------------------------------------
+// the legacy / per-thread default streams cannot be captured: slot calls run on the session's own stream, ordered after
+// everything already queued on the caller's stream (enter) and before anything queued on it afterwards (leave)
+static int slot_enter(emmax_session* s, hipStream_t user, hipStream_t* st) {
+    *st = user;
+    if ((uintptr_t)user <= 2) {
+        *st = s->own_stream;
+        HIPCHK(hipEventRecord(s->ev_in, user));
+        HIPCHK(hipStreamWaitEvent(*st, s->ev_in, 0));
+    }
+    return 0;
+}
+static int slot_leave(emmax_session* s, hipStream_t user, hipStream_t st) {
+    if (st != user) {
+        HIPCHK(hipEventRecord(s->ev_out, st));
+        HIPCHK(hipStreamWaitEvent(user, s->ev_out, 0));
+    }
+    return 0;
+}
+
+int emmax_session_set_stop(emmax_session* s, const int32_t* trigger_ids, int n_trigger, int n_after, emmax_stream stream) {
+    if (!s || (n_trigger > 0 && !trigger_ids)) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (n_trigger < 0 || n_trigger > EMMAX_MAX_STOP_IDS || n_after < 0)
+        return fail(EMMAX_ERR_INVALID, "stop rule: %d trigger ids (max %d), %d tokens after", n_trigger, EMMAX_MAX_STOP_IDS, n_after);
+    hipStream_t user = (hipStream_t)stream, st;
+    int r = slot_enter(s, user, &st);
+    if (r) return r;
+    int32_t* h = s->pinned + 2048;
+    HIPCHK(hipStreamSynchronize(st));   // the pinned staging words may still feed an earlier upload
+    for (int i = 0; i < n_trigger; ++i) h[i] = trigger_ids[i];
+    h[EMMAX_MAX_STOP_IDS] = n_trigger;
+    h[EMMAX_MAX_STOP_IDS + 1] = n_after;
+    if (n_trigger > 0) HIPCHK(hipMemcpyAsync(s->stop_ids, h, n_trigger * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->stop_cfg, h + EMMAX_MAX_STOP_IDS, 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return slot_leave(s, user, st);
+}
+
+int emmax_slots_open(emmax_session* s, int n_slots, emmax_stream stream) {
+    if (!s) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (n_slots < 1 || n_slots > s->max_batch || n_slots > EMMAX_MAX_DECODE_BATCH)
+        return fail(EMMAX_ERR_INVALID, "%d slots outside 1..min(max_batch=%d, %d)", n_slots, s->max_batch, EMMAX_MAX_DECODE_BATCH);
+    hipStream_t user = (hipStream_t)stream, st;
+    int r = slot_enter(s, user, &st);
+    if (r) return r;
+    KCHK(launch_slots_idle(n_slots, s->cur_tok, s->ctx_len, s->done, s->n_out, s->m->cfg.pad_id, st));
+    s->cur_B = n_slots;
+    s->S.assign(n_slots, 0);
+    s->slots_open = true;
+    s->prefilled = true;   // decode steps are legal: idle slots are rows that are already done
+    return slot_leave(s, user, st);
+}
+
+int emmax_slot_prefill(emmax_session* s, int slot, const int32_t* ids, int len, const void* patches, int max_new, emmax_stream stream) {
+    if (!s || !ids) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (!s->slots_open) return fail(EMMAX_ERR_STATE, "emmax_slot_prefill before emmax_slots_open");
+    if (slot < 0 || slot >= s->cur_B) return fail(EMMAX_ERR_INVALID, "slot %d outside 0..%d", slot, s->cur_B - 1);
+    if (max_new < 1 || max_new > s->max_out) return fail(EMMAX_ERR_INVALID, "max_new_tokens %d outside 1..%d", max_new, s->max_out);
+    hipStream_t user = (hipStream_t)stream, st;
+    int r = slot_enter(s, user, &st);
+    if (r) return r;
+    r = run_prefill(s, ids, &len, 1, len, patches, st, slot);
+    if (r) return r;
+    KCHK(launch_set_ints(s->max_new_d + slot, 1, max_new, st));
+    return slot_leave(s, user, st);
+}
+
+int emmax_slots_step(emmax_session* s, int n_steps, emmax_stream stream) {
+    if (!s) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (!s->slots_open) return fail(EMMAX_ERR_STATE, "emmax_slots_step before emmax_slots_open");
+    if (n_steps < 1) return fail(EMMAX_ERR_INVALID, "n_steps %d < 1", n_steps);
+    hipStream_t user = (hipStream_t)stream, st;
+    int r = slot_enter(s, user, &st);
+    if (r) return r;
+    const int B = s->cur_B;
+    const bool use_graph = ensure_graph(s, B, st) == 0;
+    for (int i = 0; i < n_steps; ++i) {
+        r = use_graph ? launch_graph_step(s, B, st) : run_decode_step(s, B, st);
+        if (r) return r;
+    }
+    return slot_leave(s, user, st);
+}
+
+int emmax_slots_state(emmax_session* s, int32_t* done_out, int32_t* n_out_out, emmax_stream stream) {
+    if (!s || !done_out || !n_out_out) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (!s->slots_open) return fail(EMMAX_ERR_STATE, "emmax_slots_state before emmax_slots_open");
+    hipStream_t user = (hipStream_t)stream, st;
+    int r = slot_enter(s, user, &st);
+    if (r) return r;
+    HIPCHK(hipMemcpyAsync(done_out, s->done, s->cur_B * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(n_out_out, s->n_out, s->cur_B * 4, hipMemcpyDeviceToDevice, st));
+    return slot_leave(s, user, st);
+}
+
+int emmax_slot_output(emmax_session* s, int slot, int32_t* ids_out, int n, emmax_stream stream) {
+    if (!s || !ids_out) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (!s->slots_open) return fail(EMMAX_ERR_STATE, "emmax_slot_output before emmax_slots_open");
+    if (slot < 0 || slot >= s->cur_B || n < 0 || n > s->max_out) return fail(EMMAX_ERR_INVALID, "slot %d / %d ids out of range", slot, n);
+    hipStream_t user = (hipStream_t)stream, st;
+    int r = slot_enter(s, user, &st);
+    if (r) return r;
+    if (n > 0) HIPCHK(hipMemcpyAsync(ids_out, s->out_ids + (size_t)slot * s->max_out, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    return slot_leave(s, user, st);
+}
+
+int emmax_slot_release(emmax_session* s, int slot, emmax_stream stream) {
+    if (!s) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (!s->slots_open) return fail(EMMAX_ERR_STATE, "emmax_slot_release before emmax_slots_open");
+    if (slot < 0 || slot >= s->cur_B) return fail(EMMAX_ERR_INVALID, "slot %d outside 0..%d", slot, s->cur_B - 1);
+    hipStream_t user = (hipStream_t)stream, st;
+    int r = slot_enter(s, user, &st);
+    if (r) return r;
+    KCHK(launch_slots_idle(1, s->cur_tok + slot, s->ctx_len + slot, s->done + slot, s->n_out + slot, s->m->cfg.pad_id, st));
+    s->S[slot] = 0;
+    return slot_leave(s, user, st);
 }
 
 int emmax_session_chain_active(emmax_session* s) { return s && s->prefilled && chain_on(s, s->cur_B) ? 1 : 0; }

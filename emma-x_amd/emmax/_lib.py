@@ -69,6 +69,13 @@ SIGNATURES = {
     "emmax_session_graph_active": (C.c_int, [_vp]),
     "emmax_session_chain_active": (C.c_int, [_vp]),
     "emmax_profile_decode_stage": (C.c_int, [_vp, C.c_int, C.c_int, _c_f32p, _vp]),
+    "emmax_session_set_stop": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
+    "emmax_slots_open": (C.c_int, [_vp, C.c_int, _vp]),
+    "emmax_slot_prefill": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp]),
+    "emmax_slots_step": (C.c_int, [_vp, C.c_int, _vp]),
+    "emmax_slots_state": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "emmax_slot_output": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp]),
+    "emmax_slot_release": (C.c_int, [_vp, C.c_int, _vp]),
     "emmax_op_gemm": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp,
                                 C.c_int, C.c_int, _vp]),
     "emmax_op_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp]),

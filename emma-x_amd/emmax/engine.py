@@ -212,6 +212,50 @@ class EmmaxEngine:
                                            _lib.current_stream()), "emmax_generate")
         return out, lens
 
+    # ---- early exit + slot serving (include/emmax.h "slot serving") ----------------------------------------------------
+    def set_stop(self, trigger_ids: Sequence[int] = (), n_after: int = 0) -> None:
+        """Device-side early exit: a row is done `n_after` tokens after it emitted `trigger_ids`; () clears the rule."""
+        trig = list(trigger_ids)
+        arr = (C.c_int32 * max(1, len(trig)))(*trig)
+        _lib.check(self.lib.emmax_session_set_stop(self._session, arr, len(trig), int(n_after), _lib.current_stream()),
+                   "emmax_session_set_stop")
+
+    def slots_open(self, n_slots: int) -> None:
+        _lib.check(self.lib.emmax_slots_open(self._session, int(n_slots), _lib.current_stream()), "emmax_slots_open")
+        self._n_slots = int(n_slots)
+        self._slot_state = torch.empty(2, n_slots, dtype=torch.int32, device=self.device)
+
+    def slot_prefill(self, slot: int, input_ids: Sequence[int], patch_embeds: Optional[torch.Tensor], max_new_tokens: int) -> None:
+        """Prefill one request (prompt ids starting with BOS, its [n_patches, hidden] bf16 patch embeddings) into `slot`."""
+        ids_d = torch.as_tensor(list(input_ids), dtype=torch.int32).to(self.device)
+        pe = None
+        if patch_embeds is not None:
+            pe = patch_embeds.contiguous()
+            assert pe.dtype == torch.bfloat16 and pe.numel() == self.cfg.n_patches * self.cfg.llm.hidden_size
+        _lib.check(self.lib.emmax_slot_prefill(self._session, int(slot), ids_d.data_ptr(), len(input_ids), _lib.ptr(pe),
+                                               int(max_new_tokens), _lib.current_stream()), "emmax_slot_prefill")
+        torch.cuda.current_stream().synchronize()   # `ids_d` must outlive the embedding gather
+
+    def slots_step(self, n_steps: int) -> None:
+        _lib.check(self.lib.emmax_slots_step(self._session, int(n_steps), _lib.current_stream()), "emmax_slots_step")
+
+    def slots_state(self) -> Tuple[List[int], List[int]]:
+        """(done flags, generated-token counts) of every slot; synchronises with the device."""
+        st = self._slot_state
+        _lib.check(self.lib.emmax_slots_state(self._session, st[0].data_ptr(), st[1].data_ptr(), _lib.current_stream()),
+                   "emmax_slots_state")
+        host = st.cpu()
+        return host[0].tolist(), host[1].tolist()
+
+    def slot_output(self, slot: int, n: int) -> List[int]:
+        out = torch.empty(max(1, n), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.emmax_slot_output(self._session, int(slot), out.data_ptr(), int(n), _lib.current_stream()),
+                   "emmax_slot_output")
+        return out[:n].cpu().tolist()
+
+    def slot_release(self, slot: int) -> None:
+        _lib.check(self.lib.emmax_slot_release(self._session, int(slot), _lib.current_stream()), "emmax_slot_release")
+
     def graph_active(self) -> bool:
         return bool(self.lib.emmax_session_graph_active(self._session))
 

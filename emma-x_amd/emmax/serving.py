@@ -1,0 +1,132 @@
+"""Continuous batching for a fleet of cameras: a slot scheduler over the engine's slot-serving C ABI.
+
+The reference answers one request at a time (`generate_actions`, prismatic.py:634-696: bs = 1, always decoded to EOS or
+512 new tokens).  Here the decode batch is a set of independent request SLOTS: every slot owns its KV pages, context length,
+token budget and stop state on the device; a finished slot is refilled (vision encode + single-row prefill) while the other
+slots keep decoding, so a long reasoning chain never holds short ones back.  With a stop rule (`stop_trigger`,
+`stop_after`) a request ends as soon as its action line is complete instead of at EOS -- the emitted ids are exactly the
+prefix of the full greedy generation, so the parsed action is unchanged.
+
+There is no shareable prompt prefix to cache across requests: the spliced sequence is [BOS] + 256 patch embeddings +
+text[1:] (modeling_prismatic.py:379-384), so everything after BOS depends on the frame.
+
+The scheduler is host logic only (testable without a GPU against a fake engine); all state it polls lives on the device.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Any, Callable, Deque, Dict, List, Optional, Sequence
+from collections import deque
+
+
+@dataclass
+class Request:
+    """One camera frame + prompt.  `frame` is whatever `encode` accepts (uint8 [H,W,3] tensor on the device)."""
+    rid: Any
+    frame: Any
+    prompt_ids: Sequence[int]
+    max_new_tokens: int = 512
+
+
+@dataclass
+class Result:
+    rid: Any
+    ids: List[int]
+    slot: int
+    t_submit: float
+    t_admit: float
+    t_done: float
+
+    @property
+    def latency_s(self) -> float:
+        return self.t_done - self.t_submit
+
+
+@dataclass
+class _Active:
+    req: Request
+    t_submit: float
+    t_admit: float
+
+
+class SlotScheduler:
+    """Greedy slot scheduler.
+
+    engine   object with slots_open / slot_prefill / slots_step / slots_state / slot_output / slot_release / set_stop
+             (emmax.engine.EmmaxEngine, or a fake in the CPU tests)
+    encode   frames (list) -> patch embeddings, one [n_patches, hidden] bf16 tensor per frame; called once per admission
+             round with every frame admitted in that round, so the ViT runs batched
+    n_slots  decode batch (<= 8)
+    poll_every   decode steps between two device polls (a poll is one tiny D2H copy + sync)
+    """
+
+    def __init__(self, engine, encode: Callable[[List[Any]], List[Any]], n_slots: int = 8, poll_every: int = 16,
+                 stop_trigger: Sequence[int] = (), stop_after: int = 0, clock: Callable[[], float] = time.perf_counter) -> None:
+        if not 1 <= n_slots <= 8:
+            raise ValueError(f"n_slots {n_slots} outside 1..8")
+        if poll_every < 1:
+            raise ValueError("poll_every must be >= 1")
+        self.engine = engine
+        self.encode = encode
+        self.n_slots = n_slots
+        self.poll_every = poll_every
+        self.clock = clock
+        self.queue: Deque[tuple] = deque()
+        self.active: Dict[int, _Active] = {}
+        self.results: List[Result] = []
+        self.steps = 0
+        self.polls = 0
+        engine.set_stop(list(stop_trigger), stop_after)
+        engine.slots_open(n_slots)
+
+    def submit(self, req: Request) -> None:
+        if len(req.prompt_ids) < 1:
+            raise ValueError("empty prompt")
+        self.queue.append((req, self.clock()))
+
+    def _admit(self) -> int:
+        free = [s for s in range(self.n_slots) if s not in self.active]
+        take = min(len(free), len(self.queue))
+        if take == 0:
+            return 0
+        batch = [self.queue.popleft() for _ in range(take)]
+        embeds = self.encode([r.frame for r, _ in batch])
+        if len(embeds) != take:
+            raise RuntimeError(f"encode returned {len(embeds)} embeddings for {take} frames")
+        for slot, (req, t_sub), pe in zip(free, batch, embeds):
+            self.engine.slot_prefill(slot, list(req.prompt_ids), pe, req.max_new_tokens)
+            self.active[slot] = _Active(req, t_sub, self.clock())
+        return take
+
+    def _retire(self) -> int:
+        done, n_out = self.engine.slots_state()
+        self.polls += 1
+        n = 0
+        for slot in sorted(self.active):
+            if done[slot]:
+                a = self.active.pop(slot)
+                ids = self.engine.slot_output(slot, int(n_out[slot]))
+                self.engine.slot_release(slot)
+                self.results.append(Result(a.req.rid, ids, slot, a.t_submit, a.t_admit, self.clock()))
+                n += 1
+        return n
+
+    def run(self) -> List[Result]:
+        """Serve until the queue is empty and every slot is idle.  Returns the results in completion order."""
+        while self.queue or self.active:
+            self._admit()
+            if not self.active:
+                continue
+            self.engine.slots_step(self.poll_every)
+            self.steps += self.poll_every
+            self._retire()
+        return self.results
+
+
+def serve_static(engine_generate: Callable[[List[Request]], List[List[int]]], requests: Sequence[Request], batch: int) -> List[List[int]]:
+    """The baseline the scheduler is measured against: fixed batches, each decoded until its slowest row is done."""
+    out: List[List[int]] = []
+    for i in range(0, len(requests), batch):
+        out.extend(engine_generate(list(requests[i:i + batch])))
+    return out

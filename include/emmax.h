@@ -136,6 +136,30 @@ int emmax_session_chain_active(emmax_session* s);
  * residual stream it leaves behind is garbage (run a new prefill afterwards). */
 int emmax_profile_decode_stage(emmax_session* s, int stage, int reps, float* avg_us_out, emmax_stream stream);
 
+/* ---- early exit + slot serving (continuous batching) -------------------------------------------------
+ * The reference always decodes to EOS / max_new_tokens (prismatic.py:655-664, generate(max_new_tokens=512)) although the
+ * Solver only reads the line after "POLICIES:" (policy_parser: extract_action_policies).  These entry points let a serving
+ * loop stop a row as soon as its action line is complete and refill the freed row while the others keep decoding. */
+/* Device-side stop rule of every later decode step: a row is done once it has emitted the id sequence trigger_ids[0..n)
+ * followed by n_after more tokens (the emitted prefix is exactly the prefix of the full greedy generation).  n_trigger = 0
+ * clears the rule; at most 16 ids; a mismatch restarts the match at the current token (no overlapping-prefix handling). */
+int emmax_session_set_stop(emmax_session* s, const int32_t* trigger_ids_host, int n_trigger, int n_after, emmax_stream stream);
+/* Turn the first n_slots rows of the session into independent, idle request slots (n_slots <= max_batch, <= 8). */
+int emmax_slots_open(emmax_session* s, int n_slots, emmax_stream stream);
+/* Prefill ONE request into `slot` without disturbing the other slots: prompt ids (device int32[len]), its
+ * [n_patches, hidden] bf16 patch embeddings (device; NULL = language-only) and its token budget.  The first generated
+ * token is in place afterwards. */
+int emmax_slot_prefill(emmax_session* s, int slot, const int32_t* ids_dev, int len, const void* patch_embeds_dev, int max_new,
+                       emmax_stream stream);
+/* n_steps greedy decode steps over all slots (hipGraph replay, no host synchronisation); idle / finished slots stay put. */
+int emmax_slots_step(emmax_session* s, int n_steps, emmax_stream stream);
+/* Copy the per-slot done flags and generated-token counts to device buffers int32[n_slots] (asynchronous on `stream`). */
+int emmax_slots_state(emmax_session* s, int32_t* done_dev, int32_t* n_out_dev, emmax_stream stream);
+/* Copy the first n generated ids of `slot` to a device buffer. */
+int emmax_slot_output(emmax_session* s, int slot, int32_t* ids_dev, int n, emmax_stream stream);
+/* Mark `slot` idle again (empty context: its share of a batched step then reads no K/V). */
+int emmax_slot_release(emmax_session* s, int slot, emmax_stream stream);
+
 /* ---- single-kernel entry points (parity tests + micro-benchmarks) -------------------------------------------------- */
 /* C[M,N] = epilogue(A[M,K] @ W[N,K]^T): bf16 in, fp32 accumulate on MFMA.  K % 64 == 0, N % 128 == 0.
  * bias/scale: bf16 [N] or NULL; residual: bf16 [M,ldr] or NULL; act: 0 none, 1 exact-erf GELU, 2 SwiGLU over

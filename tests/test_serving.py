@@ -1,0 +1,150 @@
+"""Slot scheduler host logic (emmax/serving.py) against a fake engine: no GPU, no HIP library.
+
+The fake engine mimics the device-side contract of the slot C ABI (include/emmax.h "slot serving"): a slot emits one
+token per decode step until its planned length, its budget or its stop rule is reached; finished / idle slots stay put."""
+import pytest
+
+from emmax.serving import Request, SlotScheduler, serve_static
+
+
+class FakeEngine:
+    def __init__(self, plans):
+        self.plans = plans            # rid-keyed: list of ids the "model" would emit to EOS
+        self.n = 0
+        self.slots = {}
+        self.prefills = []
+        self.steps = 0
+        self.stop = ([], 0)
+        self.released = []
+
+    def set_stop(self, trig, n_after):
+        self.stop = (list(trig), n_after)
+
+    def slots_open(self, n):
+        self.n = n
+        self.slots = {s: None for s in range(n)}
+
+    def _done(self, st):
+        if len(st["out"]) >= min(len(st["plan"]), st["budget"]):
+            return True
+        trig, after = self.stop
+        if trig:
+            out = st["out"]
+            for i in range(len(out) - len(trig) + 1):
+                if out[i:i + len(trig)] == trig:
+                    return len(out) - (i + len(trig)) >= after
+        return False
+
+    def slot_prefill(self, slot, ids, pe, max_new):
+        assert self.slots[slot] is None, "prefill into a busy slot"
+        rid = pe["rid"]
+        assert pe["encoded"] is True
+        st = {"plan": self.plans[rid], "budget": max_new, "out": [self.plans[rid][0]], "rid": rid}
+        self.slots[slot] = st
+        self.prefills.append((slot, rid, tuple(ids)))
+
+    def slots_step(self, k):
+        self.steps += k
+        for _ in range(k):
+            for st in self.slots.values():
+                if st is not None and not self._done(st):
+                    st["out"].append(st["plan"][len(st["out"])])
+
+    def slots_state(self):
+        done = [1 if (st is None or self._done(st)) else 0 for st in self.slots.values()]
+        n_out = [0 if st is None else len(st["out"]) for st in self.slots.values()]
+        return done, n_out
+
+    def slot_output(self, slot, n):
+        return list(self.slots[slot]["out"][:n])
+
+    def slot_release(self, slot):
+        self.released.append(slot)
+        self.slots[slot] = None
+
+
+def _encode_factory(calls):
+    def encode(frames):
+        calls.append(len(frames))
+        return [{"rid": f, "encoded": True} for f in frames]
+    return encode
+
+
+def _plans(lengths):
+    return {i: [100 * i + t for t in range(n)] for i, n in enumerate(lengths)}
+
+
+def test_every_request_completes_with_its_own_output():
+    lengths = [5, 40, 9, 17, 3, 64, 21, 8, 33, 12, 6]
+    plans = _plans(lengths)
+    eng, calls = FakeEngine(plans), []
+    sch = SlotScheduler(eng, _encode_factory(calls), n_slots=3, poll_every=4)
+    for i in range(len(lengths)):
+        sch.submit(Request(rid=i, frame=i, prompt_ids=[1, 7, i + 3], max_new_tokens=512))
+    res = sch.run()
+    assert sorted(r.rid for r in res) == list(range(len(lengths)))
+    for r in res:
+        assert r.ids == plans[r.rid]
+        assert r.t_submit <= r.t_admit <= r.t_done
+    assert calls[0] == 3 and sum(calls) == len(lengths)        # the first admission round encodes a full batch of frames
+    assert len(eng.released) == len(lengths)
+    assert all(st is None for st in eng.slots.values())
+    # a slot is reused as soon as it frees up: far fewer steps than static batching (sum of per-batch maxima)
+    static_steps = sum(max(lengths[i:i + 3]) for i in range(0, len(lengths), 3))
+    assert sch.steps < static_steps + 3 * 4
+
+
+def test_budget_and_stop_rule_end_a_request_early():
+    plans = {0: list(range(10, 60)), 1: [5, 6, 7, 29871, 31800, 31801, 31802, 31803, 31804, 31805, 31806, 2, 9, 9]}
+    eng = FakeEngine(plans)
+    sch = SlotScheduler(eng, _encode_factory([]), n_slots=2, poll_every=1, stop_trigger=[29871], stop_after=7)
+    assert eng.stop == ([29871], 7)
+    sch.submit(Request(0, 0, [1, 2], max_new_tokens=12))
+    sch.submit(Request(1, 1, [1, 3], max_new_tokens=512))
+    res = {r.rid: r for r in sch.run()}
+    assert res[0].ids == plans[0][:12]                          # token budget
+    assert res[1].ids == plans[1][:11]                          # trigger + 7 tokens, EOS never decoded
+
+
+def test_completion_order_and_slot_reuse():
+    plans = _plans([30, 2, 2, 2])
+    eng = FakeEngine(plans)
+    sch = SlotScheduler(eng, _encode_factory([]), n_slots=2, poll_every=2)
+    for i in range(4):
+        sch.submit(Request(i, i, [1, i + 5]))
+    res = sch.run()
+    assert [r.rid for r in res] == [1, 2, 3, 0]                 # the long request never blocks the short ones
+    assert {slot for slot, rid, _ in eng.prefills if rid in (1, 2, 3)} == {1}   # they all went through the same slot
+    assert [r.slot for r in res] == [1, 1, 1, 0]
+
+
+def test_bad_arguments():
+    eng = FakeEngine({})
+    with pytest.raises(ValueError):
+        SlotScheduler(eng, lambda f: f, n_slots=9)
+    with pytest.raises(ValueError):
+        SlotScheduler(eng, lambda f: f, n_slots=2, poll_every=0)
+    sch = SlotScheduler(eng, lambda f: f, n_slots=2)
+    with pytest.raises(ValueError):
+        sch.submit(Request(0, 0, []))
+    assert sch.run() == []
+
+
+def test_encode_count_mismatch_is_an_error():
+    eng = FakeEngine(_plans([3]))
+    sch = SlotScheduler(eng, lambda frames: [], n_slots=1)
+    sch.submit(Request(0, 0, [1, 2]))
+    with pytest.raises(RuntimeError):
+        sch.run()
+
+
+def test_static_baseline_helper():
+    reqs = [Request(i, i, [1]) for i in range(5)]
+    seen = []
+
+    def gen(batch):
+        seen.append(len(batch))
+        return [[r.rid] for r in batch]
+
+    assert serve_static(gen, reqs, 2) == [[0], [1], [2], [3], [4]]
+    assert seen == [2, 2, 1]
