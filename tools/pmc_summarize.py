@@ -1,0 +1,47 @@
+"""Turn the two rocprofv3 --pmc passes over tools/pmc_probe.py into per-launch HBM bytes per decode stage.
+
+usage: python tools/pmc_summarize.py FETCH_SIZE_counter_collection.csv WRITE_SIZE_counter_collection.csv out.json
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE is doubled because gfx950 reports half of a wide
+coalesced stream (MI355X_MICROARCH.md, HBM / rocprofv3 section); the median over the profiled launches of a stage is used
+(the probe launches every stage a few times)."""
+import csv
+import json
+import statistics
+import sys
+
+STAGE_OF = [  # (substring of the kernel name, stage)
+    ("emmax_decode_gemv_kernel<1, 0,", "qkv_gemv"), ("emmax_decode_attn_kernel", "paged_attn"),
+    ("emmax_decode_gemv_kernel<1, 1, false, true>", "oproj_gemv"), ("emmax_decode_gemv_kernel<1, 2,", "gateup_gemv"),
+    ("emmax_decode_gemv_kernel<1, 1, false, false>", "down_gemv"), ("emmax_decode_gemv_kernel<1, 3,", "lmhead_argmax"),
+]
+
+
+def read(path, counter):
+    per = {}
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            for sub, stage in STAGE_OF:
+                if sub in row["Kernel_Name"]:
+                    per.setdefault(stage, []).append(float(row["Counter_Value"]))
+    return {k: statistics.median(v) for k, v in per.items()}
+
+
+def main():
+    fetch, write = read(sys.argv[1], "FETCH_SIZE"), read(sys.argv[2], "WRITE_SIZE")
+    out = {"how": "rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --kernel-trace --kernel-include-regex emmax_decode "
+                  "-- python tools/pmc_probe.py (B=1, context 768, full-size layer shapes). FETCH_SIZE doubled: on gfx950 it reports 1/2 of a "
+                  "wide coalesced stream (MI355X_MICROARCH.md, HBM section); WRITE_SIZE taken as reported (uncalibrated).",
+           "batch": 1, "stages": {}}
+    for stage in fetch:
+        w = write.get(stage, 0.0)
+        out["stages"][stage] = {"FETCH_SIZE_KB": round(fetch[stage], 1), "WRITE_SIZE_KB": round(w, 1),
+                                "hbm_bytes_per_launch": int((2 * fetch[stage] + w) * 1024)}
+    with open(sys.argv[3], "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out["stages"]))
+
+
+if __name__ == "__main__":
+    main()
