@@ -4,177 +4,406 @@
 // (prismatic/extern/hf/modeling_prismatic.py:146-158) and HF `LlamaAttention`/`LlamaMLP` at q_len > 1.
 //
 //   C[M,N] = epi(A[M,K] . W[N,K]^T)    A, W bf16 row-major (K contiguous), fp32 accumulate.
+//   epilogues: + bias, exact-erf GELU, x LayerScale, + residual, SwiGLU over 16-column (gate, up) groups, fp32 output.
 //
-// Tiling: 128x128x64 block tile, 256 threads = 4 waves in 2x2, each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 tiles.
-// Global -> registers -> LDS staging with the next tile's loads in flight during the MFMAs of the current one.
-// LDS tile = [128 rows][8 chunks of 16 B]; chunk index XOR-swizzled with (row>>1)&7 so that every ds_read_b128 lane
-// group (16 lanes: 16 rows at one logical chunk) lands on 16 distinct 16-B slots of the 256-B bank row.
+// One kernel template, two tile geometries (Geom<WMW, WNW, MT, NT>: WMW x WNW waves, each MT x NT MFMA tiles of 16x16):
+//   big    256x256x64, 8 waves as 2(M) x 4(N), wave tile 128x64 (128 accumulator registers), one block per CU, 128 KiB LDS
+//   small  128x128x64, 4 waves as 2 x 2,      wave tile  64x64, two blocks per CU, 64 KiB LDS each
+// `launch_gemm` picks by the CU utilisation of the big geometry's last round (cross-over measured with tools/gemm_bench.py).
+//
+// Persistent blocks walk a banded, XCD-aware tile order: block ids go round-robin over the 8 XCDs; each XCD owns a
+// contiguous run of tiles, walked in bands of 4 tile columns (column fastest), so the blocks resident in one XCD form a
+// compact patch that shares a few A and W panels in that XCD's 4 MiB L2 instead of streaming one A panel per block.
+// Staging: HBM -> LDS directly with global_load_lds_dwordx4 (no staging registers, no ds_write pass), two LDS stages:
+// the DMA of K step t+1 is issued before the MFMAs of K step t and drained (vmcnt(0)) at the single barrier that ends the
+// step.  (A ring of four 32-deep stages with counted vmcnt was measured 15 % slower: twice the barriers for the same work.)
+// Fragments: ds_read_b128 two row tiles ahead of the MFMAs that consume them (A through a 4-slot register ring, the B
+// fragments of the second k half during the first), pinned with sched_group_barrier -- left alone, the scheduler sinks
+// every read to just above its first use.  (With a global_load_lds in flight hipcc models the LDS counter as unordered and
+// emits lgkmcnt(0) for every wait; inline-asm reads with hand-counted lgkmcnt(N) were tried and measured neutral, +-4 %:
+// the loop is bound by LDS and L2->LDS bandwidth, not by read latency.)
+// LDS image: operand tile = [rows][8 chunks of 16 B], rows 128 B apart.  A wave-level DMA writes 1 KiB = 8 whole rows in
+// lane order, so the image itself is linear; the bank-conflict swizzle is applied to the SOURCE address instead: physical
+// chunk c of row r holds logical chunk c ^ ((r >> 1) & 7).  A ds_read_b128 fragment read (16 lanes = 16 rows at one
+// logical chunk) then touches 16 distinct 16-byte slots of the 256-byte bank row.
+// MFMA operands are swapped (W fragment first): the accumulator of a lane then holds 4 CONSECUTIVE output columns of one
+// output row.  bf16 results leave through a wave-private LDS window as whole rows (16 bytes per lane, 128 contiguous bytes
+// per row): 2.4x the chip-wide store throughput of accumulator-layout stores, which had made the epilogue of a K = 1024
+// tile a third of its time.  The next tile's first K step is requested before the epilogue, so its latency (and the block
+// re-launch a one-tile-per-block grid would pay) hides under the stores.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+constexpr int BK = 64;
+constexpr int BAND = 4;   // tile columns per band of the tile order
 
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4); }
+template <int WMW_, int WNW_, int MT_, int NT_>
+struct Geom {
+    static constexpr int WMW = WMW_, WNW = WNW_, MT = MT_, NT = NT_;
+    static constexpr int NW = WMW * WNW;                    // waves per block
+    static constexpr int BM = WMW * MT * 16, BN = WNW * NT * 16;
+    static constexpr int OPA = BM * BK * 2, OPB = BN * BK * 2;   // operand tile bytes
+    static constexpr int STAGE = OPA + OPB;
+    static constexpr int SMEM = 2 * STAGE;
+    static constexpr int SA = BM / 8 / NW, SB = BN / 8 / NW;      // 1 KiB DMA slabs (8 rows) per wave and operand
+    static constexpr int WIN = 8192;                              // epilogue window per wave: 64 rows x 128 B
+    static_assert(NT == 4 && MT % 4 == 0 && NT <= MT, "epilogue / fragment pipeline assume 64-column wave tiles");
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW * WIN <= STAGE, "DMA slabs / epilogue windows must fit");
+};
+using GeomBig = Geom<2, 4, 8, 4>;
+using GeomSmall = Geom<2, 2, 4, 4>;
 
-template <int ACT, bool OUT_F32>
-__global__ __launch_bounds__(256) void emmax_gemm_bf16_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
-    unsigned char* sA = smem;
-    unsigned char* sB = smem + TILE_BYTES;
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int g = lane >> 4, li = lane & 15;
-
-    // XCD-aware tile order: consecutive block ids are dispatched round-robin over the 8 XCDs; give each XCD a
-    // contiguous run of tiles that walk M fastest so neighbours share the W panel in that XCD's L2.
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid % tiles_m, tn = bid / tiles_m;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    const bf16_t* __restrict__ A = (const bf16_t*)p.A;
-    const bf16_t* __restrict__ W = (const bf16_t*)p.W;
-
-    // staging map: thread -> (row = tid/8 + 32*i, chunk = tid%8), i = 0..3
-    const int srow = tid >> 3, schunk = tid & 7;
-    u32x4_t ra[4], rb[4];
-    const u32x4_t zero4 = {0u, 0u, 0u, 0u};
-
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = srow + 32 * i;
-            const int gm = m0 + row;
-            ra[i] = (gm < p.M) ? *(const u32x4_t*)(A + (size_t)gm * p.lda + k0 + schunk * 8) : zero4;
-            rb[i] = *(const u32x4_t*)(W + (size_t)(n0 + row) * p.ldw + k0 + schunk * 8);
-        }
-    };
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = srow + 32 * i;
-            *(u32x4_t*)(sA + lds_off(row, schunk)) = ra[i];
-            *(u32x4_t*)(sB + lds_off(row, schunk)) = rb[i];
-        }
-    };
-
-    f32x4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / BK;
-    load_tiles(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();  // previous tile fully consumed
-        store_tiles();
-        __syncthreads();
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);  // in flight during the MFMAs below
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t fa[4], fb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i] = *(const bf16x8_t*)(sA + lds_off(wm * 64 + i * 16 + li, kk * 4 + g));
-                fb[i] = *(const bf16x8_t*)(sB + lds_off(wn * 64 + i * 16 + li, kk * 4 + g));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-    }
-
-    // ---- epilogue: C/D layout of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg ----
+// bf16 epilogue through LDS: a wave parks 64 rows of its result (64 columns; SwiGLU: 32) in its private 8 KiB window
+// (16-byte chunks XOR-swizzled with the row, so both the 8-byte writes in accumulator layout and the 16-byte reads in row
+// layout are conflict-free) and stores them back as whole rows.
+template <class G, int ACT>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const f32x4_t (&acc)[G::MT][G::NT], int m0, int n0, int wm, int wn,
+                                                     int g, int li, int lane, unsigned char* wl) {
+    constexpr int WC = (ACT == 2) ? 32 : 64;   // output columns of this wave
+    constexpr int CH = WC / 8;                  // 16-byte chunks per staged row
+    constexpr int NG = WC / 16;                 // 16-column output groups
     const bf16_t* bias = (const bf16_t*)p.bias;
     const bf16_t* scale = (const bf16_t*)p.scale;
     const bf16_t* res = (const bf16_t*)p.residual;
-    if (ACT == 2) {
-        // SwiGLU: 16-column groups alternate (gate, up); output column = (col/32)*16 + col%16.
+    const int n_ok = (ACT == 2) ? p.N / 2 : min(p.N, p.N_store);
+    const int ocol0 = (ACT == 2) ? ((n0 + wn * 64) >> 1) : (n0 + wn * 64);
+    const bool vec_r = (p.ldr & 3) == 0;
+    float bv[NG][4], sv[NG][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int jo = 0; jo < NG; ++jo)
 #pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                const int col = n0 + wn * 64 + j * 16 + li;
-                const int ocol = (col >> 5) * 16 + (col & 15);
+        for (int r = 0; r < 4; ++r) {
+            const int col = ocol0 + jo * 16 + g * 4 + r;
+            bv[jo][r] = (ACT != 2 && bias && col < n_ok) ? bf2f(bias[col]) : 0.f;
+            sv[jo][r] = (ACT != 2 && scale && col < n_ok) ? bf2f(scale[col]) : 1.f;
+        }
+#pragma unroll
+    for (int h = 0; h < G::MT / 4; ++h) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = 4 * h + ii, rl = ii * 16 + li;          // row inside the 64-row window
+            const int row = m0 + wm * (G::MT * 16) + i * 16 + li;
+#pragma unroll
+            for (int jo = 0; jo < NG; ++jo) {
+                float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = m0 + wm * 64 + i * 16 + g * 4 + r;
-                    if (row < p.M) {
-                        const float v = silu(acc[i][j][r]) * acc[i][j + 1][r];
-                        ((bf16_t*)p.C)[(size_t)row * p.ldc + ocol] = f2bf(v);
+                    if (ACT == 2) {
+                        v[r] = silu(acc[i][2 * jo][r]) * acc[i][2 * jo + 1][r];
+                    } else {
+                        v[r] = acc[i][jo][r] + bv[jo][r];
+                        if (ACT == 1) v[r] = gelu_erf(v[r]);
+                        v[r] *= sv[jo][r];
+                    }
+                }
+                if (ACT != 2 && res && row < p.M) {
+                    const int col = ocol0 + jo * 16 + g * 4;
+                    const bf16_t* rp = res + (size_t)row * p.ldr + col;
+                    if (col + 3 < n_ok && vec_r) {
+                        const u32x2_t rv = *(const u32x2_t*)rp;
+                        v[0] += bf_lo(rv[0]); v[1] += bf_hi(rv[0]); v[2] += bf_lo(rv[1]); v[3] += bf_hi(rv[1]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col + r < n_ok) v[r] += bf2f(rp[r]);
+                    }
+                }
+                const int c = jo * 2 + (g >> 1);                  // 16-byte chunk of the row, half g & 1
+                *(u32x2_t*)(wl + rl * (WC * 2) + ((c ^ (rl & (CH - 1))) << 4) + (g & 1) * 8) =
+                    (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+        }
+        // whole rows back out: lane -> (row, chunk); LDS executes a wave's accesses in order, no barrier needed
+#pragma unroll
+        for (int itr = 0; itr < CH; ++itr) {
+            const int idx = itr * 64 + lane;
+            const int rr = idx / CH, cl = idx % CH;
+            const u32x4_t val = *(const u32x4_t*)(wl + rr * (WC * 2) + ((cl ^ (rr & (CH - 1))) << 4));
+            const int row = m0 + wm * (G::MT * 16) + h * 64 + rr, col = ocol0 + cl * 8;
+            if (row < p.M) {
+                bf16_t* dst = (bf16_t*)p.C + (size_t)row * p.ldc + col;
+                if (col + 7 < n_ok) {
+                    *(u32x4_t*)dst = val;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (col + e < n_ok) dst[e] = (bf16_t)((val[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                }
+            }
+        }
+    }
+}
+
+// direct epilogue (fp32 output, or a C whose rows are not 16-byte aligned): 8 / 16 bytes per lane in accumulator layout
+template <class G, int ACT, bool OUT_F32>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4_t (&acc)[G::MT][G::NT], int m0, int n0, int wm, int wn, int g, int li) {
+    // ---- epilogue.  Swapped-operand C/D layout: lane (g, li) holds output row m = li of the row tile and the four
+    // consecutive columns n = 4 g + r (r = register) of the column tile ----
+    const bf16_t* bias = (const bf16_t*)p.bias;
+    const bf16_t* scale = (const bf16_t*)p.scale;
+    const bf16_t* res = (const bf16_t*)p.residual;
+    const int n_ok = min(p.N, p.N_store);
+    if (ACT == 2) {
+        // SwiGLU: 16-column groups alternate (gate, up); output column = (col/32)*16 + col%16.
+        const bool vec = (p.ldc & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < G::MT; ++i) {
+            const int row = m0 + wm * (G::MT * 16) + i * 16 + li;
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const int col = n0 + wn * 64 + j * 16 + g * 4;
+                const int ocol = (col >> 5) * 16 + (col & 15);
+                if (row < p.M && col < p.N) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = silu(acc[i][j][r]) * acc[i][j + 1][r];
+                    bf16_t* dst = (bf16_t*)p.C + (size_t)row * p.ldc + ocol;
+                    if (vec) {
+                        *(u32x2_t*)dst = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dst[r] = f2bf(v[r]);
                     }
                 }
             }
+        }
         return;
     }
+    const bool vec_c = (p.ldc & 3) == 0, vec_r = (p.ldr & 3) == 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wn * 64 + j * 16 + li;
-        const bool col_ok = col < p.N_store;
-        const float bv = bias ? bf2f(bias[col]) : 0.f;
-        const float sv = scale ? bf2f(scale[col]) : 1.f;
+        const int col = n0 + wn * 64 + j * 16 + g * 4;
+        float bv[4], sv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 4; ++r) {
+            bv[r] = (bias && col + r < n_ok) ? bf2f(bias[col + r]) : 0.f;
+            sv[r] = (scale && col + r < n_ok) ? bf2f(scale[col + r]) : 1.f;
+        }
+        const bool full = col + 3 < n_ok;
+#pragma unroll
+        for (int i = 0; i < G::MT; ++i) {
+            const int row = m0 + wm * (G::MT * 16) + i * 16 + li;
+            if (row >= p.M || col >= n_ok) continue;
+            float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + i * 16 + g * 4 + r;
-                if (row < p.M && col_ok) {
-                    float v = acc[i][j][r] + bv;
-                    if (ACT == 1) v = gelu_erf(v);
-                    v *= sv;
-                    if (res) v += bf2f(res[(size_t)row * p.ldr + col]);
-                    if (OUT_F32)
-                        ((float*)p.C)[(size_t)row * p.ldc + col] = v;
-                    else
-                        ((bf16_t*)p.C)[(size_t)row * p.ldc + col] = f2bf(v);
+                v[r] = acc[i][j][r] + bv[r];
+                if (ACT == 1) v[r] = gelu_erf(v[r]);
+                v[r] *= sv[r];
+            }
+            if (res) {
+                const bf16_t* rp = res + (size_t)row * p.ldr + col;
+                if (full && vec_r) {
+                    const u32x2_t rv = *(const u32x2_t*)rp;
+                    v[0] += bf_lo(rv[0]); v[1] += bf_hi(rv[0]); v[2] += bf_lo(rv[1]); v[3] += bf_hi(rv[1]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col + r < n_ok) v[r] += bf2f(rp[r]);
                 }
             }
+            if (OUT_F32) {
+                float* dst = (float*)p.C + (size_t)row * p.ldc + col;
+                if (full && vec_c) {
+                    *(f32x4_t*)dst = (f32x4_t){v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col + r < n_ok) dst[r] = v[r];
+                }
+            } else {
+                bf16_t* dst = (bf16_t*)p.C + (size_t)row * p.ldc + col;
+                if (full && vec_c) {
+                    *(u32x2_t*)dst = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col + r < n_ok) dst[r] = f2bf(v[r]);
+                }
+            }
+        }
     }
+}
+
+template <class G, int ACT, bool OUT_F32>
+__global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams p) {
+    constexpr int BM = G::BM, BN = G::BN, MT = G::MT, NT = G::NT, STAGE_BYTES = G::STAGE, OP_BYTES = G::OPA;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / G::WNW, wn = wave % G::WNW;
+    const int g = lane >> 4, li = lane & 15;
+
+    // ---- persistent tile loop.  Block b lives on XCD b & 7 (round-robin dispatch); that XCD owns a contiguous run of the
+    // banded tile order and its gridDim/8 blocks walk it side by side ----
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+    const int rq = nwg >> 3, rr = nwg & 7;
+    const int run0 = xcd < rr ? xcd * (rq + 1) : rr * (rq + 1) + (xcd - rr) * rq, run_n = rq + (xcd < rr ? 1 : 0);
+    auto tile_origin = [&](int it, int& m0, int& n0) {
+        const int bid = run0 + it;
+        const int band = bid / (BAND * tiles_m), in_band = bid - band * (BAND * tiles_m);
+        const int bw = min(BAND, tiles_n - band * BAND);
+        const int tm = in_band / bw, tn = band * BAND + (in_band - tm * bw);
+        m0 = tm * BM;
+        n0 = tn * BN;
+    };
+
+    // ---- DMA sources: wave w fills 1 KiB slabs (8 rows each) SA*w .. of the A tile and SB*w .. of the W tile ----
+    const unsigned char* srcA[G::SA];
+    const unsigned char* srcB[G::SB];
+    auto set_sources = [&](int m0, int n0) {
+        // logical chunk landing in physical chunk lane&7: (row >> 1) & 7 with row = 8 * slab + (lane >> 3)
+#pragma unroll
+        for (int j = 0; j < G::SA; ++j) {
+            const int row = (wave * G::SA + j) * 8 + (lane >> 3);
+            const int gm = min(m0 + row, p.M - 1);   // edge tiles re-read the last row (never stored)
+            srcA[j] = (const unsigned char*)((const bf16_t*)p.A + (size_t)gm * p.lda + ((lane & 7) ^ ((row >> 1) & 7)) * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < G::SB; ++j) {
+            const int row = (wave * G::SB + j) * 8 + (lane >> 3);
+            const int gn = min(n0 + row, p.N - 1);
+            srcB[j] = (const unsigned char*)((const bf16_t*)p.W + (size_t)gn * p.ldw + ((lane & 7) ^ ((row >> 1) & 7)) * 8);
+        }
+    };
+    auto issue = [&](int kt) {
+        unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
+        const size_t koff = (size_t)kt * (BK * 2);
+#pragma unroll
+        for (int j = 0; j < G::SA; ++j) glds16(srcA[j] + koff, st + (wave * G::SA + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < G::SB; ++j) glds16(srcB[j] + koff, st + OP_BYTES + (wave * G::SB + j) * 1024);
+    };
+
+    // ---- fragment read offsets: row base + swizzled chunk; (row >> 1) & 7 == (li >> 1) & 7 for every 16-row tile ----
+    const int swz = (li >> 1) & 7;
+    const int c0 = (g ^ swz) << 4;            // k half 0: logical chunk g;  half 1: logical chunk 4 + g == c0 ^ 64
+    const int offA = (wm * (MT * 16) + li) * 128, offB = OP_BYTES + (wn * (NT * 16) + li) * 128;
+    // position s = kk * MT + i of the K step: k half kk, row tile i
+    auto ldA = [&](const unsigned char* st, int s_) { return *(const bf16x8_t*)(st + offA + (s_ % MT) * 2048 + ((s_ / MT) ? (c0 ^ 64) : c0)); };
+    auto ldB = [&](const unsigned char* st, int kk, int j) { return *(const bf16x8_t*)(st + offB + j * 2048 + (kk ? (c0 ^ 64) : c0)); };
+
+    const bool staged_ok = (p.ldc & 7) == 0 && (((size_t)p.C) & 15) == 0 && !(p.dbg & 8);   // 16-byte row-layout stores possible
+    const int nk = (p.dbg & 4) ? 1 : p.K / BK;   // dbg 4: one K step per tile (store path alone)
+    int it = blockIdx.x >> 3;
+    if (it >= run_n) return;
+    int ntrace = 0;
+    int m0, n0;
+    tile_origin(it, m0, n0);
+    set_sources(m0, n0);
+    issue(0);
+    while (true) {
+        f32x4_t acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K step 0 has landed (and the previous tile's stores retired)
+        __syncthreads();
+        if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[ntrace++] = wall_clock64();
+        for (int kt = 0; kt < nk; ++kt) {
+            const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
+            if (kt + 1 < nk && !((p.dbg & 1) && kt > 0)) issue(kt + 1);   // lands during the MFMAs below
+            bf16x8_t fb[2][NT], fa[4];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[0][j] = ldB(st, 0, j);
+            fa[0] = ldA(st, 0);
+            fa[1] = ldA(st, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, NT + 2, 0);
+#pragma unroll
+            for (int s_ = 0; s_ < 2 * MT; ++s_) {
+                const int kk = s_ / MT, i = s_ % MT;
+                if (s_ + 2 < 2 * MT) fa[(s_ + 2) & 3] = ldA(st, s_ + 2);
+                if (s_ < NT) fb[1][s_] = ldB(st, 1, s_);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[s_ & 3], acc[i][j], 0, 0, 0);
+                // pin the interleave: this position's DS reads, then its NT MFMAs
+                if (s_ < NT && s_ + 2 < 2 * MT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                else if (s_ < NT || s_ + 2 < 2 * MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage has landed ...
+            __syncthreads();                                    // ... and everybody is done reading this one
+        }
+        // the next tile's first K step is requested BEFORE this tile's epilogue: its HBM/L2 latency (and the block
+        // re-launch a one-tile-per-block grid would pay) hides under the stores
+        if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[ntrace++] = wall_clock64();
+        const int cm0 = m0, cn0 = n0;
+        it += per_xcd;
+        const bool more = it < run_n;
+        if (more) {
+            tile_origin(it, m0, n0);
+            set_sources(m0, n0);
+            issue(0);
+        }
+        if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[ntrace++] = wall_clock64();
+        if (!(p.dbg & 2)) {
+            // stage 1 is free between the last K step of this tile and the second DMA of the next one
+            if (!OUT_F32 && staged_ok) gemm_epilogue_staged<G, ACT>(p, acc, cm0, cn0, wm, wn, g, li, lane, smem + STAGE_BYTES + wave * G::WIN);
+            else gemm_epilogue<G, ACT, OUT_F32>(p, acc, cm0, cn0, wm, wn, g, li);
+        }
+        if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[ntrace++] = wall_clock64();
+        if (!more) break;
+    }
+}
+
+template <class G, int ACT, bool OUT_F32>
+int launch_t(const GemmParams& p, hipStream_t stream) {
+    auto kern = emmax_gemm_bf16_kernel<G, ACT, OUT_F32>;
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM) != hipSuccess) return -4;
+        attr_done = true;
+    }
+    // persistent: as many blocks as fit the chip at once (one big / two small per CU), a multiple of the 8 XCDs
+    const int tiles = cdiv(p.M, G::BM) * cdiv(p.N, G::BN);
+    const int resident = 256 * (160 * 1024 / G::SMEM);
+    const int grid = tiles < resident ? (tiles + 7) / 8 * 8 : resident;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NW * 64), G::SMEM, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+template <class G>
+int launch_geom(const GemmParams& p, hipStream_t stream) {
+    if (p.act == 2) {
+        if (p.out_f32) return -1;
+        return launch_t<G, 2, false>(p, stream);
+    }
+    if (p.act == 1) return p.out_f32 ? launch_t<G, 1, true>(p, stream) : launch_t<G, 1, false>(p, stream);
+    return p.out_f32 ? launch_t<G, 0, true>(p, stream) : launch_t<G, 0, false>(p, stream);
 }
 
 }  // namespace
 
-int launch_gemm(const GemmParams& p, hipStream_t stream) {
+// number of 256x256 tiles of the problem
+int gemm_big_tiles(const GemmParams& p) { return cdiv(p.M, GeomBig::BM) * cdiv(p.N, GeomBig::BN); }
+
+int launch_gemm_geom(const GemmParams& p, int big, hipStream_t stream) {
     if (p.M <= 0) return 0;
-    {
-        // The 256x256 kernel runs one tile per CU at ~1.3x the per-CU rate of this one: it wins whenever its last (or
-        // only) round keeps >= 70 % of the 256 CUs busy, and from 112 tiles up when there is a single round (measured
-        // cross-over on the prefill shapes, tools/gemm_bench.py).  EMMAX_GEMM256=0/1 forces a path.
-        static const int force = getenv("EMMAX_GEMM256") ? atoi(getenv("EMMAX_GEMM256")) : -1;
-        const int t = gemm256_tiles(p);
-        const bool big = t <= 256 ? t >= 112 : 10 * t >= 7 * 256 * cdiv(t, 256);
-        if (force == 1 || (force != 0 && big)) return launch_gemm256(p, stream);
-    }
-    if (p.K % BK != 0 || p.N % BN != 0 || p.K <= 0 || p.N <= 0) return -1;
+    if (p.K % BK != 0 || p.N % 128 != 0 || p.K <= 0 || p.N <= 0) return -1;
     if ((p.lda % 8) || (p.ldw % 8)) return -1;
-    const int tiles = cdiv(p.M, BM) * (p.N / BN);
-    dim3 grid(tiles), block(256);
-    if (p.act == 2) {
-        if (p.out_f32) return -1;
-        hipLaunchKernelGGL((emmax_gemm_bf16_kernel<2, false>), grid, block, 0, stream, p);
-    } else if (p.act == 1) {
-        if (p.out_f32)
-            hipLaunchKernelGGL((emmax_gemm_bf16_kernel<1, true>), grid, block, 0, stream, p);
-        else
-            hipLaunchKernelGGL((emmax_gemm_bf16_kernel<1, false>), grid, block, 0, stream, p);
-    } else {
-        if (p.out_f32)
-            hipLaunchKernelGGL((emmax_gemm_bf16_kernel<0, true>), grid, block, 0, stream, p);
-        else
-            hipLaunchKernelGGL((emmax_gemm_bf16_kernel<0, false>), grid, block, 0, stream, p);
-    }
-    return hipGetLastError() == hipSuccess ? 0 : -4;
+    return big ? launch_geom<GeomBig>(p, stream) : launch_geom<GeomSmall>(p, stream);
+}
+
+int launch_gemm(const GemmParams& p, hipStream_t stream) {
+    // The big geometry runs one tile per CU at ~1.3x the per-CU rate of the small one: it wins whenever its last (or only)
+    // round keeps >= 70 % of the 256 CUs busy, and from 112 tiles up when there is a single round (measured cross-over on
+    // the prefill shapes, tools/gemm_bench.py).  EMMAX_GEMM_BIG=0/1 forces a geometry.
+    static const int force = getenv("EMMAX_GEMM_BIG") ? atoi(getenv("EMMAX_GEMM_BIG")) : -1;
+    const int t = gemm_big_tiles(p);
+    const bool big = force >= 0 ? force != 0 : (t <= 256 ? t >= 112 : 10 * t >= 7 * 256 * cdiv(t, 256));
+    return launch_gemm_geom(p, big ? 1 : 0, stream);
 }

@@ -22,9 +22,9 @@ struct GemmParams {
     int dbg;               // tools only: 1 = skip the operand DMA after K step 1 (LDS + MFMA time alone), 2 = skip the stores
     long long* trace;      // tools only (tools/gemm_trace.hip): block 0 writes wall_clock64() stamps per tile phase; null in the product
 };
-int launch_gemm(const GemmParams& p, hipStream_t stream);       // picks the 128x128 or the 256x256 tile kernel
-int launch_gemm256(const GemmParams& p, hipStream_t stream);    // gemm256.hip: 256x256x64 tiles, direct-to-LDS staging
-int gemm256_tiles(const GemmParams& p);
+int launch_gemm(const GemmParams& p, hipStream_t stream);                     // picks the 256x256 or the 128x128 tile geometry
+int launch_gemm_geom(const GemmParams& p, int big, hipStream_t stream);       // explicit geometry (tools, tests)
+int gemm_big_tiles(const GemmParams& p);
 
 // ---- norm.hip ----
 int launch_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, int ldx, int ldy, float eps,

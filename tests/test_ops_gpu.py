@@ -84,7 +84,7 @@ def test_gemm_swiglu(device):
 
 @pytest.mark.parametrize("variant", ["plain", "gelu", "scale_res", "f32", "swiglu"])
 def test_gemm_big_tile(device, variant):
-    """>= 512 tiles of 256x256 route to the direct-to-LDS 256x256x64 kernel (gemm256.hip): ragged M (4100 = 16 tiles + 4
+    """>= 512 tiles of 256x256 route to the 256x256x64 geometry of the GEMM kernel (gemm.hip): ragged M (4100 = 16 tiles + 4
     rows), N = 65 * 128 (the last tile column is half empty), every epilogue; reference = fp32 matmul on the same device."""
     L, lib = _lib()
     M, N, K = 4100, 8320, 192

@@ -1,5 +1,5 @@
-// gemm_trace.hip -- tuning aid (not part of the product): phase timestamps of block 0 of the 256x256 GEMM.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iemma-x_amd/csrc tools/gemm_trace.hip emma-x_amd/csrc/gemm256.hip -o tools/bin/gemm_trace
+// gemm_trace.hip -- tuning aid (not part of the product): phase timestamps of block 0 of the GEMM (argv[5]: 1 = 256x256 geometry (default), 0 = 128x128).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iemma-x_amd/csrc tools/gemm_trace.hip emma-x_amd/csrc/gemm.hip -o tools/bin/gemm_trace
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -27,10 +27,11 @@ int main(int argc, char** argv) {
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = C; p.ldc = N; p.M = M; p.N = N; p.K = K; p.N_store = N;
     p.dbg = argc > 4 ? atoi(argv[4]) : 0;
+    const int big = argc > 5 ? atoi(argv[5]) : 1;
     for (int rep = 0; rep < 3; ++rep) {
         CHECK(hipMemset(tr, 0, 4096 * 8));
         p.trace = tr;
-        if (launch_gemm256(p, 0) != 0) { printf("launch failed\n"); return 1; }
+        if (launch_gemm_geom(p, big, 0) != 0) { printf("launch failed\n"); return 1; }
         CHECK(hipDeviceSynchronize());
     }
     std::vector<long long> t(4096);
