@@ -117,8 +117,11 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=512)
     ap.add_argument("--tiny", action="store_true", help="tiny config (plumbing check only; NOT a valid headline number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the decode step as a hipGraph (EMMAX_GRAPH=1) instead of eager launch-ahead")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5: fp8-e4m3 decode weights (NOT the bf16 headline)")
     args = ap.parse_args()
+    if args.graph:
+        os.environ["EMMAX_GRAPH"] = "1"
 
     from emmax import dist as edist
     from emmax.config import EmmaXConfig

@@ -679,6 +679,17 @@ static int graph_fail(emmax_session* s, const std::string& why) {
 // alternating launches degrade to plain sequential execution.  Eager launching costs ~0.6 ms of host time per 2.5 ms
 // step, fully overlapped with the GPU.
 static int ensure_graph(emmax_session* s, int B, hipStream_t st) {
+    // Default: eager launch-ahead.  One step is 163 launches for >= 2.9 ms of GPU time, so a single host thread stays far
+    // ahead of the device, and measured on MI355X / ROCm 7.2 the replayed graph is the SLOWER option: 3.05 vs 2.95 ms/token
+    // at B = 1 (~0.6 us more per kernel node than a same-stream launch).  EMMAX_GRAPH=1 selects graph replay (a host whose
+    // launch thread cannot be kept free); read per call so a process can switch.
+    {
+        const char* e = getenv("EMMAX_GRAPH");
+        if (!e || atoi(e) == 0) {
+            drop_graph(s);
+            return 1;
+        }
+    }
     const bool chain = chain_on(s, B);
     if (chain && !s->chain_graph) return 1;
     if (s->graph_exec && s->graph_B == B && s->graph_stream_cap == st) return 0;

@@ -226,10 +226,12 @@ def test_generate_actions_readme_form(device, tiny_planted):
     assert np.isfinite(action).all() and np.abs(action).sum() > 0
 
 
-def test_graph_replay_equals_eager(device, tiny_planted):
-    """emmax_generate (hipGraph replays of the step) and eager emmax_decode_step calls produce the same ids."""
+def test_graph_replay_equals_eager(device, tiny_planted, monkeypatch):
+    """emmax_generate with EMMAX_GRAPH=1 (hipGraph replays of the step) and eager emmax_decode_step calls produce the same
+    ids; so does the default launch-ahead loop."""
     from emmax.weights import planted_start_token
 
+    monkeypatch.setenv("EMMAX_GRAPH", "1")
     cfg, model, _ = tiny_planted
     frames, rows = _inputs(cfg, 2, [9, 13], seed=9)
     rows[0][-1] = planted_start_token(cfg, 10)
@@ -238,6 +240,7 @@ def test_graph_replay_equals_eager(device, tiny_planted):
     T = 24
     _, ids_g, lens_g = model.generate_actions_batch(fr, rows, max_new_tokens=T)
     eng = model.engine
+    assert eng.graph_active()
     model._prefill(rows, None, fr, max_new=T)
     for _ in range(T - 1):
         eng.decode_step()
@@ -245,6 +248,10 @@ def test_graph_replay_equals_eager(device, tiny_planted):
     torch.cuda.synchronize()
     assert lens_g.cpu().tolist() == lens_e.cpu().tolist()
     assert ids_g.cpu().tolist() == ids_e.cpu().tolist()
+    monkeypatch.setenv("EMMAX_GRAPH", "0")
+    _, ids_l, lens_l = model.generate_actions_batch(fr, rows, max_new_tokens=T)
+    assert not eng.graph_active()
+    assert ids_l.cpu().tolist() == ids_g.cpu().tolist() and lens_l.cpu().tolist() == lens_g.cpu().tolist()
 
 
 def test_chained_launch_equals_sequential(device, tiny_random, monkeypatch):

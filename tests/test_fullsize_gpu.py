@@ -70,7 +70,8 @@ def test_fullsize_ragged_batch_equals_bs1_and_is_deterministic(device, big):
         assert ids_b[b, : lens_b[b]].tolist() == ids_1[0, : lens_b[b]].cpu().tolist()
 
 
-def test_fullsize_graph_equals_eager(device, big):
+def test_fullsize_graph_equals_eager(device, big, monkeypatch):
+    monkeypatch.setenv("EMMAX_GRAPH", "1")
     cfg, model = big
     frames, rows = _rows(cfg, [200, 64], [25, 40], seed=5)
     fr = frames.to(device)
