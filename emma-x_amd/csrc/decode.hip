@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
     const int Hq = p.Hkv * G;
     float* part = p.part + ((size_t)(b * Hq + hk * G) * nsplit + split) * PSTRIDE;
 
-    if (k0 >= L) {   // empty split
+    if (k0 >= L || (p.done && p.done[b])) {   // empty split, or a row that no longer decodes: no K/V traffic
         for (int i = tid; i < G * PSTRIDE; i += 256) {
             const int gq = i / PSTRIDE, j = i - gq * PSTRIDE;
             part[(size_t)gq * nsplit * PSTRIDE + j] = (j == HD) ? -INFINITY : 0.f;

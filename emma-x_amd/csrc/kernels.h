@@ -115,6 +115,7 @@ struct DecodeAttnParams {
     const void* vcache;
     const int32_t* page_table;
     const int32_t* ctx_len;
+    const int32_t* done;    // int32 [B] or null: finished / idle rows read no K/V (their partials are written empty)
     float* part;            // f32 [B][Hq][nsplit][132] = { o[128] un-normalised, m, l, pad }
     int ldq, Hkv, page, max_pages;
     float scale;

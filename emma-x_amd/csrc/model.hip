@@ -570,7 +570,7 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
         case STAGE_ATTN: {
             DecodeAttnParams a;
             a.q = s->dq; a.ldq = m->q_dim; a.kcache = kcache_of(s, li); a.vcache = vcache_of(s, li);
-            a.page_table = s->page_table; a.ctx_len = s->ctx_len; a.part = s->part; a.Hkv = c.n_kv_heads; a.page = PAGE;
+            a.page_table = s->page_table; a.ctx_len = s->ctx_len; a.done = s->done; a.part = s->part; a.Hkv = c.n_kv_heads; a.page = PAGE;
             a.max_pages = s->max_pages; a.scale = 1.0f / sqrtf((float)c.head_dim);
             memset(&a.dep, 0, sizeof(a.dep));
             if (ch) a.dep = ch->dep();
