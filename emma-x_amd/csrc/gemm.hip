@@ -9,7 +9,8 @@
 // One kernel template, two tile geometries (Geom<WMW, WNW, MT, NT>: WMW x WNW waves, each MT x NT MFMA tiles of 16x16):
 //   big    256x256x64, 8 waves as 2(M) x 4(N), wave tile 128x64 (128 accumulator registers), one block per CU, 128 KiB LDS
 //   small  128x128x64, 4 waves as 2 x 2,      wave tile  64x64, two blocks per CU, 64 KiB LDS each
-// `launch_gemm` picks by the CU utilisation of the big geometry's last round (cross-over measured with tools/gemm_bench.py).
+// `launch_gemm` plans with a measured cost model: all big, all small, or whole rounds of big tiles followed by the remaining
+// rows in small tiles (tile quantisation -- e.g. 1044 big tiles = 4.08 rounds -- is the main loss left in these GEMMs).
 //
 // Persistent blocks walk a banded, XCD-aware tile order: block ids go round-robin over the 8 XCDs; each XCD owns a
 // contiguous run of tiles, walked in bands of 4 tile columns (column fastest), so the blocks resident in one XCD form a
@@ -398,12 +399,47 @@ int launch_gemm_geom(const GemmParams& p, int big, hipStream_t stream) {
     return big ? launch_geom<GeomBig>(p, stream) : launch_geom<GeomSmall>(p, stream);
 }
 
+// ---- launch plan ------------------------------------------------------------------------------------------------------
+// Cost model in units of one full round of the big geometry (256 tiles of 256x256, one per CU), calibrated with
+// tools/gemm_bench.py on the ViT / prefill shapes (predicted vs measured small/big time ratios agree within 3 %):
+//   big   : whole rounds, a partly filled round costs a full one (one tile per CU);
+//   small : 512 tiles (= 128 big tiles of work) per round at 0.63 -- i.e. 0.79x the per-CU rate of the big geometry -- and
+//           0.45 for a last round that leaves at most one block per CU.
+// Tile quantisation is the main loss left in these GEMMs (e.g. 1044 big tiles = 4.08 rounds), so besides "all big" and
+// "all small" the plan may split the rows: whole rounds of big tiles first, the remaining rows as a second launch of the
+// finer small tiles.
+static double cost_big(long tiles) { return tiles ? (double)((tiles + 255) / 256) : 0.0; }
+static double cost_small(long tiles) {
+    if (!tiles) return 0.0;
+    const long r = (tiles + 511) / 512;
+    return (double)(r - 1) * 0.63 + ((tiles - (r - 1) * 512) <= 256 ? 0.45 : 0.63);
+}
+
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
-    // The big geometry runs one tile per CU at ~1.3x the per-CU rate of the small one: it wins whenever its last (or only)
-    // round keeps >= 70 % of the 256 CUs busy, and from 112 tiles up when there is a single round (measured cross-over on
-    // the prefill shapes, tools/gemm_bench.py).  EMMAX_GEMM_BIG=0/1 forces a geometry.
-    static const int force = getenv("EMMAX_GEMM_BIG") ? atoi(getenv("EMMAX_GEMM_BIG")) : -1;
-    const int t = gemm_big_tiles(p);
-    const bool big = force >= 0 ? force != 0 : (t <= 256 ? t >= 112 : 10 * t >= 7 * 256 * cdiv(t, 256));
-    return launch_gemm_geom(p, big ? 1 : 0, stream);
+    if (p.M <= 0) return 0;
+    static const int force = getenv("EMMAX_GEMM_BIG") ? atoi(getenv("EMMAX_GEMM_BIG")) : -1;   // 0 / 1: one geometry, no split
+    if (force >= 0) return launch_gemm_geom(p, force != 0, stream);
+    const long tm = cdiv(p.M, GeomBig::BM), tn = cdiv(p.N, GeomBig::BN), sn = cdiv(p.N, GeomSmall::BN);
+    const double all_big = cost_big(tm * tn), all_small = cost_small((long)cdiv(p.M, GeomSmall::BM) * sn);
+    double best = all_big < all_small ? all_big : all_small;
+    long best_m1 = all_big <= all_small ? tm : 0;
+    for (long m1 = 1; m1 < tm; ++m1) {   // m1 big tile rows, then the rest in small tiles (+ one kernel boundary)
+        const long rem_rows = p.M - m1 * GeomBig::BM;
+        const double c = cost_big(m1 * tn) + cost_small((long)cdiv((int)rem_rows, GeomSmall::BM) * sn) + 0.03;
+        if (c < best - 1e-9) {
+            best = c;
+            best_m1 = m1;
+        }
+    }
+    if (best_m1 == tm) return launch_gemm_geom(p, 1, stream);
+    if (best_m1 == 0) return launch_gemm_geom(p, 0, stream);
+    GemmParams a = p, b = p;
+    const size_t r0 = (size_t)best_m1 * GeomBig::BM;
+    a.M = (int)r0;
+    b.M = p.M - (int)r0;
+    b.A = (const bf16_t*)p.A + r0 * p.lda;
+    b.C = p.out_f32 ? (void*)((float*)p.C + r0 * p.ldc) : (void*)((bf16_t*)p.C + r0 * p.ldc);
+    if (p.residual) b.residual = (const bf16_t*)p.residual + r0 * p.ldr;
+    const int r = launch_gemm_geom(a, 1, stream);
+    return r ? r : launch_gemm_geom(b, 0, stream);
 }

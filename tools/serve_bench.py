@@ -28,6 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--requests", type=int, default=32)
     ap.add_argument("--slots", type=int, default=8)
+    ap.add_argument("--poll", type=int, default=16, help="decode steps between two device polls")
     ap.add_argument("--tiny", action="store_true")
     args = ap.parse_args()
     cfg = EmmaXConfig.tiny() if args.tiny else EmmaXConfig.emma_x_7b()
@@ -71,7 +72,7 @@ def main():
         return [pe[i] for i in range(len(fs))]
 
     def serve(trigger, after):
-        sch = SlotScheduler(eng, encode, n_slots=args.slots, poll_every=16, stop_trigger=trigger, stop_after=after)
+        sch = SlotScheduler(eng, encode, n_slots=args.slots, poll_every=args.poll, stop_trigger=trigger, stop_after=after)
         sync(); t0 = time.perf_counter()
         for i in range(N):
             sch.submit(Request(i, frames[i], rows[i], MAXN))
@@ -103,7 +104,7 @@ def main():
     lc = [res_cont[i].latency_s for i in range(N)]
     le = [res_early[i].latency_s for i in range(N)]
     out = {
-        "model": "tiny" if args.tiny else "Emma-X-7B shapes (planted synthetic weights)", "requests": N, "slots": args.slots,
+        "model": "tiny" if args.tiny else "Emma-X-7B shapes (planted synthetic weights)", "requests": N, "slots": args.slots, "poll_every": args.poll,
         "new_tokens_to_eos": {"min": min(len(w) for w in want), "mean": float(np.mean([len(w) for w in want])), "max": max(len(w) for w in want)},
         "requests_following_the_planted_chain": n_chain,
         "static": {"seconds": round(t_static, 3), "actions_per_s": round(N / t_static, 3), "latency_p50_s": round(pct(lat_static, 50), 3),
