@@ -415,31 +415,71 @@ static double cost_small(long tiles) {
     return (double)(r - 1) * 0.63 + ((tiles - (r - 1) * 512) <= 256 ? 0.45 : 0.63);
 }
 
-int launch_gemm(const GemmParams& p, hipStream_t stream) {
-    if (p.M <= 0) return 0;
-    static const int force = getenv("EMMAX_GEMM_BIG") ? atoi(getenv("EMMAX_GEMM_BIG")) : -1;   // 0 / 1: one geometry, no split
-    if (force >= 0) return launch_gemm_geom(p, force != 0, stream);
-    const long tm = cdiv(p.M, GeomBig::BM), tn = cdiv(p.N, GeomBig::BN), sn = cdiv(p.N, GeomSmall::BN);
-    const double all_big = cost_big(tm * tn), all_small = cost_small((long)cdiv(p.M, GeomSmall::BM) * sn);
-    double best = all_big < all_small ? all_big : all_small;
+// rows [r0, r0 + rows) of the problem as one launch of the given geometry
+static int launch_rows(const GemmParams& p, size_t r0, int rows, int big, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    GemmParams q = p;
+    q.M = rows;
+    q.A = (const bf16_t*)p.A + r0 * p.lda;
+    q.C = p.out_f32 ? (void*)((float*)p.C + r0 * p.ldc) : (void*)((bf16_t*)p.C + r0 * p.ldc);
+    if (p.residual) q.residual = (const bf16_t*)p.residual + r0 * p.ldr;
+    return launch_gemm_geom(q, big, stream);
+}
+
+// plan over the rows of one column range: all big, all small, or m1 big tile rows + the rest in small tiles
+static double plan_rows(int M, int N, long* m1_out) {
+    const long tm = cdiv(M, GeomBig::BM), tn = cdiv(N, GeomBig::BN), sn = cdiv(N, GeomSmall::BN);
+    const double all_big = cost_big(tm * tn), all_small = cost_small((long)cdiv(M, GeomSmall::BM) * sn);
+    double best = all_big <= all_small ? all_big : all_small;
     long best_m1 = all_big <= all_small ? tm : 0;
-    for (long m1 = 1; m1 < tm; ++m1) {   // m1 big tile rows, then the rest in small tiles (+ one kernel boundary)
-        const long rem_rows = p.M - m1 * GeomBig::BM;
-        const double c = cost_big(m1 * tn) + cost_small((long)cdiv((int)rem_rows, GeomSmall::BM) * sn) + 0.03;
+    for (long m1 = 1; m1 < tm; ++m1) {   // + one kernel boundary
+        const double c = cost_big(m1 * tn) + cost_small((long)cdiv(M - (int)(m1 * GeomBig::BM), GeomSmall::BM) * sn) + 0.03;
         if (c < best - 1e-9) {
             best = c;
             best_m1 = m1;
         }
     }
-    if (best_m1 == tm) return launch_gemm_geom(p, 1, stream);
-    if (best_m1 == 0) return launch_gemm_geom(p, 0, stream);
-    GemmParams a = p, b = p;
-    const size_t r0 = (size_t)best_m1 * GeomBig::BM;
-    a.M = (int)r0;
-    b.M = p.M - (int)r0;
-    b.A = (const bf16_t*)p.A + r0 * p.lda;
-    b.C = p.out_f32 ? (void*)((float*)p.C + r0 * p.ldc) : (void*)((bf16_t*)p.C + r0 * p.ldc);
-    if (p.residual) b.residual = (const bf16_t*)p.residual + r0 * p.ldr;
-    const int r = launch_gemm_geom(a, 1, stream);
-    return r ? r : launch_gemm_geom(b, 0, stream);
+    *m1_out = best_m1;
+    return best;
+}
+
+static int launch_planned_rows(const GemmParams& p, long m1, hipStream_t stream) {
+    const long tm = cdiv(p.M, GeomBig::BM);
+    if (m1 >= tm) return launch_gemm_geom(p, 1, stream);
+    if (m1 <= 0) return launch_gemm_geom(p, 0, stream);
+    const size_t r0 = (size_t)m1 * GeomBig::BM;
+    const int r = launch_rows(p, 0, (int)r0, 1, stream);
+    return r ? r : launch_rows(p, r0, p.M - (int)r0, 0, stream);
+}
+
+int launch_gemm(const GemmParams& p, hipStream_t stream) {
+    if (p.M <= 0) return 0;
+    static const int force = getenv("EMMAX_GEMM_BIG") ? atoi(getenv("EMMAX_GEMM_BIG")) : -1;   // 0 / 1: one geometry, no split
+    if (force >= 0) return launch_gemm_geom(p, force != 0, stream);
+    long m1 = 0;
+    const double whole = plan_rows(p.M, p.N, &m1);
+    // a half-empty last tile column (N = 1152, 3456: 4.5 / 13.5 big tiles wide) can go to the small geometry instead:
+    // columns [0, n1) planned as above + columns [n1, N) as one all-small launch
+    const int n1 = p.N / GeomBig::BN * GeomBig::BN;
+    if (p.act != 2 && n1 > 0 && n1 < p.N) {
+        long m1a = 0;
+        const double left = plan_rows(p.M, n1, &m1a);
+        const double right = cost_small((long)cdiv(p.M, GeomSmall::BM) * cdiv(p.N - n1, GeomSmall::BN)) + 0.03;
+        if (left + right < whole - 1e-9) {
+            GemmParams a = p, b = p;
+            a.N = n1;
+            a.N_store = p.N_store < n1 ? p.N_store : n1;
+            b.N = p.N - n1;
+            b.N_store = p.N_store > n1 ? p.N_store - n1 : 0;
+            b.W = (const bf16_t*)p.W + (size_t)n1 * p.ldw;
+            b.C = p.out_f32 ? (void*)((float*)p.C + n1) : (void*)((bf16_t*)p.C + n1);
+            if (p.bias) b.bias = (const bf16_t*)p.bias + n1;
+            if (p.scale) b.scale = (const bf16_t*)p.scale + n1;
+            if (p.residual) b.residual = (const bf16_t*)p.residual + n1;
+            const int r = launch_planned_rows(a, m1a, stream);
+            if (r) return r;
+            return b.N_store > 0 ? launch_gemm_geom(b, 0, stream) : 0;
+        }
+    }
+    return launch_planned_rows(p, m1, stream);
 }

@@ -121,6 +121,32 @@ def test_gemm_big_tile(device, variant):
     assert relerr(Cd, ref) < (1e-4 if out_f32 else TOL)
 
 
+@pytest.mark.parametrize("variant", ["plain", "scale_res", "f32"])
+def test_gemm_column_split_plan(device, variant):
+    """M = 128 big tile rows, N = 1152 = 4.5 big tile columns: the launch plan sends columns 0..1023 to the 256x256 geometry
+    and the half-empty last tile column to a separate 128x128 launch (bias / LayerScale / residual / C offsets per part)."""
+    L, lib = _lib()
+    M, N, K = 32768, 1152, 128
+    g = torch.Generator().manual_seed(29)
+    A = bf(torch.randn(M, K, generator=g)).to(device)
+    W = bf(torch.randn(N, K, generator=g) * 0.05).to(device)
+    ref = A.float() @ W.float().t()
+    bias = bf(torch.randn(N, generator=g)).to(device) if variant != "plain" else None
+    scale = bf(torch.rand(N, generator=g) + 0.5).to(device) if variant == "scale_res" else None
+    res = bf(torch.randn(M, N, generator=g)).to(device) if variant == "scale_res" else None
+    if bias is not None:
+        ref = ref + bias.float()
+    if scale is not None:
+        ref = ref * scale.float() + res.float()
+    out_f32 = variant == "f32"
+    Cd = torch.full((M, N), float("nan"), dtype=torch.float32 if out_f32 else torch.bfloat16, device=device)
+    L.check(lib.emmax_op_gemm(A.data_ptr(), K, W.data_ptr(), K, Cd.data_ptr(), N, M, N, K, L.ptr(bias), 0, L.ptr(scale), L.ptr(res), N,
+                              int(out_f32), stream()), "gemm")
+    torch.cuda.synchronize()
+    assert torch.isfinite(Cd.float()).all()
+    assert relerr(Cd, ref) < (1e-4 if out_f32 else TOL)
+
+
 def test_gemm_rejects_bad_shapes(device):
     L, lib = _lib()
     x = torch.zeros(128, 128, dtype=torch.bfloat16, device=device)
