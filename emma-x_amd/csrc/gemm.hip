@@ -146,7 +146,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
 
 // direct epilogue (fp32 output, or a C whose rows are not 16-byte aligned): 8 / 16 bytes per lane in accumulator layout
 template <class G, int ACT, bool OUT_F32>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4_t (&acc)[G::MT][G::NT], int m0, int n0, int wm, int wn, int g, int li) {
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4_t (&acc)[G::MT][G::NT], int m0, int n0, int wm, int wn, int g, int li,
+                                              size_t c_off = 0) {   // c_off: element offset into C (split-K partial slab)
     // ---- epilogue.  Swapped-operand C/D layout: lane (g, li) holds output row m = li of the row tile and the four
     // consecutive columns n = 4 g + r (r = register) of the column tile ----
     const bf16_t* bias = (const bf16_t*)p.bias;
@@ -213,7 +214,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4_t
                 }
             }
             if (OUT_F32) {
-                float* dst = (float*)p.C + (size_t)row * p.ldc + col;
+                float* dst = (float*)p.C + c_off + (size_t)row * p.ldc + col;
                 if (full && vec_c) {
                     *(f32x4_t*)dst = (f32x4_t){v[0], v[1], v[2], v[3]};
                 } else {
@@ -247,13 +248,24 @@ __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams 
 
     // ---- persistent tile loop.  Block b lives on XCD b & 7 (round-robin dispatch); that XCD owns a contiguous run of the
     // banded tile order and its gridDim/8 blocks walk it side by side ----
+    // split-K: the work units are (K slice, tile), slice-major, so concurrently resident blocks work on the same K range of
+    // neighbouring tiles (shared panels) and the slices of one tile never meet inside this kernel
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
+    const int ntile = tiles_m * tiles_n;
+    const int ks = p.ksplit > 1 ? p.ksplit : 1;
+    const int nwg = ntile * ks;
     const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
     const int rq = nwg >> 3, rr = nwg & 7;
     const int run0 = xcd < rr ? xcd * (rq + 1) : rr * (rq + 1) + (xcd - rr) * rq, run_n = rq + (xcd < rr ? 1 : 0);
+    const int nk_all = (p.dbg & 4) ? 1 : p.K / BK;   // dbg 4: one K step per tile (store path alone)
+    const int nk_slice = (nk_all + ks - 1) / ks;
+    int kidx = 0, kbeg = 0, nk = nk_all;            // K slice of the current unit: steps kbeg .. kbeg + nk
     auto tile_origin = [&](int it, int& m0, int& n0) {
-        const int bid = run0 + it;
+        const int unit = run0 + it;
+        kidx = unit / ntile;
+        kbeg = kidx * nk_slice;
+        nk = min(nk_slice, nk_all - kbeg);
+        const int bid = unit - kidx * ntile;
         const int band = bid / (BAND * tiles_m), in_band = bid - band * (BAND * tiles_m);
         const int bw = min(BAND, tiles_n - band * BAND);
         const int tm = in_band / bw, tn = band * BAND + (in_band - tm * bw);
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams 
     };
     auto issue = [&](int kt) {
         unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
-        const size_t koff = (size_t)kt * (BK * 2);
+        const size_t koff = (size_t)(kbeg + kt) * (BK * 2);
 #pragma unroll
         for (int j = 0; j < G::SA; ++j) glds16(srcA[j] + koff, st + (wave * G::SA + j) * 1024);
 #pragma unroll
@@ -297,7 +309,6 @@ __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams 
     auto ldB = [&](const unsigned char* st, int kk, int j) { return *(const bf16x8_t*)(st + offB + j * 2048 + (kk ? (c0 ^ 64) : c0)); };
 
     const bool staged_ok = (p.ldc & 7) == 0 && (((size_t)p.C) & 15) == 0 && !(p.dbg & 8);   // 16-byte row-layout stores possible
-    const int nk = (p.dbg & 4) ? 1 : p.K / BK;   // dbg 4: one K step per tile (store path alone)
     int it = blockIdx.x >> 3;
     if (it >= run_n) return;
     int ntrace = 0;
@@ -343,6 +354,7 @@ __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams 
         // re-launch a one-tile-per-block grid would pay) hides under the stores
         if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[ntrace++] = wall_clock64();
         const int cm0 = m0, cn0 = n0;
+        const size_t c_off = ks > 1 ? (size_t)kidx * p.M * p.ldc : 0;
         it += per_xcd;
         const bool more = it < run_n;
         if (more) {
@@ -354,10 +366,44 @@ __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams 
         if (!(p.dbg & 2)) {
             // stage 1 is free between the last K step of this tile and the second DMA of the next one
             if (!OUT_F32 && staged_ok) gemm_epilogue_staged<G, ACT>(p, acc, cm0, cn0, wm, wn, g, li, lane, smem + STAGE_BYTES + wave * G::WIN);
-            else gemm_epilogue<G, ACT, OUT_F32>(p, acc, cm0, cn0, wm, wn, g, li);
+            else gemm_epilogue<G, ACT, OUT_F32>(p, acc, cm0, cn0, wm, wn, g, li, c_off);
         }
         if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[ntrace++] = wall_clock64();
         if (!more) break;
+    }
+}
+
+// split-K second pass: C[m, n..n+8) = epi(sum over slices of ws[s][m][n..n+8)); one thread per 8 columns, whole rows in order
+template <int ACT>
+__global__ __launch_bounds__(256) void emmax_splitk_reduce_kernel(GemmParams p) {
+    const int nc = p.N >> 3;   // 8-column groups per row (N % 128 == 0)
+    const size_t total = (size_t)p.M * nc, slab = (size_t)p.M * p.N;
+    const bf16_t* bias = (const bf16_t*)p.bias;
+    const bf16_t* scale = (const bf16_t*)p.scale;
+    const bf16_t* res = (const bf16_t*)p.residual;
+    const int n_ok = min(p.N, p.N_store);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int row = (int)(i / nc), col = (int)(i - (size_t)row * nc) * 8;
+        const float* src = p.ws + (size_t)row * p.N + col;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < p.ksplit; ++s) {
+            const f32x4_t a = *(const f32x4_t*)(src + s * slab), b = *(const f32x4_t*)(src + s * slab + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] += a[e];
+                v[4 + e] += b[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (col + e >= n_ok) continue;
+            float x = v[e] + (bias ? bf2f(bias[col + e]) : 0.f);
+            if (ACT == 1) x = gelu_erf(x);
+            if (scale) x *= bf2f(scale[col + e]);
+            if (res) x += bf2f(res[(size_t)row * p.ldr + col + e]);
+            if (p.out_f32) ((float*)p.C)[(size_t)row * p.ldc + col + e] = x;
+            else ((bf16_t*)p.C)[(size_t)row * p.ldc + col + e] = f2bf(x);
+        }
     }
 }
 
@@ -370,7 +416,7 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
         attr_done = true;
     }
     // persistent: as many blocks as fit the chip at once (one big / two small per CU), a multiple of the 8 XCDs
-    const int tiles = cdiv(p.M, G::BM) * cdiv(p.N, G::BN);
+    const int tiles = cdiv(p.M, G::BM) * cdiv(p.N, G::BN) * (p.ksplit > 1 ? p.ksplit : 1);
     const int resident = 256 * (160 * 1024 / G::SMEM);
     const int grid = tiles < resident ? (tiles + 7) / 8 * 8 : resident;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NW * 64), G::SMEM, stream, p);
@@ -452,10 +498,47 @@ static int launch_planned_rows(const GemmParams& p, long m1, hipStream_t stream)
     return r ? r : launch_rows(p, r0, p.M - (int)r0, 0, stream);
 }
 
+// Split-K for under-filled problems with a long K: fewer small tiles than CUs-and-a-half means one 4-wave block per CU
+// grinding through K alone (M = 768 prefill o / down: 192 tiles, 64-172 K steps at ~0.75 us; batch-1 ViT fc2: 24 tiles).
+// ks slices per tile fill the chip (<= 512 resident blocks), each >= 8 K steps; the partial tiles meet in a second pass.
+int launch_gemm_splitk(const GemmParams& p, int ks, hipStream_t stream) {
+    if (ks < 2 || p.act == 2 || !p.ws || p.K % BK || p.N % 128) return -1;
+    if ((long long)ks * p.M * p.N * 4 > p.ws_bytes) return -1;
+    if (p.K / BK < ks) return -1;
+    GemmParams a = p;
+    a.ksplit = ks;
+    a.C = p.ws; a.ldc = p.N; a.N_store = p.N; a.out_f32 = 1; a.act = 0;
+    a.bias = nullptr; a.scale = nullptr; a.residual = nullptr;
+    int r = launch_gemm_geom(a, 0, stream);
+    if (r) return r;
+    GemmParams b = p;
+    b.ksplit = ks;
+    const size_t groups = (size_t)p.M * (p.N >> 3);
+    const int grid = (int)((groups + 255) / 256 < 2048 ? (groups + 255) / 256 : 2048);
+    if (p.act == 1) hipLaunchKernelGGL(emmax_splitk_reduce_kernel<1>, dim3(grid), dim3(256), 0, stream, b);
+    else hipLaunchKernelGGL(emmax_splitk_reduce_kernel<0>, dim3(grid), dim3(256), 0, stream, b);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// slices for launch_gemm_splitk, or 0 when splitting does not pay
+static int splitk_plan(const GemmParams& p) {
+    if (!p.ws || p.act == 2) return 0;
+    const int nk = p.K / BK;
+    const long ts = (long)cdiv(p.M, GeomSmall::BM) * cdiv(p.N, GeomSmall::BN);
+    if (nk < 32 || ts > 224) return 0;              // K >= 2048, at most ~1 block per CU without the split
+    int ks = (int)(512 / ts);
+    if (ks > nk / 8) ks = nk / 8;
+    if (ks > 8) ks = 8;
+    while (ks >= 2 && (long long)ks * p.M * p.N * 4 > p.ws_bytes) --ks;
+    return ks >= 2 ? ks : 0;
+}
+
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0) return 0;
     static const int force = getenv("EMMAX_GEMM_BIG") ? atoi(getenv("EMMAX_GEMM_BIG")) : -1;   // 0 / 1: one geometry, no split
     if (force >= 0) return launch_gemm_geom(p, force != 0, stream);
+    static const bool no_splitk = getenv("EMMAX_GEMM_SPLITK") && atoi(getenv("EMMAX_GEMM_SPLITK")) == 0;   // tuning hook
+    if (const int ks = no_splitk ? 0 : splitk_plan(p)) return launch_gemm_splitk(p, ks, stream);
     long m1 = 0;
     const double whole = plan_rows(p.M, p.N, &m1);
     // a half-empty last tile column (N = 1152, 3456: 4.5 / 13.5 big tiles wide) can go to the small geometry instead:

@@ -19,12 +19,19 @@ struct GemmParams {
     int N_store;           // columns >= N_store are not written
     int act;               // 0 none, 1 gelu(erf), 2 swiglu over 16-col interleaved (gate,up)
     int out_f32;
+    // split-K (under-filled problems with a long K, e.g. M = 768 prefill o / down, batch-1 ViT fc2): `ksplit` K slices per
+    // tile write fp32 partial tiles to `ws` ([ksplit][M][N] floats), a second kernel sums them and applies the epilogue.
+    // ws == null: never split.  ksplit is set by launch_gemm.
+    float* ws;
+    long long ws_bytes;
+    int ksplit;
     int dbg;               // tools only: 1 = skip the operand DMA after K step 1 (LDS + MFMA time alone), 2 = skip the stores
     long long* trace;      // tools only (tools/gemm_trace.hip): block 0 writes wall_clock64() stamps per tile phase; null in the product
 };
 int launch_gemm(const GemmParams& p, hipStream_t stream);                     // picks the 256x256 or the 128x128 tile geometry
 int launch_gemm_geom(const GemmParams& p, int big, hipStream_t stream);       // explicit geometry (tools, tests)
 int gemm_big_tiles(const GemmParams& p);
+int launch_gemm_splitk(const GemmParams& p, int ksplit, hipStream_t stream);  // 128x128 geometry, ksplit K slices + reduce pass (needs p.ws)
 
 // ---- norm.hip ----
 int launch_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, int ldx, int ldy, float eps,

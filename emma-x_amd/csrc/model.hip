@@ -236,6 +236,8 @@ struct emmax_session {
     bf16 *dh, *dq, *datt, *dact;
     float *part, *part_val, *logits;
     int32_t *part_idx, *cur_tok, *ctx_len, *done, *n_out, *out_ids, *max_new_d /* [max_batch] */, *page_table;
+    float* splitk_ws;           // fp32 partial tiles of split-K GEMMs (gemm.hip)
+    int64_t splitk_bytes;
     int32_t *stop_ids /* [EMMAX_MAX_STOP_IDS] */, *stop_cfg /* {n_trigger, n_after} */, *stop_m, *stop_after;
     bool slots_open = false;    // slot serving mode: rows are independent request slots (emmax_slots_open)
     float *cos_t, *sin_t;
@@ -330,6 +332,8 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->stop_after = (int32_t*)b.take(Bd * 4);
     s->dep_ctr = (unsigned int*)b.take((256 * 32 + 16) * 4);
     s->page_table = (int32_t*)b.take((int64_t)Bd * s->max_pages * 4);
+    s->splitk_bytes = (int64_t)64 << 20;   // e.g. 4 slices of a 768 x 4096 prefill GEMM = 50 MB; smaller budgets just split less
+    s->splitk_ws = (float*)b.take(s->splitk_bytes);
     s->cos_t = (float*)b.take((int64_t)s->max_ctx * (m->cfg.head_dim / 2) * 4);
     s->sin_t = (float*)b.take((int64_t)s->max_ctx * (m->cfg.head_dim / 2) * 4);
 }
@@ -348,6 +352,14 @@ static GemmParams gp(const void* A, int lda, const void* W, int ldw, void* C, in
     return p;
 }
 
+// GEMM parameters of a session stage: as gp(), plus the session's split-K scratch
+static GemmParams gps(emmax_session* s, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K) {
+    GemmParams p = gp(A, lda, W, ldw, C, ldc, M, N, K);
+    p.ws = s->splitk_ws;
+    p.ws_bytes = s->splitk_bytes;
+    return p;
+}
+
 static int run_vision(emmax_session* s, bool from_u8, const void* src, int B, void* out, hipStream_t st) {
     emmax_model* m = s->m;
     if (!m->finalized) return fail(EMMAX_ERR_STATE, "model not finalized");
@@ -358,7 +370,7 @@ static int run_vision(emmax_session* s, bool from_u8, const void* src, int B, vo
         const TowerW& T = m->tw[t];
         const emmax_tower_config& tc = m->cfg.tower[t];
         KCHK(launch_patch_gather(from_u8, src, s->vA, B, tc.image_size, tc.patch, T.Kpe, 3 * t, tc.mean, tc.std, st));
-        GemmParams g = gp(s->vA, T.Kpe, T.patch_w, T.Kpe, s->vpe, T.Dp, B * np, T.Dp, T.Kpe);
+        GemmParams g = gps(s, s->vA, T.Kpe, T.patch_w, T.Kpe, s->vpe, T.Dp, B * np, T.Dp, T.Kpe);
         g.bias = T.patch_b;
         KCHK(launch_gemm(g, st));
         KCHK(launch_assemble_tokens(s->vpe, T.pos, T.cls, T.reg, s->vtok, B, np, T.n_prefix, tc.has_cls, T.D, T.Dp, st));
@@ -366,7 +378,7 @@ static int run_vision(emmax_session* s, bool from_u8, const void* src, int B, vo
         for (int i = 0; i < T.n_blocks; ++i) {
             const BlockW& k = T.blk[i];
             KCHK(launch_layernorm(s->vtok, s->vln, k.n1w, k.n1b, rows, T.D, T.Dp, T.Dp, tc.ln_eps, st));
-            g = gp(s->vln, T.Dp, k.qkv_w, T.Dp, s->vqkv, T.D3p, rows, T.D3p, T.Dp);
+            g = gps(s, s->vln, T.Dp, k.qkv_w, T.Dp, s->vqkv, T.D3p, rows, T.D3p, T.Dp);
             g.bias = k.qkv_b;
             KCHK(launch_gemm(g, st));
             AttnParams a;
@@ -375,14 +387,14 @@ static int run_vision(emmax_session* s, bool from_u8, const void* src, int B, vo
             a.B = B; a.max_seqlen = T.N; a.Hq = tc.num_heads; a.Hkv = tc.num_heads;
             a.scale = 1.0f / sqrtf((float)T.hd); a.causal = 0;
             KCHK(launch_attention(a, T.hd, st));
-            g = gp(s->vatt, T.Dp, k.proj_w, T.Dp, s->vtok, T.Dp, rows, T.Dp, T.Dp);
+            g = gps(s, s->vatt, T.Dp, k.proj_w, T.Dp, s->vtok, T.Dp, rows, T.Dp, T.Dp);
             g.bias = k.proj_b; g.scale = tc.layerscale ? k.ls1 : nullptr; g.residual = s->vtok; g.ldr = T.Dp;
             KCHK(launch_gemm(g, st));
             KCHK(launch_layernorm(s->vtok, s->vln, k.n2w, k.n2b, rows, T.D, T.Dp, T.Dp, tc.ln_eps, st));
-            g = gp(s->vln, T.Dp, k.fc1_w, T.Dp, s->vmlp, T.Mp, rows, T.Mp, T.Dp);
+            g = gps(s, s->vln, T.Dp, k.fc1_w, T.Dp, s->vmlp, T.Mp, rows, T.Mp, T.Dp);
             g.bias = k.fc1_b; g.act = 1;
             KCHK(launch_gemm(g, st));
-            g = gp(s->vmlp, T.Mp, k.fc2_w, T.Mp, s->vtok, T.Dp, rows, T.Dp, T.Mp);
+            g = gps(s, s->vmlp, T.Mp, k.fc2_w, T.Mp, s->vtok, T.Dp, rows, T.Dp, T.Mp);
             g.bias = k.fc2_b; g.scale = tc.layerscale ? k.ls2 : nullptr; g.residual = s->vtok; g.ldr = T.Dp;
             KCHK(launch_gemm(g, st));
         }
@@ -390,13 +402,13 @@ static int run_vision(emmax_session* s, bool from_u8, const void* src, int B, vo
         KCHK(launch_copy_rows(s->vtok, T.Dp, s->feats, B, T.N, T.n_prefix, np, T.D, m->Vp, col_off, st));
         col_off += T.D;
     }
-    GemmParams g = gp(s->feats, m->Vp, m->pj1_w, m->Vp, s->pj1, m->P1p, B * np, m->P1p, m->Vp);
+    GemmParams g = gps(s, s->feats, m->Vp, m->pj1_w, m->Vp, s->pj1, m->P1p, B * np, m->P1p, m->Vp);
     g.bias = m->pj1_b; g.act = 1;
     KCHK(launch_gemm(g, st));
-    g = gp(s->pj1, m->P1p, m->pj2_w, m->P1p, s->pj2, m->H, B * np, m->H, m->P1p);
+    g = gps(s, s->pj1, m->P1p, m->pj2_w, m->P1p, s->pj2, m->H, B * np, m->H, m->P1p);
     g.bias = m->pj2_b; g.act = 1;
     KCHK(launch_gemm(g, st));
-    g = gp(s->pj2, m->H, m->pj3_w, m->H, s->patch_embeds, m->H, B * np, m->H, m->H);
+    g = gps(s, s->pj2, m->H, m->pj3_w, m->H, s->patch_embeds, m->H, B * np, m->H, m->H);
     g.bias = m->pj3_b;
     KCHK(launch_gemm(g, st));
     if (out && out != s->patch_embeds)
@@ -515,7 +527,7 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
     for (int li = 0; li < c.n_layers; ++li) {
         const LayerW& L = m->layers[li];
         KCHK(launch_rmsnorm(s->ph, s->pxn, L.ln1, total, m->H, m->H, m->H, c.rms_eps, st));
-        GemmParams g = gp(s->pxn, m->H, L.wqkv, m->H, s->pqkv, m->qkv_dim, total, m->qkv_dim, m->H);
+        GemmParams g = gps(s, s->pxn, m->H, L.wqkv, m->H, s->pqkv, m->qkv_dim, total, m->qkv_dim, m->H);
         KCHK(launch_gemm(g, st));
         KCHK(launch_rope_kv_write(s->pqkv, m->qkv_dim, 0, m->q_dim, m->q_dim + m->kv_dim, s->cu, B, total, s->cos_t, s->sin_t,
                                   kcache_of(s, li), vcache_of(s, li), s->page_table + (size_t)r0 * s->max_pages, s->max_pages, c.n_heads,
@@ -526,14 +538,14 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
         a.B = B; a.max_seqlen = maxS; a.Hq = c.n_heads; a.Hkv = c.n_kv_heads;
         a.scale = 1.0f / sqrtf((float)c.head_dim); a.causal = 1;
         KCHK(launch_attention(a, c.head_dim, st));
-        g = gp(s->patt, m->q_dim, L.wo, m->q_dim, s->ph, m->H, total, m->H, m->q_dim);
+        g = gps(s, s->patt, m->q_dim, L.wo, m->q_dim, s->ph, m->H, total, m->H, m->q_dim);
         g.residual = s->ph; g.ldr = m->H;
         KCHK(launch_gemm(g, st));
         KCHK(launch_rmsnorm(s->ph, s->pxn, L.ln2, total, m->H, m->H, m->H, c.rms_eps, st));
-        g = gp(s->pxn, m->H, L.wgu, m->H, s->pact, m->inter_p, total, 2 * m->inter_p, m->H);
+        g = gps(s, s->pxn, m->H, L.wgu, m->H, s->pact, m->inter_p, total, 2 * m->inter_p, m->H);
         g.act = 2;
         KCHK(launch_gemm(g, st));
-        g = gp(s->pact, m->inter_p, L.wdown, m->inter_p, s->ph, m->H, total, m->H, m->inter_p);
+        g = gps(s, s->pact, m->inter_p, L.wdown, m->inter_p, s->ph, m->H, total, m->H, m->inter_p);
         g.residual = s->ph; g.ldr = m->H;
         KCHK(launch_gemm(g, st));
     }
@@ -1009,7 +1021,7 @@ int emmax_prefill_logits(emmax_session* s, float* out, emmax_stream stream) {
     emmax_model* m = s->m;
     hipStream_t st = (hipStream_t)stream;
     KCHK(launch_rmsnorm(s->ph, s->pxn, m->final_norm, s->total_rows, m->H, m->H, m->H, m->cfg.rms_eps, st));
-    GemmParams g = gp(s->pxn, m->H, m->lm_head, m->H, out, m->vocab, s->total_rows, m->vocab_p, m->H);
+    GemmParams g = gps(s, s->pxn, m->H, m->lm_head, m->H, out, m->vocab, s->total_rows, m->vocab_p, m->H);
     g.N_store = m->vocab; g.out_f32 = 1;
     KCHK(launch_gemm(g, st));
     return 0;
@@ -1257,6 +1269,17 @@ int emmax_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int l
     p.bias = bias; p.act = act; p.scale = scale; p.residual = residual; p.ldr = ldr; p.out_f32 = out_f32;
     int r = launch_gemm(p, (hipStream_t)st);
     if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_gemm: unsupported shape (K%%64, N%%128, ld%%8) or launch failure");
+    return 0;
+}
+int emmax_op_gemm_splitk(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const void* bias, int act,
+                         const void* scale, const void* residual, int ldr, int out_f32, int ksplit, void* ws, int64_t ws_bytes,
+                         emmax_stream st) {
+    GemmParams p = gp(A, lda, W, ldw, C, ldc, M, N, K);
+    p.bias = bias; p.act = act; p.scale = scale; p.residual = residual; p.ldr = ldr; p.out_f32 = out_f32;
+    p.ws = (float*)ws; p.ws_bytes = ws_bytes;
+    int r = launch_gemm_splitk(p, ksplit, (hipStream_t)st);
+    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID,
+                       "emmax_op_gemm_splitk: unsupported (2 <= ksplit <= K/64, act in {0,1}, ws >= ksplit*M*N*4 bytes, K%%64, N%%128)");
     return 0;
 }
 int emmax_op_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, float eps, emmax_stream st) {

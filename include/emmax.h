@@ -167,6 +167,12 @@ int emmax_slot_release(emmax_session* s, int slot, emmax_stream stream);
 int emmax_op_gemm(const void* A_dev, int lda, const void* W_dev, int ldw, void* C_dev, int ldc, int M, int N, int K,
                   const void* bias_dev, int act, const void* scale_dev, const void* residual_dev, int ldr, int out_f32,
                   emmax_stream stream);
+/* The same GEMM with `ksplit` K slices per 128x128 tile (fp32 partial tiles in ws_dev, >= ksplit*M*N*4 bytes) and a reduce +
+ * epilogue pass: the path the session takes by itself for under-filled problems with a long K (prefill o / down at one
+ * frame, batch-1 ViT fc2).  act in {0, 1}. */
+int emmax_op_gemm_splitk(const void* A_dev, int lda, const void* W_dev, int ldw, void* C_dev, int ldc, int M, int N, int K,
+                         const void* bias_dev, int act, const void* scale_dev, const void* residual_dev, int ldr, int out_f32,
+                         int ksplit, void* ws_dev, int64_t ws_bytes, emmax_stream stream);
 int emmax_op_layernorm(const void* x_dev, void* y_dev, const void* w_dev, const void* b_dev, int rows, int D, float eps,
                        emmax_stream stream);
 int emmax_op_rmsnorm(const void* x_dev, void* y_dev, const void* w_dev, int rows, int D, float eps, emmax_stream stream);

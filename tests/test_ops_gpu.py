@@ -147,6 +147,44 @@ def test_gemm_column_split_plan(device, variant):
     assert relerr(Cd, ref) < (1e-4 if out_f32 else TOL)
 
 
+@pytest.mark.parametrize("M,N,K,ks", [(768, 4096, 4096, 2), (768, 4096, 11008, 4), (261, 1024, 4352, 8), (300, 384, 640, 3)])
+@pytest.mark.parametrize("variant", ["plain", "gelu", "scale_res_inplace", "f32"])
+def test_gemm_splitk(device, M, N, K, ks, variant):
+    """K slices per tile + reduce / epilogue pass (under-filled problems with a long K); incl. a slice count that does not
+    divide the K steps and the in-place residual form the prefill uses (C == residual)."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(M + N + K + ks)
+    A = bf(torch.randn(M, K, generator=g)).to(device)
+    W = bf(torch.randn(N, K, generator=g) * 0.03).to(device)
+    ref = A.float() @ W.float().t()
+    bias = bf(torch.randn(N, generator=g)).to(device) if variant != "plain" else None
+    scale = bf(torch.rand(N, generator=g) + 0.5).to(device) if variant == "scale_res_inplace" else None
+    out_f32 = variant == "f32"
+    if bias is not None:
+        ref = ref + bias.float()
+    if variant == "gelu":
+        ref = F.gelu(ref)
+    if scale is not None:
+        res0 = bf(torch.randn(M, N, generator=g)).to(device)
+        ref = ref * scale.float() + res0.float()
+        Cd = res0.clone()                     # C doubles as the residual
+        res = Cd
+    else:
+        Cd = torch.full((M, N), float("nan"), dtype=torch.float32 if out_f32 else torch.bfloat16, device=device)
+        res = None
+    ws = torch.empty(ks * M * N, dtype=torch.float32, device=device)
+    L.check(lib.emmax_op_gemm_splitk(A.data_ptr(), K, W.data_ptr(), K, Cd.data_ptr(), N, M, N, K, L.ptr(bias), int(variant == "gelu"),
+                                     L.ptr(scale), L.ptr(res), N, int(out_f32), ks, ws.data_ptr(), ws.numel() * 4, stream()), "splitk")
+    torch.cuda.synchronize()
+    assert torch.isfinite(Cd.float()).all()
+    assert relerr(Cd, ref) < (1e-4 if out_f32 else TOL)
+    # too small a workspace / too many slices are errors, not silent fallbacks
+    assert lib.emmax_op_gemm_splitk(A.data_ptr(), K, W.data_ptr(), K, Cd.data_ptr(), N, M, N, K, None, 0, None, None, N, 0, ks,
+                                    ws.data_ptr(), 1024, stream()) != 0
+    assert lib.emmax_op_gemm_splitk(A.data_ptr(), K, W.data_ptr(), K, Cd.data_ptr(), N, M, N, K, None, 0, None, None, N, 0, K // 64 + 1,
+                                    ws.data_ptr(), ws.numel() * 4, stream()) != 0
+
+
 def test_gemm_rejects_bad_shapes(device):
     L, lib = _lib()
     x = torch.zeros(128, 128, dtype=torch.bfloat16, device=device)
