@@ -118,6 +118,20 @@ def test_completion_order_and_slot_reuse():
     assert [r.slot for r in res] == [1, 1, 1, 0]
 
 
+def test_encode_ahead_batches_the_vit_and_keeps_results():
+    lengths = [9, 3, 12, 5, 7, 4, 10, 6, 8, 2]
+    plans = _plans(lengths)
+    eng, calls = FakeEngine(plans), []
+    sch = SlotScheduler(eng, _encode_factory(calls), n_slots=2, poll_every=1, encode_ahead=4)
+    for i in range(len(lengths)):
+        sch.submit(Request(i, i, [1, 4, i + 3]))
+    res = sch.run()
+    assert {r.rid: r.ids for r in res} == plans
+    assert sum(calls) == len(lengths)                  # every frame is encoded exactly once ...
+    assert max(calls) == 4 and len(calls) <= 4         # ... in batches of up to 4 instead of one call per admission
+    assert sch._embeds == {}
+
+
 def test_bad_arguments():
     eng = FakeEngine({})
     with pytest.raises(ValueError):

@@ -105,7 +105,7 @@ def test_slot_serving_equals_bs1_generate(device, served, n_slots, poll):
         pe = eng.vision_encode(torch.stack(fs))
         return [pe[i] for i in range(len(fs))]
 
-    sch = SlotScheduler(eng, encode, n_slots=n_slots, poll_every=poll)
+    sch = SlotScheduler(eng, encode, n_slots=n_slots, poll_every=poll, encode_ahead=4 if n_slots == 3 else 0)
     for i in range(len(ks)):
         sch.submit(Request(i, fr[i], rows[i], max_new_tokens=48))
     res = sch.run()
