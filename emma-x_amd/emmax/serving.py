@@ -142,3 +142,16 @@ def serve_static(engine_generate: Callable[[List[Request]], List[List[int]]], re
     for i in range(0, len(requests), batch):
         out.extend(engine_generate(list(requests[i:i + batch])))
     return out
+
+
+def stop_rule_from_tokenizer(tokenizer, marker: str = "POLICIES:", n_after: int = 8) -> tuple:
+    """(trigger_ids, n_after) for `SlotScheduler(stop_trigger=..., stop_after=...)` / `engine.set_stop`.
+
+    The Solver reads the action from the first line after `marker` (policy_parser.Solver.extract_action_policies, reference
+    prismatic/vla/solver.py:107-137): a leading space token plus the 7 action-bin tokens, i.e. 8 ids.  The marker is
+    tokenised as it appears inside running text (no BOS); the device-side matcher takes at most 16 ids."""
+    ids = tokenizer(marker, add_special_tokens=False)["input_ids"]
+    ids = [int(t) for t in (ids[0] if ids and isinstance(ids[0], (list, tuple)) else ids)]
+    if not 1 <= len(ids) <= 16:
+        raise ValueError(f"marker {marker!r} tokenises to {len(ids)} ids; the stop rule takes 1..16")
+    return ids, int(n_after)

@@ -184,3 +184,37 @@ def test_bicubic_tables_match_pillow():
         assert np.array_equal(resize_u8_reference(a, 224, 224), np.asarray(Image.fromarray(a).resize((224, 224), Image.BICUBIC)))
     b, k, n = bicubic_coeffs(256, 224)
     assert n == 7 and b.shape == (224, 2) and abs(int(k[100].sum()) - (1 << 22)) <= 4
+
+
+def test_real_tokenizer_files_are_picked_up_and_give_a_stop_rule(tmp_path):
+    """A checkpoint directory with tokenizer files: the processor loads them through `transformers.AutoTokenizer` (a tiny
+    word-level vocabulary here: the LLaMA files are not available offline, so the real text<->id parity stays unpinned) and
+    `stop_rule_from_tokenizer` turns the POLICIES: marker into the device-side stop rule."""
+    tokenizers = pytest.importorskip("tokenizers")
+    pytest.importorskip("transformers")
+    import json
+
+    from emmax.config import EmmaXConfig
+    from emmax.processing import EmmaXProcessor
+    from emmax.serving import stop_rule_from_tokenizer
+
+    words = ["<unk>", "<s>", "</s>", "In:", "Out:", "What", "action", "should", "the", "robot", "take", "to", "pick", "up", "cup", "?",
+             "POLICIES:", "MOVE", "GRIPPER", "\n"]
+    vocab = {w: i for i, w in enumerate(words)}
+    tk = tokenizers.Tokenizer(tokenizers.models.WordLevel(vocab, unk_token="<unk>"))
+    tk.pre_tokenizer = tokenizers.pre_tokenizers.WhitespaceSplit()
+    tk.save(str(tmp_path / "tokenizer.json"))
+    (tmp_path / "tokenizer_config.json").write_text(json.dumps({
+        "tokenizer_class": "PreTrainedTokenizerFast", "bos_token": "<s>", "eos_token": "</s>", "unk_token": "<unk>", "pad_token": "</s>"}))
+    cfg = EmmaXConfig.tiny()
+    proc = EmmaXProcessor.from_pretrained(str(tmp_path), cfg=cfg)
+    assert type(proc.tokenizer).__name__ != "StubTokenizer"
+    img = np.zeros((224, 224, 3), dtype=np.uint8)
+    feat = proc("What action should the robot take to pick up the cup ?", img)
+    ids = feat["input_ids"][0].tolist()
+    assert ids == [vocab[w] for w in "What action should the robot take to pick up the cup ?".split()]
+    assert proc.decode(ids) == "What action should the robot take to pick up the cup ?"
+    trig, after = stop_rule_from_tokenizer(proc.tokenizer)
+    assert trig == [vocab["POLICIES:"]] and after == 8
+    with pytest.raises(ValueError):
+        stop_rule_from_tokenizer(proc.tokenizer, marker=" ".join(["cup"] * 17))
