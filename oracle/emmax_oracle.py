@@ -24,9 +24,12 @@ Pinning status (see DESIGN.md "Oracle"):
   * splice / cache dispatch / predict_action tail -> pinned against the reference's own
                                  `OpenVLAForActionPrediction` run through a stub-timm shim (tests/golden/wrapper_*.npz).
   * action tokenizer, projector, prompt builder, un-normalisation -> pinned against the reference files imported by path.
-  * ViT towers (timm 0.9.10)  -> **parity unpinned**: timm is neither vendored in the reference nor installed here;
-                                 the restatement follows SURVEY.md Appendix B and is cross-checked only against independent
-                                 torch primitives (nn.LayerNorm, F.scaled_dot_product_attention, nn.Conv2d).
+  * ViT towers (timm 0.9.10)  -> pinned against an INDEPENDENT implementation of the same published architectures:
+                                 transformers' Dinov2WithRegistersModel and SiglipVisionModel (exact-erf GELU) on seeded
+                                 weights (tests/golden/vit_hf.npz, agreement 1e-7).  **Parity with timm itself stays
+                                 unpinned**: timm is neither vendored in the reference nor installed here, so the points where
+                                 timm 0.9.10 could differ from HF (activation of the SigLIP MLP, `no_embed_class`, which block
+                                 `get_intermediate_layers` returns) follow SURVEY.md Appendix B.
   * tokenizer text<->ids round trips -> **parity unpinned** (no LLaMA tokenizer files offline); goldens operate on ids.
 
 Everything is plain PyTorch on CPU. `dtype=torch.float32` is the reference's CPU path (BASELINE config 1);
@@ -66,7 +69,8 @@ def preprocess_frames(frames_u8: np.ndarray, cfg) -> Tensor:
 
 
 # =====================================================================================================================
-# ViT towers (timm 0.9.10 VisionTransformer semantics) -- parity unpinned
+# ViT towers (timm 0.9.10 VisionTransformer semantics) -- pinned against HF Dinov2WithRegisters /
+# SiglipVision (tests/golden/vit_hf.npz); parity with timm itself unpinned
 # =====================================================================================================================
 def vit_tower(x: Tensor, sd: Dict[str, Tensor], prefix: str, tw, dtype=torch.float32, n_blocks: Optional[int] = None) -> Tensor:
     """One tower: x [B,3,224,224] -> patch tokens of block `take_index` [B,256,D], no final norm.

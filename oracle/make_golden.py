@@ -12,6 +12,12 @@ It commits DATA (inputs + expected outputs), never reference source.  What it pi
                             forward logits, predict_action ids + 7-vector  (weights = emmax synthetic seed, checksum stored)
   G6 prompts.json           PurePromptBuilder strings (base_prompter.py:28-73)
   G7 solver.json            Solver.extract_action_policies / extract_movement_plan (solver.py:8-137) with a stub tokenizer
+  G8 vit_hf.npz             the two ViT towers against an INDEPENDENT implementation of the same published architectures:
+                            transformers' Dinov2WithRegistersModel (= timm vit_*_patch14_reg4_dinov2) and SiglipVisionModel
+                            (= timm vit_so400m_patch14_siglip) with exact-erf GELU, fed the emmax synthetic weights (seed
+                            stored); expected = hidden state after block `take_index`, prefix tokens dropped.  timm itself
+                            (the reference's dependency, requirements-min.txt) is not installed, so this is the strongest pin
+                            of the tower math available offline.
 
 Usage:  python oracle/make_golden.py
 """
@@ -267,6 +273,90 @@ def g7_solver():
     print("G7 ok", [len(o["policies"]) for o in out])
 
 
+VIT_SEED, VIT_INPUT_SEED = 31, 77
+
+
+def vit_golden_inputs(cfg):
+    """Deterministic pixel input of the G8 vectors (also used by the test): [1, 3, 224, 224] per tower, normalised scale."""
+    rng = np.random.default_rng(VIT_INPUT_SEED)
+    return [torch.from_numpy(rng.standard_normal((1, 3, tw.image_size, tw.image_size)).astype(np.float32)) for tw in cfg.towers]
+
+
+def g8_vit_hf():
+    from transformers import Dinov2WithRegistersConfig, Dinov2WithRegistersModel, SiglipVisionConfig, SiglipVisionModel
+
+    cfg = EmmaXConfig.tiny()
+    sd = synthetic_state_dict(cfg, seed=VIT_SEED)
+    xs = vit_golden_inputs(cfg)
+    out = {"seed": np.int64(VIT_SEED), "input_seed": np.int64(VIT_INPUT_SEED), "checksum": np.float64(checksum(sd))}
+    for ti, (pre, tw) in enumerate(zip(orc.TOWER_PREFIXES, cfg.towers)):
+        g = lambda k: sd[pre + k].float()
+        D = tw.embed_dim
+        if tw.has_cls:   # DINOv2 with 4 registers + LayerScale
+            hc = Dinov2WithRegistersConfig(hidden_size=D, num_hidden_layers=tw.depth, num_attention_heads=tw.num_heads,
+                                           mlp_ratio=tw.mlp_hidden // D, image_size=tw.image_size, patch_size=tw.patch,
+                                           num_register_tokens=tw.n_reg, layer_norm_eps=tw.ln_eps, hidden_act="gelu",
+                                           use_swiglu_ffn=False, qkv_bias=True)
+            assert tw.mlp_hidden == hc.mlp_ratio * D
+            m = Dinov2WithRegistersModel(hc).eval()
+            t = {"embeddings.cls_token": g("cls_token"), "embeddings.register_tokens": g("reg_token"),
+                 "embeddings.mask_token": torch.zeros(1, D),
+                 # timm reg4 models: no_embed_class=True -> the class token gets no position embedding
+                 "embeddings.position_embeddings": torch.cat([torch.zeros(1, 1, D), g("pos_embed")], dim=1),
+                 "embeddings.patch_embeddings.projection.weight": g("patch_embed.proj.weight"),
+                 "embeddings.patch_embeddings.projection.bias": g("patch_embed.proj.bias"),
+                 "layernorm.weight": torch.ones(D), "layernorm.bias": torch.zeros(D)}
+            for i in range(tw.depth):
+                p, q = f"blocks.{i}.", f"encoder.layer.{i}."
+                wq, wk, wv = g(p + "attn.qkv.weight").chunk(3, dim=0)
+                bq, bk, bv = g(p + "attn.qkv.bias").chunk(3, dim=0)
+                t.update({q + "norm1.weight": g(p + "norm1.weight"), q + "norm1.bias": g(p + "norm1.bias"),
+                          q + "attention.attention.query.weight": wq, q + "attention.attention.query.bias": bq,
+                          q + "attention.attention.key.weight": wk, q + "attention.attention.key.bias": bk,
+                          q + "attention.attention.value.weight": wv, q + "attention.attention.value.bias": bv,
+                          q + "attention.output.dense.weight": g(p + "attn.proj.weight"), q + "attention.output.dense.bias": g(p + "attn.proj.bias"),
+                          q + "layer_scale1.lambda1": g(p + "ls1.scale_factor"), q + "layer_scale2.lambda1": g(p + "ls2.scale_factor"),
+                          q + "norm2.weight": g(p + "norm2.weight"), q + "norm2.bias": g(p + "norm2.bias"),
+                          q + "mlp.fc1.weight": g(p + "mlp.fc1.weight"), q + "mlp.fc1.bias": g(p + "mlp.fc1.bias"),
+                          q + "mlp.fc2.weight": g(p + "mlp.fc2.weight"), q + "mlp.fc2.bias": g(p + "mlp.fc2.bias")})
+            missing, unexpected = m.load_state_dict(t, strict=False)
+            assert not unexpected and not missing, (missing, unexpected)
+        else:            # SigLIP vision tower (no class token, learned absolute positions)
+            hc = SiglipVisionConfig(hidden_size=D, intermediate_size=tw.mlp_hidden, num_hidden_layers=tw.depth,
+                                    num_attention_heads=tw.num_heads, image_size=tw.image_size, patch_size=tw.patch,
+                                    hidden_act="gelu", layer_norm_eps=tw.ln_eps)
+            m = SiglipVisionModel(hc).eval()
+            keys = list(m.state_dict().keys())
+            root = "vision_model." if any(k.startswith("vision_model.") for k in keys) else ""
+            t = {root + "embeddings.patch_embedding.weight": g("patch_embed.proj.weight"),
+                 root + "embeddings.patch_embedding.bias": g("patch_embed.proj.bias"),
+                 root + "embeddings.position_embedding.weight": g("pos_embed")[0]}
+            for i in range(tw.depth):
+                p, q = f"blocks.{i}.", root + f"encoder.layers.{i}."
+                wq, wk, wv = g(p + "attn.qkv.weight").chunk(3, dim=0)
+                bq, bk, bv = g(p + "attn.qkv.bias").chunk(3, dim=0)
+                t.update({q + "layer_norm1.weight": g(p + "norm1.weight"), q + "layer_norm1.bias": g(p + "norm1.bias"),
+                          q + "self_attn.q_proj.weight": wq, q + "self_attn.q_proj.bias": bq,
+                          q + "self_attn.k_proj.weight": wk, q + "self_attn.k_proj.bias": bk,
+                          q + "self_attn.v_proj.weight": wv, q + "self_attn.v_proj.bias": bv,
+                          q + "self_attn.out_proj.weight": g(p + "attn.proj.weight"), q + "self_attn.out_proj.bias": g(p + "attn.proj.bias"),
+                          q + "layer_norm2.weight": g(p + "norm2.weight"), q + "layer_norm2.bias": g(p + "norm2.bias"),
+                          q + "mlp.fc1.weight": g(p + "mlp.fc1.weight"), q + "mlp.fc1.bias": g(p + "mlp.fc1.bias"),
+                          q + "mlp.fc2.weight": g(p + "mlp.fc2.weight"), q + "mlp.fc2.bias": g(p + "mlp.fc2.bias")})
+            missing, unexpected = m.load_state_dict(t, strict=False)   # post_layernorm / pooling head are not on the path
+            assert not unexpected and all(("post_layernorm" in k or "head." in k) for k in missing), (missing, unexpected)
+        with torch.no_grad():
+            hs = m(pixel_values=xs[ti], output_hidden_states=True).hidden_states
+        assert len(hs) == tw.depth + 1
+        ref = hs[tw.take_index + 1][:, tw.n_prefix:, :]          # after block take_index, prefix tokens dropped, no final norm
+        ours = orc.vit_tower(xs[ti], sd, pre, tw)
+        err = float((ours - ref).abs().max() / ref.abs().max())
+        assert ref.shape == (1, tw.n_patches, D) and err < 1e-4, (ref.shape, err)
+        out[f"tower{ti}_expected"] = ref.numpy().astype(np.float32)
+        print(f"G8 tower {ti} ({type(m).__name__}) ok, oracle rel err {err:.2e}")
+    np.savez_compressed(os.path.join(OUT, "vit_hf.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     g1_action_decode()
@@ -276,3 +366,4 @@ if __name__ == "__main__":
     g6_prompts()
     g7_solver()
     g5_wrapper()
+    g8_vit_hf()

@@ -132,3 +132,26 @@ def test_solver_matches_reference_class():
     # never raises, zeros on garbage (reference contract)
     assert mine.extract_action_policies("POLICIES:")[0] == [[0] * 7]
     assert mine.extract_movement_plan("")[1].tolist() == [-100] * 7
+
+
+def test_vit_towers_match_hf_dinov2_registers_and_siglip():
+    """G8: the oracle's tower math (written from the timm 0.9.10 semantics the reference depends on) against
+    expected outputs produced by transformers' Dinov2WithRegistersModel / SiglipVisionModel -- an independent implementation
+    of the same published architectures -- on the emmax synthetic weights (regenerated here from the stored seed) and a
+    seeded input.  Pins patch-embed, position / class / register token assembly, pre-LN blocks, attention scaling,
+    LayerScale, exact-erf GELU MLP, the `take_index` block selection and the prefix-token drop.  Tolerance 1e-5 * max|ref|
+    (fp32 both sides; the generating run measured 1e-7)."""
+    from emmax.config import EmmaXConfig
+    from emmax.weights import synthetic_state_dict
+
+    g = np.load(os.path.join(GOLDEN, "vit_hf.npz"))
+    cfg = EmmaXConfig.tiny()
+    sd = synthetic_state_dict(cfg, seed=int(g["seed"]))
+    assert abs(sum(float(v.double().abs().sum()) for v in sd.values()) - float(g["checksum"])) < 1e-6 * float(g["checksum"])
+    rng = np.random.default_rng(int(g["input_seed"]))
+    for ti, (pre, tw) in enumerate(zip(orc.TOWER_PREFIXES, cfg.towers)):
+        x = torch.from_numpy(rng.standard_normal((1, 3, tw.image_size, tw.image_size)).astype(np.float32))
+        got = orc.vit_tower(x, sd, pre, tw)
+        ref = torch.from_numpy(g[f"tower{ti}_expected"])
+        assert got.shape == ref.shape == (1, tw.n_patches, tw.embed_dim)
+        assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
