@@ -119,3 +119,40 @@ def test_fullsize_chained_launch_equals_sequential(device, big, monkeypatch):
     assert torch.equal(ia, ib) and torch.equal(la, lb) and torch.equal(ga, gb)
     monkeypatch.delenv("EMMAX_CHAIN")
     eng.new_session(eng.max_batch, eng.max_prompt, eng.max_ctx)
+
+
+def test_fullsize_vision_towers_match_oracle(device):
+    """The two ViT towers at their REAL sizes (DINOv2-L/14 reg4: D 1024, 24 blocks, 16 heads of 64; SigLIP so400m: D 1152,
+    27 blocks, 16 heads of 72, MLP 4304 -> padded 4352) + the fused projector, against the fp32 CPU oracle on the same
+    bf16-rounded random weights.  The language model is the tiny one (the 7B LLM is covered above and would not fit the
+    CPU oracle).  Tolerance 3e-2 * max|ref| after 23 + 26 fused bf16 blocks (as in test_e2e_gpu.py)."""
+    from emmax.config import EmmaXConfig
+    from emmax.modeling import EmmaXForActionPrediction
+    from emmax.weights import synthetic_state_dict
+    from oracle import emmax_oracle as orc
+
+    big, tiny = EmmaXConfig.emma_x_7b(), EmmaXConfig.tiny()
+    cfg = EmmaXConfig(big.towers, tiny.llm, norm_stats=tiny.norm_stats)
+    sd = synthetic_state_dict(cfg, seed=3)                       # CPU generator: the oracle and the device see the same values
+    sd_bf = {k: v.to(torch.bfloat16) for k, v in sd.items()}
+    model = EmmaXForActionPrediction(cfg, dict(sd_bf)).to(device, max_batch=2, max_prompt=16)
+    sd_ref = {k: v.float() for k, v in sd_bf.items() if k.startswith(("vision_backbone.", "projector."))}
+    rng = np.random.default_rng(12)
+    frames = rng.integers(0, 256, size=(2, 224, 224, 3), dtype=np.uint8)
+    got_proj = model.engine.vision_encode(torch.from_numpy(frames).to(device))
+    got_feats = model.engine.vision_features(2)
+    pix = orc.preprocess_frames(frames, cfg)
+    ref_feats = orc.vision_backbone(pix, sd_ref, cfg)
+    ref_proj = orc.projector(ref_feats, sd_ref)
+    assert got_feats.shape[-1] >= 1024 + 1152 and got_proj.shape == (2, 256, cfg.llm.hidden_size)
+
+    def rel(a, b):
+        b = b.float().cpu()
+        return ((a.float().cpu() - b).abs().max() / b.abs().max()).item()
+
+    assert rel(got_feats[..., : ref_feats.shape[-1]], ref_feats) < 3e-2
+    assert rel(got_proj, ref_proj) < 3e-2
+    # batch invariance: frame 1 alone gives the same features as inside the batch of 2, up to the fp32 summation order of the
+    # tile / split-K plan (a lone frame takes the split-K path for fc2); far inside the bf16 tolerance
+    alone = model.engine.vision_encode(torch.from_numpy(frames[1:2]).to(device))
+    assert rel(alone[0], got_proj[1]) < 1e-2
