@@ -158,50 +158,79 @@ def test_fullsize_vision_towers_match_oracle(device):
     assert rel(alone[0], got_proj[1]) < 1e-2
 
 
-def test_fullsize_llm_dims_two_layers_match_oracle(device):
-    """LLaMA-2-7B layer dimensions (hidden 4096, 32 heads of 128, intermediate 11008, vocab 32064) with 2 layers and the tiny
-    towers, random weights, against the fp32 CPU oracle: every prefill logit row (the GEMM launch plans / split-K of the real
-    shapes) and 8 teacher-forced decode steps (the GEMV / paged-attention kernels at their real K and N).  Tolerances as in
-    test_e2e_gpu.py: 3e-2 * max|ref|; argmax equal wherever the oracle's top-2 margin exceeds 2x the measured error."""
+@pytest.fixture(scope="module")
+def llm2(device):
+    """LLaMA-2-7B layer dimensions, 2 layers, tiny towers, random weights (CPU generator: oracle and device see the same)."""
     from emmax.config import EmmaXConfig, LlmConfig
     from emmax.modeling import EmmaXForActionPrediction
     from emmax.weights import synthetic_state_dict
-    from oracle import emmax_oracle as orc
 
     tiny = EmmaXConfig.tiny()
     llm = LlmConfig(hidden_size=4096, intermediate_size=11008, num_layers=2, num_heads=32, num_kv_heads=32, head_dim=128,
                     vocab_size=32064, max_position=2048)
     cfg = EmmaXConfig(tiny.towers, llm, norm_stats=tiny.norm_stats)
     sd_bf = {k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(cfg, seed=9).items()}
-    model = EmmaXForActionPrediction(cfg, dict(sd_bf)).to(device, max_batch=2, max_prompt=32)
-    sd_ref = {k: v.float() for k, v in sd_bf.items()}
+    model = EmmaXForActionPrediction(cfg, dict(sd_bf)).to(device, max_batch=4, max_prompt=32)
+    return cfg, model, {k: v.float() for k, v in sd_bf.items()}
+
+
+def _teacher_forced(model, cfg, sd_ref, frames, rows, T, device):
+    """Per-row worst relative logit error and (checked, agreed) argmax counts over T teacher-forced decode steps of a batch."""
+    from oracle import emmax_oracle as orc
+
+    B = len(rows)
+    gens, traces = [], []
+    for b in range(B):
+        ids_ref, trace = orc.greedy_generate(torch.tensor(rows[b:b + 1]), orc.preprocess_frames(frames[b:b + 1], cfg), sd_ref, cfg, T,
+                                             eos_token_id=None, return_trace=True)
+        gens.append(ids_ref[0, len(rows[b]):].tolist())
+        traces.append(trace)
+    eng = model.engine
+    model._prefill(rows, None, torch.from_numpy(frames).to(device), max_new=T + 1)
+    worst, checked, agree = 0.0, 0, 0
+    for t in range(T):
+        got = eng.last_logits().float().cpu()
+        for b in range(B):
+            ref = traces[b][t]
+            err = (got[b] - ref).abs().max().item()
+            worst = max(worst, err / ref.abs().max().item())
+            top2 = torch.topk(ref, 2).values
+            if (top2[0] - top2[1]).item() > 2 * err:
+                checked += 1
+                agree += int(int(got[b].argmax()) == gens[b][t])
+        eng.set_current_tokens([gens[b][t] for b in range(B)])
+        eng.decode_step()
+    return worst, checked, agree
+
+
+def test_fullsize_llm_dims_two_layers_match_oracle(device, llm2):
+    """LLaMA-2-7B layer dimensions (hidden 4096, 32 heads of 128, intermediate 11008, vocab 32064) with 2 layers and the tiny
+    towers, random weights, against the fp32 CPU oracle: every prefill logit row (the GEMM launch plans / split-K of the real
+    shapes) and 8 teacher-forced decode steps (the GEMV / paged-attention kernels at their real K and N).  Tolerances as in
+    test_e2e_gpu.py: 3e-2 * max|ref|; argmax equal wherever the oracle's top-2 margin exceeds 2x the measured error."""
+    from oracle import emmax_oracle as orc
+
+    cfg, model, sd_ref = llm2
     rng = np.random.default_rng(4)
     frames = rng.integers(0, 256, size=(1, 224, 224, 3), dtype=np.uint8)
     rows = [[1] + [int(x) for x in rng.integers(3, 31744, size=13)]]
-    fr = torch.from_numpy(frames).to(device)
-    pix = orc.preprocess_frames(frames, cfg)
-
-    out = model.forward(input_ids=rows, frames_u8=fr, use_cache=True)
-    ref, _, _ = orc.vla_prefill_logits(torch.tensor(rows), pix, sd_ref, cfg)
+    out = model.forward(input_ids=rows, frames_u8=torch.from_numpy(frames).to(device), use_cache=True)
+    ref, _, _ = orc.vla_prefill_logits(torch.tensor(rows), orc.preprocess_frames(frames, cfg), sd_ref, cfg)
     got = out.logits[0].float().cpu()
     assert got.shape == ref[0].shape == (256 + 14, 32064)
     assert ((got - ref[0]).abs().max() / ref[0].abs().max()).item() < 3e-2
-
-    T = 8
-    ids_ref, trace = orc.greedy_generate(torch.tensor(rows), pix, sd_ref, cfg, T, eos_token_id=None, return_trace=True)
-    gen = ids_ref[0, len(rows[0]):].tolist()
-    eng = model.engine
-    model._prefill(rows, None, fr, max_new=T + 1)
-    worst, checked, agree = 0.0, 0, 0
-    for t in range(T):
-        g = eng.last_logits()[0].float().cpu()
-        err = (g - trace[t]).abs().max().item()
-        worst = max(worst, err / trace[t].abs().max().item())
-        top2 = torch.topk(trace[t], 2).values
-        if (top2[0] - top2[1]).item() > 2 * err:
-            checked += 1
-            agree += int(int(g.argmax()) == gen[t])
-        eng.set_current_tokens([gen[t]])
-        eng.decode_step()
+    worst, checked, agree = _teacher_forced(model, cfg, sd_ref, frames, rows, 8, device)
     assert worst < 3e-2, worst
     assert agree == checked
+
+
+def test_fullsize_llm_dims_batch3_mfma_path_matches_oracle(device, llm2):
+    """The same at batch 3 (ragged prompts): the MFMA small-batch projections over the fragment-major weight copy and the
+    batched split-KV attention at the real dimensions, every row against its own oracle run."""
+    cfg, model, sd_ref = llm2
+    rng = np.random.default_rng(6)
+    frames = rng.integers(0, 256, size=(3, 224, 224, 3), dtype=np.uint8)
+    rows = [[1] + [int(x) for x in rng.integers(3, 31744, size=n)] for n in (9, 17, 5)]
+    worst, checked, agree = _teacher_forced(model, cfg, sd_ref, frames, rows, 5, device)
+    assert worst < 3e-2, worst
+    assert checked >= 4 and agree == checked
