@@ -9,8 +9,10 @@
 // One kernel template, two tile geometries (Geom<WMW, WNW, MT, NT>: WMW x WNW waves, each MT x NT MFMA tiles of 16x16):
 //   big    256x256x64, 8 waves as 2(M) x 4(N), wave tile 128x64 (128 accumulator registers), one block per CU, 128 KiB LDS
 //   small  128x128x64, 4 waves as 2 x 2,      wave tile  64x64, two blocks per CU, 64 KiB LDS each
-// `launch_gemm` plans with a measured cost model: all big, all small, or whole rounds of big tiles followed by the remaining
-// rows in small tiles (tile quantisation -- e.g. 1044 big tiles = 4.08 rounds -- is the main loss left in these GEMMs).
+// `launch_gemm` plans with a measured cost model: all big, all small, whole rounds of big tiles followed by the remaining
+// rows in small tiles (tile quantisation -- e.g. 1044 big tiles = 4.08 rounds -- is the main loss left in these GEMMs), a
+// separate small-tile launch for a half-empty last tile column, or split-K (K slices per small tile into an fp32 scratch +
+// a reduce / epilogue pass) when a long-K problem has fewer tiles than the chip has CUs.
 //
 // Persistent blocks walk a banded, XCD-aware tile order: block ids go round-robin over the 8 XCDs; each XCD owns a
 // contiguous run of tiles, walked in bands of 4 tile columns (column fastest), so the blocks resident in one XCD form a
