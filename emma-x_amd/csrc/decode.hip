@@ -187,6 +187,22 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
 
     // stage x[:, kc0 : kc0 + 8*nch] into LDS (normalised if NORM, merged from the attention partials if XATTN)
     auto stage_x = [&](int kc0, int nch) {
+        if (!XATTN && !NORM) {
+            // plain rows (down projection: 22 KB per row): four loads in flight per thread, then the LDS writes
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const u32x4_t* xr = (const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx + kc0);
+                for (int c0 = tid; c0 < nch; c0 += 4 * NT) {
+                    u32x4_t v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (c0 + j * NT < nch) ? xr[c0 + j * NT] : (u32x4_t){0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c0 + j * NT < nch) xs[b * (KC >> 3) + c0 + j * NT] = v[j];
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             const u32x4_t* xr = (const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx + kc0);
@@ -232,9 +248,38 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
         for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
 
     float red0[B], red1[B];
+    // Epilogue operands are fetched when a group STARTS, not when its dot products are done: the old residual values (RESID)
+    // and the row's position / page id / cos-sin pair (QKV) are dependent global loads (~0.7-1.5 us from L2) that would
+    // otherwise sit at the tail of every group with the wave's weight ring idle behind them.  Lane b serves batch row b.
+    const int eb = lane < B ? lane : 0;
+    int pre_pos = 0, pre_pg = 0;
+    float pre_a = 0.f, pre_b = 0.f;                      // RESID: h[r0], h[r1];  QKV: cos, sin
+    if (MODE == MODE_QKV) {
+        pre_pos = p.ctx_len[eb];
+        pre_pg = p.page_table[(size_t)eb * p.max_pages + pre_pos / p.page];
+    }
+    auto prefetch_epilogue = [&](int rd) {
+        const int g = g_lo + rd * GW + wave;
+        if (g >= g_hi || lane >= B) return;
+        if (MODE == MODE_RESID) {
+            int r0, r1;
+            group_rows(g, r0, r1);
+            const bf16_t* hp = (const bf16_t*)p.y + (size_t)eb * p.ldy;
+            pre_a = bf2f(hp[r0]);
+            pre_b = bf2f(hp[r1]);
+        } else if (MODE == MODE_QKV) {
+            const int half = p.head_dim >> 1;
+            const int hb = g / half, d = g - hb * half;
+            if (hb < p.Hq + p.Hkv) {
+                pre_a = p.cos_t[(size_t)pre_pos * half + d];
+                pre_b = p.sin_t[(size_t)pre_pos * half + d];
+            }
+        }
+    };
     // every wave of the block walks the same number of rounds (block-uniform barriers in the multi-phase case)
     while (Cc.rd < rounds) {
         const bool valid = Cc.rd < my_rounds;
+        if (Cc.blk == 0 && Cc.ph == 0) prefetch_epilogue(Cc.rd);
         if (multi_phase && Cc.blk == 0 && (Cc.rd != 0 || Cc.ph != 0)) {   // new phase: restage x (loads keep flying)
             __syncthreads();
             stage_x(Cc.ph * KC, phase_nch(Cc.ph));
@@ -293,8 +338,8 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
             for (int b = 0; b < B; ++b)
                 if (lane == b) {
                     bf16_t* hp = (bf16_t*)p.y + (size_t)b * p.ldy;
-                    hp[r0] = f2bf(bf2f(hp[r0]) + red0[b]);
-                    if (2 * g + 1 < p.n_rows) hp[r1] = f2bf(bf2f(hp[r1]) + red1[b]);
+                    hp[r0] = f2bf(pre_a + red0[b]);
+                    if (2 * g + 1 < p.n_rows) hp[r1] = f2bf(pre_b + red1[b]);
                 }
         } else if (MODE == MODE_GATEUP) {
 #pragma unroll
@@ -306,24 +351,24 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
 #pragma unroll
             for (int b = 0; b < B; ++b)
                 if (lane == b) {
-                    const int pos = p.ctx_len[b];
+                    const int pos = pre_pos;
                     // linear outputs are bf16 activations in the reference; RoPE acts on those
                     const float x0 = bf2f(f2bf(red0[b])), x1 = bf2f(f2bf(red1[b]));
                     if (hb < p.Hq + p.Hkv) {
-                        const float cs = p.cos_t[(size_t)pos * half + d], sn = p.sin_t[(size_t)pos * half + d];
+                        const float cs = pre_a, sn = pre_b;
                         const bf16_t y0 = f2bf(x0 * cs - x1 * sn), y1 = f2bf(x1 * cs + x0 * sn);
                         if (hb < p.Hq) {
                             bf16_t* q = (bf16_t*)p.y + (size_t)b * p.ldy + hb * hd;
                             q[d] = y0;
                             q[d + half] = y1;
                         } else {
-                            const int pg = p.page_table[(size_t)b * p.max_pages + pos / p.page];
+                            const int pg = pre_pg;
                             bf16_t* kc = (bf16_t*)p.kcache + (((size_t)pg * p.Hkv + (hb - p.Hq)) * p.page + pos % p.page) * hd;
                             kc[d] = y0;
                             kc[d + half] = y1;
                         }
                     } else {
-                        const int pg = p.page_table[(size_t)b * p.max_pages + pos / p.page];
+                        const int pg = pre_pg;
                         bf16_t* vc = (bf16_t*)p.vcache + (((size_t)pg * p.Hkv + (hb - p.Hq - p.Hkv)) * p.page + pos % p.page) * hd;
                         vc[d] = f2bf(x0);
                         vc[d + half] = f2bf(x1);
