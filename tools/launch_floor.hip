@@ -45,6 +45,40 @@ __global__ __launch_bounds__(512) void k_stream(const u32x4* __restrict__ w, uin
     if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) out[0] = 1;
 }
 
+// the same stream, consumed the way the GEMV consumes it: one 16-byte x chunk from LDS per pair of weight loads, 8 v_dot2c
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+}
+__global__ __launch_bounds__(512) void k_stream_dot(const u32x4* __restrict__ w, float* out, size_t stride, int rounds) {
+    __shared__ u32x4 xs[2048];
+    for (int i = threadIdx.x; i < 2048; i += 512) xs[i] = (u32x4){0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    const size_t wave = (size_t)blockIdx.x * 8 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const u32x4* base = w + wave * stride + lane;
+    u32x4 r[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) r[u] = __builtin_nontemporal_load(base + u * 64);
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f;
+    for (int it = 1; it <= rounds; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) {
+            const u32x4 x = xs[((it * 8 + (u >> 1)) * 64 + lane) & 2047];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a0 = dot2(r[u][j], x[j], a0);
+                a1 = dot2(r[u + 1][j], x[j], a1);
+            }
+            if (it < rounds) {
+                r[u] = __builtin_nontemporal_load(base + (size_t)(it * 16 + u) * 64);
+                r[u + 1] = __builtin_nontemporal_load(base + (size_t)(it * 16 + u + 1) * 64);
+            }
+        }
+    }
+    if (a0 + a1 == 12345.678f) out[0] = a0;
+}
+
 template <class F>
 static double time_chain(F launch, int n) {
     hipEvent_t e0, e1;
@@ -84,6 +118,13 @@ int main() {
         const int nb = (int)((per_launch * nbuf) / bytes);
         const double us = time_chain([&](int i) { hipLaunchKernelGGL(k_stream, dim3(grid), dim3(512), 0, 0, w + (size_t)(i % nb) * (bytes / 16), out, (size_t)rounds * 16 * 64, rounds); }, N);
         printf("stream %3d blocks x 8 waves x %d ring-fulls = %6.1f MB per launch: %.2f us  %.2f TB/s\n", grid, rounds, bytes / 1e6, us, bytes / us / 1e6);
+    }
+    for (int cfg = 0; cfg < 2; ++cfg) {
+        const int grid = cfg ? 256 : 512, rounds = cfg ? 3 : 3;
+        const size_t bytes = (size_t)grid * 8 * rounds * 16 * 1024;
+        const int nb = (int)((per_launch * nbuf) / bytes);
+        const double us = time_chain([&](int i) { hipLaunchKernelGGL(k_stream_dot, dim3(grid), dim3(512), 0, 0, w + (size_t)(i % nb) * (bytes / 16), (float*)out, (size_t)rounds * 16 * 64, rounds); }, N);
+        printf("stream+dot2 %3d blocks x 8 waves x %d ring-fulls = %6.1f MB per launch: %.2f us  %.2f TB/s\n", grid, rounds, bytes / 1e6, us, bytes / us / 1e6);
     }
     return 0;
 }
