@@ -218,3 +218,33 @@ def test_real_tokenizer_files_are_picked_up_and_give_a_stop_rule(tmp_path):
     assert trig == [vocab["POLICIES:"]] and after == 8
     with pytest.raises(ValueError):
         stop_rule_from_tokenizer(proc.tokenizer, marker=" ".join(["cup"] * 17))
+
+
+def test_bench_contract_flags_and_committed_bench_line():
+    """The driver's contract for bench.py: the flags it passes exist, and the bench line committed under profiles/ carries every
+    required key (incl. the `roofline` and `cpu_baseline` objects) with sane values."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in out.stdout
+    line = open(os.path.join(ROOT, "profiles", "r01_bench_n1.json")).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "actions/sec" and d["unit"] == "actions/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]          # one action per step at N = 1, B = 1
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.4 < r["frac"] < 1.0
+    assert r["traffic"] is None or 0.9 < r["traffic"] / r["bytes_per_launch"] < 1.2
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "actions/s" and c["sample"]
