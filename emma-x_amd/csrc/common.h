@@ -60,21 +60,65 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x));
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Chained launch: consecutive decode kernels run on two alternating streams, so kernel k+1 becomes resident and requests
-// its (x-independent) weights while kernel k drains; the DATA dependency k -> k+1 is enforced inside the kernel with the
-// placement-independent agent-scope release/acquire hand-off of cdna_hip_programming.md Guideline 16:
-//   producer block: every wave drains its stores -> barrier -> lane 0: release fence, drain, relaxed counter increment
-//   consumer block: lane 0 polls the counter relaxed (bounded), ONE acquire fence, barrier, then plain loads.
+// its (x-independent) weights while kernel k drains; the DATA dependency k -> k+1 is enforced inside the kernel WITHOUT
+// cache-maintenance fences (a release fence is a full L2 write-back walk per block -- 32 of them queue up per XCD -- and
+// measured ~13 us per edge under streaming load):
+//   producer block: every activation store is an agent-scope write-through store (sc1: acknowledged once it is past the
+//                   XCD-private L2); every wave drains its stores (vmcnt(0)) -> barrier -> lane 0: relaxed counter
+//                   increment; the last arriver raises the flag
+//   consumer block: lane 0 polls the flag with agent-scope (sc1) loads (bounded), barrier, then reads the activations
+//                   with agent-scope loads, which never hit a stale line of the XCD-private L2.
+// (MI355X_MICROARCH.md, "handoff-flag": drained sc1 payload, then the flag.)  The `coh` argument of the helpers below is
+// block-uniform: plain accesses under ordinary stream ordering, agent-scope accesses under the chained launch.
 // Stream order still serialises k and k+2, so at most two kernels are in flight and both fit the chip (grids <= 256
 // blocks, <= 128 VGPRs): the spinning consumer can never starve its producer.
 // ---------------------------------------------------------------------------------------------------------------------
 struct DepInfo {
     unsigned int* wait_flag;    // null: ordinary stream ordering, no in-kernel wait.  Polled word: != 0 once the producer is done
     unsigned int* signal_ctr;   // null: nobody waits on this kernel.  Arrival counter of THIS kernel's blocks ...
-    unsigned int* signal_flag;  // ... and the flag its last-arriving block raises (a different 64-byte line than the counter,
+    unsigned int* signal_flag;  // ... and the flag its last-arriving block raises (a different 128-byte line than the counter,
                                 // so the consumer's pollers never contend with the producers' atomics)
     unsigned int n_blocks;      // blocks of this kernel (the last arriver sees n_blocks - 1)
     unsigned int* err;          // set to 1 when a wait gave up (bounded spin)
 };
+__host__ __device__ __forceinline__ bool dep_coherent(const DepInfo& d) { return d.wait_flag != nullptr || d.signal_ctr != nullptr; }
+
+__device__ __forceinline__ u32x4_t ld_act16(const u32x4_t* p, bool coh) {
+    if (!coh) return *p;
+    const unsigned long long* q = (const unsigned long long*)p;
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (u32x4_t){(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+}
+__device__ __forceinline__ void st_act16(u32x4_t* p, u32x4_t v, bool coh) {
+    if (!coh) { *p = v; return; }
+    unsigned long long* q = (unsigned long long*)p;
+    __hip_atomic_store(q, (unsigned long long)v[0] | ((unsigned long long)v[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, (unsigned long long)v[2] | ((unsigned long long)v[3] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bf16_t ld_act_bf16(const bf16_t* p, bool coh) {
+    return coh ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+__device__ __forceinline__ void st_act_bf16(bf16_t* p, bf16_t v, bool coh) {
+    if (coh) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+__device__ __forceinline__ float ld_act_f32(const float* p, bool coh) {
+    return coh ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+__device__ __forceinline__ void st_act_f32(float* p, float v, bool coh) {
+    if (coh) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+__device__ __forceinline__ int ld_act_i32(const int* p, bool coh) {
+    return coh ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+__device__ __forceinline__ void st_act_i32(int* p, int v, bool coh) {
+    if (coh) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+__device__ __forceinline__ f32x4_t ld_act_f32x4(const float* p, bool coh) {
+    if (!coh) return *(const f32x4_t*)p;
+    const u32x4_t v = ld_act16((const u32x4_t*)p, true);
+    return __builtin_bit_cast(f32x4_t, v);
+}
 
 __device__ __forceinline__ void dep_wait(const DepInfo& d) {
     if (d.wait_flag) {
@@ -84,14 +128,13 @@ __device__ __forceinline__ void dep_wait(const DepInfo& d) {
             unsigned int spins = 0;
             if (__hip_atomic_load(d.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                 while (__hip_atomic_load(d.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1u << 18)) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > (1u << 19)) {
                         __hip_atomic_store(d.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
     }
@@ -99,11 +142,9 @@ __device__ __forceinline__ void dep_wait(const DepInfo& d) {
 
 __device__ __forceinline__ void dep_signal(const DepInfo& d) {
     if (d.signal_ctr) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own stores
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own write-through stores
         __syncthreads();
         if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler may drop the wait behind buffer_wbl2 (G16 pitfall 12)
             const unsigned int prev = __hip_atomic_fetch_add(d.signal_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (prev == d.n_blocks - 1u) __hip_atomic_store(d.signal_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -157,16 +198,16 @@ __device__ __forceinline__ u32x4_t attn_merge_chunk(const float* __restrict__ pp
 }
 // generic split count, small register footprint (the dot2 GEMV keeps its 16-load weight ring live across the prologue
 // and must stay under 128 VGPRs)
-__device__ __forceinline__ u32x4_t attn_merge_chunk_loop(const float* __restrict__ pp, int d0, int nsplit) {
+__device__ __forceinline__ u32x4_t attn_merge_chunk_loop(const float* __restrict__ pp, int d0, int nsplit, bool coh = false) {
     float M = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pp[s * EMMAX_PSTRIDE + 128]);
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ld_act_f32(pp + s * EMMAX_PSTRIDE + 128, coh));
     float den = 0.f, a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < nsplit; ++s) {
-        const float m = pp[s * EMMAX_PSTRIDE + 128];
+        const float m = ld_act_f32(pp + s * EMMAX_PSTRIDE + 128, coh);
         const float wgt = (m == -INFINITY) ? 0.f : __expf(m - M);
-        den += pp[s * EMMAX_PSTRIDE + 129] * wgt;
-        const f32x4_t o0 = *(const f32x4_t*)(pp + s * EMMAX_PSTRIDE + d0);
-        const f32x4_t o1 = *(const f32x4_t*)(pp + s * EMMAX_PSTRIDE + d0 + 4);
+        den += ld_act_f32(pp + s * EMMAX_PSTRIDE + 129, coh) * wgt;
+        const f32x4_t o0 = ld_act_f32x4(pp + s * EMMAX_PSTRIDE + d0, coh);
+        const f32x4_t o1 = ld_act_f32x4(pp + s * EMMAX_PSTRIDE + d0 + 4, coh);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             a8[j] += o0[j] * wgt;

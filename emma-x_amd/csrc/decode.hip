@@ -40,7 +40,9 @@ constexpr int PSTRIDE = EMMAX_PSTRIDE;   // floats per attention split partial: 
 constexpr int GW = 8;   // waves per GEMV block
 
 // B <= 2: two resident blocks per CU (<= 128 VGPRs); larger batches keep more accumulators and run one block per CU
-template <int B, int MODE, bool NORM, bool XATTN = false>
+// COH: chained launch (B <= 2 only) -- activations move with agent-scope accesses (common.h); a compile-time switch so that
+// the plain path keeps its exact code (a run-time flag cost 3 us per layer)
+template <int B, int MODE, bool NORM, bool XATTN = false, bool COH = false>
 __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_kernel(GemvParams p) {
     constexpr int NR = 2;   // weight rows per group
     constexpr int U = 8;    // 16-byte loads per row per chunk (8 * 64 lanes * 8 elems = 4096 elements)
@@ -113,7 +115,8 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
 #pragma unroll
     for (int u = 0; u < U; ++u) issue_step(P, u, my_rounds > 0);
     advance(P);
-    dep_wait(p.dep);   // everything below reads data of the previous kernel
+    constexpr bool coh = COH;
+    if (COH) dep_wait(p.dep);   // everything below reads data of the previous kernel
 
     // ---- RMSNorm statistics ----
     float rstd[B];
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
         const u32x4_t wv = mine ? *((const u32x4_t*)p.norm_w + tid) : (u32x4_t){0u, 0u, 0u, 0u};
 #pragma unroll
         for (int b = 0; b < B; ++b)
-            xv[b] = mine ? *((const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx) + tid) : (u32x4_t){0u, 0u, 0u, 0u};
+            xv[b] = mine ? ld_act16((const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx) + tid, coh) : (u32x4_t){0u, 0u, 0u, 0u};
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             float ss = 0.f;
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
             float ss = 0.f;
             const u32x4_t* xr = (const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx);
             for (int c = tid; c < (K >> 3); c += NT) {
-                const u32x4_t v = xr[c];
+                const u32x4_t v = ld_act16(xr + c, coh);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float a = bf_lo(v[j]), bb = bf_hi(v[j]);
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
                 for (int c0 = tid; c0 < nch; c0 += 4 * NT) {
                     u32x4_t v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = (c0 + j * NT < nch) ? xr[c0 + j * NT] : (u32x4_t){0u, 0u, 0u, 0u};
+                    for (int j = 0; j < 4; ++j) v[j] = (c0 + j * NT < nch) ? ld_act16(xr + c0 + j * NT, coh) : (u32x4_t){0u, 0u, 0u, 0u};
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (c0 + j * NT < nch) xs[b * (KC >> 3) + c0 + j * NT] = v[j];
@@ -212,9 +215,9 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
                     // chunk cg = head (cg>>4), elements (cg&15)*8..+8 of the split partials
                     const int cg = (kc0 >> 3) + c;
                     const float* pp = p.attn_part + (size_t)(b * p.Hq + (cg >> 4)) * p.nsplit * PSTRIDE;
-                    v = attn_merge_chunk_loop(pp, (cg & 15) * 8, p.nsplit);
+                    v = attn_merge_chunk_loop(pp, (cg & 15) * 8, p.nsplit, coh);
                 } else {
-                    v = xr[c];
+                    v = ld_act16(xr + c, coh);
                 }
                 if (NORM) {
                     const u32x4_t wv = *((const u32x4_t*)((const bf16_t*)p.norm_w + kc0) + c);
@@ -265,8 +268,8 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
             int r0, r1;
             group_rows(g, r0, r1);
             const bf16_t* hp = (const bf16_t*)p.y + (size_t)eb * p.ldy;
-            pre_a = bf2f(hp[r0]);
-            pre_b = bf2f(hp[r1]);
+            pre_a = bf2f(ld_act_bf16(hp + r0, coh));
+            pre_b = bf2f(ld_act_bf16(hp + r1, coh));
         } else if (MODE == MODE_QKV) {
             const int half = p.head_dim >> 1;
             const int hb = g / half, d = g - hb * half;
@@ -330,21 +333,21 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
 #pragma unroll
             for (int b = 0; b < B; ++b)
                 if (lane == b) {
-                    ((bf16_t*)p.y)[(size_t)b * p.ldy + r0] = f2bf(red0[b]);
-                    if (2 * g + 1 < p.n_rows) ((bf16_t*)p.y)[(size_t)b * p.ldy + r1] = f2bf(red1[b]);
+                    st_act_bf16((bf16_t*)p.y + (size_t)b * p.ldy + r0, f2bf(red0[b]), coh);
+                    if (2 * g + 1 < p.n_rows) st_act_bf16((bf16_t*)p.y + (size_t)b * p.ldy + r1, f2bf(red1[b]), coh);
                 }
         } else if (MODE == MODE_RESID) {
 #pragma unroll
             for (int b = 0; b < B; ++b)
                 if (lane == b) {
                     bf16_t* hp = (bf16_t*)p.y + (size_t)b * p.ldy;
-                    hp[r0] = f2bf(pre_a + red0[b]);
-                    if (2 * g + 1 < p.n_rows) hp[r1] = f2bf(pre_b + red1[b]);
+                    st_act_bf16(hp + r0, f2bf(pre_a + red0[b]), coh);
+                    if (2 * g + 1 < p.n_rows) st_act_bf16(hp + r1, f2bf(pre_b + red1[b]), coh);
                 }
         } else if (MODE == MODE_GATEUP) {
 #pragma unroll
             for (int b = 0; b < B; ++b)
-                if (lane == b) ((bf16_t*)p.y)[(size_t)b * p.ldy + g] = f2bf(silu(red0[b]) * red1[b]);
+                if (lane == b) st_act_bf16((bf16_t*)p.y + (size_t)b * p.ldy + g, f2bf(silu(red0[b]) * red1[b]), coh);
         } else if (MODE == MODE_QKV) {
             const int hd = p.head_dim, half = hd >> 1;
             const int hb = g / half, d = g - hb * half;
@@ -359,19 +362,19 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
                         const bf16_t y0 = f2bf(x0 * cs - x1 * sn), y1 = f2bf(x1 * cs + x0 * sn);
                         if (hb < p.Hq) {
                             bf16_t* q = (bf16_t*)p.y + (size_t)b * p.ldy + hb * hd;
-                            q[d] = y0;
-                            q[d + half] = y1;
+                            st_act_bf16(q + d, y0, coh);
+                            st_act_bf16(q + d + half, y1, coh);
                         } else {
                             const int pg = pre_pg;
                             bf16_t* kc = (bf16_t*)p.kcache + (((size_t)pg * p.Hkv + (hb - p.Hq)) * p.page + pos % p.page) * hd;
-                            kc[d] = y0;
-                            kc[d + half] = y1;
+                            st_act_bf16(kc + d, y0, coh);
+                            st_act_bf16(kc + d + half, y1, coh);
                         }
                     } else {
                         const int pg = pre_pg;
                         bf16_t* vc = (bf16_t*)p.vcache + (((size_t)pg * p.Hkv + (hb - p.Hq - p.Hkv)) * p.page + pos % p.page) * hd;
-                        vc[d] = f2bf(x0);
-                        vc[d + half] = f2bf(x1);
+                        st_act_bf16(vc + d, f2bf(x0), coh);
+                        st_act_bf16(vc + d + half, f2bf(x1), coh);
                     }
                 }
         } else if (MODE == MODE_LMHEAD) {
@@ -416,11 +419,11 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
                     i0 = ii;
                 }
             }
-            p.part_val[(size_t)blockIdx.x * B + tid] = v0;
-            p.part_idx[(size_t)blockIdx.x * B + tid] = i0;
+            st_act_f32(p.part_val + (size_t)blockIdx.x * B + tid, v0, coh);
+            st_act_i32(p.part_idx + (size_t)blockIdx.x * B + tid, i0, coh);
         }
     }
-    dep_signal(p.dep);
+    if (COH) dep_signal(p.dep);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -433,7 +436,8 @@ __global__ __launch_bounds__(256) void emmax_decode_embed_kernel(const int32_t* 
     id = min(max(id, 0), vocab - 1);
     const u32x4_t* s = (const u32x4_t*)(E + (size_t)id * hidden);
     u32x4_t* o = (u32x4_t*)(h + (size_t)b * hidden);
-    for (int c = threadIdx.x; c < hidden / 8; c += blockDim.x) o[c] = s[c];
+    const bool coh = dep_coherent(dep);
+    for (int c = threadIdx.x; c < hidden / 8; c += blockDim.x) st_act16(o + c, s[c], coh);
     dep_signal(dep);
 }
 
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(256) void emmax_decode_embed_kernel(const int32_t* 
 //   part[((b*Hq + h)*nsplit + s) * PSTRIDE] = { o[0..HD) un-normalised, m, l, pad }
 // The cross-split merge is fused into the staging prologue of the o-proj GEMV (XATTN).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int HD, int G>
+template <int HD, int G, bool COH = false>
 __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams p) {
     static_assert(HD == 128, "decode attention maps 16 lanes x 8 elements onto one 128-wide K/V row");
     constexpr int KU = G <= 2 ? 4 : 2;    // keys per lane group per chunk (block chunk = 16 * KU keys), two chunks in flight
@@ -459,7 +463,8 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
     const int kg = lane >> 4, ch = lane & 15;       // key group within the wave, 16-byte chunk within the row
     const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
     const int nsplit = gridDim.x;
-    dep_wait(p.dep);   // q, ctx_len and the freshly appended K/V row come from the kernels before
+    constexpr bool coh = COH;
+    if (COH) dep_wait(p.dep);   // q, ctx_len and the freshly appended K/V row come from the kernels before
     // one L2 round trip for everything that does not depend on the context length: the row's whole page table -> LDS
     // (no dependent global load in front of the K/V loads), q, and the length itself
     for (int i = tid; i < min(p.max_pages, SP); i += 256) s_pages[i] = p.page_table[(size_t)b * p.max_pages + i];
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
     u32x4_t q[G];
 #pragma unroll
     for (int gq = 0; gq < G; ++gq)
-        q[gq] = *(const u32x4_t*)((const bf16_t*)p.q + (size_t)b * p.ldq + (hk * G + gq) * HD + ch * 8);
+        q[gq] = ld_act16((const u32x4_t*)((const bf16_t*)p.q + (size_t)b * p.ldq + (hk * G + gq) * HD + ch * 8), coh);
     const int L = p.ctx_len[b] + 1;                 // keys including the one appended by the qkv kernel of this step
     int kps = (L + nsplit - 1) / nsplit;
     kps = (kps + 15) & ~15;
@@ -479,9 +484,9 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
     if (k0 >= L || (p.done && p.done[b])) {   // empty split, or a row that no longer decodes: no K/V traffic
         for (int i = tid; i < G * PSTRIDE; i += 256) {
             const int gq = i / PSTRIDE, j = i - gq * PSTRIDE;
-            part[(size_t)gq * nsplit * PSTRIDE + j] = (j == HD) ? -INFINITY : 0.f;
+            st_act_f32(part + (size_t)gq * nsplit * PSTRIDE + j, (j == HD) ? -INFINITY : 0.f, coh);
         }
-        dep_signal(p.dep);
+        if (COH) dep_signal(p.dep);
         return;
     }
 
@@ -513,6 +518,10 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
             const size_t off = (((size_t)pg * p.Hkv + hk) * p.page + kk % p.page) * HD + ch * 8;
             kv[u] = *(const u32x4_t*)(kc + off);
             vv[u] = *(const u32x4_t*)(vc + off);
+            if (coh && kk == L - 1) {   // the row appended by the qkv kernel of THIS step (one kernel back): agent-scope re-read
+                kv[u] = ld_act16((const u32x4_t*)(kc + off), true);
+                vv[u] = ld_act16((const u32x4_t*)(vc + off), true);
+            }
         }
     };
     auto consume_chunk = [&](const u32x4_t (&kv)[KU], const u32x4_t (&vv)[KU], const bool (&ok)[KU]) {
@@ -606,9 +615,9 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
 #pragma unroll
             for (int w = 0; w < 4; ++w) v += red_ml[w][gq][1] * __expf(red_ml[w][gq][0] - msafe);
         }
-        part[(size_t)gq * nsplit * PSTRIDE + j] = v;
+        st_act_f32(part + (size_t)gq * nsplit * PSTRIDE + j, v, coh);
     }
-    dep_signal(p.dep);
+    if (COH) dep_signal(p.dep);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -616,14 +625,15 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void emmax_decode_finish_kernel(FinishParams p) {
     const int b = blockIdx.x, tid = threadIdx.x;
+    const bool coh = dep_coherent(p.dep);
     dep_wait(p.dep);
     __shared__ float sv[256];
     __shared__ int si[256];
     float best = -INFINITY;
     int besti = 0x7fffffff;
     for (int i = tid; i < p.n_part; i += 256) {
-        const float v = p.part_val[(size_t)i * p.B + b];
-        const int ii = p.part_idx[(size_t)i * p.B + b];
+        const float v = ld_act_f32(p.part_val + (size_t)i * p.B + b, coh);
+        const int ii = ld_act_i32(p.part_idx + (size_t)i * p.B + b, coh);
         if (v > best || (v == best && ii < besti)) {
             best = v;
             besti = ii;
@@ -734,8 +744,17 @@ static int launch_gemv_t(const GemvParams& p, hipStream_t stream, int* grid_out)
     if (grid_out) *grid_out = grid;
     GemvParams q = p;
     q.dep.n_blocks = (unsigned)grid;
-    auto kern = emmax_decode_gemv_kernel<B, MODE, NORM, XATTN>;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(GW * 64), smem, stream, q);
+    if (dep_coherent(q.dep)) {   // chained launch
+        if constexpr (B <= 2) {
+            auto kern = emmax_decode_gemv_kernel<B, MODE, NORM, XATTN, true>;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(GW * 64), smem, stream, q);
+        } else {
+            return -1;
+        }
+    } else {
+        auto kern = emmax_decode_gemv_kernel<B, MODE, NORM, XATTN>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(GW * 64), smem, stream, q);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
@@ -763,6 +782,9 @@ static int gemv_init_mode() {
 #define SETB(BB) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_gemv_kernel<BB, MODE, NORM, XATTN>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
     SETB(1); SETB(2); SETB(3); SETB(4); SETB(5); SETB(6); SETB(7); SETB(8);
 #undef SETB
+#define SETC(BB) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_gemv_kernel<BB, MODE, NORM, XATTN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
+    SETC(1); SETC(2);
+#undef SETC
     return e == hipSuccess ? 0 : -4;
 }
 int decode_gemv_init() {
@@ -817,10 +839,13 @@ int launch_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_dim
     const int G = Hq / p.Hkv;
     dim3 grid(nsplit, p.Hkv, B), block(256);
     switch (G) {
-        case 1: hipLaunchKernelGGL((emmax_decode_attn_kernel<128, 1>), grid, block, 0, stream, p); break;
-        case 2: hipLaunchKernelGGL((emmax_decode_attn_kernel<128, 2>), grid, block, 0, stream, p); break;
-        case 4: hipLaunchKernelGGL((emmax_decode_attn_kernel<128, 4>), grid, block, 0, stream, p); break;
-        case 8: hipLaunchKernelGGL((emmax_decode_attn_kernel<128, 8>), grid, block, 0, stream, p); break;
+#define ATTN_CASE(GG)                                                                                                   \
+    case GG:                                                                                                           \
+        if (dep_coherent(p.dep)) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true>), grid, block, 0, stream, p); \
+        else hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG>), grid, block, 0, stream, p);                         \
+        break
+        ATTN_CASE(1); ATTN_CASE(2); ATTN_CASE(4); ATTN_CASE(8);
+#undef ATTN_CASE
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -4;

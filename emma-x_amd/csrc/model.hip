@@ -330,7 +330,7 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->stop_cfg = (int32_t*)b.take(2 * 4);
     s->stop_m = (int32_t*)b.take(Bd * 4);
     s->stop_after = (int32_t*)b.take(Bd * 4);
-    s->dep_ctr = (unsigned int*)b.take((256 * 32 + 16) * 4);
+    s->dep_ctr = (unsigned int*)b.take((256 * 64 + 16) * 4);
     s->page_table = (int32_t*)b.take((int64_t)Bd * s->max_pages * 4);
     s->splitk_bytes = (int64_t)64 << 20;   // e.g. 4 slices of a 768 x 4096 prefill GEMM = 50 MB; smaller budgets just split less
     s->splitk_ws = (float*)b.take(s->splitk_bytes);
@@ -433,7 +433,7 @@ static bf16* kcache_of(emmax_session* s, int layer) { return s->kv + (size_t)lay
 static bf16* vcache_of(emmax_session* s, int layer) { return s->kv + (size_t)layer * s->kv_layer_stride + s->kv_layer_stride / 2; }
 
 constexpr int DEP_MAX_KERNELS = 256;
-constexpr int DEP_WORDS = DEP_MAX_KERNELS * 32 + 16;
+constexpr int DEP_WORDS = DEP_MAX_KERNELS * 64 + 16;
 struct Chain;
 static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, Chain* ch = nullptr,
                             int slot0 = 0);
@@ -444,12 +444,12 @@ struct Chain {
     hipStream_t st[2];
     int k = 0;
     hipStream_t stream() const { return st[k & 1]; }
-    // kernel k: arrival counter at word 32k, done flag at word 32k+16 (separate 64-byte lines); error word at the end
+    // kernel k: arrival counter at word 64k, done flag at word 64k+32 (separate 128-byte lines); error word at the end
     DepInfo dep() const {   // n_blocks is filled in by the launcher, which knows its grid
         DepInfo d;
-        d.wait_flag = k > 0 ? s->dep_ctr + 32 * (k - 1) + 16 : nullptr;
-        d.signal_ctr = s->dep_ctr + 32 * k;
-        d.signal_flag = s->dep_ctr + 32 * k + 16;
+        d.wait_flag = k > 0 ? s->dep_ctr + 64 * (k - 1) + 32 : nullptr;
+        d.signal_ctr = s->dep_ctr + 64 * k;
+        d.signal_flag = s->dep_ctr + 64 * k + 32;
         d.n_blocks = 0;
         d.err = s->dep_ctr + DEP_WORDS - 1;
         return d;

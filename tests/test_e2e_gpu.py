@@ -255,8 +255,8 @@ def test_graph_replay_equals_eager(device, tiny_planted, monkeypatch):
 
 
 def test_chained_launch_equals_sequential(device, tiny_random, monkeypatch):
-    """The experimental two-stream chained launch (EMMAX_CHAIN=1; in-kernel release/acquire hand-off between consecutive
-    decode kernels; off by default because it is slower) must give
+    """The experimental two-stream chained launch (EMMAX_CHAIN=1; in-kernel fence-free hand-off between consecutive decode
+    kernels -- write-through stores, counter, agent-scope loads; off by default because it is slower) must give
     bit-identical logits to plain single-stream ordering, step after step (a stale hand-off would show up here)."""
     cfg, model, _ = tiny_random
     eng = model.engine
