@@ -31,15 +31,31 @@ __device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float acc) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), acc, false);
 }
 
+// Wave-wide reductions on the DPP path.  `__shfl_xor` compiles to ds_bpermute_b32 + index arithmetic + s_waitcnt
+// lgkmcnt(0): six serial trips through the LDS crossbar per reduction (~0.35 us; the eight RMSNorm row statistics of a
+// batch-8 decode prologue took 2.7 us).  Here: a butterfly inside each row of 16 lanes (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror -- plain VALU instructions with a DPP operand), then the four row totals are read into
+// SGPRs and combined; every lane returns the same value.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);   // row_half_mirror
+    v += dpp_move<0x140>(v);   // row_mirror: every lane holds its row's sum
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_move<0xB1>(v));
+    v = fmaxf(v, dpp_move<0x4E>(v));
+    v = fmaxf(v, dpp_move<0x141>(v));
+    v = fmaxf(v, dpp_move<0x140>(v));
+    return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
 // exact-erf GELU, 0.5 x (1 + erf(x / sqrt 2)), with erfc(z) = poly(t) exp(-z^2), t = 1 / (1 + p z) (Abramowitz-Stegun

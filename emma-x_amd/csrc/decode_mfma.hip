@@ -11,6 +11,8 @@
 // A block (8 waves) owns one task (1 or 2 row tiles) at a time and splits K 8 ways; the partial tiles meet in LDS.
 // Same fused prologues / epilogues as the GEMV: RMSNorm, attention split merge | RoPE + paged K/V append, +residual,
 // SiLU*mul, greedy argmax.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -103,14 +105,27 @@ __device__ __forceinline__ void stage_attn_rows(const float* __restrict__ attn_p
 template <int MODE, bool NORM, bool XATTN, bool FP8 = false>
 __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParams p) {
     constexpr int TILES = (MODE == MODE_QKV || MODE == MODE_GATEUP) ? 2 : 1;
-    constexpr int U = 8;
+    // k-steps per ring block: 8 KiB of weights in flight per wave (64 KiB per CU, 16 MiB on the chip) is the measured optimum
+    // once the ring really rolls -- 16 KiB per wave costs 1-3 us per launch, 32 KiB up to 20 us (the first burst alone is then
+    // 64 MB: everything else, the activations of the prologue included, queues behind it)
+    constexpr int U = TILES == 2 ? 4 : 8;
     constexpr int NT = GW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int B = p.batch;
     const int K = p.K, KC = p.kc;
+    {   // every kernel argument the start-up path needs in ONE scalar-load round (hipcc otherwise fetches them where they are
+        // first used: five dependent round trips, ~1 us, in front of the first weight request)
+        const int a0 = p.n_groups, a1 = p.sk_kt8, a2 = p.sk_q, a3 = p.sk_r, a4 = p.qk_shift, a5 = p.head_dim;
+        const unsigned a6 = p.sk_magic;
+        const void* a7 = p.W;
+        const void* a8 = p.x;
+        const void* a9 = p.norm_w;
+        asm volatile("" ::"s"(B), "s"(K), "s"(KC), "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6), "s"(a7), "s"(a8), "s"(a9));
+    }
     const int pitch = KC * 2 + 16;                               // bytes per staged x row
-    float* red = (float*)(smem + (size_t)(B + 1) * pitch);      // [GW][TILES][4][64]
-    float* srstd = red + GW * TILES * 256;                      // [B]
+    constexpr int RSZ = GW * TILES * 256;                       // floats of one reduction buffer
+    float* red = (float*)(smem + (size_t)(B + 1) * pitch);      // [2][GW][TILES][4][64], double-buffered (deferred reduction)
+    float* srstd = red + 2 * RSZ;                               // [B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, c16 = lane & 15;
@@ -118,22 +133,60 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
     const int KT = K / KS;                                       // k-steps of the whole row
     const int n_tasks = p.n_groups;
     const int G = gridDim.x, bid = blockIdx.x;
-    const int tq = n_tasks / G, tr = n_tasks % G;
-    const int t_lo = bid * tq + min(bid, tr), t_hi = t_lo + tq + (bid < tr ? 1 : 0);
     const int n_phase = (K + KC - 1) / KC;
+    // Work split.  A task's K range is KT8 = KT / 8 super-steps (one k-step per wave).  Plain split: whole tasks per block --
+    // 384 qkv tasks on 256 blocks means half the blocks stream twice as much as the others.  STREAM-K split (single K phase,
+    // n_tasks >= grid): every block owns the same number of super-steps of the linearised (task, super-step) sequence, so a
+    // task may straddle two consecutive blocks.  The block that holds the END of the task's K range (it is the first thing
+    // that block does) publishes its partial tile sums as data-tagged 8-byte granules {f32, tag} (agent-scope write-through
+    // stores, no flag, no fence); the block that holds the START adds them to its own sums, clears the granules for the next
+    // launch and runs the epilogue.  It takes that task just before its last whole task, so the wait (if any) and the
+    // granule round trip hide under the weight stream instead of sitting at the tail of the block.
+    // The launcher decides (sk_kt8 > 0: stream-K) and precomputes the per-block share q, r and the magic multiplier of the
+    // division by KT8, so the start-up path has no integer division.
+    const bool sk = p.sk_kt8 > 0;
+    const int KT8 = sk ? p.sk_kt8 : 1;
+    auto divk = [&](int n) { return (int)__umulhi((unsigned)n, p.sk_magic); };   // n / KT8, exact for n < 2^32 / KT8
+    const int u_lo = bid * p.sk_q + min(bid, p.sk_r);            // sk: super-step range; else task range
+    const int u_hi = u_lo + p.sk_q + (bid < p.sk_r ? 1 : 0);
+    const int t_first = sk ? divk(u_lo) : u_lo;
+    const int n_seg = u_hi <= u_lo ? 0 : (sk ? divk(u_hi - 1) - t_first + 1 : u_hi - u_lo);
+    const bool head_part = sk && u_lo != t_first * KT8, tail_part = sk && u_hi != divk(u_hi) * KT8;
+    // processing order: natural, except that a partial tail segment swaps places with the whole task before it
+    const bool swap_tail = n_seg >= 2 && tail_part && !(n_seg == 2 && head_part);
+    struct Seg { int t, gb, ge; };   // task, super-step range [gb, ge) of its K range
+    auto seg_of = [&](int i) {
+        Seg sg;
+        if (!sk) {
+            sg.t = min(u_lo + i, n_tasks - 1); sg.gb = 0; sg.ge = KT8;
+            return sg;
+        }
+        int j = i;
+        if (swap_tail) j = (i == n_seg - 2) ? n_seg - 1 : ((i == n_seg - 1) ? n_seg - 2 : i);
+        j = min(j, n_seg - 1);
+        sg.t = t_first + j;
+        sg.gb = (j == 0) ? u_lo - t_first * KT8 : 0;
+        sg.ge = min(KT8, u_hi - sg.t * KT8);
+        return sg;
+    };
     const u32x4_t* __restrict__ Wfm = (const u32x4_t*)p.W;
 
     // tile index (16-row units) of tile tt of task t
     auto tile_of = [&](int t, int tt) {
         if (MODE == MODE_QKV) {
-            const int per_head = p.head_dim / 16, halfb = per_head / 2;     // 8 tiles per head, 4 low + 4 high
-            const int hb = t / halfb, db = t - hb * halfb;
-            return hb * per_head + db + tt * halfb;
+            const int halfb = 1 << p.qk_shift;                               // head_dim / 32: 8 tiles per head, 4 low + 4 high
+            const int hb = t >> p.qk_shift, db = t & (halfb - 1);
+            return hb * 2 * halfb + db + tt * halfb;
         }
         return t * TILES + tt;
     };
     // this wave's k-step range inside phase ph
-    auto slice = [&](int ph, int& k_lo, int& k_n) {
+    auto slice = [&](const Seg& sg, int ph, int& k_lo, int& k_n) {
+        if (sk) {   // every wave takes (ge - gb) consecutive k-steps of the segment
+            k_n = sg.ge - sg.gb;
+            k_lo = sg.gb * GW + wave * k_n;
+            return;
+        }
         const int kt0 = ph * (KC / KS), ktn = min(KC, K - ph * KC) / KS;
         const int q = ktn / GW, r = ktn % GW;
         k_lo = kt0 + wave * q + min(wave, r);
@@ -144,16 +197,21 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
     // cursor runs exactly one block ahead of the consumer: right after the MFMAs of step u are issued, step u of the next
     // block is requested into the same registers (rolling ring, TILES*U KiB in flight per wave at every instant, across
     // task and phase boundaries and underneath the block barriers of the reduction).
-    struct Cursor { int t, ph, kb; };
+    struct Cursor { int i, ph, kb; Seg sg; };   // segment index (processing order), K phase, U-block; sg = seg_of(i)
     // block-uniform trip count: the longest k-slice of the phase
-    auto nkb_of = [&](int ph) {
+    auto nkb_of = [&](const Seg& sg, int ph) {
+        if (sk) return (sg.ge - sg.gb + U - 1) / U;
         const int ktn = min(KC, K - ph * KC) / KS;
         return (ktn / GW + (ktn % GW ? 1 : 0) + U - 1) / U;
     };
     auto advance = [&](Cursor& c) {
-        if (++c.kb >= nkb_of(c.ph)) {
+        if (++c.kb >= nkb_of(c.sg, c.ph)) {
             c.kb = 0;
-            if (++c.ph >= n_phase) { c.ph = 0; ++c.t; }
+            if (++c.ph >= n_phase) {
+                c.ph = 0;
+                ++c.i;
+                c.sg = seg_of(c.i);
+            }
         }
     };
     u32x4_t wr[TILES][U];
@@ -161,39 +219,55 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
     int p_n = 0;                   // producer: k-steps in its slice
     auto producer_setup = [&](const Cursor& c) {
         int k_lo;
-        slice(c.ph, k_lo, p_n);
-        const int t = min(c.t, t_hi - 1);
+        slice(c.sg, c.ph, k_lo, p_n);
 #pragma unroll
-        for (int tt = 0; tt < TILES; ++tt) wbase[tt] = Wfm + ((size_t)tile_of(t, tt) * KT + k_lo) * 64 + lane;
+        for (int tt = 0; tt < TILES; ++tt) wbase[tt] = Wfm + ((size_t)tile_of(c.sg.t, tt) * KT + k_lo) * 64 + lane;
     };
+    // UNCONDITIONAL loads (callers guarantee c.i < n_seg): a predicated load leaves hipcc's s_waitcnt bookkeeping one load
+    // short at the merge point, every MFMA then waits for vmcnt(0) -- i.e. for the refill issued one step earlier -- and the
+    // "ring" degenerates to one k-step in flight per wave (a latency-bound kernel: 0.84 us per step, 4.9 TB/s).  Steps past the
+    // end of the slice re-read its last step (an L2 hit) and are never consumed.
     auto issue_step = [&](const Cursor& c, int u) {
-        const int k = c.kb * U + u;
-        const bool ok = c.t < t_hi && k < p_n;
+        const int k = min(c.kb * U + u, p_n - 1);
 #pragma unroll
-        for (int tt = 0; tt < TILES; ++tt) wr[tt][u] = ok ? ld_nt(wbase[tt] + (size_t)k * 64) : (u32x4_t){0u, 0u, 0u, 0u};
+        for (int tt = 0; tt < TILES; ++tt) wr[tt][u] = ld_nt(wbase[tt] + (size_t)k * 64);
     };
 
-    Cursor P = {t_lo, 0, 0}, C = {t_lo, 0, 0};
-    if (t_lo < t_hi) {   // head of the stream before the prologue
+    if (n_seg == 0) return;   // grid <= n_groups: cannot happen; keeps the unconditional loads below in bounds
+    Cursor P = {0, 0, 0, seg_of(0)}, C = P;
+    // head of the stream: requested before the prologue computes anything -- but AFTER the prologue's own loads where those
+    // are a fixed handful (one-pass): loads return in order, so x queued behind 16 KiB of weights per wave would keep the
+    // whole prologue waiting for HBM
+    auto issue_head = [&]() {
         producer_setup(P);
 #pragma unroll
         for (int u = 0; u < U; ++u) issue_step(P, u);
         advance(P);
-    }
+    };
 
     // ---- prologue: x (B rows + one zero row) into LDS.  Every variant issues all of a thread's loads before the first
     // use: B sequential L2 round trips (one per row) used to cost 12-16 us of every launch at B = 8 ----
     // one pass (norm'd projections, K/8 <= 512): thread c keeps chunk c of every row in registers, the statistics come
     // from those registers and the normalised rows go straight to LDS
     const bool one_pass = NORM && !XATTN && n_phase == 1 && (K >> 3) <= NT;
+    if (!one_pass) issue_head();
     if (one_pass) {
-        __shared__ float rsum1[GW][EMMAX_MAX_DECODE_BATCH];
+        __shared__ __attribute__((aligned(16))) float rsum1[GW][EMMAX_MAX_DECODE_BATCH];
         const bool mine = tid < (K >> 3);
         u32x4_t xv[EMMAX_MAX_DECODE_BATCH];
-        const u32x4_t wv = mine ? *((const u32x4_t*)p.norm_w + tid) : (u32x4_t){0u, 0u, 0u, 0u};
+        // unconditional (clamped) loads, masked afterwards: hipcc can then count them and waits for exactly these nine loads
+        // -- behind predicated loads it waited for the whole first ring as well (the prologue ended when 32 MB of weights had
+        // landed, ~10 us into the launch, with HBM idle for half of that)
+        const int ct = min(tid, (K >> 3) - 1);
+        u32x4_t wv = *((const u32x4_t*)p.norm_w + ct);
 #pragma unroll
         for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b)
-            xv[b] = (mine && b < B) ? *((const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx) + tid) : (u32x4_t){0u, 0u, 0u, 0u};
+            xv[b] = *((const u32x4_t*)((const bf16_t*)p.x + (size_t)min(b, B - 1) * p.ldx) + ct);
+        issue_head();
+#pragma unroll
+        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[b][j] = (mine && b < B) ? xv[b][j] : 0u;
 #pragma unroll
         for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b) {
             float ss = 0.f;
@@ -206,13 +280,24 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
             if (lane == 0) rsum1[wave][b] = ss;
         }
         __syncthreads();
+        // the 8 x 8 wave partials as sixteen broadcast 16-byte LDS reads per thread (64 scalar reads cost ~2 us)
+        static_assert(EMMAX_MAX_DECODE_BATCH == 8, "row statistics are read as two float4 per wave");
+        float tot[EMMAX_MAX_DECODE_BATCH];
+#pragma unroll
+        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b) tot[b] = 0.f;
+#pragma unroll
+        for (int w = 0; w < GW; ++w) {
+            const f32x4_t lo = *(const f32x4_t*)&rsum1[w][0], hi = *(const f32x4_t*)&rsum1[w][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tot[j] += lo[j];
+                tot[4 + j] += hi[j];
+            }
+        }
 #pragma unroll
         for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b) {
             if (b < B && mine) {
-                float t = 0.f;
-#pragma unroll
-                for (int w = 0; w < GW; ++w) t += rsum1[w][b];
-                const float rs = rsqrtf(t / (float)K + p.eps);
+                const float rs = rsqrtf(tot[b] / (float)K + p.eps);
                 u32x4_t v = xv[b];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -302,62 +387,36 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
     if (!one_pass) stage_x(0);
     __syncthreads();
 
-    const int xrow = c16 < B ? c16 : B;   // padding columns of the 16-wide batch side read the zero row
     // LMHEAD: per-thread running best of the (row slot, batch) it finalises
     float best = -INFINITY;
     int besti = 0x7fffffff;
 
-    f32x4_t acc[TILES];
-#pragma unroll
-    for (int tt = 0; tt < TILES; ++tt) acc[tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    int c_n = 0;
-    const unsigned char* xb = smem;
-    while (C.t < t_hi) {
-        if (n_phase > 1 && C.kb == 0 && (C.ph != 0 || C.t != t_lo)) {   // new phase: restage x (the ring keeps flying)
-            __syncthreads();
-            stage_x(C.ph);
-            __syncthreads();
-        }
-        if (C.kb == 0) {
-            int k_lo;
-            slice(C.ph, k_lo, c_n);
-            xb = smem + (size_t)xrow * pitch + ((size_t)(k_lo - C.ph * (KC / KS)) * KS + g4 * 8) * 2;
-        }
-        if (P.kb == 0 && P.t < t_hi) producer_setup(P);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = C.kb * U + u;
-            if (k < c_n) {   // wave-uniform
-                const bf16x8_t xf = *(const bf16x8_t*)(xb + (size_t)k * (KS * 2));
-                if (FP8) {
-                    const bf16x8_t xf2 = *(const bf16x8_t*)(xb + (size_t)k * (KS * 2) + 64);
-#pragma unroll
-                    for (int tt = 0; tt < TILES; ++tt) {
-                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(wr[tt][u][0], wr[tt][u][1]), xf, acc[tt], 0, 0, 0);
-                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(wr[tt][u][2], wr[tt][u][3]), xf2, acc[tt], 0, 0, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int tt = 0; tt < TILES; ++tt)
-                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wr[tt][u]), xf, acc[tt], 0, 0, 0);
-                }
+    // ---- deferred cross-wave reduction + epilogue of a finished segment (waves 0-3; rb = its reduction buffer) ----
+    // Epilogue operands that have to be LOADED (RoPE cos / sin, the old residual value) are fetched when the segment's
+    // partial sums are written, one U-block before they are used; position and page id once per launch.
+    const int ec = tid & 15;   // batch column this thread finalises (tid < 256)
+    int pre_pos = 0, pre_pg = 0;
+    float pf_a = 0.f, pf_b = 0.f;
+    if (MODE == MODE_QKV && tid < 256 && ec < B) {
+        pre_pos = p.ctx_len[ec];
+        pre_pg = p.page_table[(size_t)ec * p.max_pages + pre_pos / p.page];
+    }
+    auto prefetch_epilogue = [&](const Seg& cs) {
+        if (tid >= 256 || ec >= B || cs.gb != 0) return;   // segments that only publish partial sums have no epilogue
+        const int row_in = 4 * ((tid & 63) >> 4) + (tid >> 6);
+        if (MODE == MODE_RESID) {
+            pf_a = bf2f(((const bf16_t*)p.y)[(size_t)ec * p.ldy + cs.t * 16 + row_in]);
+        } else if (MODE == MODE_QKV) {
+            const int half = p.head_dim >> 1;
+            const int hb = cs.t >> p.qk_shift, d = (cs.t & ((1 << p.qk_shift) - 1)) * 16 + row_in;
+            if (hb < p.Hq + p.Hkv) {
+                pf_a = p.cos_t[(size_t)pre_pos * half + d];
+                pf_b = p.sin_t[(size_t)pre_pos * half + d];
             }
-            issue_step(P, u);   // refill the registers just consumed with the same step of the next block
         }
-        const bool task_done = (C.ph == n_phase - 1) && (C.kb == nkb_of(C.ph) - 1);
-        const int t = C.t;
-        advance(C);
-        advance(P);
-        if (!task_done) continue;
-
-        // ---- cross-wave reduction: red[wave][tile][r][lane] ----
-#pragma unroll
-        for (int tt = 0; tt < TILES; ++tt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[((wave * TILES + tt) * 4 + r) * 64 + lane] = acc[tt][r];
-#pragma unroll
-        for (int tt = 0; tt < TILES; ++tt) acc[tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        __syncthreads();
+    };
+    auto reduce_epilogue = [&](const Seg& cs, const float* rb) {
+        const int t = cs.t;
         if (tid < 256) {
             const int l = tid & 63, r = tid >> 6;
             const int c = l & 15, row_in = 4 * (l >> 4) + r;       // batch column, row inside the tile
@@ -366,38 +425,66 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
             for (int tt = 0; tt < TILES; ++tt) {
                 float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < GW; ++w) s += red[((w * TILES + tt) * 4 + r) * 64 + l];
-                if (FP8) s *= p.wscale[tile_of(t, tt) * 16 + row_in];
+                for (int w = 0; w < GW; ++w) s += rb[((w * TILES + tt) * 4 + r) * 64 + l];
                 v[tt] = s;
             }
-            if (c < B) {
+            bool finalise = true;
+            if (sk && cs.ge - cs.gb < KT8) {   // a task shared with a neighbour block (see the work split above)
+                constexpr unsigned long long TAG = 0x7a6b5c4dull << 32;
+                if (cs.gb > 0) {   // END of the K range: publish, the previous block finalises
+                    unsigned long long* gr = p.sk_ws + ((size_t)(bid - 1) * TILES) * 256 + tid;
+#pragma unroll
+                    for (int tt = 0; tt < TILES; ++tt)
+                        __hip_atomic_store(gr + tt * 256, TAG | (unsigned long long)__float_as_uint(v[tt]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    finalise = false;
+                } else {           // START of the K range: add the next block's partial sums, clear the granules
+                    unsigned long long* gr = p.sk_ws + ((size_t)bid * TILES) * 256 + tid;
+#pragma unroll
+                    for (int tt = 0; tt < TILES; ++tt) {
+                        unsigned long long g = __hip_atomic_load(gr + tt * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        unsigned int spins = 0;
+                        while ((g & 0xffffffff00000000ull) != TAG) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (++spins > (1u << 22)) __builtin_trap();   // a broken hand-off must never become a silent wrong answer
+                            g = __hip_atomic_load(gr + tt * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        v[tt] += __uint_as_float((unsigned int)g);
+                        __hip_atomic_store(gr + tt * 256, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            if (FP8) {
+#pragma unroll
+                for (int tt = 0; tt < TILES; ++tt) v[tt] *= p.wscale[tile_of(t, tt) * 16 + row_in];
+            }
+            if (finalise && c < B) {
                 if (MODE == MODE_PLAIN) {
                     ((bf16_t*)p.y)[(size_t)c * p.ldy + t * 16 + row_in] = f2bf(v[0]);
                 } else if (MODE == MODE_RESID) {
                     bf16_t* hp = (bf16_t*)p.y + (size_t)c * p.ldy + t * 16 + row_in;
-                    *hp = f2bf(bf2f(*hp) + v[0]);
+                    *hp = f2bf(pf_a + v[0]);
                 } else if (MODE == MODE_GATEUP) {
                     ((bf16_t*)p.y)[(size_t)c * p.ldy + t * 16 + row_in] = f2bf(silu(v[0]) * v[TILES - 1]);
                 } else if (MODE == MODE_QKV) {
-                    const int hd = p.head_dim, half = hd >> 1, halfb = hd / 32;
-                    const int hb = t / halfb, d = (t - hb * halfb) * 16 + row_in;
-                    const int pos = p.ctx_len[c];
+                    const int hd = p.head_dim, half = hd >> 1;
+                    const int hb = t >> p.qk_shift, d = (t & ((1 << p.qk_shift) - 1)) * 16 + row_in;
+                    const int pos = pre_pos;
                     const float x0 = bf2f(f2bf(v[0])), x1 = bf2f(f2bf(v[TILES - 1]));
                     if (hb < p.Hq + p.Hkv) {
-                        const float cs = p.cos_t[(size_t)pos * half + d], sn = p.sin_t[(size_t)pos * half + d];
+                        const float cs = pf_a, sn = pf_b;
                         const bf16_t y0 = f2bf(x0 * cs - x1 * sn), y1 = f2bf(x1 * cs + x0 * sn);
                         if (hb < p.Hq) {
                             bf16_t* q = (bf16_t*)p.y + (size_t)c * p.ldy + hb * hd;
                             q[d] = y0;
                             q[d + half] = y1;
                         } else {
-                            const int pg = p.page_table[(size_t)c * p.max_pages + pos / p.page];
+                            const int pg = pre_pg;
                             bf16_t* kc = (bf16_t*)p.kcache + (((size_t)pg * p.Hkv + (hb - p.Hq)) * p.page + pos % p.page) * hd;
                             kc[d] = y0;
                             kc[d + half] = y1;
                         }
                     } else {
-                        const int pg = p.page_table[(size_t)c * p.max_pages + pos / p.page];
+                        const int pg = pre_pg;
                         bf16_t* vc = (bf16_t*)p.vcache + (((size_t)pg * p.Hkv + (hb - p.Hq - p.Hkv)) * p.page + pos % p.page) * hd;
                         vc[d] = f2bf(x0);
                         vc[d + half] = f2bf(x1);
@@ -414,10 +501,88 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
                 }
             }
         }
-        __syncthreads();   // red[] is reused by the next task
+    };
+
+    const int xrow = c16 < B ? c16 : B;   // padding columns of the 16-wide batch side read the zero row
+    f32x4_t acc[TILES];
+#pragma unroll
+    for (int tt = 0; tt < TILES; ++tt) acc[tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    int c_n = 0;
+    const unsigned char* xb = smem;
+    bool pend = false;
+    Seg pend_sg = {0, 0, 0};
+    int par = 0, pend_par = 0;
+    while (C.i < n_seg) {
+        if (n_phase > 1 && C.kb == 0 && (C.ph != 0 || C.i != 0)) {   // new phase: restage x (the ring keeps flying)
+            __syncthreads();
+            stage_x(C.ph);
+            __syncthreads();
+        }
+        if (C.kb == 0) {
+            int k_lo;
+            slice(C.sg, C.ph, k_lo, c_n);
+            xb = smem + (size_t)xrow * pitch + ((size_t)(k_lo - C.ph * (KC / KS)) * KS + g4 * 8) * 2;
+        }
+        if (P.kb == 0 && P.i < n_seg) producer_setup(P);
+        // one U-block: consume step u, then refill its registers with step u of the NEXT block (unconditionally -- the last
+        // block of the wave's work runs the copy of the loop without loads)
+        auto run_block = [&](auto refill_tag) {
+            constexpr bool REFILL = decltype(refill_tag)::value;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = C.kb * U + u;
+                if (k < c_n) {   // wave-uniform
+                    const bf16x8_t xf = *(const bf16x8_t*)(xb + (size_t)k * (KS * 2));
+                    if (FP8) {
+                        const bf16x8_t xf2 = *(const bf16x8_t*)(xb + (size_t)k * (KS * 2) + 64);
+#pragma unroll
+                        for (int tt = 0; tt < TILES; ++tt) {
+                            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(wr[tt][u][0], wr[tt][u][1]), xf, acc[tt], 0, 0, 0);
+                            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(wr[tt][u][2], wr[tt][u][3]), xf2, acc[tt], 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int tt = 0; tt < TILES; ++tt)
+                            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wr[tt][u]), xf, acc[tt], 0, 0, 0);
+                    }
+                }
+                if (REFILL) issue_step(P, u);
+            }
+        };
+        if (P.i < n_seg) run_block(std::true_type{}); else run_block(std::false_type{});
+        const bool task_done = (C.ph == n_phase - 1) && (C.kb == nkb_of(C.sg, C.ph) - 1);
+        const Seg cs = C.sg;
+        const int t = cs.t;
+        advance(C);
+        advance(P);
+        // ---- partial tile sums -> red[par][wave][tile][r][lane]; the cross-wave reduction and the epilogue run one U-block
+        // later (after the refills of the next segment are in flight): a barrier + epilogue right here kept every wave of the
+        // block from issuing loads for 0.7-2 us per task ----
+        if (pend) {
+            __syncthreads();
+            reduce_epilogue(pend_sg, red + pend_par * RSZ);
+            pend = false;
+        }
+        if (!task_done) continue;
+#pragma unroll
+        for (int tt = 0; tt < TILES; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[par * RSZ + ((wave * TILES + tt) * 4 + r) * 64 + lane] = acc[tt][r];
+#pragma unroll
+        for (int tt = 0; tt < TILES; ++tt) acc[tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        prefetch_epilogue(cs);
+        pend = true;
+        pend_sg = cs;
+        pend_par = par;
+        par ^= 1;
+    }
+    if (pend) {
+        __syncthreads();
+        reduce_epilogue(pend_sg, red + pend_par * RSZ);
     }
 
     if (MODE == MODE_LMHEAD) {
+        __syncthreads();                      // the last reduction has read red[]
         float* bv = red;                      // [256]
         int* bi = (int*)(red + 256);          // [256]
         if (tid < 256) {
@@ -452,11 +617,11 @@ int launch_repack_fm(const void* src, int ld, void* dst, int N, int K, hipStream
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-static size_t mfma_smem(int B, int kc, int tiles) { return (size_t)(B + 1) * (kc * 2 + 16) + (size_t)GW * tiles * 256 * 4 + 64; }
+static size_t mfma_smem(int B, int kc, int tiles) { return (size_t)(B + 1) * (kc * 2 + 16) + (size_t)2 * GW * tiles * 256 * 4 + 64; }
 
 // K phase length: multiple of 32, activations (B+1 rows) + reduction buffer within ~150 KiB
 static int mfma_kc(int B, int K, int tiles, int kstep) {
-    const size_t budget = 150 * 1024 - (size_t)GW * tiles * 256 * 4 - 64;
+    const size_t budget = 150 * 1024 - (size_t)2 * GW * tiles * 256 * 4 - 64;
     int cap = (int)(budget / (B + 1) - 16) / 2;
     cap = cap / kstep * kstep;
     if (K <= cap) return K;
@@ -479,6 +644,21 @@ static int launch_mfma_t(GemvParams p, int B, hipStream_t stream) {
     p.n_groups = p.n_rows / (16 * TILES);
     int grid = min(256, p.n_groups);
     if (MODE == MODE_LMHEAD) grid = min(grid, p.max_parts);
+    if (MODE == MODE_QKV) {
+        p.qk_shift = 0;
+        while ((32 << p.qk_shift) < p.head_dim) ++p.qk_shift;
+        if ((32 << p.qk_shift) != p.head_dim) return -1;   // head_dim / 32 must be a power of two
+    }
+    {   // work split (see the kernel): stream-K when it applies, whole tasks otherwise
+        const int KT = p.K / (FP8 ? 64 : 32);
+        const bool sk = p.sk_ws != nullptr && p.kc == p.K && KT % GW == 0 && KT / GW >= 2 && p.n_groups >= grid &&
+                        (long long)p.n_groups * KT < (1ll << 31) / (KT / GW);
+        p.sk_kt8 = sk ? KT / GW : 0;
+        const int total = sk ? p.n_groups * p.sk_kt8 : p.n_groups;
+        p.sk_q = total / grid;
+        p.sk_r = total % grid;
+        p.sk_magic = sk ? (unsigned)(((1ull << 32) + (unsigned)p.sk_kt8 - 1) / (unsigned)p.sk_kt8) : 0u;
+    }
     const size_t smem = mfma_smem(B, p.kc, TILES);
     hipLaunchKernelGGL((emmax_decode_mfma_kernel<MODE, NORM, XATTN, FP8>), dim3(grid), dim3(GW * 64), smem, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;

@@ -108,6 +108,10 @@ struct GemvParams {
     const float* attn_part;
     int nsplit;
     const float* wscale;    // MFMA path: per-row fp32 scales when W is the fp8 fragment-major copy (null: bf16 copy)
+    unsigned long long* sk_ws;   // MFMA path: stream-K granules [256 blocks][2 tiles][256] of {f32, tag} (null: whole tasks per block)
+    int sk_kt8, sk_q, sk_r;      // MFMA path, set by the launcher: super-steps per task (0: whole tasks), per-block share and remainder
+    unsigned int sk_magic;       // ... and ceil(2^32 / sk_kt8)
+    int qk_shift;                // MFMA QKV, set by the launcher: log2(head_dim / 32)
     int max_grid;           // 0: default persistent grid; chained launch caps it at 256 (two kernels co-resident)
     DepInfo dep;            // chained-launch hand-off (all null: plain stream ordering)
 };

@@ -238,6 +238,7 @@ struct emmax_session {
     int32_t *part_idx, *cur_tok, *ctx_len, *done, *n_out, *out_ids, *max_new_d /* [max_batch] */, *page_table;
     float* splitk_ws;           // fp32 partial tiles of split-K GEMMs (gemm.hip)
     int64_t splitk_bytes;
+    unsigned long long* sk_ws = nullptr;     // device: stream-K granules of the MFMA decode projections (decode_mfma.hip), all zero between launches
     int32_t *stop_ids /* [EMMAX_MAX_STOP_IDS] */, *stop_cfg /* {n_trigger, n_after} */, *stop_m, *stop_after;
     bool slots_open = false;    // slot serving mode: rows are independent request slots (emmax_slots_open)
     float *cos_t, *sin_t;
@@ -332,6 +333,7 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->stop_after = (int32_t*)b.take(Bd * 4);
     s->dep_ctr = (unsigned int*)b.take((256 * 64 + 16) * 4);
     s->page_table = (int32_t*)b.take((int64_t)Bd * s->max_pages * 4);
+    s->sk_ws = (unsigned long long*)b.take((int64_t)256 * 2 * 256 * 8);
     s->splitk_bytes = (int64_t)64 << 20;   // e.g. 4 slices of a 768 x 4096 prefill GEMM = 50 MB; smaller budgets just split less
     s->splitk_ws = (float*)b.take(s->splitk_bytes);
     s->cos_t = (float*)b.take((int64_t)s->max_ctx * (m->cfg.head_dim / 2) * 4);
@@ -417,6 +419,12 @@ static int run_vision(emmax_session* s, bool from_u8, const void* src, int B, vo
     return 0;
 }
 
+// tuning hook: EMMAX_STREAMK=0 gives every MFMA decode block whole tasks (the split before stream-K)
+static bool streamk_on() {
+    const char* e = getenv("EMMAX_STREAMK");
+    return !(e && atoi(e) == 0);
+}
+
 // B <= 2: per-lane dot-product GEMV over the row-major weights; B >= 3: MFMA over the fragment-major copy
 static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_fm, int B, hipStream_t st, int* grid_out = nullptr,
                        const float* w_scale = nullptr) {
@@ -462,6 +470,7 @@ static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* log
     emmax_model* m = s->m;
     GemvParams p;
     memset(&p, 0, sizeof(p));
+    p.sk_ws = streamk_on() ? s->sk_ws : nullptr;
     p.x = s->dh + (size_t)slot0 * m->H; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = m->final_norm; p.eps = m->cfg.rms_eps;
     p.n_rows = m->vocab; p.max_parts = s->n_lm_blocks; p.part_val = s->part_val; p.part_idx = s->part_idx; p.logits_out = logits_out;
     int lm_grid = 0;
@@ -565,6 +574,7 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
     const LayerW& L = m->layers[li];
     GemvParams p;
     memset(&p, 0, sizeof(p));
+    p.sk_ws = streamk_on() ? s->sk_ws : nullptr;
     int grid = 0;
     if (ch) st = ch->stream();
     auto arm = [&]() { if (ch) { p.dep = ch->dep(); p.max_grid = 256; } };
