@@ -118,8 +118,7 @@ __global__ __launch_bounds__(256) void emmax_attention_kernel(AttnParams p) {
                 st[t][r] = s;
                 m_tile = fmaxf(m_tile, s);
             }
-        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16, 64));
-        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+        m_tile = rows_max(m_tile);
         const float m_new = fmaxf(m_run, m_tile);
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = __expf(m_run - m_safe);   // m_run = -inf -> 0
@@ -132,8 +131,7 @@ __global__ __launch_bounds__(256) void emmax_attention_kernel(AttnParams p) {
                 st[t][r] = pv;
                 psum += pv;
             }
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
+        psum = rows_sum(psum);
         l_run = l_run * alpha + psum;
         m_run = m_new;
 #pragma unroll

@@ -43,6 +43,38 @@ __device__ __forceinline__ float dpp_move(float v) {
 __device__ __forceinline__ float lane_value(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
+// sum over the 16 lanes of each DPP row (lane >> 4), in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);   // row_half_mirror
+    v += dpp_move<0x140>(v);   // row_mirror
+    return v;
+}
+// exchange across the four rows (lanes with equal lane & 15) with the gfx950 swap instructions:
+//   v_permlane32_swap a, b: a.hi <-> b.lo   => with a = b = v:  a = {v.lo, v.lo}, b = {v.hi, v.hi}
+//   v_permlane16_swap a, b: odd rows of a <-> even rows of b
+// written as asm: the builtin form folded the two results into one register here (hipcc 7.2).
+__device__ __forceinline__ void swap_halves(float v, float& a, float& b) {
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap_rows(float v, float& a, float& b) {
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float rows_sum(float v) {
+    float a, b;
+    swap_halves(v, a, b);
+    swap_rows(a + b, a, b);
+    return a + b;
+}
+__device__ __forceinline__ float rows_max(float v) {
+    float a, b;
+    swap_halves(v, a, b);
+    swap_rows(fmaxf(a, b), a, b);
+    return fmaxf(a, b);
+}
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
     v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]

@@ -536,10 +536,7 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
                 s = dot2_bf16(kv[u][1], q[gq][1], s);
                 s = dot2_bf16(kv[u][2], q[gq][2], s);
                 s = dot2_bf16(kv[u][3], q[gq][3], s);
-                s += __shfl_xor(s, 1, 64);
-                s += __shfl_xor(s, 2, 64);
-                s += __shfl_xor(s, 4, 64);
-                s += __shfl_xor(s, 8, 64);
+                s = row16_sum(s);   // the 16 lanes of a key group are one DPP row
                 s = ok[u] ? s * p.scale : -INFINITY;
                 sc[u] = s;
                 mc = fmaxf(mc, s);
@@ -580,19 +577,14 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
     // ---- merge the 4 key groups of the wave (lanes with equal ch), then the 4 waves through LDS ----
 #pragma unroll
     for (int gq = 0; gq < G; ++gq) {
-        float mw = fmaxf(m[gq], __shfl_xor(m[gq], 16, 64));
-        mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
+        const float mw = rows_max(m[gq]);
         const float msafe = (mw == -INFINITY) ? 0.f : mw;
         const float f = __expf(m[gq] - msafe);
         // every lane of a 16-lane key group carries the same l: after the two exchanges each lane holds the wave sum
-        float lv = l[gq] * f;
-        lv += __shfl_xor(lv, 16, 64);
-        lv += __shfl_xor(lv, 32, 64);
+        const float lv = rows_sum(l[gq] * f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float v = o[gq][j] * f;
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
+            const float v = rows_sum(o[gq][j] * f);
             if (kg == 0) red_o[wave][gq][ch * 8 + j] = v;
         }
         if (lane == 0) {
