@@ -454,7 +454,7 @@ template <int HD, int G, bool COH = false>
 __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams p) {
     static_assert(HD == 128, "decode attention maps 16 lanes x 8 elements onto one 128-wide K/V row");
     constexpr int KU = G <= 2 ? 4 : 2;    // keys per lane group per chunk (block chunk = 16 * KU keys), two chunks in flight
-    constexpr int SP = 512;  // page ids kept in LDS; longer tables fall back to the global table
+    constexpr int SP = 512;  // page ids kept in LDS = the longest page table the launcher accepts (32 K tokens at 64 per page)
     __shared__ int s_pages[SP];
     __shared__ float red_o[4][G][HD];
     __shared__ float red_ml[4][G][2];
@@ -465,15 +465,23 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
     const int nsplit = gridDim.x;
     constexpr bool coh = COH;
     if (COH) dep_wait(p.dep);   // q, ctx_len and the freshly appended K/V row come from the kernels before
-    // one L2 round trip for everything that does not depend on the context length: the row's whole page table -> LDS
-    // (no dependent global load in front of the K/V loads), q, and the length itself
-    for (int i = tid; i < min(p.max_pages, SP); i += 256) s_pages[i] = p.page_table[(size_t)b * p.max_pages + i];
+    // ONE memory round trip for everything in front of the K/V loads: the context length and the done flag (scalar loads,
+    // requested first), the row's whole page table (<= SP entries, two per thread, kept in registers until all requests are
+    // out, then written to LDS) and q.  (A loop that waited for each table load, then a dependent scalar load for the length,
+    // then another for the flag cost three extra round trips -- half of this 7 us kernel.)
+    const int ctx_now = p.ctx_len[b];
+    const int row_done = p.done ? p.done[b] : 0;
+    const int32_t* ptab = p.page_table + (size_t)b * p.max_pages;
     // q (already rotated, bf16) for the G heads of this kv head: lane holds elements ch*8 .. +8
     u32x4_t q[G];
 #pragma unroll
     for (int gq = 0; gq < G; ++gq)
         q[gq] = ld_act16((const u32x4_t*)((const bf16_t*)p.q + (size_t)b * p.ldq + (hk * G + gq) * HD + ch * 8), coh);
-    const int L = p.ctx_len[b] + 1;                 // keys including the one appended by the qkv kernel of this step
+    const int pt0 = ptab[min(tid, p.max_pages - 1)], pt1 = ptab[min(tid + 256, p.max_pages - 1)];
+    __builtin_amdgcn_sched_barrier(0);   // every request above is out before the first wait (hipcc sinks the q load below the LDS write otherwise)
+    s_pages[tid] = pt0;
+    s_pages[tid + 256] = pt1;
+    const int L = ctx_now + 1;                      // keys including the one appended by the qkv kernel of this step
     int kps = (L + nsplit - 1) / nsplit;
     kps = (kps + 15) & ~15;
     const int k0 = split * kps;
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
     const int Hq = p.Hkv * G;
     float* part = p.part + ((size_t)(b * Hq + hk * G) * nsplit + split) * PSTRIDE;
 
-    if (k0 >= L || (p.done && p.done[b])) {   // empty split, or a row that no longer decodes: no K/V traffic
+    if (k0 >= L || row_done) {   // empty split, or a row that no longer decodes: no K/V traffic
         for (int i = tid; i < G * PSTRIDE; i += 256) {
             const int gq = i / PSTRIDE, j = i - gq * PSTRIDE;
             st_act_f32(part + (size_t)gq * nsplit * PSTRIDE + j, (j == HD) ? -INFINITY : 0.f, coh);
@@ -513,9 +521,11 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
             const int key = kb + u * 16 + wave * 4 + kg;
             ok[u] = key < k1;
             const int kk = ok[u] ? key : k0;
-            const int pi = kk / p.page;
-            const int pg = pi < SP ? s_pages[pi] : p.page_table[(size_t)b * p.max_pages + pi];
-            const size_t off = (((size_t)pg * p.Hkv + hk) * p.page + kk % p.page) * HD + ch * 8;
+            // the page id ALWAYS comes from LDS (the launcher rejects tables longer than SP): a select between the LDS copy and
+            // the global table became a FLAT load, whose wait (vmcnt(0) lgkmcnt(0)) also drained the K/V loads in flight --
+            // every key's lookup waited for the previous key's rows
+            const int pg = s_pages[kk >> p.page_shift];
+            const size_t off = ((((size_t)pg * p.Hkv + hk) << p.page_shift) + (kk & (p.page - 1))) * HD + ch * 8;
             kv[u] = *(const u32x4_t*)(kc + off);
             vv[u] = *(const u32x4_t*)(vc + off);
             if (coh && kk == L - 1) {   // the row appended by the qkv kernel of THIS step (one kernel back): agent-scope re-read
@@ -827,6 +837,9 @@ int decode_attn_nsplit(int B, int Hkv) {
 int launch_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_dim, int nsplit, hipStream_t stream) {
     if (head_dim != 128) return -1;
     DecodeAttnParams p = p_in;
+    if (p.max_pages < 1 || p.max_pages > 512 || p.page < 1 || (p.page & (p.page - 1))) return -1;   // table fits the kernel's LDS copy; page = 2^k
+    p.page_shift = 0;
+    while ((1 << p.page_shift) < p.page) ++p.page_shift;
     p.dep.n_blocks = (unsigned)(nsplit * p.Hkv * B);
     const int G = Hq / p.Hkv;
     dim3 grid(nsplit, p.Hkv, B), block(256);

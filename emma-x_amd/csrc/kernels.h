@@ -129,6 +129,7 @@ struct DecodeAttnParams {
     const int32_t* done;    // int32 [B] or null: finished / idle rows read no K/V (their partials are written empty)
     float* part;            // f32 [B][Hq][nsplit][132] = { o[128] un-normalised, m, l, pad }
     int ldq, Hkv, page, max_pages;
+    int page_shift;         // log2(page), set by the launcher
     float scale;
     DepInfo dep;
 };
