@@ -48,13 +48,14 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
     constexpr int U = 8;    // 16-byte loads per row per chunk (8 * 64 lanes * 8 elems = 4096 elements)
     constexpr int NT = GW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4_t* xs = (u32x4_t*)smem;   // [B][KC/8] 16-byte chunks
+    u32x4_t* xs = (u32x4_t*)smem;   // [B][KC/8 + 1] 16-byte chunks; chunk nch of a row is zero (lanes past the end of K read it)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bf16_t* __restrict__ W = (const bf16_t*)p.W;
     const int K = p.K;
     const int KC = p.kc;   // elements per K phase (multiple of 8)
     const bool multi_phase = KC < K;
+    const int XS = (KC >> 3) + 1;   // chunks per staged row
 
     // contiguous share of the groups for this block
     const int G = gridDim.x, bid = blockIdx.x;
@@ -108,14 +109,34 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
         wr[1][u] = ok ? ld_nt(w1p + ch) : (u32x4_t){0u, 0u, 0u, 0u};
     };
 
-    // ---- first block requested before the prologue: it does not depend on x ----
+    // ---- head of the weight stream: it does not depend on x.  UNCONDITIONAL loads (clamped addresses; lanes and waves past
+    // the end fetch a valid row again and meet the zero chunk of x), so that hipcc can count them: the prologue's own loads
+    // are requested FIRST where they are a fixed handful, and waited for with vmcnt(16) while the 64 MB first burst of the
+    // chip is still landing -- loads return in order, so x queued BEHIND the burst arrived ~10 us into the launch ----
     Cursor P = {0, 0, 0}, Cc = {0, 0, 0};
     const int my_rounds = (g_lo + wave < g_hi) ? (g_hi - g_lo - wave + GW - 1) / GW : 0;   // groups this wave really owns
-    producer_rows(P);
+    auto issue_head = [&](bool counted) {
+        producer_rows(P);
+        const int nch0 = phase_nch(0);
+        if (counted) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) issue_step(P, u, my_rounds > 0);
-    advance(P);
+            for (int u = 0; u < U; ++u) {
+                const int ch = min(u * 64 + lane, nch0 - 1);
+                wr[0][u] = ld_nt(w0p + ch);
+                wr[1][u] = ld_nt(w1p + ch);
+            }
+        } else {   // nothing is waited for by count behind these: the predicated form (it keeps hipcc's loop shape at B = 2)
+#pragma unroll
+            for (int u = 0; u < U; ++u) issue_step(P, u, my_rounds > 0);
+        }
+        advance(P);
+    };
     constexpr bool coh = COH;
+    const bool one_pass = NORM && !XATTN && !multi_phase && (K >> 3) <= NT;
+    // x first pays for the qkv projection only (-0.9 us); gate/up and lm-head lose 1.5 us with it, the plain rows of the down
+    // projection gain nothing.  The chained launch waits for its producer first, so there the stream always goes out ahead.
+    const bool head_first = COH || !(one_pass && MODE == MODE_QKV);
+    if (head_first) issue_head(false);
     if (COH) dep_wait(p.dep);   // everything below reads data of the previous kernel
 
     // ---- RMSNorm statistics ----
@@ -123,15 +144,19 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
     // single-pass prologue: when the whole row fits one 16-byte chunk per thread, x and the norm weight are read ONCE
     // (both loads issued together), the statistics come from registers and the normalised row goes straight to LDS --
     // one L2 round trip instead of two on the critical path of every qkv / gate-up / lm-head launch
-    const bool one_pass = NORM && !XATTN && !multi_phase && (K >> 3) <= NT;
     if (one_pass) {
         __shared__ float red1p[GW][B];
         const bool mine = tid < (K >> 3);
+        const int ct = min(tid, (K >> 3) - 1);
         u32x4_t xv[B];
-        const u32x4_t wv = mine ? *((const u32x4_t*)p.norm_w + tid) : (u32x4_t){0u, 0u, 0u, 0u};
+        const u32x4_t wv = *((const u32x4_t*)p.norm_w + ct);
+#pragma unroll
+        for (int b = 0; b < B; ++b) xv[b] = ld_act16((const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx) + ct, coh);
+        if (!head_first) issue_head(true);
 #pragma unroll
         for (int b = 0; b < B; ++b)
-            xv[b] = mine ? ld_act16((const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx) + tid, coh) : (u32x4_t){0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[b][j] = mine ? xv[b][j] : 0u;
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             float ss = 0.f;
@@ -158,8 +183,9 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
                     const float bb = bf2f(f2bf(bf_hi(v[j]) * rstd[b])) * bf_hi(wv[j]);
                     v[j] = pack_bf16x2(a, bb);
                 }
-                xs[b * (KC >> 3) + tid] = v;
+                xs[b * XS + tid] = v;
             }
+            if (tid == NT - 1) xs[b * XS + (K >> 3)] = (u32x4_t){0u, 0u, 0u, 0u};
         }
     } else if (NORM) {
         __shared__ float red[GW][B];
@@ -201,8 +227,9 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
                     for (int j = 0; j < 4; ++j) v[j] = (c0 + j * NT < nch) ? ld_act16(xr + c0 + j * NT, coh) : (u32x4_t){0u, 0u, 0u, 0u};
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (c0 + j * NT < nch) xs[b * (KC >> 3) + c0 + j * NT] = v[j];
+                        if (c0 + j * NT < nch) xs[b * XS + c0 + j * NT] = v[j];
                 }
+                if (tid == NT - 1) xs[b * XS + nch] = (u32x4_t){0u, 0u, 0u, 0u};
             }
             return;
         }
@@ -229,8 +256,9 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
                         v[j] = pack_bf16x2(a, bb);
                     }
                 }
-                xs[b * (KC >> 3) + c] = v;
+                xs[b * XS + c] = v;
             }
+            if (tid == NT - 1) xs[b * XS + nch] = (u32x4_t){0u, 0u, 0u, 0u};
         }
     };
     if (!one_pass) stage_x(0, phase_nch(0));
@@ -295,10 +323,10 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
         for (int u = 0; u < U; ++u) {
             const int c = Cc.blk * 64 * U + u * 64 + lane;
             if (valid && Cc.blk * 64 * U + u * 64 < nch) {   // wave-uniform
-                const int cc = (c < nch) ? c : 0;
+                const int cc = min(c, nch);   // past the end: the zero chunk
 #pragma unroll
                 for (int b = 0; b < B; ++b) {
-                    const u32x4_t xv = xs[b * (KC >> 3) + cc];
+                    const u32x4_t xv = xs[b * XS + cc];
 #pragma unroll
                     for (int r = 0; r < NR; ++r) {
                         float a = acc[r][b];
@@ -310,8 +338,12 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
                     }
                 }
             }
-            issue_step(P, u, p_active);   // refill the register just consumed with the same step of the next block
         }
+        // refill the whole block AFTER it is consumed: sixteen requests back to back (two rows x 8 KiB, consecutive addresses).
+        // This is the order hipcc picked by itself at B = 1 and it is the fast one -- the per-step interleaving it chose at
+        // B = 2 (refill of step u between the dot products of steps u and u+1, counted waits) is 2 us slower per gate/up launch
+#pragma unroll
+        for (int u = 0; u < U; ++u) issue_step(P, u, p_active);
         const bool group_done = (Cc.ph == n_phase - 1) && (Cc.blk == phase_nblk(Cc.ph) - 1);
         const int g = g_lo + Cc.rd * GW + wave;
         advance(Cc);
@@ -724,7 +756,7 @@ int decode_lmhead_grid(int B, int K, int n_rows, int max_parts, int max_grid) {
 
 template <int B, int MODE, bool NORM, bool XATTN = false>
 static int launch_gemv_t(const GemvParams& p, hipStream_t stream, int* grid_out) {
-    const size_t smem = (size_t)B * p.kc * 2;
+    const size_t smem = (size_t)B * (p.kc * 2 + 16);
     int grid = gemv_grid(B, smem, p.n_groups, p.max_grid);
     {   // tuning hook: EMMAX_GEMV_GRID="qkv,resid,gateup,lmhead,plain" (0 = default) overrides the persistent grid per mode
         static int forced[8] = {0, 0, 0, 0, 0, 0, 0, 0};
