@@ -229,12 +229,14 @@ __device__ __forceinline__ u32x4_t attn_merge_chunk(const float* __restrict__ pp
         }
 #pragma unroll
         for (int s = 0; s < GS; ++s) {
+            // explicit fma: the two merge variants (this one and the loop below) must round identically -- the chained launch
+            // uses the loop, the plain launch this one, and their logits are compared bit for bit
             const float wgt = (ms[s0 + s] == -INFINITY) ? 0.f : __expf(ms[s0 + s] - M);
-            den += dn[s0 + s] * wgt;
+            den = __builtin_fmaf(dn[s0 + s], wgt, den);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                a8[j] += o0[s][j] * wgt;
-                a8[4 + j] += o1[s][j] * wgt;
+                a8[j] = __builtin_fmaf(o0[s][j], wgt, a8[j]);
+                a8[4 + j] = __builtin_fmaf(o1[s][j], wgt, a8[4 + j]);
             }
         }
     }
@@ -253,13 +255,13 @@ __device__ __forceinline__ u32x4_t attn_merge_chunk_loop(const float* __restrict
     for (int s = 0; s < nsplit; ++s) {
         const float m = ld_act_f32(pp + s * EMMAX_PSTRIDE + 128, coh);
         const float wgt = (m == -INFINITY) ? 0.f : __expf(m - M);
-        den += ld_act_f32(pp + s * EMMAX_PSTRIDE + 129, coh) * wgt;
+        den = __builtin_fmaf(ld_act_f32(pp + s * EMMAX_PSTRIDE + 129, coh), wgt, den);
         const f32x4_t o0 = ld_act_f32x4(pp + s * EMMAX_PSTRIDE + d0, coh);
         const f32x4_t o1 = ld_act_f32x4(pp + s * EMMAX_PSTRIDE + d0 + 4, coh);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a8[j] += o0[j] * wgt;
-            a8[4 + j] += o1[j] * wgt;
+        for (int j = 0; j < 4; ++j) {   // explicit fma: see attn_merge_chunk
+            a8[j] = __builtin_fmaf(o0[j], wgt, a8[j]);
+            a8[4 + j] = __builtin_fmaf(o1[j], wgt, a8[4 + j]);
         }
     }
     const float inv = den > 0.f ? 1.0f / den : 0.f;

@@ -17,6 +17,7 @@
 // a split, log-sum-exp merge of the splits in a tiny combine kernel.
 // All step-varying state (positions, current tokens, done flags) is read from device memory -> hipGraph-capturable.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -135,7 +136,11 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
     const bool one_pass = NORM && !XATTN && !multi_phase && (K >> 3) <= NT;
     // x first pays for the qkv projection only (-0.9 us); gate/up and lm-head lose 1.5 us with it, the plain rows of the down
     // projection gain nothing.  The chained launch waits for its producer first, so there the stream always goes out ahead.
-    const bool head_first = COH || !(one_pass && MODE == MODE_QKV);
+    // The o-proj prologue (XATTN: merge of the attention split partials) also goes first: with every load of a chunk's merge
+    // requested up front (branch-free, split count as a template argument -- only affordable while the weight block is not
+    // occupying 64 registers) it is one round trip of ~1 us; as a loop BEHIND the weight stream it was sixteen dependent
+    // round trips, ~5 of the 11 us of the launch.
+    const bool head_first = COH || !((one_pass && MODE == MODE_QKV) || XATTN);
     if (head_first) issue_head(false);
     if (COH) dep_wait(p.dep);   // everything below reads data of the previous kernel
 
@@ -215,7 +220,8 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
     }
 
     // stage x[:, kc0 : kc0 + 8*nch] into LDS (normalised if NORM, merged from the attention partials if XATTN)
-    auto stage_x = [&](int kc0, int nch) {
+    auto stage_x = [&](int kc0, int nch, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;   // the call in front of the main loop (no weight block live yet)
         if (!XATTN && !NORM) {
             // plain rows (down projection: 22 KB per row): four loads in flight per thread, then the LDS writes
 #pragma unroll
@@ -231,6 +237,34 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
                 }
                 if (tid == NT - 1) xs[b * XS + nch] = (u32x4_t){0u, 0u, 0u, 0u};
             }
+            return;
+        }
+        if (XATTN && !COH) {
+            // chunk cg = head (cg>>4), elements (cg&15)*8..+8 of the split partials.  A thread's FIRST chunk is merged with
+            // every load in flight at once (needs ~60 registers: before the weight block exists); the weight stream is
+            // requested right behind it; any further chunk (K > 4096) takes the low-register loop.
+            auto merge_at = [&](int c, int b, bool fast) {
+                const int cg = (kc0 >> 3) + c;
+                const float* pp = p.attn_part + (size_t)(b * p.Hq + (cg >> 4)) * p.nsplit * PSTRIDE;
+                const int d0 = (cg & 15) * 8;
+                // 8 splits is what decode_attn_nsplit gives at batch 1-2 for every head count up to 32
+                return (fast && p.nsplit == 8) ? attn_merge_chunk<8, 4>(pp, d0) : attn_merge_chunk_loop(pp, d0, p.nsplit);
+            };
+            if (tid < nch) {
+#pragma unroll
+                for (int b = 0; b < B; ++b) xs[b * XS + tid] = merge_at(tid, b, FIRST);
+            }
+            if (FIRST) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_head(true);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (int c = tid + NT; c < nch; c += NT)
+#pragma unroll
+                for (int b = 0; b < B; ++b) xs[b * XS + c] = merge_at(c, b, false);
+            if (tid == NT - 1)
+#pragma unroll
+                for (int b = 0; b < B; ++b) xs[b * XS + nch] = (u32x4_t){0u, 0u, 0u, 0u};
             return;
         }
 #pragma unroll
@@ -261,7 +295,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
             if (tid == NT - 1) xs[b * XS + nch] = (u32x4_t){0u, 0u, 0u, 0u};
         }
     };
-    if (!one_pass) stage_x(0, phase_nch(0));
+    if (!one_pass) stage_x(0, phase_nch(0), std::true_type{});
     __syncthreads();
 
     // LMHEAD: running best over this wave's rows
@@ -313,7 +347,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
         if (Cc.blk == 0 && Cc.ph == 0) prefetch_epilogue(Cc.rd);
         if (multi_phase && Cc.blk == 0 && (Cc.rd != 0 || Cc.ph != 0)) {   // new phase: restage x (loads keep flying)
             __syncthreads();
-            stage_x(Cc.ph * KC, phase_nch(Cc.ph));
+            stage_x(Cc.ph * KC, phase_nch(Cc.ph), std::false_type{});
             __syncthreads();
         }
         const bool p_active = P.rd < my_rounds;
