@@ -183,10 +183,9 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
             if (mine) {
                 u32x4_t v = xv[b];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float a = bf2f(f2bf(bf_lo(v[j]) * rstd[b])) * bf_lo(wv[j]);
-                    const float bb = bf2f(f2bf(bf_hi(v[j]) * rstd[b])) * bf_hi(wv[j]);
-                    v[j] = pack_bf16x2(a, bb);
+                for (int j = 0; j < 4; ++j) {   // one v_cvt_pk_bf16_f32 per rounding of a pair
+                    const uint32_t r = pack_bf16x2(bf_lo(v[j]) * rstd[b], bf_hi(v[j]) * rstd[b]);
+                    v[j] = pack_bf16x2(bf_lo(r) * bf_lo(wv[j]), bf_hi(r) * bf_hi(wv[j]));
                 }
                 xs[b * XS + tid] = v;
             }

@@ -296,17 +296,17 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
         }
 #pragma unroll
         for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b) {
-            if (b < B && mine) {
+            if (b < B) {   // block-uniform: a scalar branch, no exec-mask juggling per row
                 const float rs = rsqrtf(tot[b] / (float)K + p.eps);
                 u32x4_t v = xv[b];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    // HF LlamaRMSNorm: fp32 normalise -> downcast -> * weight (-> downcast)
-                    const float a = bf2f(f2bf(bf_lo(v[j]) * rs)) * bf_lo(wv[j]);
-                    const float bb = bf2f(f2bf(bf_hi(v[j]) * rs)) * bf_hi(wv[j]);
-                    v[j] = pack_bf16x2(a, bb);
+                    // HF LlamaRMSNorm: fp32 normalise -> downcast -> * weight (-> downcast); both halves of a pair go
+                    // through ONE v_cvt_pk_bf16_f32 per rounding
+                    const uint32_t r = pack_bf16x2(bf_lo(v[j]) * rs, bf_hi(v[j]) * rs);
+                    v[j] = pack_bf16x2(bf_lo(r) * bf_lo(wv[j]), bf_hi(r) * bf_hi(wv[j]));
                 }
-                *(u32x4_t*)(smem + (size_t)b * pitch + (size_t)tid * 16) = v;
+                if (mine) *(u32x4_t*)(smem + (size_t)b * pitch + (size_t)tid * 16) = v;
             }
         }
         if (mine) *(u32x4_t*)(smem + (size_t)B * pitch + (size_t)tid * 16) = (u32x4_t){0u, 0u, 0u, 0u};
