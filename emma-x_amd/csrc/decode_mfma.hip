@@ -265,14 +265,12 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
             xv[b] = *((const u32x4_t*)((const bf16_t*)p.x + (size_t)min(b, B - 1) * p.ldx) + ct);
         issue_head();
 #pragma unroll
-        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xv[b][j] = (mine && b < B) ? xv[b][j] : 0u;
-#pragma unroll
         for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b) {
+            if (b >= B) break;   // block-uniform: rows the batch does not have cost nothing (fp8 runs this kernel at B = 1 too)
             float ss = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                xv[b][j] = mine ? xv[b][j] : 0u;
                 const float a = bf_lo(xv[b][j]), bb = bf_hi(xv[b][j]);
                 ss += a * a + bb * bb;
             }
