@@ -85,6 +85,26 @@ def test_fullsize_graph_equals_eager(device, big, monkeypatch):
     assert torch.equal(ids_g, ids_e) and torch.equal(lens_g, lens_e)
 
 
+def test_fullsize_graph_replay_on_the_mfma_streamk_path(device, big, monkeypatch):
+    """B = 4 at 7B shapes: the small-batch MFMA projections split their work stream-K (tasks straddle two blocks and meet
+    through tagged granules that the finishing block clears).  A captured step replays the same launches 40 times: if a
+    granule survived a launch, or a replay read one too early, the ids would leave the eager run's."""
+    cfg, model = big
+    frames, rows = _rows(cfg, [300, 64, 128, 33], [20, 33, 9, 28], seed=17)
+    fr = frames.to(device)
+    monkeypatch.setenv("EMMAX_GRAPH", "1")
+    _, ids_g, lens_g = model.generate_actions_batch(fr, rows, max_new_tokens=40)
+    assert model.engine.graph_active()
+    monkeypatch.setenv("EMMAX_GRAPH", "0")
+    _, ids_e, lens_e = model.generate_actions_batch(fr, rows, max_new_tokens=40)
+    assert not model.engine.graph_active()
+    assert torch.equal(ids_g, ids_e) and torch.equal(lens_g, lens_e)
+    monkeypatch.setenv("EMMAX_STREAMK", "0")                     # the whole-task split gives the same ids as well
+    model.engine.new_session(model.engine.max_batch, model.engine.max_prompt, model.engine.max_ctx)
+    _, ids_w, lens_w = model.generate_actions_batch(fr, rows, max_new_tokens=40)
+    assert torch.equal(ids_w, ids_e) and torch.equal(lens_w, lens_e)
+
+
 def test_fullsize_prefill_logits_consistent_with_decode_head(device, big):
     cfg, model = big
     frames, rows = _rows(cfg, [96], [3], seed=9)
