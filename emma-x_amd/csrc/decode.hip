@@ -535,7 +535,8 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
     // out, then written to LDS) and q.  (A loop that waited for each table load, then a dependent scalar load for the length,
     // then another for the flag cost three extra round trips -- half of this 7 us kernel.)
     const int ctx_now = p.ctx_len[b];
-    const int row_done = p.done ? p.done[b] : 0;
+    const int done_word = *(p.done ? p.done + b : p.ctx_len + b);   // always a load, never a branch with its own wait in front of
+    const int row_done = p.done ? done_word : 0;                  // the q / page-table requests
     const int32_t* ptab = p.page_table + (size_t)b * p.max_pages;
     // q (already rotated, bf16) for the G heads of this kv head: lane holds elements ch*8 .. +8
     u32x4_t q[G];
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
     s_pages[tid] = pt0;
     s_pages[tid + 256] = pt1;
     const int L = ctx_now + 1;                      // keys including the one appended by the qkv kernel of this step
-    int kps = (L + nsplit - 1) / nsplit;
+    int kps = (L + nsplit - 1) >> __builtin_ctz(nsplit);   // the split count is a power of two (launcher)
     kps = (kps + 15) & ~15;
     const int k0 = split * kps;
     const int k1 = min(L, k0 + kps);
@@ -891,7 +892,11 @@ int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, i
 // splits of the KV range per (row, kv head): ~512 blocks in flight, at most 8 partials to merge
 int decode_attn_nsplit(int B, int Hkv) {
     static const int forced = getenv("EMMAX_ATTN_NSPLIT") ? atoi(getenv("EMMAX_ATTN_NSPLIT")) : 0;   // tuning hook
-    if (forced > 0) return forced > 16 ? 16 : forced;
+    if (forced > 0) {   // rounded down to a power of two (the kernel divides by shifting)
+        int f = forced > 16 ? 16 : forced;
+        while (f & (f - 1)) f &= f - 1;
+        return f;
+    }
     int ns = 512 / (B * Hkv);
     if (ns < 1) ns = 1;
     if (ns > 8) ns = 8;
@@ -903,6 +908,7 @@ int launch_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_dim
     if (head_dim != 128) return -1;
     DecodeAttnParams p = p_in;
     if (p.max_pages < 1 || p.max_pages > 512 || p.page < 1 || (p.page & (p.page - 1))) return -1;   // table fits the kernel's LDS copy; page = 2^k
+    if (nsplit < 1 || (nsplit & (nsplit - 1))) return -1;   // the kernel divides the keys among the splits by shifting
     p.page_shift = 0;
     while ((1 << p.page_shift) < p.page) ++p.page_shift;
     p.dep.n_blocks = (unsigned)(nsplit * p.Hkv * B);
