@@ -34,9 +34,10 @@ constexpr int PSTRIDE = EMMAX_PSTRIDE;   // floats per attention split partial: 
 // GEMV.  Persistent blocks of 512 threads = 8 waves; block b owns a contiguous range of row GROUPS, its waves interleave
 // inside the range.  A group is 2 weight rows: (row d, row d+hd/2) of one head for QKV, (gate_i, up_i) for GATEUP, two
 // consecutive rows otherwise.  The activation prologue (RMSNorm / attention-split merge + staging into LDS) runs once
-// per block; a wave keeps 2 rows x 8 x 16 B of weights in flight, requests the head of its next group before reducing
-// the current one, and the very first request is issued before the prologue.  (tools/gemv_sweep.hip: this structure
-// streams 180 MB at ~6.1 TB/s, 97 % of a read-only kernel with the same access pattern.)
+// per block; a wave keeps one block of 2 rows x 8 x 16 B of weights in flight: the block is consumed, its successor (the
+// next 8 steps of the group, or the head of the next group) is requested, and only then is a finished group reduced;
+// the very first block is requested before the prologue (qkv / o-proj: right behind the prologue's own loads).
+// (tools/gemv_sweep.hip: this structure streams 180 MB at ~6.1 TB/s, 97 % of a read-only kernel with the same pattern.)
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int GW = 8;   // waves per GEMV block
 
@@ -81,8 +82,8 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
 
     // The wave's work is a linear sequence of 8-step blocks: for every round (group) x K phase x 512-chunk block.
     // A step = one 16-byte load per lane per row.  The producer cursor runs exactly one block ahead of the consumer:
-    // after step u of the current block is consumed, step u of the next block is requested into the same registers
-    // (rolling ring: ~16 loads per lane are in flight at every instant, across group and phase boundaries).
+    // once the current block is consumed, the next one is requested into the same registers (sixteen loads back to back),
+    // across group and phase boundaries.
     const int n_phase = (K + KC - 1) / KC;
     struct Cursor { int rd, ph, blk; };
     auto phase_nch = [&](int ph) { return min(KC, K - ph * KC) >> 3; };           // 16-byte chunks in a phase
