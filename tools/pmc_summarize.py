@@ -1,6 +1,6 @@
 """Turn the two rocprofv3 --pmc passes over tools/pmc_probe.py into per-launch HBM bytes per decode stage.
 
-usage: python tools/pmc_summarize.py FETCH_SIZE_counter_collection.csv WRITE_SIZE_counter_collection.csv out.json
+usage: python tools/pmc_summarize.py FETCH_SIZE_counter_collection.csv WRITE_SIZE_counter_collection.csv out.json [batch]
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE is doubled because gfx950 reports half of a wide
 coalesced stream (MI355X_MICROARCH.md, HBM / rocprofv3 section); the median over the profiled launches of a stage is used
 (the probe launches every stage a few times)."""
@@ -13,6 +13,10 @@ STAGE_OF = [  # (substring of the kernel name, stage)
     ("emmax_decode_gemv_kernel<1, 0,", "qkv_gemv"), ("emmax_decode_attn_kernel", "paged_attn"),
     ("emmax_decode_gemv_kernel<1, 1, false, true,", "oproj_gemv"), ("emmax_decode_gemv_kernel<1, 2,", "gateup_gemv"),
     ("emmax_decode_gemv_kernel<1, 1, false, false,", "down_gemv"), ("emmax_decode_gemv_kernel<1, 3,", "lmhead_argmax"),
+    # batch >= 3 (PROBE_BATCH=8): the MFMA small-batch kernel <MODE, NORM, XATTN, FP8>
+    ("emmax_decode_mfma_kernel<0,", "qkv_gemv"), ("emmax_decode_mfma_kernel<1, false, true,", "oproj_gemv"),
+    ("emmax_decode_mfma_kernel<2,", "gateup_gemv"), ("emmax_decode_mfma_kernel<1, false, false,", "down_gemv"),
+    ("emmax_decode_mfma_kernel<3,", "lmhead_argmax"),
 ]
 
 
@@ -33,7 +37,7 @@ def main():
     out = {"how": "rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --kernel-trace --kernel-include-regex emmax_decode "
                   "-- python tools/pmc_probe.py (B=1, context 768, full-size layer shapes). FETCH_SIZE doubled: on gfx950 it reports 1/2 of a "
                   "wide coalesced stream (MI355X_MICROARCH.md, HBM section); WRITE_SIZE taken as reported (uncalibrated).",
-           "batch": 1, "stages": {}}
+           "batch": int(sys.argv[4]) if len(sys.argv) > 4 else 1, "stages": {}}
     for stage in fetch:
         w = write.get(stage, 0.0)
         out["stages"][stage] = {"FETCH_SIZE_KB": round(fetch[stage], 1), "WRITE_SIZE_KB": round(w, 1),
