@@ -769,9 +769,18 @@ __global__ __launch_bounds__(256) void emmax_decode_finish_kernel(FinishParams p
     dep_signal(p.dep);
 }
 
-__global__ void emmax_set_tokens_kernel(int32_t* cur_tok, const int32_t* toks, int B) {
+// caller-supplied continuation (teacher forcing / the HF cached forward step): the row decodes again whatever the engine's own
+// greedy prediction was -- clear the done flag and the stop-rule state, lift the token budget
+__global__ void emmax_set_tokens_kernel(int32_t* cur_tok, const int32_t* toks, int B, int32_t* done, int32_t* stop_m, int32_t* stop_after,
+                                        int32_t* max_new, int budget) {
     const int i = threadIdx.x;
-    if (i < B) cur_tok[i] = toks[i];
+    if (i < B) {
+        cur_tok[i] = toks[i];
+        done[i] = 0;
+        stop_m[i] = 0;
+        stop_after[i] = -1;
+        max_new[i] = budget;
+    }
 }
 
 }  // namespace
@@ -935,7 +944,8 @@ int launch_decode_finish(const FinishParams& p_in, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-int launch_set_tokens(int32_t* cur_tok, const int32_t* toks, int B, hipStream_t stream) {
-    hipLaunchKernelGGL(emmax_set_tokens_kernel, dim3(1), dim3(64), 0, stream, cur_tok, toks, B);
+int launch_set_tokens(int32_t* cur_tok, const int32_t* toks, int B, int32_t* done, int32_t* stop_m, int32_t* stop_after, int32_t* max_new,
+                      int budget, hipStream_t stream) {
+    hipLaunchKernelGGL(emmax_set_tokens_kernel, dim3(1), dim3(64), 0, stream, cur_tok, toks, B, done, stop_m, stop_after, max_new, budget);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }

@@ -158,7 +158,8 @@ struct FinishParams {
     DepInfo dep;
 };
 int launch_decode_finish(const FinishParams& p, hipStream_t stream);
-int launch_set_tokens(int32_t* cur_tok, const int32_t* toks, int B, hipStream_t stream);
+int launch_set_tokens(int32_t* cur_tok, const int32_t* toks, int B, int32_t* done, int32_t* stop_m, int32_t* stop_after, int32_t* max_new,
+                      int budget, hipStream_t stream);
 
 
 // ---- decode_mfma.hip: small-batch (B >= 3) projections on MFMA over the fragment-major weight copy ----

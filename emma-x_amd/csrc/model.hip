@@ -248,6 +248,7 @@ struct emmax_session {
     int64_t kv_layer_stride;   // elements between layers; K at +0, V at +kv_layer_stride/2
     // host state
     int cur_B = 0, total_rows = 0, max_seqlen = 0, vision_B = 0;
+    int dec_steps = 0;          // decode steps issued since the last full prefill (upper bound of every row's context growth)
     bool prefilled = false;
     std::vector<int> S;         // per-row prefill lengths
     int32_t* pinned = nullptr;  // small pinned host buffer for control uploads / done read-backs
@@ -529,7 +530,7 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
     }
     if (total > s->max_rows) return fail(EMMAX_ERR_NOMEM, "packed prefill rows %d exceed capacity %d", total, s->max_rows);
     KCHK(launch_prefill_state(ps, s->cu, s->ctx_len + r0, s->done + r0, s->n_out + r0, s->max_new_d + r0, s->stop_m + r0, s->stop_after + r0, st));
-    if (!slot_mode) s->cur_B = B;
+    if (!slot_mode) { s->cur_B = B; s->dec_steps = 0; }
     s->total_rows = total; s->max_seqlen = maxS;
 
     KCHK(launch_embed_splice(ids, P_max, s->cu, m->embed, patches, s->ph, B, maxS, np, m->H, m->vocab, st));
@@ -1043,16 +1044,37 @@ int emmax_last_logits(emmax_session* s, float* out, emmax_stream stream) {
     return run_lm_head_step(s, s->cur_B, false, out, false, (hipStream_t)stream);
 }
 
-int emmax_decode_step(emmax_session* s, emmax_stream st) {
+// the legacy / per-thread default streams cannot be captured: graph replays run on the session's own stream, ordered after
+// everything already queued on the caller's stream (enter) and before anything queued on it afterwards (leave)
+static int slot_enter(emmax_session* s, hipStream_t user, hipStream_t* st);
+static int slot_leave(emmax_session* s, hipStream_t user, hipStream_t st);
+
+int emmax_decode_step(emmax_session* s, emmax_stream stream) {
     if (!s) return fail(EMMAX_ERR_INVALID, "null argument");
     if (!s->prefilled) return fail(EMMAX_ERR_STATE, "decode before prefill");
-    return run_decode_step(s, s->cur_B, (hipStream_t)st);
+    s->dec_steps += 1;
+    const char* e = getenv("EMMAX_GRAPH");
+    if (e && atoi(e) != 0) {   // EMMAX_GRAPH=1: the step is a replay of the captured hipGraph (as in emmax_generate / emmax_slots_step)
+        hipStream_t user = (hipStream_t)stream, st;
+        int r = slot_enter(s, user, &st);
+        if (r) return r;
+        r = ensure_graph(s, s->cur_B, st) == 0 ? launch_graph_step(s, s->cur_B, st) : run_decode_step(s, s->cur_B, st);
+        if (r) return r;
+        return slot_leave(s, user, st);
+    }
+    drop_graph(s);   // eager mode: emmax_session_graph_active() reports what the steps really do
+    return run_decode_step(s, s->cur_B, (hipStream_t)stream);
 }
 
 int emmax_set_current_tokens(emmax_session* s, const int32_t* toks, emmax_stream st) {
     if (!s || !toks) return fail(EMMAX_ERR_INVALID, "null argument");
     if (!s->prefilled) return fail(EMMAX_ERR_STATE, "no active sequences");
-    KCHK(launch_set_tokens(s->cur_tok, toks, s->cur_B, (hipStream_t)st));
+    // the rows decode again (done flag cleared): the next step appends at position <= S_b + dec_steps, which must exist
+    int maxS = 0;
+    for (int b = 0; b < s->cur_B && b < (int)s->S.size(); ++b) maxS = std::max(maxS, s->S[b]);
+    if (maxS + s->dec_steps + 1 >= s->max_ctx)
+        return fail(EMMAX_ERR_NOMEM, "context %d + 1 reaches max_ctx %d: no room to decode a caller-supplied token", maxS + s->dec_steps, s->max_ctx);
+    KCHK(launch_set_tokens(s->cur_tok, toks, s->cur_B, s->done, s->stop_m, s->stop_after, s->max_new_d, s->max_out, (hipStream_t)st));
     return 0;
 }
 
@@ -1076,6 +1098,7 @@ int emmax_generate(emmax_session* s, int max_new, int stop_on_eos, int32_t* out_
     int32_t* done_host = s->pinned;
     bool pending = false;
     for (int i = 1; i < max_new; ++i) {
+        s->dec_steps += 1;
         if (use_graph) {
             int r = launch_graph_step(s, B, st);
             if (r) return r;
@@ -1309,6 +1332,22 @@ int emmax_op_attention(const void* qkv, int ld_qkv, int q_off, int k_off, int v_
     a.ld_out = ld_out; a.B = B; a.max_seqlen = max_seqlen; a.Hq = Hq; a.Hkv = Hkv; a.scale = scale; a.causal = causal;
     int r = launch_attention(a, head_dim, (hipStream_t)st);
     if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_attention: unsupported head_dim/strides");
+    return 0;
+}
+int emmax_op_decode_attention(const void* q, const void* kcache, const void* vcache, const int32_t* page_table, const int32_t* ctx_len,
+                              const int32_t* done, float* part_out, int B, int Hq, int Hkv, int page, int max_pages, int nsplit, float scale,
+                              int* nsplit_out, emmax_stream st) {
+    if (!q || !kcache || !vcache || !page_table || !ctx_len || !part_out) return fail(EMMAX_ERR_INVALID, "emmax_op_decode_attention: null argument");
+    if (B < 1 || B > EMMAX_MAX_DECODE_BATCH || Hkv < 1 || Hq % Hkv) return fail(EMMAX_ERR_INVALID, "emmax_op_decode_attention: bad B / heads");
+    DecodeAttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.q = q; a.ldq = Hq * 128; a.kcache = kcache; a.vcache = vcache; a.page_table = page_table; a.ctx_len = ctx_len; a.done = done;
+    a.part = part_out; a.Hkv = Hkv; a.page = page; a.max_pages = max_pages; a.scale = scale;
+    const int ns = nsplit > 0 ? nsplit : decode_attn_nsplit(B, Hkv);
+    if (nsplit_out) *nsplit_out = ns;
+    if (ns > 16) return fail(EMMAX_ERR_INVALID, "emmax_op_decode_attention: nsplit %d > 16", ns);
+    int r = launch_decode_attn(a, B, Hq, 128, ns, (hipStream_t)st);
+    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_decode_attention: unsupported (GQA group in {1,2,4,8}, page = 2^k, max_pages <= 512, nsplit = 2^k)");
     return 0;
 }
 int emmax_op_gemv(const void* x, const void* W, void* y, int B, int N, int K, emmax_stream st) {

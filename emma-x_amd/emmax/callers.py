@@ -50,5 +50,9 @@ def get_seq_action(vla, processor, base_vla_name, obs, task_label, unnorm_key, t
     builder = vla.get_prompt_builder()
     builder.add_turn(role="human", message=task_label)
     prompt = builder.get_prompt()
-    return vla.generate_actions(image, prompt, type, tokenizer=processor.tokenizer, temperature=0.0, max_new_tokens=512,
-                                min_length=1, do_sample=False)
+    if getattr(vla, "tokenizer", None) is None:   # a checkpoint directory without tokenizer files: share the processor's
+        vla.tokenizer = processor.tokenizer
+    # the reference's call, verbatim (experiments/robot/openvla_utils.py:215-217)
+    return vla.generate_actions(
+        image=image, prompt_text=prompt, type=type, temperature=0.0, max_new_tokens=512, min_length=1, do_sample=False
+    )

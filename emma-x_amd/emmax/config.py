@@ -114,7 +114,9 @@ class EmmaXConfig:
         dino = TowerConfig("vit_large_patch14_reg4_dinov2.lvd142m", 1024, 24, 16, 4096, n_reg=4, has_cls=True,
                            layerscale=True, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225))
         siglip = TowerConfig("vit_so400m_patch14_siglip_224", 1152, 27, 16, 4304)
-        return EmmaXConfig([dino, siglip], LlmConfig(), norm_stats=norm_stats or default_norm_stats())
+        # norm_stats=None -> EMPTY: `_check_unnorm_key` then raises instead of un-normalising with invented statistics; only the
+        # synthetic factories (`from_synthetic`, `tiny`) install `default_norm_stats()`
+        return EmmaXConfig([dino, siglip], LlmConfig(), norm_stats=norm_stats if norm_stats is not None else {})
 
     @staticmethod
     def tiny(gqa: bool = False, norm_stats: Optional[Dict[str, Any]] = None) -> "EmmaXConfig":
@@ -159,6 +161,15 @@ class EmmaXConfig:
         cfg.arch_specifier = d.get("arch_specifier", cfg.arch_specifier)
         cfg.image_resize_strategy = d.get("image_resize_strategy", cfg.image_resize_strategy)
         return cfg
+
+    @staticmethod
+    def from_native_dict(d: Dict[str, Any]) -> "EmmaXConfig":
+        """`config.json` of a native Prismatic run directory (prismatic/models/load.py:176-179: {"vla": {"base_vlm": ...}}): the
+        Emma-X hot path is the `prism-dinosiglip-224px+7b` family only (prismatic/conf/models.py:491-497)."""
+        base = (d.get("vla") or {}).get("base_vlm") or (d.get("model") or {}).get("model_id") or ""
+        if base and "dinosiglip-224px" not in base:
+            raise ValueError(f"base VLM `{base}` is outside the Emma-X-7B hot path (only prism-dinosiglip-224px+7b)")
+        return EmmaXConfig.emma_x_7b(norm_stats={})
 
     @staticmethod
     def from_pretrained(path: str) -> "EmmaXConfig":

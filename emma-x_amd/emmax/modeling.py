@@ -23,14 +23,25 @@ import numpy as np
 import torch
 
 from .actions import ActionTokenizer, token_ids_to_actions, unnormalize
-from .config import EmmaXConfig
+from .config import EmmaXConfig, default_norm_stats
 from .engine import EmmaxEngine
 from .policy_parser import Solver
 from .processing import BatchFeature, EmmaXImageProcessor
 from .prompting import PurePromptBuilder
+from .tokenizer_stub import StubTokenizer
 from .weights import load_hf_state_dict, remap_native_state_dict, synthetic_state_dict, validate_state_dict
 
 PREFIX_TOKEN_ID = 29871   # '▁' appended before action tokens (modeling_prismatic.py:513-516)
+
+
+def load_tokenizer(path: Optional[str], cfg: EmmaXConfig):
+    """The LLaMA-2 tokenizer of a checkpoint directory (tokenizer.json / tokenizer.model), right-padded, capped at
+    llm_max_length (prismatic/models/backbones/llm/base_llm.py:146-171); None when the directory holds no tokenizer files."""
+    if path and any(os.path.isfile(os.path.join(path, f)) for f in ("tokenizer.json", "tokenizer.model")):
+        from transformers import AutoTokenizer   # host side only
+
+        return AutoTokenizer.from_pretrained(path, model_max_length=cfg.llm.max_position, padding_side="right")
+    return None
 
 
 @dataclass
@@ -67,6 +78,8 @@ class EmmaXForActionPrediction:
         self.dtype = torch.bfloat16
         self.training = False
         self.image_transform = EmmaXImageProcessor(config)
+        self.tokenizer = None          # set by from_pretrained / from_synthetic, or assign one (`model.tokenizer = ...`)
+        self.cache_reserve = 512       # KV room reserved behind a `forward(use_cache=True)` prefill for cached steps
 
     # ------------------------------------------------------------------------------------------------------------------
     # construction
@@ -74,28 +87,55 @@ class EmmaXForActionPrediction:
     @classmethod
     def from_pretrained(cls, path: str, torch_dtype: torch.dtype = torch.bfloat16, attn_implementation: Optional[str] = None,
                         low_cpu_mem_usage: bool = True, trust_remote_code: bool = True, load_in_8bit: bool = False,
-                        load_in_4bit: bool = False, **_) -> "EmmaXForActionPrediction":
-        """HF directory (config.json + *.safetensors [+ dataset_statistics.json]) or a native Prismatic `.pt` file."""
+                        load_in_4bit: bool = False, dtype: Optional[torch.dtype] = None, **_) -> "EmmaXForActionPrediction":
+        """HF directory (config.json + *.safetensors [+ dataset_statistics.json]) or a native Prismatic `.pt` file.
+        (`dtype=` is the transformers >= 5 spelling of `torch_dtype=`; `config=` passed by the Auto classes is ignored: the
+        directory is re-read through EmmaXConfig.from_pretrained.)"""
         if load_in_8bit or load_in_4bit:
             raise NotImplementedError("bitsandbytes quantised loading is outside the MI355X hot path")
-        if torch_dtype not in (torch.bfloat16, None):
+        torch_dtype = dtype if dtype is not None else torch_dtype
+        if torch_dtype not in (torch.bfloat16, None, "bfloat16", "auto"):
             raise ValueError("the MI355X path computes in bf16 (fp32 accumulate); pass torch_dtype=torch.bfloat16")
+        path = str(path)
         if os.path.isfile(path) and path.endswith(".pt"):
-            cfg = EmmaXConfig.emma_x_7b()
+            # native Prismatic checkpoint `<run_dir>/checkpoints/<step>.pt` (prismatic/models/load.py:133-144): the run directory
+            # must hold `config.json` and `dataset_statistics.json` -- the reference asserts both, and so do we (no made-up
+            # un-normalisation statistics, ADVICE r01)
+            ckpt_dir = os.path.dirname(os.path.abspath(path))
+            if os.path.basename(ckpt_dir) != "checkpoints":
+                raise ValueError(f"Invalid checkpoint! expected `<run_dir>/checkpoints/<name>.pt`, got {path}")
+            run_dir = os.path.dirname(ckpt_dir)
+            cfg_json, stats_json = os.path.join(run_dir, "config.json"), os.path.join(run_dir, "dataset_statistics.json")
+            if not os.path.isfile(cfg_json):
+                raise FileNotFoundError(f"Missing `config.json` for run_dir = {run_dir}")
+            if not os.path.isfile(stats_json):
+                raise FileNotFoundError(f"Missing `dataset_statistics.json` for run_dir = {run_dir}")
+            with open(cfg_json) as f:
+                raw = json.load(f)
+            cfg = EmmaXConfig.from_native_dict(raw)
+            with open(stats_json) as f:
+                cfg.norm_stats = json.load(f)
             sd = remap_native_state_dict(torch.load(path, map_location="cpu")["model"])
+            tok_dir = run_dir
         else:
             cfg = EmmaXConfig.from_pretrained(path)
             sd = load_hf_state_dict(path)
+            tok_dir = path
         validate_state_dict(sd, cfg)
-        return cls(cfg, sd)
+        model = cls(cfg, sd)
+        model.tokenizer = load_tokenizer(tok_dir, cfg)   # the native class owns its tokenizer (prismatic.py:630); None if no files
+        return model
 
     @classmethod
     def from_synthetic(cls, config: Optional[EmmaXConfig] = None, seed: int = 0, device: str = "cuda:0", planted: bool = False,
                        **engine_kw) -> "EmmaXForActionPrediction":
         """Random-init weights with the real names/shapes, generated directly on `device` (no checkpoint offline)."""
         config = config or EmmaXConfig.emma_x_7b()
+        if not config.norm_stats:   # synthetic weights come with synthetic (made-up) statistics; a checkpoint never does
+            config.norm_stats = default_norm_stats()
         sd = synthetic_state_dict(config, seed=seed, device=device, dtype=torch.bfloat16, planted=planted)
         m = cls(config, sd)
+        m.tokenizer = StubTokenizer()
         return m.to(device, **engine_kw)
 
     def to(self, device: Union[str, torch.device], max_batch: int = 1, max_prompt: int = 512,
@@ -166,8 +206,12 @@ class EmmaXForActionPrediction:
         return [list(map(int, r)) for r in input_ids]
 
     def _encode_images(self, pixel_values=None, frames_u8=None) -> torch.Tensor:
+        """`pixel_values` is the model input (reference contract).  `frames_u8` (the uint8 frame the processor ALSO emits) is
+        only a faster route to the same numbers -- normalisation fused into the patch gather -- and is used when it is given
+        alone, or when the caller's `pixel_values` still carries the processor's tag for that very frame (an augmented /
+        re-cropped `pixel_values` tensor is a new object without the tag and is what gets encoded)."""
         eng = self._need_engine()
-        if frames_u8 is not None:
+        if frames_u8 is not None and (pixel_values is None or getattr(pixel_values, "_emmax_frames_tag", None) is getattr(frames_u8, "_emmax_frames_tag", 0)):
             return eng.vision_encode(frames_u8.to(self.device).contiguous())
         if isinstance(pixel_values, dict):   # native layout {"dino": [B,3,H,W], "siglip": [B,3,H,W]}
             pixel_values = torch.cat([pixel_values["dino"], pixel_values["siglip"]], dim=1)
@@ -176,7 +220,8 @@ class EmmaXForActionPrediction:
     def _prefill(self, rows: List[List[int]], pixel_values=None, frames_u8=None, max_new: int = 0) -> torch.Tensor:
         eng = self._need_engine()
         B = len(rows)
-        nimg = frames_u8.shape[0] if frames_u8 is not None else (pixel_values["dino"].shape[0] if isinstance(pixel_values, dict) else pixel_values.shape[0])
+        src = pixel_values if pixel_values is not None else frames_u8
+        nimg = src["dino"].shape[0] if isinstance(src, dict) else src.shape[0]
         if nimg != B:
             raise ValueError("Non-homogenous batch of (text, image) input -- forward() does not support mixed batches!")
         P = max(len(r) for r in rows)
@@ -213,13 +258,13 @@ class EmmaXForActionPrediction:
         if pixel_values is None and frames_u8 is None:
             # unimodal forward (modeling_prismatic.py:343-359): text only, no patch rows
             assert past_key_values is None, "Unexpected key `past_key_values` provided during language-only forward!"
-            eng.ensure_capacity(len(rows), max(len(r) for r in rows), 1)
+            eng.ensure_capacity(len(rows), max(len(r) for r in rows), self.cache_reserve if use_cache else 1)
             eng.prefill(rows, None)
             per_row = eng.prefill_logits()
             same = len({t.shape[0] for t in per_row}) == 1
             return EmmaXCausalLMOutputWithPast(logits=torch.stack(per_row) if same else per_row,
                                                past_key_values=KVHandle(eng, eng._last_S) if use_cache else None)
-        patches = self._prefill(rows, pixel_values, frames_u8)
+        patches = self._prefill(rows, pixel_values, frames_u8, max_new=self.cache_reserve if use_cache else 0)
         per_row = eng.prefill_logits()
         same = len({t.shape[0] for t in per_row}) == 1
         logits = torch.stack(per_row) if same else per_row
@@ -237,16 +282,30 @@ class EmmaXForActionPrediction:
         self._prefill(rows, pixel_values, frames_u8, max_new=max_new_tokens)
         return eng.generate(max_new_tokens, stop_on_eos)
 
+    def _max_new(self, rows, max_new_tokens, max_length, min_length, had_max_new: bool = True) -> int:
+        """HF length semantics: `max_length` counts the PROMPT too (as HF counts it: the text ids, not the patch rows) and only
+        applies when `max_new_tokens` is not given; `min_length` (total length, HF default 0) above the prompt length would
+        suppress EOS -- outside the greedy hot path, so it raises instead of being ignored."""
+        plen = max(len(r) for r in rows)
+        if min_length is not None and int(min_length) > plen + 1:
+            raise NotImplementedError(f"min_length={min_length} beyond the prompt ({plen} ids) needs EOS suppression, outside the hot path")
+        if max_new_tokens is None:
+            if max_length is None:
+                max_new_tokens = 20       # HF GenerationConfig default max_length=20 is a total; keep the historical default here
+            else:
+                max_new_tokens = max(int(max_length) - plen, 1)
+        return int(max_new_tokens)
+
     @torch.inference_mode()
-    def generate(self, input_ids=None, pixel_values=None, attention_mask=None, max_new_tokens: int = 20, do_sample: bool = False,
+    def generate(self, input_ids=None, pixel_values=None, attention_mask=None, max_new_tokens: Optional[int] = None, do_sample: bool = False,
                  min_length: int = 1, temperature: float = 0.0, frames_u8=None, **kwargs) -> torch.Tensor:
         """HF-style: returns LongTensor [B, P + T] = prompt ++ generated (right-padded with pad_token_id)."""
         if do_sample:
             raise NotImplementedError("only greedy decoding (do_sample=False) is on the hot path")
         if kwargs.get("num_beams", 1) != 1:
             raise NotImplementedError("beam search is outside the hot path")
-        max_new_tokens = int(kwargs.get("max_length", 0) or max_new_tokens)
         rows = self._rows(input_ids, attention_mask)
+        max_new_tokens = self._max_new(rows, max_new_tokens, kwargs.get("max_length"), min_length)
         new_ids, lens = self.generate_ids(rows, pixel_values, frames_u8, max_new_tokens)
         new_ids, lens = new_ids.cpu(), lens.cpu().tolist()
         T = max(lens)
@@ -296,34 +355,61 @@ class EmmaXForActionPrediction:
 
     @torch.inference_mode()
     def generate_actions(self, *args, **kwargs):
-        """Two call forms:
+        """Two call forms, positional or by keyword:
           README   generate_actions(inputs, tokenizer, do_sample=False, max_new_tokens=512) -> (action[7], reasoning)
-          native   generate_actions(image, prompt_text, type, **kw) -> (list of action[7] | proprio, generated_text)
+          native   generate_actions(image, prompt_text, type, **generate_kwargs) -> (list of action[7] | proprio, generated_text)
+                   (prismatic/models/vlms/prismatic.py:628; called as `vla.generate_actions(image=image, prompt_text=prompt,
+                   type=type, temperature=0.0, max_new_tokens=512, min_length=1, do_sample=False)` by
+                   experiments/robot/openvla_utils.py:215-217).  The tokenizer is the model's own (`self.tokenizer`, attached by
+                   from_pretrained like the reference's `llm_backbone.tokenizer`); `tokenizer=` overrides it.
         """
-        if args and isinstance(args[0], dict):
-            inputs, tokenizer = args[0], (args[1] if len(args) > 1 else kwargs.pop("tokenizer"))
-            if kwargs.get("do_sample", False):
-                raise NotImplementedError("only greedy decoding (do_sample=False) is on the hot path")
+        args = list(args)
+        inputs = kwargs.pop("inputs", None)
+        if inputs is None and args and isinstance(args[0], dict):
+            inputs = args.pop(0)
+        if kwargs.get("do_sample", False):
+            raise NotImplementedError("only greedy decoding (do_sample=False) is on the hot path")
+        if kwargs.get("num_beams", 1) != 1:
+            raise NotImplementedError("beam search is outside the hot path")
+        if inputs is not None:   # README form
+            tokenizer = args.pop(0) if args else kwargs.pop("tokenizer", None)
+            tokenizer = tokenizer if tokenizer is not None else self.tokenizer
+            if tokenizer is None:
+                raise ValueError("generate_actions(inputs, tokenizer): no tokenizer given and none attached to the model")
             rows = self._rows(inputs["input_ids"], inputs.get("attention_mask"))
             if len(rows) != 1:
                 raise ValueError("Generation with batch size > 1 is not currently supported!")
-            new_ids, lens = self.generate_ids(rows, inputs.get("pixel_values"), inputs.get("frames_u8"),
-                                              max_new_tokens=int(kwargs.get("max_new_tokens", 512)))
+            max_new = self._max_new(rows, kwargs.get("max_new_tokens", None if "max_length" in kwargs else 512), kwargs.get("max_length"),
+                                    kwargs.get("min_length"))
+            new_ids, lens = self.generate_ids(rows, inputs.get("pixel_values"), inputs.get("frames_u8"), max_new_tokens=max_new)
             actions, text = self._postprocess(new_ids[0, : int(lens[0])].cpu().tolist(), tokenizer, "act")
             return actions[0], text
         # native form
-        image, prompt_text = args[0], args[1]
-        type_ = args[2] if len(args) > 2 else kwargs.pop("type", "act")
-        tokenizer = kwargs.pop("tokenizer", None) or getattr(self, "tokenizer", None)
+        names = ("image", "prompt_text", "type")
+        vals = {}
+        for n in names:
+            if args:
+                if n in kwargs:
+                    raise TypeError(f"generate_actions() got multiple values for argument '{n}'")
+                vals[n] = args.pop(0)
+            elif n in kwargs:
+                vals[n] = kwargs.pop(n)
+            else:
+                raise TypeError(f"generate_actions() missing required argument: '{n}'")
+        if args:
+            raise TypeError(f"generate_actions() takes 3 positional arguments but {3 + len(args)} were given")
+        tokenizer = kwargs.pop("tokenizer", None)
+        tokenizer = tokenizer if tokenizer is not None else self.tokenizer
         if tokenizer is None:
-            raise ValueError("no tokenizer attached: pass tokenizer=... or set model.tokenizer")
-        if kwargs.get("do_sample", False):
-            raise NotImplementedError("only greedy decoding (do_sample=False) is on the hot path")
-        enc = tokenizer(prompt_text, truncation=True, return_tensors="pt")
-        feat = self.image_transform(image)
-        new_ids, lens = self.generate_ids(self._rows(enc.input_ids), feat["pixel_values"].to(self.device, torch.bfloat16),
-                                          None, max_new_tokens=int(kwargs.get("max_new_tokens", 512)))
-        return self._postprocess(new_ids[0, : int(lens[0])].cpu().tolist(), tokenizer, type_)
+            raise ValueError("no tokenizer attached: the checkpoint directory holds no tokenizer files; set model.tokenizer")
+        if vals["type"] not in ("act", "pos"):
+            raise ValueError(f"Unsupported generate_actions type `{vals['type']}` (expected 'act' or 'pos')")
+        enc = tokenizer(vals["prompt_text"], truncation=True, return_tensors="pt")
+        rows = self._rows(enc.input_ids)
+        max_new = self._max_new(rows, kwargs.get("max_new_tokens"), kwargs.get("max_length"), kwargs.get("min_length"))
+        feat = self.image_transform(vals["image"])
+        new_ids, lens = self.generate_ids(rows, feat["pixel_values"], feat.get("frames_u8"), max_new_tokens=max_new)
+        return self._postprocess(new_ids[0, : int(lens[0])].cpu().tolist(), tokenizer, vals["type"])
 
     @torch.inference_mode()
     def generate_actions_batch(self, frames_u8: torch.Tensor, prompt_rows: Sequence[Sequence[int]], max_new_tokens: int = 512,

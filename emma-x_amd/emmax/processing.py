@@ -46,6 +46,8 @@ class BatchFeature(dict):
                     out[k] = v.to(device=device, dtype=dtype)
                 else:
                     out[k] = v.to(device=device)
+                if hasattr(v, "_emmax_frames_tag"):   # a device / dtype move keeps the (pixel_values, frames_u8) pairing
+                    out[k]._emmax_frames_tag = v._emmax_frames_tag
             else:
                 out[k] = v
         return out
@@ -108,7 +110,11 @@ class EmmaXImageProcessor:
         if not isinstance(images, (list, tuple)):
             images = [images]
         pix, raw = zip(*(self.apply_transform(im) for im in images))
-        return BatchFeature(pixel_values=torch.stack(pix), frames_u8=torch.from_numpy(np.stack(raw)))
+        pv, fr = torch.stack(pix), torch.from_numpy(np.stack(raw))
+        # `pixel_values` is the model input; `frames_u8` is the same frame before normalisation.  The shared tag lets the model
+        # take the fused uint8 route ONLY while `pixel_values` is still this very tensor (modeling._encode_images)
+        pv._emmax_frames_tag = fr._emmax_frames_tag = object()
+        return BatchFeature(pixel_values=pv, frames_u8=fr)
 
     __call__ = preprocess
 

@@ -148,10 +148,22 @@ def stop_rule_from_tokenizer(tokenizer, marker: str = "POLICIES:", n_after: int 
     """(trigger_ids, n_after) for `SlotScheduler(stop_trigger=..., stop_after=...)` / `engine.set_stop`.
 
     The Solver reads the action from the first line after `marker` (policy_parser.Solver.extract_action_policies, reference
-    prismatic/vla/solver.py:107-137): a leading space token plus the 7 action-bin tokens, i.e. 8 ids.  The marker is
-    tokenised as it appears inside running text (no BOS); the device-side matcher takes at most 16 ids."""
-    ids = tokenizer(marker, add_special_tokens=False)["input_ids"]
-    ids = [int(t) for t in (ids[0] if ids and isinstance(ids[0], (list, tuple)) else ids)]
+    prismatic/vla/solver.py:107-137): a leading space token plus the 7 action-bin tokens, i.e. 8 ids.
+
+    The marker is tokenised IN CONTEXT -- as it appears in generated text, right after a newline ("...MOVEMENT:\n..\nPOLICIES:\n"):
+    a SentencePiece / LLaMA tokenizer given the bare string prepends its dummy prefix (`▁POL...`, or a lone 29871 `▁`), pieces
+    that never occur after `\n` in running text, so a bare-string trigger would never fire and every request would run to EOS.
+    Here "\n" + marker is encoded and everything up to and including the last id of the encoding of "\n" alone is dropped;
+    the result is what the model actually emits for the marker.  At most 16 ids (the device-side matcher's capacity)."""
+    def enc(text):
+        ids = tokenizer(text, add_special_tokens=False)["input_ids"]
+        return [int(t) for t in (ids[0] if ids and isinstance(ids[0], (list, tuple)) else ids)]
+
+    head, full = enc("\n"), enc("\n" + marker)
+    k = 0
+    while k < len(head) and k < len(full) and head[k] == full[k]:
+        k += 1
+    ids = full[k:]
     if not 1 <= len(ids) <= 16:
-        raise ValueError(f"marker {marker!r} tokenises to {len(ids)} ids; the stop rule takes 1..16")
+        raise ValueError(f"marker {marker!r} tokenises to {len(ids)} ids in context; the stop rule takes 1..16")
     return ids, int(n_after)

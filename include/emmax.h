@@ -182,6 +182,16 @@ int emmax_op_rmsnorm(const void* x_dev, void* y_dev, const void* w_dev, int rows
 int emmax_op_attention(const void* qkv_dev, int ld_qkv, int q_off, int k_off, int v_off, void* out_dev, int ld_out,
                        const int32_t* cu_seqlens_dev, int B, int max_seqlen, int Hq, int Hkv, int head_dim, float scale,
                        int causal, emmax_stream stream);
+/* Split-KV decode attention over a paged cache (the kernel of emmax_decode_step; HF cached attention at q_len = 1,
+ * modeling_prismatic.py:325-341): row b attends to keys 0..ctx_len_dev[b] (inclusive: the key appended by this step's qkv
+ * kernel sits at position ctx_len[b]).  q: bf16 [B, Hq*128] rotated queries; k/vcache: bf16 [n_pages][Hkv][page][128];
+ * page_table: int32 [B][max_pages] (token t of row b lives in page page_table[b][t / page]); done_dev: int32 [B] or NULL
+ * (rows flagged done read no K/V).  Writes the un-merged partials f32 [B][Hq][nsplit][132] = {o[128] un-normalised, m, l,
+ * pad}; the decode step merges them in the o-proj prologue.  nsplit: power of two <= 16, or 0 = what the session picks
+ * for this (B, Hkv) (returned through nsplit_out when non-NULL).  head_dim 128, page = 2^k, max_pages <= 512. */
+int emmax_op_decode_attention(const void* q_dev, const void* kcache_dev, const void* vcache_dev, const int32_t* page_table_dev,
+                              const int32_t* ctx_len_dev, const int32_t* done_dev, float* part_out_dev, int B, int Hq, int Hkv,
+                              int page, int max_pages, int nsplit, float scale, int* nsplit_out, emmax_stream stream);
 /* Decode-path weight-streaming GEMV: y[b,n] = sum_k x[b,k] W[n,k]  (bf16 in, fp32 accumulate, bf16 out), B <= 8. */
 int emmax_op_gemv(const void* x_dev, const void* W_dev, void* y_dev, int B, int N, int K, emmax_stream stream);
 

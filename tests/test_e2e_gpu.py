@@ -208,12 +208,32 @@ def test_predict_action_matches_reference_wrapper(device):
     assert int(logits[-1].argmax()) == int(g["logits_argmax"][-1])
 
 
+def _oracle_actions(cfg, sd_ref, ids_prompt, frame_u8, tokenizer, max_new, kind="act"):
+    """The oracle's end of `generate_actions`: greedy ids -> text -> Solver -> un-normalise (prismatic.py:659-696)."""
+    from oracle import emmax_oracle as orc
+
+    ids = orc.greedy_generate(torch.tensor([ids_prompt]), orc.preprocess_frames(frame_u8[None], cfg), sd_ref, cfg, max_new)
+    new = ids[0, len(ids_prompt):].tolist()
+    text = tokenizer.decode(new, skip_special_tokens=True).strip()
+    solver = orc.Solver(tokenizer, cfg.action_vocab_size, cfg.n_action_bins)
+    if kind == "act":
+        acts, _ = solver.extract_action_policies(text)
+        stats = cfg.norm_stats["bridge_orig"]["action"]
+        return new, text, [orc.unnormalize_actions(np.array(a), stats) for a in acts]
+    req, delta = solver.extract_movement_plan(text)
+    if req:
+        st = cfg.norm_stats["bridge_orig"]["proprio"]
+        delta = orc.unnormalize_actions(np.array(delta), {"q01": st["Q1"], "q99": st["Q99"], "mask": st["mask"]})
+    return new, text, delta
+
+
 def test_generate_actions_readme_form(device, tiny_planted):
-    """README.md:27-50 call sequence with the stub tokenizer: processor -> .to -> generate_actions -> (action, text)."""
+    """README.md:27-50 call sequence with the stub tokenizer: processor -> .to -> generate_actions -> (action, text); ids must
+    equal the oracle's greedy ids and the action the oracle Solver's un-normalised first policy."""
     from emmax.processing import EmmaXProcessor
     from emmax.weights import planted_start_token
 
-    cfg, model, _ = tiny_planted
+    cfg, model, sd_ref = tiny_planted
     proc = EmmaXProcessor.from_pretrained(cfg=cfg)
     rng = np.random.default_rng(3)
     image = rng.integers(0, 256, size=(224, 224, 3), dtype=np.uint8)
@@ -221,9 +241,63 @@ def test_generate_actions_readme_form(device, tiny_planted):
     inputs = proc(prompt, image).to(device, dtype=torch.bfloat16)
     # steer the planted chain: overwrite the last prompt token so the walk reaches the action range
     inputs["input_ids"][0, -1] = planted_start_token(cfg, 2)
+    ids_prompt = inputs["input_ids"][0].tolist()
+    new_ref, text_ref, acts_ref = _oracle_actions(cfg, sd_ref, ids_prompt, image, proc.tokenizer, 64)
     action, reasoning = model.generate_actions(inputs, proc.tokenizer, do_sample=False, max_new_tokens=64)
-    assert isinstance(reasoning, str) and action.shape == (7,)
-    assert np.isfinite(action).all() and np.abs(action).sum() > 0
+    assert reasoning == text_ref
+    got_ids = model.generate(inputs["input_ids"], frames_u8=inputs["frames_u8"], max_new_tokens=64)[0, len(ids_prompt):].tolist()
+    assert got_ids == new_ref and new_ref[-1] == cfg.eos_token_id and len(new_ref) == 2 + 8 + 1
+    assert action.shape == (7,) and np.abs(action - acts_ref[0]).max() <= 1e-3 and np.abs(action).sum() > 0
+    # keyword spelling of the same call, and the model's own tokenizer when none is passed
+    model.tokenizer = proc.tokenizer
+    a2, r2 = model.generate_actions(inputs=inputs, do_sample=False, max_new_tokens=64)
+    assert r2 == reasoning and np.array_equal(a2, action)
+    # `pixel_values` is the model input: a caller that edits it (augmentation, custom crop) must see the edit take effect, not
+    # the untouched uint8 frame that rides along in the BatchFeature
+    edited = dict(inputs)
+    edited["pixel_values"] = torch.zeros_like(inputs["pixel_values"])
+    f_zero = model.forward(input_ids=edited["input_ids"], pixel_values=edited["pixel_values"], frames_u8=edited["frames_u8"]).logits
+    f_orig = model.forward(input_ids=inputs["input_ids"], pixel_values=inputs["pixel_values"], frames_u8=inputs["frames_u8"]).logits
+    f_pix = model.forward(input_ids=inputs["input_ids"], pixel_values=inputs["pixel_values"]).logits
+    assert not torch.equal(f_zero, f_orig)
+    assert rel(f_orig[0, -1], f_pix[0, -1].float().cpu()) < 1e-2      # fused uint8 route == pixel_values route
+
+
+def test_generate_actions_native_keyword_form_matches_oracle(device, tiny_planted):
+    """The reference's own call, by keyword (experiments/robot/openvla_utils.py:215-217 -> prismatic.py:628):
+    `vla.generate_actions(image=..., prompt_text=..., type=..., temperature=0.0, max_new_tokens=.., min_length=1, do_sample=False)`
+    for type "act" and "pos" (planted weights: the walk from the prompt's last id is long, so the text carries no POLICIES /
+    MOVEMENT marker -- the Solver's fall-back branches, identical on both sides), against the oracle end to end."""
+    from emmax.tokenizer_stub import StubTokenizer
+
+    cfg, model, sd_ref = tiny_planted
+    tok = StubTokenizer()
+    model.tokenizer = tok
+    rng = np.random.default_rng(21)
+    image = rng.integers(0, 256, size=(224, 224, 3), dtype=np.uint8)
+    builder = model.get_prompt_builder()
+    builder.add_turn(role="human", message="What action should the robot take to achieve the instruction\nINSTRUCTION: \nput it down\n")
+    prompt = builder.get_prompt()
+    ids_prompt = tok(prompt, truncation=True, return_tensors="pt").input_ids[0].tolist()
+    T = 40
+    for kind in ("act", "pos"):
+        new_ref, text_ref, want = _oracle_actions(cfg, sd_ref, ids_prompt, image, tok, T, kind)
+        got, text = model.generate_actions(image=image, prompt_text=prompt, type=kind, temperature=0.0, max_new_tokens=T, min_length=1,
+                                           do_sample=False)
+        assert text == text_ref
+        if kind == "act":
+            assert len(got) == len(want) and all(np.abs(np.asarray(a) - np.asarray(b)).max() <= 1e-3 for a, b in zip(got, want))
+        else:
+            assert np.abs(np.asarray(got, dtype=np.float64) - np.asarray(want, dtype=np.float64)).max() <= 1e-3
+    # positional spelling; wrong type; sampling is outside the hot path
+    got_p, text_p = model.generate_actions(image, prompt, "act", max_new_tokens=T)
+    assert text_p == text_ref or isinstance(text_p, str)
+    with pytest.raises(ValueError):
+        model.generate_actions(image=image, prompt_text=prompt, type="nope")
+    with pytest.raises(TypeError):
+        model.generate_actions(image=image, type="act")
+    with pytest.raises(NotImplementedError):
+        model.generate_actions(image=image, prompt_text=prompt, type="act", do_sample=True)
 
 
 def test_graph_replay_equals_eager(device, tiny_planted, monkeypatch):
@@ -284,7 +358,8 @@ def test_chained_launch_equals_sequential(device, tiny_random, monkeypatch):
 
 def test_checkpoint_ingest_and_caller_shims(device, tmp_path):
     """HF-format directory (config.json + sharded safetensors + dataset_statistics.json) -> from_pretrained -> the
-    reference's caller functions (experiments/robot/openvla_utils.py get_vla_action / get_seq_action)."""
+    reference's caller functions (experiments/robot/openvla_utils.py get_vla_action / get_seq_action), each compared with the
+    ORACLE run on the same weights, prompt ids and frame (not with a second product model)."""
     import sys
 
     from conftest import ROOT
@@ -296,6 +371,7 @@ def test_checkpoint_ingest_and_caller_shims(device, tmp_path):
     from emmax.modeling import EmmaXForActionPrediction
     from emmax.processing import EmmaXProcessor
     from emmax.weights import synthetic_state_dict
+    from oracle import emmax_oracle as orc
 
     cfg = EmmaXConfig.tiny()
     ck = str(tmp_path / "ckpt")
@@ -303,17 +379,27 @@ def test_checkpoint_ingest_and_caller_shims(device, tmp_path):
     vla = EmmaXForActionPrediction.from_pretrained(ck, torch_dtype=torch.bfloat16, trust_remote_code=True).to(device)
     assert vla.config.llm.hidden_size == cfg.llm.hidden_size and vla.config.towers[1].mlp_hidden == cfg.towers[1].mlp_hidden
     assert list(vla.norm_stats) == ["bridge_orig"]
+    assert vla.tokenizer is None          # the directory holds no tokenizer files: nothing is invented
     proc = EmmaXProcessor.from_pretrained(ck)
+    sd_ref = {k: v.to(torch.bfloat16).float() for k, v in synthetic_state_dict(cfg, seed=5, planted=True).items()}
     rng = np.random.default_rng(8)
     obs = {"full_image": rng.integers(0, 256, size=(224, 224, 3), dtype=np.uint8)}
-    # reference model built directly from the same synthetic weights must agree exactly
-    direct = EmmaXForActionPrediction(cfg, {k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(cfg, seed=5, planted=True).items()}).to(device)
-    a1 = get_vla_action(vla, proc, "openvla", obs, "Put the carrot on the plate", "bridge_orig")
-    a2 = get_vla_action(direct, proc, "openvla", obs, "Put the carrot on the plate", "bridge_orig")
-    assert a1.shape == (7,) and np.array_equal(a1, a2)
-    acts, text = get_seq_action(vla, proc, "openvla", obs, "What action should the robot take to achieve the instruction\nINSTRUCTION: \nput it down\n", "bridge_orig", "act")
-    acts2, text2 = get_seq_action(direct, proc, "openvla", obs, "What action should the robot take to achieve the instruction\nINSTRUCTION: \nput it down\n", "bridge_orig", "act")
-    assert text == text2 and len(acts) == len(acts2) and all(np.array_equal(x, y) for x, y in zip(acts, acts2))
+    # get_vla_action: OpenVLA prompt, predict_action appends 29871 and reads 7 new tokens (modeling_prismatic.py:506-537)
+    task = "Put the carrot on the plate"
+    a1 = get_vla_action(vla, proc, "openvla", obs, task, "bridge_orig")
+    ids_prompt = proc.tokenizer(f"In: What action should the robot take to {task.lower()}?\nOut:", return_tensors="pt").input_ids[0].tolist()
+    if ids_prompt[-1] != 29871:
+        ids_prompt.append(29871)
+    ids = orc.greedy_generate(torch.tensor([ids_prompt]), orc.preprocess_frames(obs["full_image"][None], cfg), sd_ref, cfg, 7)
+    want = orc.predict_action_tail(ids[0].numpy(), cfg.norm_stats["bridge_orig"]["action"], cfg.action_vocab_size, cfg.n_action_bins)
+    assert a1.shape == (7,) and np.abs(a1 - want).max() <= 1e-3
+    # get_seq_action: PurePromptBuilder prompt, the reference's keyword call, Solver on the decoded text
+    label = "What action should the robot take to achieve the instruction\nINSTRUCTION: \nput it down\n"
+    acts, text = get_seq_action(vla, proc, "openvla", obs, label, "bridge_orig", "act")
+    ids_prompt = proc.tokenizer(orc.pure_prompt(label), truncation=True, return_tensors="pt").input_ids[0].tolist()
+    _, text_ref, acts_ref = _oracle_actions(cfg, sd_ref, ids_prompt, obs["full_image"], proc.tokenizer, 512)
+    assert text == text_ref and len(acts) == len(acts_ref)
+    assert all(np.abs(np.asarray(x) - np.asarray(y)).max() <= 1e-3 for x, y in zip(acts, acts_ref))
     with pytest.raises(NotImplementedError):
         get_vla_action(vla, proc, "openvla", obs, "x", "bridge_orig", center_crop=True)
 
@@ -387,3 +473,29 @@ def test_generate_actions_dp_single_process(device, tiny_planted):
     assert a.shape == (10, 7) and i.shape == (10, 20) and n.shape == (10,)
     a1, i1, n1 = model.generate_actions_batch(fr[3:4].to(device).contiguous(), [rows[3]], max_new_tokens=20)
     assert torch.equal(i[3], i1[0]) and int(n[3]) == int(n1[0]) and np.abs(a[3].cpu().numpy() - a1[0]).max() == 0
+
+
+def test_teacher_forcing_past_an_eos_argmax(device, tiny_planted):
+    """a caller-supplied continuation (`forward(input_ids[B,1], past_key_values)`, teacher-forced scoring) must keep
+    decoding after the engine's OWN greedy prediction was EOS: emmax_set_current_tokens clears the row's done flag, so the
+    context keeps advancing and the logits stay those of the oracle fed the same tokens (modeling_prismatic.py:325-341)."""
+    from emmax.weights import planted_chain
+    from oracle import emmax_oracle as orc
+
+    cfg, model, sd_ref = tiny_planted
+    chain = planted_chain(cfg, 29871, 20)
+    assert chain[-1] == cfg.eos_token_id
+    frames, rows = _inputs(cfg, 1, 9, seed=77, last=chain[-2])          # the prefill's argmax is EOS
+    forced = [17, 4242, 31000, 905]
+    out = model.forward(input_ids=torch.tensor(rows), frames_u8=torch.from_numpy(frames).to(device), use_cache=True)
+    assert int(out.logits[0, -1].argmax()) == cfg.eos_token_id
+    logits, cache, _ = orc.vla_prefill_logits(torch.tensor(rows), orc.preprocess_frames(frames, cfg), sd_ref, cfg)
+    past = out.past_key_values
+    for t in forced:
+        step = model.forward(input_ids=torch.tensor([[t]]), past_key_values=past, use_cache=True)
+        logits, cache = orc.llama_forward(orc.embed_tokens(torch.tensor([[t]]), sd_ref), sd_ref, cfg.llm, cache)
+        got, ref = step.logits[0, -1].float().cpu(), logits[0, -1]
+        assert rel(got, ref) < FEAT_TOL
+        assert int(got.argmax()) == int(ref.argmax())      # planted margins: the argmax is unambiguous
+        past = step.past_key_values
+    assert past.lengths == [256 + 9 + len(forced)]

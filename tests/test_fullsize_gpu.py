@@ -178,6 +178,43 @@ def test_fullsize_vision_towers_match_oracle(device):
     assert rel(alone[0], got_proj[1]) < 1e-2
 
 
+def test_fullsize_vision_towers_large_batch_plans(device):
+    """BASELINE configs[3] (ViT-only, batch 256): at B >= 16 `launch_gemm` takes the big-tile / row-split plans instead of the
+    small-tile and split-K plans of B <= 2.  B = 16 at the real tower dimensions against the fp32 oracle (3e-2 * max|ref| as
+    above), then B = 256 (the 16 frames tiled 16x) against the B = 16 result of the same frames: a different launch plan may
+    change the fp32 summation order only (1e-2)."""
+    from emmax.config import EmmaXConfig
+    from emmax.modeling import EmmaXForActionPrediction
+    from emmax.weights import synthetic_state_dict
+    from oracle import emmax_oracle as orc
+
+    big, tiny = EmmaXConfig.emma_x_7b(), EmmaXConfig.tiny()
+    cfg = EmmaXConfig(big.towers, tiny.llm, norm_stats=tiny.norm_stats)
+    sd_bf = {k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(cfg, seed=4).items()}
+    model = EmmaXForActionPrediction(cfg, dict(sd_bf)).to(device, max_batch=256, max_prompt=8)
+    sd_ref = {k: v.float() for k, v in sd_bf.items() if k.startswith(("vision_backbone.", "projector."))}
+    rng = np.random.default_rng(31)
+    frames = rng.integers(0, 256, size=(16, 224, 224, 3), dtype=np.uint8)
+    got_proj = model.engine.vision_encode(torch.from_numpy(frames).to(device)).float().cpu()
+    got_feats = model.engine.vision_features(16).float().cpu()
+    with torch.inference_mode():
+        ref_feats = orc.vision_backbone(orc.preprocess_frames(frames, cfg), sd_ref, cfg)
+        ref_proj = orc.projector(ref_feats, sd_ref)
+
+    def rel(a, b):
+        return ((a - b).abs().max() / b.abs().max()).item()
+
+    assert rel(got_feats[..., : ref_feats.shape[-1]], ref_feats) < 3e-2
+    assert rel(got_proj, ref_proj) < 3e-2
+    per_frame = (got_proj - ref_proj).abs().amax(dim=(1, 2)) / ref_proj.abs().amax()
+    assert per_frame.max().item() < 3e-2
+    big_b = torch.from_numpy(np.tile(frames, (16, 1, 1, 1))).to(device)
+    got256 = model.engine.vision_encode(big_b).float().cpu()
+    assert got256.shape[0] == 256
+    for r in range(16):
+        assert rel(got256[16 * r:16 * r + 16], got_proj) < 1e-2, r
+
+
 @pytest.fixture(scope="module")
 def llm2(device):
     """LLaMA-2-7B layer dimensions, 2 layers, tiny towers, random weights (CPU generator: oracle and device see the same)."""

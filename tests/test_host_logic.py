@@ -248,3 +248,105 @@ def test_bench_contract_flags_and_committed_bench_line():
     assert r["traffic"] is None or 0.9 < r["traffic"] / r["bytes_per_launch"] < 1.2
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "actions/s" and c["sample"]
+
+
+def test_stop_rule_is_tokenised_in_context_sentencepiece_style():
+    """a SentencePiece / LLaMA tokenizer prepends a dummy `▁` to a bare string, giving `▁POLICIES` -- a piece that
+    never follows `\\n` in generated text.  The stop rule must be what the model emits after a newline."""
+    tokenizers = pytest.importorskip("tokenizers")
+    from tokenizers import normalizers
+
+    from emmax.serving import stop_rule_from_tokenizer
+    from emmax.tokenizer_stub import StubTokenizer
+
+    pieces = ["<unk>", "▁", "\n", "POLICIES", "▁POLICIES", ":", "MOVEMENT", "▁MOVEMENT"] + [chr(c) for c in range(65, 91)]
+    tk = tokenizers.Tokenizer(tokenizers.models.Unigram([(p, -1.0 if len(p) > 1 else -5.0) for p in pieces], unk_id=0))
+    tk.normalizer = normalizers.Sequence([normalizers.Prepend("▁"), normalizers.Replace(" ", "▁")])
+
+    class Wrap:   # the HF call surface stop_rule_from_tokenizer uses
+        def __call__(self, text, add_special_tokens=False):
+            return {"input_ids": tk.encode(text, add_special_tokens=add_special_tokens).ids}
+
+    vocab = {p: i for i, p in enumerate(pieces)}
+    bare = Wrap()("POLICIES:")["input_ids"]
+    assert bare == [vocab["▁POLICIES"], vocab[":"]]                  # what the old rule armed: never emitted after "\n"
+    trig, after = stop_rule_from_tokenizer(Wrap())
+    assert trig == [vocab["POLICIES"], vocab[":"]] and after == 8
+    trig, _ = stop_rule_from_tokenizer(StubTokenizer())              # stub: no leading 29871 either
+    assert 29871 not in trig and StubTokenizer().decode(trig) == "POLICIES:"
+
+
+def test_norm_stats_are_never_invented(tmp_path):
+    """a checkpoint without statistics must not un-normalise with made-up values."""
+    from emmax.modeling import EmmaXForActionPrediction
+
+    assert EmmaXConfig.emma_x_7b().norm_stats == {}
+    d = {"vision_backbone_id": "dinosiglip-vit-so-224px", "llm_backbone_id": "llama2-7b-pure", "text_config": {}}
+    cfg = EmmaXConfig.from_hf_dict(d)
+    assert cfg.norm_stats == {}
+    m = EmmaXForActionPrediction(cfg, None)
+    with pytest.raises(ValueError):
+        m.get_action_stats(None)
+    with pytest.raises(ValueError):
+        m.get_action_dim("bridge_orig")
+    assert "bridge_orig" in EmmaXConfig.tiny().norm_stats            # synthetic factories keep their synthetic statistics
+    # native `.pt`: the run directory must hold config.json AND dataset_statistics.json (prismatic/models/load.py:133-144)
+    run = tmp_path / "run" / "checkpoints"
+    run.mkdir(parents=True)
+    pt = run / "step-000001.pt"
+    torch.save({"model": {}}, str(pt))
+    with pytest.raises(FileNotFoundError, match="config.json"):
+        EmmaXForActionPrediction.from_pretrained(str(pt))
+    (tmp_path / "run" / "config.json").write_text(json.dumps({"vla": {"base_vlm": "prism-dinosiglip-224px+7b"}}))
+    with pytest.raises(FileNotFoundError, match="dataset_statistics.json"):
+        EmmaXForActionPrediction.from_pretrained(str(pt))
+    bad = tmp_path / "elsewhere.pt"
+    torch.save({"model": {}}, str(bad))
+    with pytest.raises(ValueError, match="Invalid checkpoint"):
+        EmmaXForActionPrediction.from_pretrained(str(bad))
+
+
+def test_generate_length_arguments_follow_hf():
+    """`max_length` is a TOTAL (prompt included) and yields to `max_new_tokens`; `min_length` beyond the prompt would need EOS
+    suppression and raises."""
+    from emmax.modeling import EmmaXForActionPrediction
+
+    m = EmmaXForActionPrediction(EmmaXConfig.tiny(), None)
+    rows = [[1] * 30, [1] * 12]
+    assert m._max_new(rows, 512, None, 1) == 512
+    assert m._max_new(rows, None, 100, None) == 70
+    assert m._max_new(rows, 7, 100, None) == 7
+    assert m._max_new(rows, None, 10, None) == 1
+    assert m._max_new(rows, None, None, None) == 20
+    with pytest.raises(NotImplementedError):
+        m._max_new(rows, 64, None, 40)
+
+
+def test_register_auto_classes_resolves_to_the_mi355x_classes(tmp_path):
+    """The reference's plug-in point (experiments/robot/openvla_utils.py:38-41): after `emmax.register_auto_classes()` the
+    Auto classes resolve an `openvla` checkpoint directory to the MI355X model / processor (no device work here)."""
+    transformers = pytest.importorskip("transformers")
+    import sys
+
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import emmax
+    from emmax.modeling import EmmaXForActionPrediction
+    from emmax.processing import EmmaXProcessor
+    from tools.make_synthetic_checkpoint import write_checkpoint
+
+    report = emmax.register_auto_classes()
+    assert report["AutoConfig"] == "ok" and report["AutoProcessor"] == "ok"
+    assert emmax.register_auto_classes()["AutoConfig"] == "ok"       # idempotent
+    ck = str(tmp_path / "ckpt")
+    write_checkpoint(ck, EmmaXConfig.tiny(), seed=1, tiny_towers=True)
+    cfg = transformers.AutoConfig.from_pretrained(ck)
+    assert cfg.model_type == "openvla" and type(cfg).__name__ == "OpenVLAConfig"
+    auto = getattr(transformers, "AutoModelForVision2Seq", None) or transformers.AutoModelForImageTextToText
+    assert report[auto.__name__] == "ok"
+    kw = {"dtype": torch.bfloat16} if int(transformers.__version__.split(".")[0]) >= 5 else {"torch_dtype": torch.bfloat16}
+    vla = auto.from_pretrained(ck, low_cpu_mem_usage=True, trust_remote_code=True, **kw)
+    assert isinstance(vla, EmmaXForActionPrediction) and list(vla.norm_stats) == ["bridge_orig"]
+    assert isinstance(transformers.AutoProcessor.from_pretrained(ck, trust_remote_code=True), EmmaXProcessor)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        vla.to("cpu")

@@ -347,3 +347,99 @@ def test_fp8_weight_projection(device, B, N, K):
     L.check(lib.emmax_op_gemm_small_fp8(xd.data_ptr(), W8.data_ptr(), sc.data_ptr(), y.data_ptr(), B, N, K, stream()), "gemm fp8")
     torch.cuda.synchronize()
     assert relerr(y, ref) < TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Paged split-KV decode attention (emmax_decode_attn_kernel) at the benchmark's operating point: contexts 768..1280,
+# ragged batches, MHA and GQA, every split count the launcher can pick, page tables that are NOT the identity.
+# Reference = the oracle's cached attention (oracle.emmax_oracle.llama_layer: fp32 softmax over keys 0..ctx) on the same
+# bf16-rounded q / K / V.
+# ---------------------------------------------------------------------------------------------------------------------
+def _paged_cache(K, V, page, max_pages, gen):
+    """K, V: lists (per row) of [L_b, Hkv, 128] bf16 -> (kcache, vcache [n_pages][Hkv][page][128], page_table [B][max_pages])."""
+    B = len(K)
+    Hkv = K[0].shape[1]
+    n_pages = B * max_pages
+    perm = torch.randperm(n_pages, generator=gen)
+    table = perm.view(B, max_pages).to(torch.int32)
+    kc = torch.randn(n_pages, Hkv, page, 128, generator=gen).to(torch.bfloat16)   # garbage beyond the context must not matter
+    vc = torch.randn(n_pages, Hkv, page, 128, generator=gen).to(torch.bfloat16)
+    for b in range(B):
+        L = K[b].shape[0]
+        for t0 in range(0, L, page):
+            pg = int(table[b, t0 // page])
+            n = min(page, L - t0)
+            kc[pg, :, :n] = K[b][t0:t0 + n].transpose(0, 1)
+            vc[pg, :, :n] = V[b][t0:t0 + n].transpose(0, 1)
+    return kc, vc, table
+
+
+def _merge_partials(part, nsplit):
+    """f32 [B,Hq,nsplit,132] -> normalised o [B,Hq,128] (the merge the o-proj prologue performs, in fp32)."""
+    o, m, l = part[..., :128], part[..., 128], part[..., 129]
+    M = m.max(dim=-1, keepdim=True).values
+    w = torch.where(torch.isinf(m), torch.zeros_like(m), torch.exp(m - M))
+    den = (l * w).sum(-1)
+    return (o * w[..., None]).sum(-2) / den[..., None]
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(32, 32), (4, 2), (8, 1)])
+@pytest.mark.parametrize("ctxs", [[63], [64], [65], [767], [768], [1023], [1024], [1025], [1279], [768, 63, 1279], [1279, 1, 64, 1024, 65, 767, 1025, 300]])
+def test_decode_attention_paged_matches_oracle(device, Hq, Hkv, ctxs):
+    L_, lib = _lib()
+    B, page, max_pages = len(ctxs), 64, 21
+    g = torch.Generator().manual_seed(Hq * 1000 + sum(ctxs))
+    scale = 128 ** -0.5
+    q = bf(torch.randn(B, Hq, 128, generator=g))
+    K = [bf(torch.randn(c + 1, Hkv, 128, generator=g)) for c in ctxs]   # keys 0..ctx inclusive
+    V = [bf(torch.randn(c + 1, Hkv, 128, generator=g)) for c in ctxs]
+    kc, vc, table = _paged_cache(K, V, page, max_pages, g)
+    rep = Hq // Hkv
+    ref = torch.empty(B, Hq, 128)
+    for b in range(B):
+        kk = K[b].float().repeat_interleave(rep, dim=1)          # [L, Hq, 128]
+        vv = V[b].float().repeat_interleave(rep, dim=1)
+        att = torch.einsum("hd,lhd->hl", q[b].float(), kk) * scale
+        ref[b] = torch.einsum("hl,lhd->hd", F.softmax(att, dim=-1, dtype=torch.float32), vv)
+    qd, kcd, vcd, td = q.view(B, Hq * 128).contiguous().to(device), kc.to(device), vc.to(device), table.to(device)
+    ctx_d = torch.tensor(ctxs, dtype=torch.int32, device=device)
+    ns_auto = C.c_int()
+    for nsplit in (0, 1, 2, 4, 8, 16):
+        ns = nsplit
+        part = torch.full((B, Hq, max(nsplit, 16), 132), float("nan"), dtype=torch.float32, device=device)
+        L_.check(lib.emmax_op_decode_attention(qd.data_ptr(), kcd.data_ptr(), vcd.data_ptr(), td.data_ptr(), ctx_d.data_ptr(), None,
+                                               part.data_ptr(), B, Hq, Hkv, page, max_pages, nsplit, scale, C.byref(ns_auto), stream()),
+                 "decode attention")
+        torch.cuda.synchronize()
+        ns = ns_auto.value
+        assert ns >= 1 and (ns & (ns - 1)) == 0
+        got = _merge_partials(part.view(-1)[: B * Hq * ns * 132].view(B, Hq, ns, 132).cpu(), ns)
+        assert torch.isfinite(got).all(), (nsplit, ns)
+        assert relerr(got, ref) < 5e-3, (nsplit, ns, relerr(got, ref))   # inputs are exact bf16, math fp32: only exp/ordering noise
+
+
+def test_decode_attention_done_rows_read_nothing(device):
+    """Rows flagged done (finished / idle slots) must produce empty partials (m = -inf, l = 0) and leave the others untouched."""
+    L_, lib = _lib()
+    B, Hq, Hkv, page, max_pages = 3, 32, 32, 64, 21
+    ctxs = [900, 500, 1100]
+    g = torch.Generator().manual_seed(77)
+    q = bf(torch.randn(B, Hq * 128, generator=g))
+    K = [bf(torch.randn(c + 1, Hkv, 128, generator=g)) for c in ctxs]
+    V = [bf(torch.randn(c + 1, Hkv, 128, generator=g)) for c in ctxs]
+    kc, vc, table = _paged_cache(K, V, page, max_pages, g)
+    dev = lambda t: t.to(device)
+    qd, kcd, vcd, td = dev(q), dev(kc), dev(vc), dev(table)
+    ctx_d = torch.tensor(ctxs, dtype=torch.int32, device=device)
+    outs = []
+    for done in ([0, 0, 0], [0, 1, 0]):
+        done_d = torch.tensor(done, dtype=torch.int32, device=device)
+        part = torch.full((B, Hq, 4, 132), float("nan"), dtype=torch.float32, device=device)
+        L_.check(lib.emmax_op_decode_attention(qd.data_ptr(), kcd.data_ptr(), vcd.data_ptr(), td.data_ptr(), ctx_d.data_ptr(),
+                                               done_d.data_ptr(), part.data_ptr(), B, Hq, Hkv, page, max_pages, 4, 128 ** -0.5, None, stream()),
+                 "decode attention")
+        torch.cuda.synchronize()
+        outs.append(part.cpu())
+    a, b_ = outs
+    assert torch.equal(a[0], b_[0]) and torch.equal(a[2], b_[2])
+    assert torch.isinf(b_[1, :, :, 128]).all() and (b_[1, :, :, 128] < 0).all() and (b_[1, :, :, 129] == 0).all() and (b_[1, :, :, :128] == 0).all()
