@@ -36,15 +36,17 @@ def _timed(fn, reps=1):
     return (time.perf_counter() - t0) / reps
 
 
-def cpu_baseline(cfg, prompt_tokens, new_tokens, seed=0):
-    """Time the CPU oracle (fp32, host cores) on a bounded sample of the same workload and extrapolate linearly.
+def cpu_baseline(cfg, prompt_tokens, new_tokens, seed=0, decode_steps=16, distinct_layers=4):
+    """Time the CPU oracle (fp32, host cores) on a bounded sample of the same workload.
 
-    Sample: ONE full-size LLaMA decoder layer (prefill at S = 256+P, cached decode steps at that context), the lm-head,
-    ONE block (+ patch embed) of each ViT tower on one frame, and the projector.  Everything else is the same layer
-    repeated, so
-        t_action = sum_t (take_t+1)*t_block_t + t_proj + 32*t_prefill_layer + t_head + (T-1) * (32*t_decode_layer + t_head).
-    PyTorch CPU ops do not scale to every hardware thread of a big host: the thread count is chosen from {32, 64, all}
-    by timing the decode layer (the dominant term) and is reported as `cores`."""
+    Executed in full, once: both ViT towers (every block up to take_index) + the projector on one frame, and the LLaMA prefill
+    at S = 256 + P over all `num_layers` layer passes + the lm-head.  Then `decode_steps` cached greedy steps (every layer pass,
+    growing KV cache, lm-head + argmax each) are timed and their mean is extrapolated to the remaining new tokens:
+        t_action = t_vision + t_projector + t_prefill + t_head + (T - 1) * mean(t_decode_step).
+    The only economy is the weight VALUES: `distinct_layers` random LLaMA layers are cycled through the layer passes (fp32 they
+    are 0.8 GB each -- four of them are far larger than any host cache, so every pass streams from DRAM like 32 distinct
+    layers would) instead of generating 27 GB of random numbers.  PyTorch CPU ops do not scale to every hardware thread of a
+    big host: the thread count is chosen from {32, 64, all} by timing a decode layer pass and reported as `cores`."""
     from emmax.weights import tower_param_shapes
     from oracle import emmax_oracle as orc
 
@@ -52,59 +54,105 @@ def cpu_baseline(cfg, prompt_tokens, new_tokens, seed=0):
     ncpu = os.cpu_count() or 1
     L = cfg.llm
     S = cfg.n_patches + prompt_tokens
+    nl = L.num_layers
+    nd = max(1, min(distinct_layers, nl))
 
     def w(*shape):
         return torch.randn(*shape) * 0.02
 
-    p = "language_model.model.layers.0."
     qd, kvd = L.num_heads * L.head_dim, L.num_kv_heads * L.head_dim
-    sd = {p + "input_layernorm.weight": torch.ones(L.hidden_size), p + "post_attention_layernorm.weight": torch.ones(L.hidden_size),
-          p + "self_attn.q_proj.weight": w(qd, L.hidden_size), p + "self_attn.k_proj.weight": w(kvd, L.hidden_size),
-          p + "self_attn.v_proj.weight": w(kvd, L.hidden_size), p + "self_attn.o_proj.weight": w(L.hidden_size, qd),
-          p + "mlp.gate_proj.weight": w(L.intermediate_size, L.hidden_size), p + "mlp.up_proj.weight": w(L.intermediate_size, L.hidden_size),
-          p + "mlp.down_proj.weight": w(L.hidden_size, L.intermediate_size)}
+    sd = {}
+    for i in range(nd):
+        p = f"language_model.model.layers.{i}."
+        sd.update({p + "input_layernorm.weight": torch.ones(L.hidden_size), p + "post_attention_layernorm.weight": torch.ones(L.hidden_size),
+                   p + "self_attn.q_proj.weight": w(qd, L.hidden_size), p + "self_attn.k_proj.weight": w(kvd, L.hidden_size),
+                   p + "self_attn.v_proj.weight": w(kvd, L.hidden_size), p + "self_attn.o_proj.weight": w(L.hidden_size, qd),
+                   p + "mlp.gate_proj.weight": w(L.intermediate_size, L.hidden_size), p + "mlp.up_proj.weight": w(L.intermediate_size, L.hidden_size),
+                   p + "mlp.down_proj.weight": w(L.hidden_size, L.intermediate_size)})
     head = w(L.vocab_size, L.hidden_size)
+    norm_w = torch.ones(L.hidden_size)
     t = {}
     with torch.inference_mode():
-        h = torch.randn(1, S, L.hidden_size)
-        x = torch.randn(1, 1, L.hidden_size)
+        # ---- thread count: one cached decode layer pass at context S (the dominant term) ----
+        h0 = torch.randn(1, S, L.hidden_size)
+        x0 = torch.randn(1, 1, L.hidden_size)
         torch.set_num_threads(min(ncpu, 64))
-        _, kv = orc.llama_layer(h, sd, 0, L, torch.arange(S), None, torch.float32)
-        dec = lambda: orc.llama_layer(x, sd, 0, L, torch.arange(S, S + 1), kv, torch.float32)
+        _, kv0 = orc.llama_layer(h0, sd, 0, L, torch.arange(S), None, torch.float32)
+        probe = lambda: orc.llama_layer(x0, sd, 0, L, torch.arange(S, S + 1), kv0, torch.float32)
         best = None
         for nt in sorted({min(ncpu, 32), min(ncpu, 64), ncpu}):
             torch.set_num_threads(nt)
-            dt = _timed(dec, reps=3)
+            dt = _timed(probe, reps=3)
             if best is None or dt < best[1]:
                 best = (nt, dt)
         nthreads = best[0]
         torch.set_num_threads(nthreads)
-        t["decode_layer"] = best[1]
-        t["prefill_layer"] = _timed(lambda: orc.llama_layer(h, sd, 0, L, torch.arange(S), None, torch.float32))
-        t["lm_head"] = _timed(lambda: torch.nn.functional.linear(orc.rms_norm(x, torch.ones(L.hidden_size), L.rms_eps), head), reps=3)
-        del sd, kv, head
+        del kv0
+        # ---- vision + projector, in full, one frame (second call timed: the first creates the oneDNN primitives) ----
         pix = torch.randn(1, 6, 224, 224)
-        vt = 0.0
+        sdv = {}
         for i, tw in enumerate(cfg.towers):
-            sdv = {orc.TOWER_PREFIXES[i] + k: torch.randn(*shp) * 0.02 for k, shp, _ in tower_param_shapes(tw)
-                   if k.startswith("blocks.0.") or not k.startswith("blocks.")}
-            vt += (tw.take_index + 1) * _timed(lambda: orc.vit_tower(pix[:, 3 * i:3 * i + 3], sdv, orc.TOWER_PREFIXES[i], tw,
-                                                                     torch.float32, n_blocks=1))
-        t["vision_towers"] = vt
+            for k, shp, _ in tower_param_shapes(tw):
+                blk = int(k.split(".")[1]) if k.startswith("blocks.") else -1
+                if blk <= tw.take_index:
+                    sdv[orc.TOWER_PREFIXES[i] + k] = torch.randn(*shp) * 0.02
         v, p1, hdim, _ = cfg.projector_dims
-        sdp = {"projector.fc1.weight": w(p1, v), "projector.fc1.bias": torch.zeros(p1), "projector.fc2.weight": w(hdim, p1),
-               "projector.fc2.bias": torch.zeros(hdim), "projector.fc3.weight": w(hdim, hdim), "projector.fc3.bias": torch.zeros(hdim)}
-        feats = torch.randn(1, cfg.n_patches, v)
-        t["projector"] = _timed(lambda: orc.projector(feats, sdp))
-    nl = L.num_layers
-    t_action = (t["vision_towers"] + t["projector"] + nl * t["prefill_layer"] + t["lm_head"]
-                + (new_tokens - 1) * (nl * t["decode_layer"] + t["lm_head"]))
+        sdv.update({"projector.fc1.weight": w(p1, v), "projector.fc1.bias": torch.zeros(p1), "projector.fc2.weight": w(hdim, p1),
+                    "projector.fc2.bias": torch.zeros(hdim), "projector.fc3.weight": w(hdim, hdim), "projector.fc3.bias": torch.zeros(hdim)})
+        feats = {}
+        t["vision_towers"] = _timed(lambda: feats.__setitem__("f", orc.vision_backbone(pix, sdv, cfg)))
+        t["projector"] = _timed(lambda: orc.projector(feats["f"], sdv))
+        del sdv
+        # ---- prefill: all layer passes at S rows, once (the thread-count probe above warmed the primitives up) ----
+        caches = []
+        t0 = time.perf_counter()
+        h = h0
+        pos = torch.arange(S)
+        for li in range(nl):
+            h, kv = orc.llama_layer(h, sd, li % nd, L, pos, None, torch.float32)
+            caches.append(kv)
+        t["prefill_layers"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        nxt = int(torch.argmax(torch.nn.functional.linear(orc.rms_norm(h[:, -1:], norm_w, L.rms_eps), head)))
+        t["lm_head"] = time.perf_counter() - t0
+        # ---- cached greedy decode: `decode_steps` full steps, KV cache growing ----
+        steps = []
+        x = x0
+        for st in range(decode_steps):
+            t0 = time.perf_counter()
+            hh = x
+            pos = torch.arange(S + st, S + st + 1)
+            for li in range(nl):
+                hh, caches[li] = orc.llama_layer(hh, sd, li % nd, L, pos, caches[li], torch.float32)
+            nxt = int(torch.argmax(torch.nn.functional.linear(orc.rms_norm(hh, norm_w, L.rms_eps), head)))
+            steps.append(time.perf_counter() - t0)
+            x = torch.roll(x0, nxt % 97, dims=-1)   # next-token embedding stand-in (the 8 KB row gather is not timed work)
+        t["decode_step_mean"] = float(np.mean(steps))
+        t["decode_step_min"] = float(np.min(steps))
+    t_action = t["vision_towers"] + t["projector"] + t["prefill_layers"] + t["lm_head"] + (new_tokens - 1) * t["decode_step_mean"]
     return {"value": 1.0 / t_action, "unit": "actions/s", "cores": nthreads, "kind": "port",
-            "sample": ("fp32 PyTorch oracle on %d of %d host threads: 1 of %d LLaMA layers (prefill S=%d, cached decode at that context), "
-                       "lm-head, 1 block + patch-embed per ViT tower, projector; each timed after one untimed call and extrapolated "
-                       "linearly to %d layers / %d+%d blocks / %d new tokens" %
-                       (nthreads, ncpu, nl, S, nl, cfg.towers[0].take_index + 1, cfg.towers[1].take_index + 1, new_tokens)),
+            "sample": ("fp32 PyTorch oracle on %d of %d host threads: both ViT towers (%d+%d blocks) + projector on one frame and the "
+                       "LLaMA prefill (S=%d, all %d layer passes) + lm-head executed in full, once; then %d cached greedy decode "
+                       "steps (all %d layer passes + lm-head + argmax each, context %d..%d) timed, their mean extrapolated to the "
+                       "other %d new tokens; %d distinct random layers (%.1f GB fp32) are cycled through the layer passes" %
+                       (nthreads, ncpu, cfg.towers[0].take_index + 1, cfg.towers[1].take_index + 1, S, nl, decode_steps, nl, S, S + decode_steps - 1,
+                        new_tokens - 1 - decode_steps, nd, nd * (4 * qd * L.hidden_size + 3 * L.intermediate_size * L.hidden_size) * 4 / 1e9)),
             "seconds_per_action": round(t_action, 3), "parts_s": {k: round(v, 5) for k, v in t.items()}}
+
+
+def _workload(args, world, B, P, T):
+    if args.tiny:
+        return "TINY plumbing config (invalid as headline)"
+    if args.fp8:
+        head = "BASELINE configs[4] (fp8-e4m3 decode weights, batch %d%s)" % (B, ", hipGraph step" if args.graph else "")
+    elif world == 1 and B == 1:
+        head = "BASELINE configs[1]"
+    elif B == 8:
+        head = "BASELINE configs[2] shard (8 frames/GPU; 64 frames over 8 GPUs at N=8), data-parallel over %d GPU(s), one RCCL all_gather of the results per batch" % world
+    else:
+        head = "BASELINE configs[1] extended to %d frame(s)/GPU" % B
+    return head + (": Emma-X-7B bf16, %d frame(s)/GPU 224x224, %d-token prompt, greedy, %d new tokens (EOS disabled), random-init weights"
+                   % (B, P, T))
 
 
 def main():
@@ -112,7 +160,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch-per-gpu", type=int, default=1)
+    ap.add_argument("--batch-per-gpu", type=int, default=None,
+                    help="frames per GPU per step; default 1 at --gpus 1 (BASELINE configs[1]), 8 at --gpus > 1 (configs[2]: 64 frames over 8 GPUs)")
     ap.add_argument("--prompt-tokens", type=int, default=512)
     ap.add_argument("--new-tokens", type=int, default=512)
     ap.add_argument("--tiny", action="store_true", help="tiny config (plumbing check only; NOT a valid headline number)")
@@ -127,6 +176,8 @@ def main():
     from emmax.config import EmmaXConfig
     from emmax.modeling import EmmaXForActionPrediction
 
+    if args.batch_per_gpu is None:
+        args.batch_per_gpu = 1 if args.gpus == 1 else 8
     rank, world, local = edist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -148,12 +199,22 @@ def main():
     frames = torch.from_numpy(rng.integers(0, 256, size=(B, 224, 224, 3), dtype=np.uint8)).to(dev)
     prompts = [[1] + [int(x) for x in rng.integers(3, 31744, size=P - 1)] for _ in range(B)]
 
+    gather_s = []
+
     def step():
         acts, ids, lens = model.generate_actions_batch(frames, prompts, max_new_tokens=T, stop_on_eos=False)
-        return edist.gather_results(torch.from_numpy(acts).to(dev), ids, lens)
+        a = torch.from_numpy(acts).to(dev)
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        out = edist.gather_results(a, ids, lens)      # the ONE collective of the data path (RCCL all_gather over xGMI when N > 1)
+        torch.cuda.synchronize()
+        gather_s.append(time.perf_counter() - g0)
+        return out
 
     for _ in range(args.warmup):
         step()
+    gather_s.clear()
+    rccl_ranks = edist.collective_world_size(dev)     # counted by an actual all_reduce, not read from the environment
     edist.barrier()
     torch.cuda.synchronize()
     lat = []
@@ -168,6 +229,7 @@ def main():
     elapsed = edist.max_over_ranks(time.perf_counter() - t0, dev)
     ms_per_step = elapsed / args.steps * 1e3
     actions_per_s = world * B * args.steps / elapsed
+    gather_ms = edist.max_over_ranks(float(np.mean(gather_s)) * 1e3 if gather_s else 0.0, dev)
 
     # ---- stage breakdown + roofline of the dominant kernel (rank 0) ----
     out = None
@@ -211,10 +273,11 @@ def main():
             "metric": "actions/sec", "value": round(actions_per_s, 4), "unit": "actions/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not args.fp8 else "bf16 activations / fp8-e4m3 decode weights", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[4] (fp8 decode weights): " if args.fp8 else "") + ("BASELINE configs[1]: Emma-X-7B bf16, %d frame(s)/GPU 224x224, %d-token prompt, greedy, %d new tokens "
-                                    "(EOS disabled), random-init weights" % (B, P, T)) if not args.tiny else "TINY plumbing config (invalid as headline)",
+            "config": {"workload": _workload(args, world, B, P, T),
                        "batch_per_gpu": B, "global_batch": B * world, "prompt_tokens": P, "new_tokens": T, "context": ctx + T,
                        "parallelism": f"dp{world}", "hipgraph": eng.graph_active(), "chained_launch": eng.chain_active()},
+            "rccl_ranks": rccl_ranks, "dist_backend": edist.backend_name(),
+            "gather_ms": round(gather_ms, 4), "gather_share": round(gather_ms / ms_per_step, 6),
             "p50_latency_ms": round(float(np.median(lat)) * 1e3, 2),
             "decode_ms_per_token": round(step_ms, 4), "decode_tokens_per_s": round(B * 1e3 / step_ms, 1),
             "decode_step_hbm_gbs": round(step_gbs, 1), "decode_step_hbm_frac": round(step_gbs / HBM_PEAK_GBS, 4),

@@ -110,3 +110,16 @@ def generate_actions_dp(model, frames_u8: torch.Tensor, prompt_rows, max_new_tok
         ids = torch.zeros(0, max_new_tokens, dtype=torch.int32, device=dev)
         lens = torch.zeros(0, dtype=torch.int32, device=dev)
     return gather_results(acts, ids, lens, counts)
+
+
+def backend_name() -> str:
+    return dist.get_backend() if dist.is_initialized() else "none"
+
+
+def collective_world_size(device) -> int:
+    """Ranks that took part in an ACTUAL collective (all_reduce of ones): what `bench.py` reports as `rccl_ranks`."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 1
+    t = torch.ones(1, dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())

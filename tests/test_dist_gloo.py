@@ -37,6 +37,7 @@ def _worker(rank, world, port, q):
     A, I, Ls = edist.gather_results(acts, ids, lens, counts)
     edist.barrier()
     mx = edist.max_over_ranks(float(rank + 1), "cpu")
+    assert edist.collective_world_size("cpu") == world and edist.backend_name() == "gloo"
     q.put((rank, A.tolist(), I.tolist(), Ls.tolist(), mx))
     dist.destroy_process_group()
 
