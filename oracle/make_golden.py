@@ -19,7 +19,14 @@ It commits DATA (inputs + expected outputs), never reference source.  What it pi
                             (the reference's dependency, requirements-min.txt) is not installed, so this is the strongest pin
                             of the tower math available offline.
 
-Usage:  python oracle/make_golden.py
+  G9 simpler_env.json       the SimplerEnv policy wrapper OpenVLAInference.step (experiments/SimplerEnv-OpenVLA/simpler_env/
+                            policies/openvla/openvla_model.py:72-145) driven by a SCRIPTED fake model: raw action sequences ->
+                            (raw_action, action) dicts for both policy setups (sticky-gripper state machine, scaling, keys).
+                            cv2 / transforms3d / matplotlib are absent offline: the file is imported with stub modules --
+                            euler2axangle backed by scipy's Rotation (an independent implementation), cv2.resize never
+                            reached (inputs are 224x224 -- the stub raises otherwise).
+
+Usage:  python oracle/make_golden.py [g9]
 """
 
 import importlib.util
@@ -357,8 +364,86 @@ def g8_vit_hf():
     np.savez_compressed(os.path.join(OUT, "vit_hf.npz"), **out)
 
 
+def g9_simpler_env():
+    from scipy.spatial.transform import Rotation
+
+    def euler2axangle(ai, aj, ak):
+        rv = Rotation.from_euler("xyz", [ai, aj, ak]).as_rotvec()
+        ang = float(np.linalg.norm(rv))
+        return (rv / ang, ang) if ang > 0 else (np.array([1.0, 0.0, 0.0]), 0.0)
+
+    def no_resize(image, size, interpolation=None):
+        assert tuple(image.shape[:2]) == (size[1], size[0]), "golden inputs are already at image_size"
+        return image
+
+    stubs = {"cv2": types.SimpleNamespace(resize=no_resize, INTER_AREA=3), "matplotlib": types.ModuleType("matplotlib"),
+             "matplotlib.pyplot": types.ModuleType("matplotlib.pyplot"), "transforms3d": types.ModuleType("transforms3d"),
+             "transforms3d.euler": types.SimpleNamespace(euler2axangle=euler2axangle)}
+    saved = {k: sys.modules.get(k) for k in stubs}
+    sys.modules.update(stubs)
+    import transformers
+    had_v2s = hasattr(transformers, "AutoModelForVision2Seq")
+    if not had_v2s:   # transformers >= 5 dropped the name the reference imports (never called here: the constructor is bypassed)
+        transformers.AutoModelForVision2Seq = transformers.AutoModelForImageTextToText
+    try:
+        mod = load(f"{REF}/experiments/SimplerEnv-OpenVLA/simpler_env/policies/openvla/openvla_model.py", "ref_simpler")
+    finally:
+        if not had_v2s:
+            del transformers.AutoModelForVision2Seq
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+    class FakeVLA:
+        def __init__(self, seq):
+            self.seq, self.i, self.calls = seq, 0, []
+
+        def predict_action(self, **kw):
+            self.calls.append(kw.get("unnorm_key"))
+            a = np.asarray(self.seq[self.i], dtype=np.float64)
+            self.i += 1
+            return a
+
+    class FakeInputs(dict):
+        def to(self, *a, **k):
+            return self
+
+    rng = np.random.default_rng(5)
+    grip = [1.0, 0.9, 0.1, 0.05, 0.0, 0.0, 0.95, 1.0, 0.2, 0.2, 0.9, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.8, 0.8]
+    seq = [list(rng.uniform(-0.05, 0.05, 3)) + list(rng.uniform(-0.3, 0.3, 3)) + [g] for g in grip]
+    seq[3][3:6] = [0.0, 0.0, 0.0]                         # null rotation
+    out = {"raw_sequence": seq, "runs": []}
+    for setup, scale in (("widowx_bridge", 1.0), ("google_robot", 1.0), ("google_robot", 0.5)):
+        pol = mod.OpenVLAInference.__new__(mod.OpenVLAInference)   # the constructor downloads from the hub: set its state by hand
+        pol.policy_setup, pol.unnorm_key = setup, {"widowx_bridge": "bridge_orig", "google_robot": "fractal20220817_data"}[setup]
+        pol.sticky_gripper_num_repeat = {"widowx_bridge": 1, "google_robot": 15}[setup]
+        pol.image_size, pol.action_scale = [224, 224], scale
+        pol.horizon = pol.pred_action_horizon = pol.exec_horizon = 1
+        pol.task = pol.task_description = None
+        pol.num_image_history = 0
+        pol.sticky_action_is_on, pol.gripper_action_repeat, pol.sticky_gripper_action, pol.previous_gripper_action = False, 0, 0.0, None
+        pol.vla = FakeVLA(seq)
+        pol.processor = lambda prompt, image: FakeInputs()
+        steps = []
+        img = np.zeros((224, 224, 3), dtype=np.uint8)
+        for i in range(len(seq)):
+            task = "pick up the spoon" if i < 20 else "close the drawer"      # a new description resets the policy state
+            raw, act = pol.step(img, task)
+            steps.append({"task": task, "raw": {k: np.asarray(v).tolist() for k, v in raw.items()},
+                          "action": {k: np.asarray(v, dtype=np.float64).tolist() for k, v in act.items()}})
+        out["runs"].append({"policy_setup": setup, "action_scale": scale, "unnorm_keys_seen": sorted(set(pol.vla.calls)), "steps": steps})
+    with open(os.path.join(OUT, "simpler_env.json"), "w") as f:
+        json.dump(out, f)
+    print("G9 ok", [len(r["steps"]) for r in out["runs"]])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["g9"]:
+        g9_simpler_env()
+        sys.exit(0)
     g1_action_decode()
     g3_projector()
     g4_llama("mha", 4, 4, 16)
@@ -367,3 +452,4 @@ if __name__ == "__main__":
     g7_solver()
     g5_wrapper()
     g8_vit_hf()
+    g9_simpler_env()

@@ -1,0 +1,215 @@
+"""
+verify_checkpoint.py -- one-command closure of the three "parity unpinned" gaps the day a real checkpoint is at hand
+(the protocol of /root/reference/vla-scripts/extern/verify_openvla.py:71-85 with an oracle beside it).
+
+    python tests/verify_checkpoint.py <hf_checkpoint_dir> [--device cuda:0] [--prompts 5] [--new-tokens 7]
+                                      [--oracle-dtype fp32|bf16] [--skip-model] [--json out.json]
+
+It lives under tests/ because it drives the CPU oracle (oracle/ is test infrastructure; the product never imports it).
+Sections -- each prints PASS / FAIL / SKIPPED (reason) and lands in the JSON summary; exit code 1 if any section FAILS:
+
+  files      config.json / *.safetensors / dataset_statistics.json / tokenizer files present, state dict matches the config
+  tokenizer  (needs tokenizer files) LLaMA tokenizer text <-> ids round trips the hot path relies on: BOS first; action bins ->
+             text -> ids -> `Solver.extract_action_policies` gives the bins back (solver.py:107-137: the "meaningless" first
+             token is the dummy prefix); `predict_action`'s 29871 rule (modeling_prismatic.py:513-516); the in-context stop rule
+  timm       (needs `timm`) the reference's own towers -- timm.create_model(<timm id>), weights from the checkpoint,
+             get_intermediate_layers(n={depth-2}) (modeling_prismatic.py:78-101) -- against the oracle's restatement (fp32,
+             1e-4) and, with a GPU, against emmax_vision_features (3e-2): closes "ViT pinned to HF, not to timm"
+  model      (needs a GPU) verify_openvla.py-style: N random 256x256 images + the OpenVLA prompt -> `predict_action` on the
+             HIP path vs the CPU oracle (fp32 = the reference's CPU path, or bf16 = per-op-rounded emulation of its accelerator
+             path): generated ids identical, action within 1e-3, per-step top-2 margins reported
+On the synthetic checkpoint of tools/make_synthetic_checkpoint.py the tokenizer / timm sections report SKIPPED.
+"""
+
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "emma-x_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+INSTRUCTIONS = ["put spoon on towel", "pick up the carrot", "close the drawer", "move the pot to the left burner", "stack the cups"]
+
+
+def openvla_prompt(instruction: str) -> str:
+    return f"In: What action should the robot take to {instruction.lower()}?\nOut:"   # verify_openvla.py:22-26
+
+
+def section_files(path, report):
+    from emmax.config import EmmaXConfig
+    from emmax.weights import load_hf_state_dict, validate_state_dict
+
+    has = {f: os.path.isfile(os.path.join(path, f)) for f in ("config.json", "dataset_statistics.json", "tokenizer.json", "tokenizer.model")}
+    shards = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
+    if not has["config.json"] or not shards:
+        report["files"] = {"status": "FAIL", "why": "config.json or *.safetensors missing", "present": has, "shards": shards}
+        return None, None
+    cfg = EmmaXConfig.from_pretrained(path)
+    sd = load_hf_state_dict(path)
+    try:
+        validate_state_dict(sd, cfg)
+    except ValueError as e:
+        report["files"] = {"status": "FAIL", "why": str(e)[:500]}
+        return None, None
+    report["files"] = {"status": "PASS", "present": has, "shards": len(shards), "tensors": len(sd), "norm_stats_keys": sorted(cfg.norm_stats),
+                       "warn": None if cfg.norm_stats else "no dataset statistics: predict_action will raise until norm_stats is set"}
+    return cfg, sd
+
+
+def section_tokenizer(path, cfg, report):
+    from emmax.actions import ActionTokenizer
+    from emmax.modeling import load_tokenizer
+    from emmax.policy_parser import Solver
+    from emmax.serving import stop_rule_from_tokenizer
+
+    tok = load_tokenizer(path, cfg)
+    if tok is None:
+        report["tokenizer"] = {"status": "SKIPPED", "why": "no tokenizer.json / tokenizer.model in the checkpoint directory (parity stays unpinned)"}
+        return None
+    fails = []
+    ids = tok(openvla_prompt(INSTRUCTIONS[0]), return_tensors="pt").input_ids[0].tolist()
+    if ids[0] != cfg.bos_token_id:
+        fails.append(f"first id {ids[0]} is not BOS {cfg.bos_token_id}")
+    at = ActionTokenizer(tok, bins=cfg.n_action_bins)
+    solver = Solver(at, verbose=False)
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for _ in range(20):
+        action = rng.uniform(-1, 1, 7)
+        text = at(action)                                   # bins -> the text the model was trained to emit
+        pol, _ = solver.extract_action_policies("POLICIES:\n" + text + "\n")
+        worst = max(worst, float(np.abs(np.asarray(pol[0]) - action).max()))
+    if worst > 2.0 / (cfg.n_action_bins - 1):
+        fails.append(f"action text round trip is off by {worst:.4f} (> one bin)")
+    trig, after = stop_rule_from_tokenizer(tok)
+    sample = tok("MOVEMENT:\nmove forward 3\nPOLICIES:\n" + at(np.zeros(7)), add_special_tokens=False).input_ids
+    hit = any(sample[i:i + len(trig)] == trig for i in range(len(sample)))
+    if not hit:
+        fails.append(f"stop trigger {trig} does not occur in a tokenised sample generation")
+    report["tokenizer"] = {"status": "FAIL" if fails else "PASS", "fails": fails, "class": type(tok).__name__, "round_trip_worst": worst,
+                           "stop_trigger": trig, "prompt_ends_with_29871": ids[-1] == 29871}
+    return tok
+
+
+def section_timm(cfg, sd, device, report):
+    if importlib.util.find_spec("timm") is None:
+        report["timm"] = {"status": "SKIPPED", "why": "timm is not installed (the reference pins timm==0.9.10); tower parity stays pinned to HF only"}
+        return
+    import timm
+
+    from oracle import emmax_oracle as orc
+
+    rng = np.random.default_rng(1)
+    frames = rng.integers(0, 256, size=(2, 224, 224, 3), dtype=np.uint8)
+    pix = orc.preprocess_frames(frames, cfg)
+    out = {"status": "PASS", "timm_version": timm.__version__, "towers": []}
+    feats = []
+    for i, (pre, tw) in enumerate(zip(orc.TOWER_PREFIXES, cfg.towers)):
+        m = timm.create_model(tw.timm_id.split(".")[0], pretrained=False, num_classes=0, img_size=tw.image_size).eval()
+        own = {}
+        for k, v in sd.items():
+            if k.startswith(pre):
+                k2 = k[len(pre):]
+                own[k2[:-len(".scale_factor")] + ".gamma" if k2.endswith(".scale_factor") else k2] = v.float()
+        missing, unexpected = m.load_state_dict(own, strict=False)
+        with torch.inference_mode():
+            ref = m.get_intermediate_layers(pix[:, 3 * i:3 * i + 3], n={len(m.blocks) - 2})[0]
+            ours = orc.vit_tower(pix[:, 3 * i:3 * i + 3], {k: v.float() for k, v in sd.items() if k.startswith(pre)}, pre, tw)
+        err = float((ours - ref).abs().max() / ref.abs().max())
+        out["towers"].append({"timm_id": tw.timm_id, "oracle_vs_timm": err, "missing": list(missing)[:8], "unexpected": list(unexpected)[:8]})
+        if err > 1e-4:
+            out["status"] = "FAIL"
+        feats.append(ref)
+    if device is not None:
+        from emmax.modeling import EmmaXForActionPrediction
+
+        model = EmmaXForActionPrediction(cfg, {k: v.to(torch.bfloat16) for k, v in sd.items()}).to(device, max_batch=2, max_prompt=16)
+        model.engine.vision_encode(torch.from_numpy(frames).to(device))
+        got = model.engine.vision_features(2).float().cpu()
+        ref = torch.cat(feats, dim=2)
+        err = float((got[..., : ref.shape[-1]] - ref).abs().max() / ref.abs().max())
+        out["hip_vs_timm"] = err
+        if err > 3e-2:
+            out["status"] = "FAIL"
+    report["timm"] = out
+
+
+def section_model(path, cfg, sd, tok, device, n_prompts, new_tokens, oracle_dtype, report):
+    from emmax.modeling import EmmaXForActionPrediction
+    from emmax.processing import EmmaXProcessor
+    from oracle import emmax_oracle as orc
+
+    if not cfg.norm_stats:
+        report["model"] = {"status": "SKIPPED", "why": "no dataset statistics in the checkpoint directory"}
+        return
+    proc = EmmaXProcessor.from_pretrained(path, cfg=cfg)
+    unnorm_key = "bridge_orig" if "bridge_orig" in cfg.norm_stats else next(iter(cfg.norm_stats))
+    vla = EmmaXForActionPrediction(cfg, {k: v.to(torch.bfloat16) for k, v in sd.items()}).to(device, max_batch=1, max_prompt=128)
+    dt = torch.float32 if oracle_dtype == "fp32" else torch.bfloat16
+    sd_ref = {k: (v.to(torch.bfloat16).float() if dt == torch.float32 else v.to(torch.bfloat16)) for k, v in sd.items()}
+    rng = np.random.default_rng(7)
+    rows, ok = [], True
+    for i in range(n_prompts):
+        image = np.asarray(rng.random((256, 256, 3)) * 255, dtype=np.uint8)          # verify_openvla.py:74
+        prompt = openvla_prompt(INSTRUCTIONS[i % len(INSTRUCTIONS)])
+        inputs = proc(prompt, image).to(device, dtype=torch.bfloat16)
+        t0 = time.time()
+        action = vla.predict_action(**inputs, unnorm_key=unnorm_key, do_sample=False)
+        dt_hip = time.time() - t0
+        ids = inputs["input_ids"][0].tolist()
+        if ids[-1] != 29871:
+            ids.append(29871)
+        frame = inputs["frames_u8"].cpu().numpy()                                   # the processor's 224x224 resize of the image
+        with torch.inference_mode():
+            ref_ids, trace = orc.greedy_generate(torch.tensor([ids]), orc.preprocess_frames(frame, cfg), sd_ref, cfg, new_tokens, dtype=dt,
+                                                 return_trace=True)
+        want = orc.predict_action_tail(ref_ids[0].numpy(), cfg.norm_stats[unnorm_key]["action"], cfg.action_vocab_size, cfg.n_action_bins)
+        got_ids = vla.generate(torch.tensor([ids]), frames_u8=inputs["frames_u8"], max_new_tokens=new_tokens)[0, len(ids):].tolist()
+        margins = [float((lambda t2: t2[0] - t2[1])(torch.topk(tr, 2).values)) for tr in trace]
+        same = got_ids == ref_ids[0, len(ids):].tolist()
+        err = float(np.abs(action - want).max())
+        ok = ok and same and err <= 1e-3
+        rows.append({"prompt": i, "ids_equal": same, "action_err": err, "min_margin": min(margins), "hip_seconds": round(dt_hip, 4)})
+    report["model"] = {"status": "PASS" if ok else "FAIL", "oracle_dtype": oracle_dtype, "unnorm_key": unnorm_key, "prompts": rows}
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("path")
+    ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--prompts", type=int, default=5)
+    ap.add_argument("--new-tokens", type=int, default=7)
+    ap.add_argument("--oracle-dtype", choices=("fp32", "bf16"), default="fp32")
+    ap.add_argument("--skip-model", action="store_true")
+    ap.add_argument("--json", default=None)
+    a = ap.parse_args(argv)
+    report = {}
+    cfg, sd = section_files(a.path, report)
+    if cfg is not None:
+        tok = section_tokenizer(a.path, cfg, report)
+        gpu = torch.cuda.is_available() and not a.skip_model
+        section_timm(cfg, sd, a.device if gpu else None, report)
+        if gpu:
+            section_model(a.path, cfg, sd, tok, a.device, a.prompts, a.new_tokens, a.oracle_dtype, report)
+        else:
+            report["model"] = {"status": "SKIPPED", "why": "no HIP device (or --skip-model)"}
+    for k, v in report.items():
+        print(f"[{v['status']:7s}] {k}: " + json.dumps({kk: vv for kk, vv in v.items() if kk != 'status'})[:400])
+    if a.json:
+        with open(a.json, "w") as f:
+            json.dump(report, f, indent=1)
+    return 1 if any(v["status"] == "FAIL" for v in report.values()) else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
