@@ -3,192 +3,365 @@
 //   * the LLaMA prefill (causal, head_dim 128, GQA-generic)              = HF `LlamaAttention` at q_len > 1
 // Both are called from prismatic/extern/hf/modeling_prismatic.py:121 and :404-415 in the reference.
 //
-// "Swapped" formulation so the softmax statistics are lane-local and P never leaves registers:
-//   S^T = K . Q^T   (A = K tile from LDS, B = Q^T kept in registers)      -> lane (g,c) holds S^T[key = 16t+4g+r][q = c]
-//   O^T = V^T . P^T (A = V^T tile from LDS, B = P^T = the lane's own S^T registers, converted to bf16)
-// The 32-wide MFMA reduction index is free to be any bijection onto the 32 keys of a half tile as long as A and B use
-// the same one; we pick  slot (g,j) -> key 16*t0 + 4g + j (j<4), 16*t1 + 4g + (j-4) (j>=4),  which is exactly what a
-// lane already holds after the QK^T step.  V is transposed while it is staged into LDS (2-byte scatter), K is staged
-// row-major with an odd 16-byte-slot row pitch (conflict-free ds_read_b128 over 16 rows).
-// Softmax runs in fp32 with the online (running max / running sum) recurrence; masked keys get -inf.
+// Structure (gfx950): a block = 3 or 4 waves = 96 / 128 queries of one (sequence, head); wave w owns 32 consecutive queries and
+// keeps their Q^T, running softmax statistics and whole O^T accumulator in registers (the kernel template also builds with two
+// query blocks per wave, 8-wave blocks and 3-4 deep LDS rings; none of them measured faster -- see launch_attention).  The ViT
+// sequences are only 4-5 key tiles long, so a block is mostly prologue (Q / first tile from HBM) and epilogue: blocks are kept
+// light -- 3-4 share a CU and one block's memory latency hides under another's math (8-wave blocks, one per CU, ran at 16 %
+// MFMA utilisation).  The grid is 1-D and XCD-aware: the query chunks of a head, neighbouring heads and (with many sequences)
+// all heads of a sequence run on ONE XCD, back to back, so the 128-byte lines that neighbouring heads share in the packed qkv rows (head pitch 128 / 144 B) and the K / V
+// re-read by the other query chunks are served by that XCD's L2: HBM traffic measured = the qkv buffer once + the output
+// (profiles/r02_pmc_attention.json).  Keys / values stream through LDS in tiles of 64, double buffered, by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass): the DMA of tile j+1 is issued before the math of tile j
+// and drained at the one barrier that ends the tile.  A wave-level DMA writes 64 consecutive 16-byte slots; the row padding
+// slots are simply lanes that stay inactive (zeroed once).  Both images are ROW-major, exactly as they sit in the qkv buffer
+// -- no transpose on the way in (bank conflicts measured: 0):
+//   S^T = K . Q^T   v_mfma_f32_32x32x16_bf16, A = K rows via ds_read_b128 (odd 16-byte row pitch: conflict-free), B = Q^T from
+//                   registers.  Lane (q = lane & 31, hi = lane >> 5) receives the scores of query q against keys
+//                   crow(r, hi) = (r & 3) + 8 (r >> 2) + 4 hi, r = 0..15, of a 32-key group: a whole P row is lane-local up to
+//                   ONE v_permlane32_swap (row max); the row sum stays per lane until the epilogue.
+//   O^T = V^T . P^T the same MFMA; B = P^T = the lane's own score registers converted to bf16 (the 16-wide reduction index may
+//                   be any bijection onto 16 keys as long as A uses the same one, so P never moves between lanes); A = V^T
+//                   fetched from the row-major V image with ds_read_b64_tr_b16, the LDS transpose read: lane i of a 16-lane
+//                   group supplies the address of 4 contiguous d of key i >> 2 and receives 4 consecutive keys of column i
+//                   (map pinned on hardware by tools/tr_read_test.hip).  V row pitch = 64 B x odd: the four key rows of a read
+//                   land in different bank quarters.
+// Softmax in fp32 with the online (running max / running sum) recurrence, exp2 with the scale folded in; masked keys get -inf;
+// mask code runs only on tiles that touch the sequence end or the causal diagonal.  Causal blocks stop at their diagonal and a
+// wave skips the tiles past its own 32 queries.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
-template <int HD>
-struct AttnDims {
-    static constexpr int HDK = (HD + 31) / 32 * 32;   // QK^T reduction length, zero padded
-    static constexpr int HDV = (HD + 15) / 16 * 16;   // PV output rows, zero padded
-    static constexpr int KPITCH = HDK + 8;            // bf16 elements; (KPITCH*2)/16 is odd for HDK in {64,96,128}
-    static constexpr int VPITCH = 64 + 4;             // bf16 elements per V^T row (64 keys + pad)
-    static constexpr int CH = HD / 8;                 // 16-byte chunks per K/V row
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+template <int HD_, int NW_, int QB_, int NBUF_, int BPC_>
+struct AttnCfg {
+    static constexpr int HD = HD_;
+    static constexpr int HDK = (HD + 15) / 16 * 16;     // QK^T reduction length (k steps of 16), zero padded
+    static constexpr int NKK = HDK / 16;
+    static constexpr int NDB = (HD + 31) / 32;          // O^T row blocks of 32
+    static constexpr int KP = HDK + 8;                  // K row pitch, bf16 elements: (2 KP) / 16 is odd for HDK in {64, 80, 128}
+    static constexpr int VP = (NDB * 32 <= 96) ? 96 : 160;   // V row pitch: 192 B / 320 B = 64 B x odd, >= 2 * 32 * NDB bytes
+    static constexpr int CH = HD / 8;                   // 16-byte chunks per K / V row
+    static constexpr int TILE = 64;
+    static constexpr int NW = NW_;                      // waves per block
+    static constexpr int NT = NW * 64;
+    static constexpr int QB = QB_;                      // 32-query blocks per wave
+    static constexpr int QCH = NW * 32 * QB;            // queries per block
+    static constexpr int NBUF = NBUF_;                  // LDS ring depth: NBUF - 1 tiles of DMA in flight
+    static constexpr int KS = KP / 8, VS = VP / 8;      // 16-byte slots per LDS row
+    static constexpr int NKI = (TILE * KS + 63) / 64, NVI = (TILE * VS + 63) / 64;   // 1 KiB DMA instructions per tile
+    static constexpr bool GS = HD == 72 || (HD == 128 && QB == 2);   // softmax step = one 32-key group instead of the 64-key tile (registers)
+    static constexpr int MINW = BPC_ * NW / 4;          // waves per SIMD the register budget is planned for (BPC blocks per CU)
 };
 
-template <int HD>
-__global__ __launch_bounds__(256) void emmax_attention_kernel(AttnParams p) {
-    using DM = AttnDims<HD>;
-    constexpr int HDK = DM::HDK, HDV = DM::HDV, KP = DM::KPITCH, VP = DM::VPITCH, CH = DM::CH;
-    constexpr int NKK = HDK / 32, NDT = HDV / 16;
-    __shared__ __attribute__((aligned(16))) bf16_t sK[64 * KP];
-    __shared__ __attribute__((aligned(16))) bf16_t sVt[HDV * VP];
+// 16 bytes per lane, HBM/L2 -> LDS, no VGPR in between: lane i's data lands at lds_dst + 16 i (lds_dst wave-uniform).
+// Issued as asm on purpose: for the builtin form hipcc tracks "an LDS-DMA write is in flight" and puts s_waitcnt vmcnt(0) in
+// front of the next LDS read it cannot prove disjoint -- here the first V^T read of EVERY tile, which drained the tiles being
+// prefetched into the other ring buffers.  The ring's ordering is carried by the counted waits + barriers in the kernel.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned int lds_dst) {
+    const unsigned int m0v = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "m0", "memory");
+}
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, c = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
+__device__ __forceinline__ float half_max(float v) {   // max over the two half-waves (lanes l and l ^ 32)
+    float a, b;
+    swap_halves(v, a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float half_sum(float v) {
+    float a, b;
+    swap_halves(v, a, b);
+    return a + b;
+}
+
+template <class DM>
+__global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnParams p, int nchunk, int per_xcd) {
+    constexpr int HD = DM::HD, NBUF = DM::NBUF;
+    constexpr int NKK = DM::NKK, NDB = DM::NDB, KP = DM::KP, VP = DM::VP, CH = DM::CH, TILE = DM::TILE, NT = DM::NT, NW = DM::NW;
+    constexpr int QB = DM::QB, QCH = DM::QCH, KS = DM::KS, VS = DM::VS, NKI = DM::NKI, NVI = DM::NVI;
+    constexpr bool GS = DM::GS;
+    __shared__ __attribute__((aligned(16))) bf16_t sK[NBUF][TILE * KP];
+    __shared__ __attribute__((aligned(16))) bf16_t sV[NBUF][TILE * VP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: an SGPR
+    const int ql = lane & 31, hi = lane >> 5;
+    // XCD-aware work map: linear block id L runs on XCD L % 8.  The (sequence, head) items are dealt out in contiguous runs of
+    // `per_xcd`, so neighbouring heads of a sequence -- and, when there are many sequences, whole sequences -- stay on one XCD;
+    // an item's query chunks occupy consecutive slots of that XCD, heavy (late) causal chunks first
+    const int L = (int)blockIdx.x;
+    const int slot = L >> 3;
+    const int item = (L & 7) * per_xcd + slot / nchunk;
+    if (item >= p.B * p.Hq) return;
+    const int b = item / p.Hq, h = item - b * p.Hq;
+    const int qc = nchunk - 1 - slot % nchunk;
     const int start = p.cu_seqlens[b];
     const int len = p.cu_seqlens[b + 1] - start;
-    const int q_tile0 = qt * 64;
-    if (q_tile0 >= len) return;
+    const int q_blk0 = qc * QCH;
+    if (q_blk0 >= len) return;
     const int hk = h / (p.Hq / p.Hkv);
     const bf16_t* __restrict__ base = (const bf16_t*)p.qkv + (size_t)start * p.ld_qkv;
     const bf16_t* qptr = base + p.q_off + h * HD;
     const bf16_t* kptr = base + p.k_off + hk * HD;
     const bf16_t* vptr = base + p.v_off + hk * HD;
 
-    // zero the padding (columns HD..HDK of K rows, rows HD..HDV of V^T): never overwritten by the tile loads
-    if (HDK > HD) {
-        for (int i = tid; i < 64 * (HDK - HD); i += 256) sK[(i / (HDK - HD)) * KP + HD + (i % (HDK - HD))] = 0;
-    }
-    if (HDV > HD) {
-        for (int i = tid; i < (HDV - HD) * VP; i += 256) sVt[HD * VP + i] = 0;
-    }
-
-    // Q^T fragments (B operand): lane (g,c) holds Q[q_base + c][kk*32 + g*8 .. +8]
-    const int q_row = q_tile0 + wave * 16 + c;
-    bf16x8_t qf[NKK];
-#pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) {
-        const int k0 = kk * 32 + g * 8;
-        u32x4_t v = {0u, 0u, 0u, 0u};
-        if (q_row < len && k0 < HD) v = *(const u32x4_t*)(qptr + (size_t)q_row * p.ld_qkv + k0);
-        qf[kk] = __builtin_bit_cast(bf16x8_t, v);
+    // zero the padding once: K columns HD..HDK (HD = 72) enter the QK^T reduction; V columns past HD only feed discarded O^T rows
+    // but must be finite.  The tile DMA never touches them (those lanes stay inactive), so nothing orders against it.
+    {
+        constexpr int KZ = (KP - HD) / 8, VZ = (VP - HD) / 8;    // 16-byte slots of padding per row (HD % 8 == 0)
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+        for (int i = tid; i < NBUF * TILE * KZ; i += NT) *(u32x4_t*)(&sK[0][0] + (i / KZ) * KP + HD + (i % KZ) * 8) = z;
+        for (int i = tid; i < NBUF * TILE * VZ; i += NT) *(u32x4_t*)(&sV[0][0] + (i / VZ) * VP + HD + (i % VZ) * 8) = z;
     }
 
-    f32x4_t o[NDT];
+    // Q^T fragments (B operand): lane (ql, hi) holds Q[q_row][16 kk + 8 hi .. +8] of each of its QB query blocks
+    const int q_w0 = q_blk0 + wave * 32 * QB;
+    const bool wave_live = q_w0 < len;
+    bf16x8_t qf[QB][NKK];
 #pragma unroll
-    for (int i = 0; i < NDT; ++i) o[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-
-    int kv_end = len;
-    if (p.causal) kv_end = min(len, q_tile0 + 64);
-    const float scale = p.scale;
-
-    for (int kv0 = 0; kv0 < kv_end; kv0 += 64) {
-        __syncthreads();  // previous tile consumed (also orders the pad zero-fill before first use)
-        // ---- stage K (row-major) and V (transposed) ----
-        for (int ci = tid; ci < 64 * CH; ci += 256) {
-            const int key = ci / CH, ch = ci - key * CH;
-            const int kg = kv0 + key;
-            u32x4_t kvv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-            if (kg < len) {
-                kvv = *(const u32x4_t*)(kptr + (size_t)kg * p.ld_qkv + ch * 8);
-                vv = *(const u32x4_t*)(vptr + (size_t)kg * p.ld_qkv + ch * 8);
-            }
-            *(u32x4_t*)(&sK[key * KP + ch * 8]) = kvv;
+    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                sVt[(ch * 8 + 2 * j) * VP + key] = (bf16_t)(vv[j] & 0xffffu);
-                sVt[(ch * 8 + 2 * j + 1) * VP + key] = (bf16_t)(vv[j] >> 16);
-            }
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int q_row = q_w0 + qb * 32 + ql;
+            const int k0 = kk * 16 + hi * 8;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (q_row < len && k0 < HD) v = *(const u32x4_t*)(qptr + (size_t)q_row * p.ld_qkv + k0);
+            qf[qb][kk] = __builtin_bit_cast(bf16x8_t, v);
         }
-        __syncthreads();
 
-        // ---- S^T = K . Q^T : 4 key tiles of 16 ----
-        f32x4_t st[4];
+    f32x16_t o[QB][NDB];
+    float m_run[QB], l_run[QB];   // l_run: this lane's share of the row sum (its 16 keys of every 32-key group)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            st[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = -INFINITY;
+        l_run[qb] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
+    }
+
+    const int kv_end = p.causal ? min(len, q_blk0 + QCH) : len;                 // block
+    const int kv_end_w = p.causal ? min(len, q_w0 + 32 * QB) : len;             // this wave
+    const float c = p.scale * 1.44269504088896340736f;                          // exp(x * scale) = exp2(x * c)
+    const int ntile = (kv_end + TILE - 1) / TILE;
+
+    // ---- tile staging by LDS-DMA: instruction i of a tile fills the 64 slots 64 i .. 64 i + 63 of the row-major image; slot n is
+    // row n / KS, chunk n % KS; padding chunks are inactive lanes; rows past the sequence end re-read its last row (finite, and
+    // masked where it matters), so every data slot of a tile is rewritten.  Every wave issues exactly PT instructions per tile
+    // (the surplus slots of the last round re-issue instructions 0.. of the same tile: same data to the same place), so the
+    // waits can count: vmcnt(n PT) = "all but the n youngest tiles have landed".  Everything that does not depend on the tile is
+    // computed once: per instruction the lane's row, its source pointer at row 0 and its LDS slab. ----
+    constexpr int TOT = NKI + NVI, PT = (TOT + NW - 1) / NW;
+    int d_row[PT];                // lane's row inside the tile, -1: padding slot (lane stays inactive)
+    unsigned int d_off[PT];       // lane's source byte offset from `base` at row 0 (head column + chunk)
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+        int idx = wave + u * NW;
+        idx = idx >= TOT ? idx - TOT : idx;
+        const bool isk = idx < NKI;
+        const int n = (isk ? idx : idx - NKI) * 64 + lane;
+        const int rk = n / KS, rv = n / VS;
+        const int row = isk ? rk : rv, ch = isk ? n - rk * KS : n - rv * VS;
+        d_row[u] = (ch < CH && row < TILE) ? row : -1;
+        d_off[u] = (unsigned int)(((isk ? p.k_off : p.v_off) + hk * HD + ch * 8) * 2);
+    }
+    const unsigned int ldsK0 = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) void*)&sK[0][0];
+    const unsigned int ldsV0 = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) void*)&sV[0][0];
+    const unsigned int row_bytes = (unsigned int)p.ld_qkv * 2u;
+    auto dma_tile = [&](int kv0, int buf) {
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            int idx = wave + u * NW;                       // scalar: which 1 KiB slab of which image
+            idx = idx >= TOT ? idx - TOT : idx;
+            const bool isk = idx < NKI;
+            const unsigned int slab = isk ? ldsK0 + buf * (TILE * KP * 2) + idx * 1024 : ldsV0 + buf * (TILE * VP * 2) + (idx - NKI) * 1024;
+            const int kg = min(kv0 + d_row[u], len - 1);
+            if (d_row[u] >= 0) glds16((const char*)base + ((size_t)(unsigned int)kg * row_bytes + d_off[u]), slab);
+        }
+    };
+    auto wait_all_but = [&](int younger) {   // wave-uniform
+        if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
+    };
+    static_assert(NBUF >= 2 && NBUF <= 4 && 2 * PT <= 63, "ring depth / wait counter range");
+
+#pragma unroll
+    for (int t = 0; t < NBUF - 1; ++t)
+        if (t < ntile) dma_tile(t * TILE, t);
+    // a wait the COMPILER sees (vmcnt(0), other counters untouched): it now knows the Q loads have returned.  With only the asm
+    // waits it keeps "Q may be pending" alive around the loop and emits its own vmcnt(0) before the first MFMA of every tile --
+    // which, unknown to it, also drains the tiles the asm DMA is prefetching.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();      // tile 0 (and its successors) and the zero fill are in place
+
+    // lane-constant LDS offsets
+    const int k_off = ql * KP + hi * 8;                                        // K fragment: row ql of a 32-key group, + 16 kk
+    const int i16 = lane & 15;
+    const int v_off = (4 * hi + (i16 >> 2)) * VP + 16 * ((lane >> 4) & 1) + (i16 & 3) * 4;   // + key base * VP + 32 db
+
+    // ---- one softmax step: NG groups of 32 keys starting at key ks0 (Kg / Vg = their rows in the LDS images).  EDGE steps
+    // (sequence end / causal diagonal) mask; the others carry no mask code at all ----
+    constexpr int NG = GS ? 1 : 2;
+    auto step = [&](auto edge_tag, int ks0, const bf16_t* __restrict__ Kg, const bf16_t* __restrict__ Vg) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        // S^T = K . Q^T ; one K fragment read feeds the MFMAs of all QB query blocks
+        f32x16_t st[QB][NG];
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
-                const bf16x8_t kf = *(const bf16x8_t*)(&sK[(t * 16 + c) * KP + kk * 32 + g * 8]);
-                st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], st[t], 0, 0, 0);
+                const bf16x8_t kf = *(const bf16x8_t*)(&Kg[gi * 32 * KP + k_off + kk * 16]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    st[qb][gi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][kk], kk == 0 ? zero : st[qb][gi], 0, 0, 0);
+                }
             }
+        // online softmax per query block; P^T packed to bf16
+        u32x4_t pf[QB][NG][2];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            if (EDGE) {
+                // key of register r: ks0 + 32 gi + (r & 3) + 8 (r >> 2) + 4 hi; visible iff below lim (sequence end, causal diagonal)
+                const int q_row = q_w0 + qb * 32 + ql;
+                const int lim = (p.causal ? min(len, q_row + 1) : len) - ks0 - 4 * hi;
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        st[qb][gi][r] = (gi * 32 + (r & 3) + 8 * (r >> 2) < lim) ? st[qb][gi][r] : -INFINITY;
+            }
+            float m_tile = st[qb][0][0];
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m_tile = fmaxf(m_tile, st[qb][gi][r]);
+            m_tile = half_max(m_tile);
+            const float m_new = fmaxf(m_run[qb], m_tile);     // finite from the first step on: key 0 is visible to every query
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
+            const float mc = m_new * c;
+            float psum = 0.f;
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qb][gi][8 * mm + 2 * t], c, -mc));
+                        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qb][gi][8 * mm + 2 * t + 1], c, -mc));
+                        psum += p0 + p1;
+                        pf[qb][gi][mm][t] = pack_bf16x2(p0, p1);
+                    }
+            l_run[qb] = __builtin_fmaf(l_run[qb], alpha, psum);
+            m_run[qb] = m_new;
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[qb][i][r] *= alpha;
         }
-        // ---- mask + online softmax (per query = per lane column c; rows spread over r, t and the 4 lane groups) ----
-        float m_tile = -INFINITY;
+        // O^T += V^T . P^T : k steps of 16 keys; one V^T fragment (two transpose reads) feeds all QB query blocks
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kv0 + t * 16 + g * 4 + r;
-                float s = st[t][r] * scale;
-                const bool ok = (key < len) && (!p.causal || key <= q_row);
-                s = ok ? s : -INFINITY;
-                st[t][r] = s;
-                m_tile = fmaxf(m_tile, s);
+            for (int mm = 0; mm < 2; ++mm) {
+                const bf16_t* vb = Vg + (gi * 32 + mm * 16) * VP + v_off;
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+                    const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + db * 32));
+                    const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + 8 * VP + db * 32));
+                    const u32x2_t w0 = __builtin_bit_cast(u32x2_t, a0), w1 = __builtin_bit_cast(u32x2_t, a1);
+                    const u32x4_t av = {w0[0], w0[1], w1[0], w1[1]};
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb)
+                        o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av),
+                                                                            __builtin_bit_cast(bf16x8_t, pf[qb][gi][mm]), o[qb][db], 0, 0, 0);
+                }
             }
-        m_tile = rows_max(m_tile);
-        const float m_new = fmaxf(m_run, m_tile);
-        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __expf(m_run - m_safe);   // m_run = -inf -> 0
-        float psum = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = __expf(st[t][r] - m_safe);
-                st[t][r] = pv;
-                psum += pv;
-            }
-        psum = rows_sum(psum);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < NDT; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[i][r] *= alpha;
+    };
 
-        // ---- O^T += V^T . P^T over the two 32-key halves ----
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int t0 = 2 * hh, t1 = 2 * hh + 1;
-            u32x4_t pp;
-            pp[0] = pack_bf16x2(st[t0][0], st[t0][1]);
-            pp[1] = pack_bf16x2(st[t0][2], st[t0][3]);
-            pp[2] = pack_bf16x2(st[t1][0], st[t1][1]);
-            pp[3] = pack_bf16x2(st[t1][2], st[t1][3]);
-            const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pp);
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                const bf16_t* vrow = &sVt[(dt * 16 + c) * VP];
-                const u32x2_t a0 = *(const u32x2_t*)(vrow + t0 * 16 + g * 4);
-                const u32x2_t a1 = *(const u32x2_t*)(vrow + t1 * 16 + g * 4);
-                const u32x4_t av = {a0[0], a0[1], a1[0], a1[1]};
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av), pf, o[dt], 0, 0, 0);
+    // ---- tile loop.  A wave computes the tiles its own queries can see (all of them unless causal) and only keeps the ring and
+    // the barriers going for the rest: the compute loop has no conditional around its loop-carried accumulators ----
+    const int ntile_w = wave_live ? (kv_end_w + TILE - 1) / TILE : 0;
+    constexpr int STEP = 32 * NG;
+    for (int j = 0; j < ntile; ++j) {
+        const int kv0 = j * TILE;
+        const int buf = j % NBUF;
+        // tile j + NBUF - 1 goes into the buffer tile j - 1 was read from (everybody passed the barrier that ended it)
+        if (j + NBUF - 1 < ntile) dma_tile(kv0 + (NBUF - 1) * TILE, (j + NBUF - 1) % NBUF);
+        if (j < ntile_w) {
+            const int nst = min(TILE / STEP, (kv_end_w - kv0 + STEP - 1) / STEP);
+            for (int sidx = 0; sidx < nst; ++sidx) {
+                const int ks0 = kv0 + sidx * STEP;
+                const bf16_t* Kg = &sK[buf][sidx * STEP * KP];
+                const bf16_t* Vg = &sV[buf][sidx * STEP * VP];
+                const bool edge = (ks0 + STEP > len) || (p.causal && ks0 + STEP - 1 > q_w0);
+                if (edge) step(std::true_type{}, ks0, Kg, Vg);
+                else step(std::false_type{}, ks0, Kg, Vg);
             }
         }
+        wait_all_but(min(NBUF - 2, ntile - 2 - j));        // tile j + 1 has landed (younger ones may still fly) ...
+        __syncthreads();                                    // ... and everybody is done reading tile j
     }
 
-    // ---- write O[q][d]: lane (g,c) holds d = dt*16 + g*4 + r of query c ----
-    if (q_row < len) {
-        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-        bf16_t* orow = (bf16_t*)p.out + (size_t)(start + q_row) * p.ld_out + h * HD;
+    // ---- write O[q][d]: lane (ql, hi) holds d = 32 db + 8 a + 4 hi + (0..3) in o[db][4 a .. 4 a + 3] ----
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            const int d0 = dt * 16 + g * 4;
-            if (d0 < HD) {
-                u32x2_t w;
-                w[0] = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
-                w[1] = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
-                *(u32x2_t*)(orow + d0) = w;
-            }
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l_tot = half_sum(l_run[qb]);
+        const int q_row = q_w0 + qb * 32 + ql;
+        if (q_row < len) {
+            const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+            bf16_t* orow = (bf16_t*)p.out + (size_t)(start + q_row) * p.ld_out + h * HD;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int d0 = db * 32 + a * 8 + hi * 4;
+                    if (d0 < HD) {
+                        u32x2_t w;
+                        w[0] = pack_bf16x2(o[qb][db][4 * a] * inv, o[qb][db][4 * a + 1] * inv);
+                        w[1] = pack_bf16x2(o[qb][db][4 * a + 2] * inv, o[qb][db][4 * a + 3] * inv);
+                        *(u32x2_t*)(orow + d0) = w;
+                    }
+                }
         }
     }
 }
 
 }  // namespace
 
+template <class DM>
+static int launch_attention_t(const AttnParams& p, hipStream_t stream) {
+    const int nchunk = cdiv(p.max_seqlen, DM::QCH);
+    const int per_xcd = cdiv(p.B * p.Hq, 8);     // (sequence, head) items per XCD
+    const int grid = 8 * per_xcd * nchunk;
+    hipLaunchKernelGGL(emmax_attention_kernel<DM>, dim3(grid), dim3(DM::NT), 0, stream, p, nchunk, per_xcd);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
 int launch_attention(const AttnParams& p, int head_dim, hipStream_t stream) {
     if (p.B <= 0 || p.max_seqlen <= 0) return 0;
     if (p.Hq % p.Hkv != 0) return -1;
     if ((p.ld_qkv % 8) || (p.q_off % 8) || (p.k_off % 8) || (p.v_off % 8) || (p.ld_out % 4)) return -1;
-    dim3 grid(cdiv(p.max_seqlen, 64), p.Hq, p.B), block(256);
+    // Block shape: 4 waves (128 queries) unless 3 waves (96) waste fewer padded query rows -- DINOv2's 261 tokens are 3 x 96 - 27
+    // against 3 x 128 - 123.  One 32-query block per wave and 2-4 light blocks per CU measured best on all three head sizes
+    // (tools/attn_probe.py; two query blocks per wave halve the LDS fragment reads but need ~250 registers and lose to spills /
+    // occupancy; deeper LDS rings and 8-wave blocks changed nothing: the loop is bound by its VALU softmax work, not by DMA latency).
+    const bool three = cdiv(p.max_seqlen, 96) * 96 < cdiv(p.max_seqlen, 128) * 128;
+    //                                            HD  NW QB NBUF blocks/CU
     switch (head_dim) {
-        case 64: hipLaunchKernelGGL(emmax_attention_kernel<64>, grid, block, 0, stream, p); break;
-        case 72: hipLaunchKernelGGL(emmax_attention_kernel<72>, grid, block, 0, stream, p); break;
-        case 128: hipLaunchKernelGGL(emmax_attention_kernel<128>, grid, block, 0, stream, p); break;
+        case 64: return three ? launch_attention_t<AttnCfg<64, 3, 1, 2, 4>>(p, stream) : launch_attention_t<AttnCfg<64, 4, 1, 2, 3>>(p, stream);
+        case 72: return three ? launch_attention_t<AttnCfg<72, 3, 1, 2, 4>>(p, stream) : launch_attention_t<AttnCfg<72, 4, 1, 2, 3>>(p, stream);
+        case 128:   // a single 768-token prefill is only 32 x 6 blocks of 128 queries for 256 CUs: halve the block below two per CU
+            if ((long long)p.B * p.Hq * cdiv(p.max_seqlen, 128) < 512) return launch_attention_t<AttnCfg<128, 2, 1, 2, 2>>(p, stream);
+            return launch_attention_t<AttnCfg<128, 4, 1, 2, 2>>(p, stream);
         default: return -1;
     }
-    return hipGetLastError() == hipSuccess ? 0 : -4;
 }

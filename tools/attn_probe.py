@@ -14,7 +14,7 @@ from emmax import _lib
 lib = _lib.load()
 dev = "cuda:0"
 REPS = int(os.environ.get("ATTN_REPS", "20"))
-shapes = [("dino<64>", 256, 261, 16, 64, 0), ("siglip<72>", 256, 256, 16, 72, 0), ("llama<128> causal", 8, 768, 32, 128, 1)]
+shapes = [("llama<128> causal B=1", 1, 768, 32, 128, 1), ("dino<64>", 256, 261, 16, 64, 0), ("siglip<72>", 256, 256, 16, 72, 0), ("llama<128> causal", 8, 768, 32, 128, 1)]
 for name, B, N, H, hd, causal in shapes:
     D = H * hd
     ld = (3 * D + 127) // 128 * 128
