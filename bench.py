@@ -4,7 +4,8 @@ bench.py -- headline measurement of the Emma-X hot path on MI355X.
 One "step" = one generate_actions pass over one batch of synthetic frames on every rank: fused DINOv2+SigLIP encode ->
 projector -> LLaMA-2-7B prefill (256 patches + 512 prompt tokens) -> 512 greedy decode steps (EOS disabled so every step
 does the full work) -> action de-tokenisation (+ one RCCL all_gather of the results when N > 1).
-Workload at N=1 = BASELINE.json configs[1]; N>1 = the same per-GPU work on every rank (weak scaling, data parallel).
+Workload at N=1 = BASELINE.json configs[1] (one frame); N>1 = configs[2]'s shard on every rank: 8 frames per GPU (64 frames over
+8 GPUs), weak scaling, data parallel, the line then carries `rccl_ranks` (counted by a real collective), `gather_ms` and its share.
 
 Prints ONE JSON line (rank 0) with the driver's contract + `roofline` (dominant kernel = gate/up decode GEMV, timed
 live with HIP events through emmax_profile_decode_stage) + `cpu_baseline` (the oracle timed on the host cores, N=1 only).
@@ -255,7 +256,7 @@ def main():
         # HBM traffic of the same kernel from PMC counters (separate rocprofv3 --pmc passes over tools/pmc_probe.py, B=1;
         # FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); not collected during this run
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if B == 1 and not args.tiny and not args.fp8 and os.path.isfile(pmc_file):
             with open(pmc_file) as f:
                 traffic = json.load(f)["stages"].get(dom, {}).get("hbm_bytes_per_launch")
@@ -286,7 +287,7 @@ def main():
             "roofline": {"kernel": ("emmax_decode_gemv_kernel<B=%d,GATEUP,NORM>" % B if (B <= 2 and not args.fp8) else "emmax_decode_mfma_kernel<GATEUP,NORM%s> (B=%d)" % (",FP8" if args.fp8 else "", B)) + " (gate/up projection + SiLU*mul)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "bytes_per_launch": stage_bytes[dom], "us_per_launch": round(stage_us[dom], 2), "traffic": traffic,
-                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, offline)" if traffic else None},
+                         "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc, offline)" if traffic else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, P, T)

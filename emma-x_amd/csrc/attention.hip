@@ -208,9 +208,10 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
 
     // ---- one softmax step: NG groups of 32 keys starting at key ks0 (Kg / Vg = their rows in the LDS images).  EDGE steps
     // (sequence end / causal diagonal) mask; the others carry no mask code at all ----
-    constexpr int NG = GS ? 1 : 2;
-    auto step = [&](auto edge_tag, int ks0, const bf16_t* __restrict__ Kg, const bf16_t* __restrict__ Vg) {
+    constexpr int NGMAX = GS ? 1 : 2;
+    auto step = [&](auto edge_tag, auto ng_tag, int ks0, const bf16_t* __restrict__ Kg, const bf16_t* __restrict__ Vg) {
         constexpr bool EDGE = decltype(edge_tag)::value;
+        constexpr int NG = decltype(ng_tag)::value;
         // S^T = K . Q^T ; one K fragment read feeds the MFMAs of all QB query blocks
         f32x16_t st[QB][NG];
 #pragma unroll
@@ -290,7 +291,9 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
     // ---- tile loop.  A wave computes the tiles its own queries can see (all of them unless causal) and only keeps the ring and
     // the barriers going for the rest: the compute loop has no conditional around its loop-carried accumulators ----
     const int ntile_w = wave_live ? (kv_end_w + TILE - 1) / TILE : 0;
-    constexpr int STEP = 32 * NG;
+    constexpr int STEP = 32 * NGMAX;
+    using NGfull = std::integral_constant<int, NGMAX>;
+    using NGone = std::integral_constant<int, 1>;
     for (int j = 0; j < ntile; ++j) {
         const int kv0 = j * TILE;
         const int buf = j % NBUF;
@@ -303,8 +306,9 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
                 const bf16_t* Kg = &sK[buf][sidx * STEP * KP];
                 const bf16_t* Vg = &sV[buf][sidx * STEP * VP];
                 const bool edge = (ks0 + STEP > len) || (p.causal && ks0 + STEP - 1 > q_w0);
-                if (edge) step(std::true_type{}, ks0, Kg, Vg);
-                else step(std::false_type{}, ks0, Kg, Vg);
+                if (!edge) step(std::false_type{}, NGfull{}, ks0, Kg, Vg);
+                else if (NGMAX == 2 && kv_end_w - ks0 <= 32) step(std::true_type{}, NGone{}, ks0, Kg, Vg);   // a tail of <= 32 keys (DINOv2: 261 = 4 x 64 + 5)
+                else step(std::true_type{}, NGfull{}, ks0, Kg, Vg);
             }
         }
         wait_all_but(min(NBUF - 2, ntile - 2 - j));        // tile j + 1 has landed (younger ones may still fly) ...

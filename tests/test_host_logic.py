@@ -233,7 +233,7 @@ def test_bench_contract_flags_and_committed_bench_line():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout
-    line = open(os.path.join(ROOT, "profiles", "r01_bench_n1.json")).read().strip().splitlines()[-1]
+    line = open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")).read().strip().splitlines()[-1]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -248,6 +248,8 @@ def test_bench_contract_flags_and_committed_bench_line():
     assert r["traffic"] is None or 0.9 < r["traffic"] / r["bytes_per_launch"] < 1.2
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "actions/s" and c["sample"]
+    assert "executed in full" in c["sample"] and c["parts_s"]["prefill_layers"] > 0 and c["parts_s"]["decode_step_mean"] > 0
+    assert d["rccl_ranks"] == 1 and d["gather_ms"] >= 0 and d["config"]["workload"].startswith("BASELINE configs[1]")
 
 
 def test_stop_rule_is_tokenised_in_context_sentencepiece_style():

@@ -7,3 +7,6 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_s
 bash tools/gpucmd_attn_pmc.sh prof_round/attn_pmc > $O/attn_pmc.log 2>&1
 timeout 600 python tools/gemm_bench.py > $O/gemm_bench.json 2>/dev/null
 ls -R $O | head -60
+# the kernel trace of the bench is ~50 MB: keep the stats, drop the per-dispatch trace (gpurun_out/ merges back <= 64 MiB)
+rm -f $O/rocprof/*kernel_trace.csv $O/rocprof_stage/*kernel_trace.csv
+du -sh $O
