@@ -158,18 +158,26 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
     // waits can count: vmcnt(n PT) = "all but the n youngest tiles have landed".  Everything that does not depend on the tile is
     // computed once: per instruction the lane's row, its source pointer at row 0 and its LDS slab. ----
     constexpr int TOT = NKI + NVI, PT = (TOT + NW - 1) / NW;
-    int d_row[PT];                // lane's row inside the tile, -1: padding slot (lane stays inactive)
-    unsigned int d_off[PT];       // lane's source byte offset from `base` at row 0 (head column + chunk)
-#pragma unroll
-    for (int u = 0; u < PT; ++u) {
+    // per instruction: the lane's row inside the tile (-1: padding slot, the lane stays inactive) and its source byte offset
+    // from `base` at row 0 (head column + chunk)
+    const int k_col0 = p.k_off + hk * HD, v_col0 = p.v_off + hk * HD;   // locals: selecting between two FIELDS of the by-value
+                                                                      // argument struct at run time made hipcc copy it to scratch
+    auto slot_of = [&](int u, int& row, unsigned int& off) {
         int idx = wave + u * NW;
         idx = idx >= TOT ? idx - TOT : idx;
         const bool isk = idx < NKI;
         const int n = (isk ? idx : idx - NKI) * 64 + lane;
         const int rk = n / KS, rv = n / VS;
-        const int row = isk ? rk : rv, ch = isk ? n - rk * KS : n - rv * VS;
-        d_row[u] = (ch < CH && row < TILE) ? row : -1;
-        d_off[u] = (unsigned int)(((isk ? p.k_off : p.v_off) + hk * HD + ch * 8) * 2);
+        const int r = isk ? rk : rv, ch = isk ? n - rk * KS : n - rv * VS;
+        row = (ch < CH && r < TILE) ? r : -1;
+        off = (unsigned int)(((isk ? k_col0 : v_col0) + ch * 8) * 2);
+    };
+    constexpr bool PRE = PT <= 12;            // kept in registers; beyond that (2-wave blocks: 19) hipcc indexes them from scratch
+    int d_row[PRE ? PT : 1];
+    unsigned int d_off[PRE ? PT : 1];
+    if (PRE) {
+#pragma unroll
+        for (int u = 0; u < PT; ++u) slot_of(u, d_row[PRE ? u : 0], d_off[PRE ? u : 0]);
     }
     const unsigned int ldsK0 = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) void*)&sK[0][0];
     const unsigned int ldsV0 = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) void*)&sV[0][0];
@@ -181,8 +189,12 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
             idx = idx >= TOT ? idx - TOT : idx;
             const bool isk = idx < NKI;
             const unsigned int slab = isk ? ldsK0 + buf * (TILE * KP * 2) + idx * 1024 : ldsV0 + buf * (TILE * VP * 2) + (idx - NKI) * 1024;
-            const int kg = min(kv0 + d_row[u], len - 1);
-            if (d_row[u] >= 0) glds16((const char*)base + ((size_t)(unsigned int)kg * row_bytes + d_off[u]), slab);
+            int row;
+            unsigned int off;
+            if (PRE) { row = d_row[PRE ? u : 0]; off = d_off[PRE ? u : 0]; }
+            else slot_of(u, row, off);
+            const int kg = min(kv0 + row, len - 1);
+            if (row >= 0) glds16((const char*)base + ((size_t)(unsigned int)kg * row_bytes + off), slab);
         }
     };
     auto wait_all_but = [&](int younger) {   // wave-uniform
@@ -288,31 +300,50 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
             }
     };
 
-    // ---- tile loop.  A wave computes the tiles its own queries can see (all of them unless causal) and only keeps the ring and
-    // the barriers going for the rest: the compute loop has no conditional around its loop-carried accumulators ----
+    // ---- tile loops.  A wave computes the tiles its own queries can see (all of them unless causal) and only keeps the ring and
+    // the barriers going for the rest.  Steps that need the mask (sequence end, causal diagonal) are always the LAST ones of a
+    // wave's key range, so the tiles are walked in three consecutive loops -- mask-free tiles, tiles with the mask, ring-only
+    // tiles -- each with ONE call site of the step: with the masked and the unmasked step as the two arms of a branch inside one
+    // loop, hipcc kept the O^T accumulators in different registers per arm and copied all of them (24-48 v_mov per step) ----
     const int ntile_w = wave_live ? (kv_end_w + TILE - 1) / TILE : 0;
     constexpr int STEP = 32 * NGMAX;
     using NGfull = std::integral_constant<int, NGMAX>;
     using NGone = std::integral_constant<int, 1>;
-    for (int j = 0; j < ntile; ++j) {
-        const int kv0 = j * TILE;
-        const int buf = j % NBUF;
+    auto step_is_edge = [&](int ks0) { return (ks0 + STEP > len) || (p.causal && ks0 + STEP - 1 > q_w0); };
+    auto steps_of = [&](int kv0) { return min(TILE / STEP, (kv_end_w - kv0 + STEP - 1) / STEP); };
+    int j_plain = 0;   // leading tiles without a masked step
+    while (j_plain < ntile_w && !step_is_edge(j_plain * TILE + (steps_of(j_plain * TILE) - 1) * STEP)) ++j_plain;
+    auto ring = [&](int j) {
         // tile j + NBUF - 1 goes into the buffer tile j - 1 was read from (everybody passed the barrier that ended it)
-        if (j + NBUF - 1 < ntile) dma_tile(kv0 + (NBUF - 1) * TILE, (j + NBUF - 1) % NBUF);
-        if (j < ntile_w) {
-            const int nst = min(TILE / STEP, (kv_end_w - kv0 + STEP - 1) / STEP);
-            for (int sidx = 0; sidx < nst; ++sidx) {
-                const int ks0 = kv0 + sidx * STEP;
-                const bf16_t* Kg = &sK[buf][sidx * STEP * KP];
-                const bf16_t* Vg = &sV[buf][sidx * STEP * VP];
-                const bool edge = (ks0 + STEP > len) || (p.causal && ks0 + STEP - 1 > q_w0);
-                if (!edge) step(std::false_type{}, NGfull{}, ks0, Kg, Vg);
-                else if (NGMAX == 2 && kv_end_w - ks0 <= 32) step(std::true_type{}, NGone{}, ks0, Kg, Vg);   // a tail of <= 32 keys (DINOv2: 261 = 4 x 64 + 5)
-                else step(std::true_type{}, NGfull{}, ks0, Kg, Vg);
-            }
-        }
+        if (j + NBUF - 1 < ntile) dma_tile((j + NBUF - 1) * TILE, (j + NBUF - 1) % NBUF);
+    };
+    auto tile_end = [&](int j) {
         wait_all_but(min(NBUF - 2, ntile - 2 - j));        // tile j + 1 has landed (younger ones may still fly) ...
         __syncthreads();                                    // ... and everybody is done reading tile j
+    };
+    int j = 0;
+    for (; j < j_plain; ++j) {
+        ring(j);
+        const int kv0 = j * TILE, buf = j % NBUF, nst = steps_of(kv0);
+        for (int sidx = 0; sidx < nst; ++sidx)
+            step(std::false_type{}, NGfull{}, kv0 + sidx * STEP, &sK[buf][sidx * STEP * KP], &sV[buf][sidx * STEP * VP]);
+        tile_end(j);
+    }
+    for (; j < ntile_w; ++j) {
+        ring(j);
+        const int kv0 = j * TILE, buf = j % NBUF, nst = steps_of(kv0);
+        for (int sidx = 0; sidx < nst; ++sidx) {
+            const int ks0 = kv0 + sidx * STEP;
+            if (NGMAX == 2 && kv_end_w - ks0 <= 32)   // a tail of <= 32 keys (DINOv2: 261 = 4 x 64 + 5; causal diagonal): half a step
+                step(std::true_type{}, NGone{}, ks0, &sK[buf][sidx * STEP * KP], &sV[buf][sidx * STEP * VP]);
+            else
+                step(std::true_type{}, NGfull{}, ks0, &sK[buf][sidx * STEP * KP], &sV[buf][sidx * STEP * VP]);
+        }
+        tile_end(j);
+    }
+    for (; j < ntile; ++j) {
+        ring(j);
+        tile_end(j);
     }
 
     // ---- write O[q][d]: lane (ql, hi) holds d = 32 db + 8 a + 4 hi + (0..3) in o[db][4 a .. 4 a + 3] ----
@@ -363,9 +394,7 @@ int launch_attention(const AttnParams& p, int head_dim, hipStream_t stream) {
     switch (head_dim) {
         case 64: return three ? launch_attention_t<AttnCfg<64, 3, 1, 2, 4>>(p, stream) : launch_attention_t<AttnCfg<64, 4, 1, 2, 3>>(p, stream);
         case 72: return three ? launch_attention_t<AttnCfg<72, 3, 1, 2, 4>>(p, stream) : launch_attention_t<AttnCfg<72, 4, 1, 2, 3>>(p, stream);
-        case 128:   // a single 768-token prefill is only 32 x 6 blocks of 128 queries for 256 CUs: halve the block below two per CU
-            if ((long long)p.B * p.Hq * cdiv(p.max_seqlen, 128) < 512) return launch_attention_t<AttnCfg<128, 2, 1, 2, 2>>(p, stream);
-            return launch_attention_t<AttnCfg<128, 4, 1, 2, 2>>(p, stream);
+        case 128: return launch_attention_t<AttnCfg<128, 4, 1, 2, 2>>(p, stream);
         default: return -1;
     }
 }
