@@ -12,7 +12,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/pmc*/pmc_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        k = k[k.find("emmax_attention_kernel"):][:32]
+        i = k.find("AttnCfg<")
+        k = ("emmax_attention_kernel<" + k[i:k.find(">", i) + 1] + ">") if i >= 0 else k[k.find("emmax_attention_kernel"):][:32]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         agg[k]["_vgpr"] = [float(r["VGPR_Count"])]
         agg[k]["_lds"] = [float(r["LDS_Block_Size"])]
