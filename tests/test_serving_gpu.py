@@ -142,3 +142,69 @@ def test_slot_api_state_errors(device, served):
         eng.slot_prefill(5, rows[0], None, 8)
     with pytest.raises(EmmaxError):
         eng.set_stop(list(range(17)), 1)
+
+
+def test_eight_slots_random_weights_against_the_oracle(device):
+    """The product allows 8 slots; here all 8 are used (12 requests, ragged prompts, refills while the others decode) on RANDOM
+    weights, and every request is compared with the ORACLE's bs = 1 greedy run (not with another product run): ids must be
+    identical up to the first step whose fp32 top-2 margin is below 3x the logit error MEASURED on this model (a teacher-forced
+    product run of request 0 against the oracle, as in test_e2e_gpu.py) -- past a near-tie a bf16 pipeline may legitimately
+    take the other branch."""
+    from emmax.config import EmmaXConfig
+    from emmax.modeling import EmmaXForActionPrediction
+    from emmax.serving import Request, SlotScheduler
+    from emmax.weights import synthetic_state_dict
+    from oracle import emmax_oracle as orc
+
+    cfg = EmmaXConfig.tiny()
+    sd_bf = {k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(cfg, seed=13).items()}
+    model = EmmaXForActionPrediction(cfg, dict(sd_bf)).to(device, max_batch=8, max_prompt=40)
+    sd_ref = {k: v.float() for k, v in sd_bf.items()}
+    eng = model.engine
+    rng = np.random.default_rng(41)
+    n_req, T = 12, 20
+    frames = rng.integers(0, 256, size=(n_req, 224, 224, 3), dtype=np.uint8)
+    rows = [[1] + [int(x) for x in rng.integers(3, 31744, size=5 + (i * 7) % 23)] for i in range(n_req)]
+    budgets = [T if i % 3 else 9 for i in range(n_req)]                      # a few short budgets: slots free up and refill early
+    fr = torch.from_numpy(frames).to(device)
+    runs = [orc.greedy_generate(torch.tensor([rows[i]]), orc.preprocess_frames(frames[i:i + 1], cfg), sd_ref, cfg, T, eos_token_id=None,
+                                return_trace=True) for i in range(n_req)]
+    # measured logit error of the product on this model (request 0, teacher-forced along the oracle's ids)
+    gen0, trace0 = runs[0][0][0, len(rows[0]):].tolist(), runs[0][1]
+    model._prefill(rows[:1], None, fr[:1], max_new=T + 1)
+    err_rel = 0.0
+    for t in range(T):
+        got = eng.last_logits()[0].float().cpu()
+        err_rel = max(err_rel, ((got - trace0[t]).abs().max() / trace0[t].abs().max()).item())
+        eng.set_current_tokens([gen0[t]])
+        eng.decode_step()
+    assert err_rel < 3e-2
+    want, safe = [], []
+    for i in range(n_req):
+        ids, trace = runs[i]
+        want.append(ids[0, len(rows[i]):].tolist())
+        n_safe = T
+        for t in range(T):
+            top2 = torch.topk(trace[t], 2).values
+            if (top2[0] - top2[1]).item() <= 3 * err_rel * trace[t].abs().max().item():
+                n_safe = t
+                break
+        safe.append(n_safe)
+
+    def encode(fs):
+        pe = eng.vision_encode(torch.stack(fs))
+        return [pe[i] for i in range(len(fs))]
+
+    sch = SlotScheduler(eng, encode, n_slots=8, poll_every=4, encode_ahead=4)
+    for i in range(n_req):
+        sch.submit(Request(i, fr[i], rows[i], max_new_tokens=budgets[i]))
+    res = {r.rid: r for r in sch.run()}
+    assert sorted(res) == list(range(n_req)) and {r.slot for r in res.values()} == set(range(8))
+    checked = 0
+    for i in range(n_req):
+        got = res[i].ids
+        assert len(got) == budgets[i] or (len(got) < budgets[i] and got[-1] == cfg.eos_token_id)
+        n = min(len(got), safe[i])
+        assert got[:n] == want[i][:n], f"request {i} (slot {res[i].slot}) leaves the oracle's ids before its first near-tie at step {safe[i]}"
+        checked += n
+    assert checked >= 4 * n_req      # the margin filter left enough steps for the comparison to mean something
