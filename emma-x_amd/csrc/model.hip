@@ -1069,6 +1069,7 @@ int emmax_decode_step(emmax_session* s, emmax_stream stream) {
 int emmax_set_current_tokens(emmax_session* s, const int32_t* toks, emmax_stream st) {
     if (!s || !toks) return fail(EMMAX_ERR_INVALID, "null argument");
     if (!s->prefilled) return fail(EMMAX_ERR_STATE, "no active sequences");
+    if (s->slots_open) return fail(EMMAX_ERR_STATE, "caller-supplied tokens are not supported while request slots are open");
     // the rows decode again (done flag cleared): the next step appends at position <= S_b + dec_steps, which must exist
     int maxS = 0;
     for (int b = 0; b < s->cur_B && b < (int)s->S.size(); ++b) maxS = std::max(maxS, s->S[b]);

@@ -118,7 +118,10 @@ int emmax_last_logits(emmax_session* s, float* logits_out_dev, emmax_stream stre
  * and records it in the session's output buffer.  Rows that already emitted EOS (or ran out of context) emit pad_id.
  * Reads all step-varying state from device memory, so it is hipGraph-capturable. */
 int emmax_decode_step(emmax_session* s, emmax_stream stream);
-/* Overwrite the current token of every row (teacher forcing in tests): tokens_dev int32 [B]. */
+/* Overwrite the current token of every row with a CALLER-supplied one: tokens_dev int32 [B] (teacher-forced scoring, external
+ * sampling loops, the HF cached step `forward(input_ids[B,1], past_key_values)`).  The rows decode again whatever the engine's
+ * own greedy prediction was: done flags, stop-rule state and token budgets are cleared.  EMMAX_ERR_NOMEM when a row's context
+ * is full (the next append would leave the KV pages), EMMAX_ERR_STATE while request slots are open. */
 int emmax_set_current_tokens(emmax_session* s, const int32_t* tokens_dev, emmax_stream stream);
 /* Run up to max_new_tokens steps (including the token produced by prefill) as replays of a captured hipGraph of
  * emmax_decode_step; stop early once all rows are done if stop_on_eos != 0.

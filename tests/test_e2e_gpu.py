@@ -499,3 +499,25 @@ def test_teacher_forcing_past_an_eos_argmax(device, tiny_planted):
         assert int(got.argmax()) == int(ref.argmax())      # planted margins: the argmax is unambiguous
         past = step.past_key_values
     assert past.lengths == [256 + 9 + len(forced)]
+
+
+def test_caller_tokens_refused_when_the_context_is_full(device, tiny_planted):
+    """emmax_set_current_tokens clears the done flag; at the end of the KV pages it must refuse (EMMAX_ERR_NOMEM) instead of
+    letting the next step append past them."""
+    from emmax._lib import EmmaxError
+
+    cfg, model, _ = tiny_planted
+    eng = model.engine
+    frames, rows = _inputs(cfg, 1, 9, seed=3)
+    eng.new_session(1, 9, cfg.n_patches + 9 + 4)             # room for 3 decode steps behind the 265-token prefill
+    try:
+        model._prefill(rows, None, torch.from_numpy(frames).to(device), max_new=1)
+        for _ in range(2):
+            eng.set_current_tokens([17])
+            eng.decode_step()
+        with pytest.raises(EmmaxError, match="max_ctx"):
+            for _ in range(4):
+                eng.set_current_tokens([17])
+                eng.decode_step()
+    finally:
+        eng.new_session(4, 40, None)
