@@ -141,6 +141,26 @@ def cpu_baseline(cfg, prompt_tokens, new_tokens, seed=0, decode_steps=16, distin
             "seconds_per_action": round(t_action, 3), "parts_s": {k: round(v, 5) for k, v in t.items()}}
 
 
+def _profiled_single_gpu(args, B):
+    """The committed 1-GPU rate of the SAME per-GPU workload (profiles/r02_bench_variants.jsonl), so that an N > 1 line (8
+    frames per GPU) can be read against the right N = 1 number -- the N = 1 default of this script is configs[1] (1 frame)."""
+    if args.tiny or args.prompt_tokens != 512 or args.new_tokens != 512:
+        return None
+    try:
+        lines = list(open(os.path.join(ROOT, "profiles", "r02_bench_variants.jsonl"))) + list(open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")))
+        for line in lines:
+            if not line.strip().startswith("{"):
+                continue
+            d = json.loads(line)
+            c = d.get("config", {})
+            if (d.get("n_gpus") == 1 and c.get("batch_per_gpu") == B and bool(c.get("hipgraph")) == bool(args.graph)
+                    and ("fp8" in d.get("dtype", "")) == bool(args.fp8)):
+                return {"value": d["value"], "unit": d["unit"], "source": "profiles/r02_bench_variants.jsonl / r02_bench_n1.json"}
+    except OSError:
+        pass
+    return None
+
+
 def _workload(args, world, B, P, T):
     if args.tiny:
         return "TINY plumbing config (invalid as headline)"
@@ -277,6 +297,7 @@ def main():
             "config": {"workload": _workload(args, world, B, P, T),
                        "batch_per_gpu": B, "global_batch": B * world, "prompt_tokens": P, "new_tokens": T, "context": ctx + T,
                        "parallelism": f"dp{world}", "hipgraph": eng.graph_active(), "chained_launch": eng.chain_active()},
+            "value_per_gpu": round(actions_per_s / world, 4), "single_gpu_same_workload": _profiled_single_gpu(args, B),
             "rccl_ranks": rccl_ranks, "dist_backend": edist.backend_name(),
             "gather_ms": round(gather_ms, 4), "gather_share": round(gather_ms / ms_per_step, 6),
             "p50_latency_ms": round(float(np.median(lat)) * 1e3, 2),
