@@ -443,3 +443,43 @@ def test_decode_attention_done_rows_read_nothing(device):
     a, b_ = outs
     assert torch.equal(a[0], b_[0]) and torch.equal(a[2], b_[2])
     assert torch.isinf(b_[1, :, :, 128]).all() and (b_[1, :, :, 128] < 0).all() and (b_[1, :, :, 129] == 0).all() and (b_[1, :, :, :128] == 0).all()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_attention_random_ragged_shapes(device, seed):
+    """Seeded random ragged batches through the attention kernel (the LDS-DMA ring, the masked / 32-key tail steps, the
+    3- and 4-wave block shapes and the XCD work map all depend on the lengths): 1..6 sequences of 1..900 tokens, each head
+    size, causal for head_dim 128, against the fp32 reference."""
+    L, lib = _lib()
+    rng = np.random.default_rng(1000 + seed)
+    hd = [64, 72, 128][seed % 3]
+    causal = 1 if hd == 128 else int(rng.integers(0, 2))
+    Hkv = int(rng.choice([1, 2, 4]))
+    Hq = Hkv * (int(rng.choice([1, 2])) if hd == 128 else 1)
+    lens = [int(x) for x in rng.integers(1, 900, size=int(rng.integers(1, 7)))]
+    if seed % 4 == 0:
+        lens[0] = [261, 256, 768, 97][seed // 4 % 4]        # the production lengths and an odd one
+    g = torch.Generator().manual_seed(seed)
+    total = sum(lens)
+    qd, kvd = Hq * hd, Hkv * hd
+    ld = (qd + 2 * kvd + 127) // 128 * 128
+    qkv = bf(torch.randn(total, ld, generator=g))
+    cu = [0]
+    for n in lens:
+        cu.append(cu[-1] + n)
+    scale = hd ** -0.5
+    ref = _attn_ref(qkv, cu, Hq, Hkv, hd, 0, qd, qd + kvd, scale, causal)
+    qkv_d = qkv.to(device)
+    cu_d = torch.tensor(cu, dtype=torch.int32, device=device)
+    ld_out = (qd + 127) // 128 * 128
+    out = torch.zeros(total, ld_out, dtype=torch.bfloat16, device=device)
+    for _ in range(3):      # repeated launches: a ring / barrier race would not be deterministic
+        L.check(lib.emmax_op_attention(qkv_d.data_ptr(), ld, 0, qd, qd + kvd, out.data_ptr(), ld_out, cu_d.data_ptr(), len(lens), max(lens),
+                                       Hq, Hkv, hd, scale, causal, stream()), "attention")
+        torch.cuda.synchronize()
+        got = out[:, :qd]
+        assert torch.isfinite(got.float()).all()
+        assert relerr(got, ref) < TOL, (hd, Hq, Hkv, lens, causal, relerr(got, ref))
+        # per-row check as well: a wrong row with small values hides under the max-norm
+        err_row = (got.float().cpu() - ref).abs().amax(dim=1) / ref.abs().amax(dim=1).clamp_min(1e-3)
+        assert err_row.max().item() < 5e-2, (hd, lens, causal, err_row.max().item())
