@@ -250,7 +250,6 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
     // one pass (norm'd projections, K/8 <= 512): thread c keeps chunk c of every row in registers, the statistics come
     // from those registers and the normalised rows go straight to LDS
     const bool one_pass = NORM && !XATTN && n_phase == 1 && (K >> 3) <= NT;
-    if (!one_pass) issue_head();
     if (one_pass) {
         __shared__ __attribute__((aligned(16))) float rsum1[GW][EMMAX_MAX_DECODE_BATCH];
         const bool mine = tid < (K >> 3);
@@ -334,9 +333,11 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
         __syncthreads();
     }
 
-    auto stage_x = [&](int ph) {
+    auto stage_x = [&](int ph, auto head_tag) {
+        constexpr bool HEAD = decltype(head_tag)::value;   // also start the weight stream (first phase)
         const int kc0 = ph * KC, nch = min(KC, K - kc0) >> 3;
         if (XATTN) {
+            if (HEAD) issue_head();
             // x = merged attention split partials; chunk cg = head (cg >> 4), elements (cg & 15) * 8 .. +8
             for (int c = tid; c < nch; c += NT) {
                 const int cg = (kc0 >> 3) + c;
@@ -353,7 +354,34 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
                 }
                 *(u32x4_t*)(dst + (size_t)B * pitch) = (u32x4_t){0u, 0u, 0u, 0u};
             }
+        } else if (!NORM) {
+            // flattened (row, chunk) space, SX unconditional (clamped) loads in flight per thread, masked at the store: one L2
+            // round trip stages a whole phase of the down projection at B = 8 (688 chunks x 8 rows = 10.75 per thread); the
+            // predicated four-at-a-time form took three, each behind a full vmcnt(0).  HEAD (first phase): the weight stream
+            // starts after these loads are queued, not in front of them
+            constexpr int SX = 12;
+            for (int c = tid; c < nch; c += NT) *(u32x4_t*)(smem + (size_t)B * pitch + (size_t)c * 16) = (u32x4_t){0u, 0u, 0u, 0u};
+            const int total = B * nch;
+            const float inv = 1.0f / (float)nch;
+            for (int base = 0; base < total; base += SX * NT) {   // block-uniform
+                u32x4_t v[SX];
+                int off[SX];
+#pragma unroll
+                for (int j = 0; j < SX; ++j) {
+                    const int i = base + tid + j * NT, ic = min(i, total - 1);
+                    int b = (int)(((float)ic + 0.5f) * inv), c = ic - b * nch;   // float quotient, one step of correction
+                    if (c < 0) { --b; c += nch; }
+                    if (c >= nch) { ++b; c -= nch; }
+                    off[j] = i < total ? (int)(b * pitch + c * 16) : -1;
+                    v[j] = *((const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx + kc0) + c);
+                }
+                if (HEAD && base == 0) issue_head();
+#pragma unroll
+                for (int j = 0; j < SX; ++j)
+                    if (off[j] >= 0) *(u32x4_t*)(smem + off[j]) = v[j];
+            }
         } else {
+            if (HEAD) issue_head();
             // flattened (row, chunk) space, four loads in flight per thread
             const int total = (B + 1) * nch;
             for (int i0 = tid; i0 < total; i0 += 4 * NT) {
@@ -382,7 +410,7 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
             }
         }
     };
-    if (!one_pass) stage_x(0);
+    if (!one_pass) stage_x(0, std::true_type{});
     __syncthreads();
 
     // LMHEAD: per-thread running best of the (row slot, batch) it finalises
@@ -513,7 +541,7 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
     while (C.i < n_seg) {
         if (n_phase > 1 && C.kb == 0 && (C.ph != 0 || C.i != 0)) {   // new phase: restage x (the ring keeps flying)
             __syncthreads();
-            stage_x(C.ph);
+            stage_x(C.ph, std::false_type{});
             __syncthreads();
         }
         if (C.kb == 0) {
