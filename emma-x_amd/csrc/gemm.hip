@@ -60,9 +60,17 @@ struct Geom {
 using GeomBig = Geom<2, 4, 8, 4>;
 using GeomSmall = Geom<2, 2, 4, 4>;
 
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+// LDS-DMA, 16 bytes per lane: lane i's data lands at M0 + immediate + 16 i.  The LDS base goes to M0 ONCE per group of
+// slabs (`glds_base`); the slab inside the group is chosen by the instruction's immediate offset, which the hardware adds to
+// BOTH addresses (the global address is pre-decremented by it).  Issued as asm: hipcc's builtin form rewrites M0 before every
+// instruction.
+__device__ __forceinline__ void glds_base(const void* lds_base) {
+    const unsigned int b = __builtin_amdgcn_readfirstlane((unsigned int)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(b) : "m0", "memory");
+}
+template <int J>   // slab J (1 KiB) behind the base
+__device__ __forceinline__ void glds16_slab(const unsigned char* gsrc) {
+    asm volatile("global_load_lds_dwordx4 %0, off offset:%1" ::"v"(gsrc - J * 1024), "n"(J * 1024) : "memory");
 }
 
 // bf16 epilogue through LDS: a wave parks 64 rows of its result (64 columns; SwiGLU: 32) in its private 8 KiB window
@@ -296,10 +304,17 @@ __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams 
     auto issue = [&](int kt) {
         unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
         const size_t koff = (size_t)(kbeg + kt) * (BK * 2);
-#pragma unroll
-        for (int j = 0; j < G::SA; ++j) glds16(srcA[j] + koff, st + (wave * G::SA + j) * 1024);
-#pragma unroll
-        for (int j = 0; j < G::SB; ++j) glds16(srcB[j] + koff, st + OP_BYTES + (wave * G::SB + j) * 1024);
+        static_assert(G::SA <= 4 && G::SB <= 4, "a wave's slabs of one operand share one M0 (immediates 0 .. 3072)");
+        glds_base(st + wave * G::SA * 1024);
+        glds16_slab<0>(srcA[0] + koff);
+        if (G::SA > 1) glds16_slab<1>(srcA[G::SA > 1 ? 1 : 0] + koff);
+        if (G::SA > 2) glds16_slab<2>(srcA[G::SA > 2 ? 2 : 0] + koff);
+        if (G::SA > 3) glds16_slab<3>(srcA[G::SA > 3 ? 3 : 0] + koff);
+        glds_base(st + OP_BYTES + wave * G::SB * 1024);
+        glds16_slab<0>(srcB[0] + koff);
+        if (G::SB > 1) glds16_slab<1>(srcB[G::SB > 1 ? 1 : 0] + koff);
+        if (G::SB > 2) glds16_slab<2>(srcB[G::SB > 2 ? 2 : 0] + koff);
+        if (G::SB > 3) glds16_slab<3>(srcB[G::SB > 3 ? 3 : 0] + koff);
     };
 
     // ---- fragment read offsets: row base + swizzled chunk; (row >> 1) & 7 == (li >> 1) & 7 for every 16-row tile ----

@@ -23,6 +23,16 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, uint32_t seed) {
             const float ww = __uint_as_float(w), xx = __uint_as_float(x);
             a0 = fmaf(ww, xx, a0); a1 = fmaf(ww, xx, a1); a2 = fmaf(ww, xx, a2); a3 = fmaf(ww, xx, a3);
             a4 = fmaf(ww, xx, a4); a5 = fmaf(ww, xx, a5); a6 = fmaf(ww, xx, a6); a7 = fmaf(ww, xx, a7);
+        } else if (KIND == 3) {   // v_exp_f32, 8 independent
+            a0 = __builtin_amdgcn_exp2f(a0); a1 = __builtin_amdgcn_exp2f(a1); a2 = __builtin_amdgcn_exp2f(a2); a3 = __builtin_amdgcn_exp2f(a3);
+            a4 = __builtin_amdgcn_exp2f(a4); a5 = __builtin_amdgcn_exp2f(a5); a6 = __builtin_amdgcn_exp2f(a6); a7 = __builtin_amdgcn_exp2f(a7);
+        } else if (KIND == 4) {   // v_exp_f32 and v_fma_f32 alternating, 4 + 4 independent
+            a0 = __builtin_amdgcn_exp2f(a0); a4 = fmaf(a4, 1.0001f, 0.5f); a1 = __builtin_amdgcn_exp2f(a1); a5 = fmaf(a5, 1.0001f, 0.5f);
+            a2 = __builtin_amdgcn_exp2f(a2); a6 = fmaf(a6, 1.0001f, 0.5f); a3 = __builtin_amdgcn_exp2f(a3); a7 = fmaf(a7, 1.0001f, 0.5f);
+        } else if (KIND == 5) {   // v_max3_f32, 8 independent
+            const float ww = __uint_as_float(w), xx = __uint_as_float(x);
+            a0 = __builtin_fmaxf(__builtin_fmaxf(a0, ww), xx); a1 = __builtin_fmaxf(__builtin_fmaxf(a1, ww), xx); a2 = __builtin_fmaxf(__builtin_fmaxf(a2, ww), xx); a3 = __builtin_fmaxf(__builtin_fmaxf(a3, ww), xx);
+            a4 = __builtin_fmaxf(__builtin_fmaxf(a4, ww), xx); a5 = __builtin_fmaxf(__builtin_fmaxf(a5, ww), xx); a6 = __builtin_fmaxf(__builtin_fmaxf(a6, ww), xx); a7 = __builtin_fmaxf(__builtin_fmaxf(a7, ww), xx);
         } else {   // v_pk_fma_f32 (4 per iteration = 8 MACs)
             p0 = __builtin_elementwise_fma(p0, m, c); p1 = __builtin_elementwise_fma(p1, m, c);
             p2 = __builtin_elementwise_fma(p2, m, c); p3 = __builtin_elementwise_fma(p3, m, c);
@@ -34,14 +44,17 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, uint32_t seed) {
 int main() {
     float* out; CHECK(hipMalloc(&out, 256 * 4 * 256 * 16));
     const int iters = 20000, blocks = 256 * 8;
-    const char* names[] = {"v_dot2c_f32_bf16 (2 MAC/lane)", "v_fma_f32 (1 MAC/lane)", "v_pk_fma_f32 (2 MAC/lane)"};
-    for (int kind = 0; kind < 3; ++kind) {
+    const char* names[] = {"v_dot2c_f32_bf16 (2 MAC/lane)", "v_fma_f32 (1 MAC/lane)", "v_pk_fma_f32 (2 MAC/lane)", "v_exp_f32", "v_exp_f32 + v_fma_f32 alternating", "v_max3_f32"};
+    for (int kind = 0; kind < 6; ++kind) {
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
         for (int rep = 0; rep < 2; ++rep) {
             CHECK(hipEventRecord(e0));
             if (kind == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, out, iters, 7u);
             if (kind == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, out, iters, 7u);
             if (kind == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, out, iters, 7u);
+            if (kind == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, out, iters, 7u);
+            if (kind == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, out, iters, 7u);
+            if (kind == 5) hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(256), 0, 0, out, iters, 7u);
             CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
         }
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
