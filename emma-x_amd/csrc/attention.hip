@@ -69,6 +69,19 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned int lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "m0", "memory");
 }
 
+// The same with the LDS base left in M0 by the caller (`glds_base`) and the 1 KiB slab chosen by the instruction's IMMEDIATE offset,
+// which the hardware adds to BOTH addresses (so the global address is pre-decremented by it).  Rewriting M0 between two LDS-DMA
+// instructions serialises them on the first one's data return when the data comes from HBM (tools/dma_issue_rate.hip: 64
+// instructions per CU land in 9.5 k clocks with M0 per instruction, in 2.1 k with one M0 per eight); eight slabs,
+// immediates -4096 .. 3072, share one M0 = their base + 4096.
+__device__ __forceinline__ void glds_base(unsigned int lds_base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(__builtin_amdgcn_readfirstlane(lds_base)) : "m0", "memory");
+}
+template <int J>   // slab J of the eight
+__device__ __forceinline__ void glds16_slab(const char* gsrc) {
+    asm volatile("global_load_lds_dwordx4 %0, off offset:%1" ::"v"(gsrc - (J - 4) * 1024), "n"((J - 4) * 1024) : "memory");
+}
+
 __device__ __forceinline__ float half_max(float v) {   // max over the two half-waves (lanes l and l ^ 32)
     float a, b;
     swap_halves(v, a, b);
@@ -370,6 +383,318 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Resident form for short non-causal sequences (the ViT towers: 261 / 256 tokens, thousands of (sequence, head) items).  One
+// persistent block per CU: NW query waves (32 queries each) + NP producer waves; an item's WHOLE K and V live in LDS, double
+// buffered.  While the query waves free-run over all keys of item i (no ring, no per-tile barrier), the producer waves request
+// every slab of item i + 1 by LDS-DMA and the query waves' Q fragments of item i + 1 are in flight; one barrier per item.
+// What the phase stamps (tools/attn_lab.hip, ATTN_LAB_TRACE) and micro-benchmarks behind this shape say:
+//   * one item per block at a time with the load phase exposed (two blocks per CU, single buffered): 60 % of an item's time was
+//     descriptor loads + DMA issue + HBM latency + two barriers;
+//   * the vector-memory front end of a CU takes 50-100 clocks per row-strided 1 KiB request and a wave stalls while it issues:
+//     requests issued by the query waves -- in one burst or one per softmax step -- add their issue time to the compute time,
+//     issued by dedicated waves they do not (one producer wave alone is too slow: ~600 clocks per request against HBM, two are
+//     enough);
+//   * rewriting M0 between two LDS-DMA instructions costs (tools/dma_issue_rate.hip), so eight slabs share one M0 and are
+//     selected by the immediate offset;
+//   * MFMA and VALU instructions of one SIMD do NOT overlap, not even from different waves (tools/mfma_valu_overlap.hip: an
+//     MFMA wave and a VALU wave on one SIMD take the sum of their times): a step costs its MFMA clocks PLUS its VALU clocks,
+//     more waves per SIMD only hide LDS / memory latency.  Hence the lazy rescale and the read pipelining in the step below.
+//   head_dim 64: 128-byte rows without padding, bank conflicts removed by an XOR swizzle of the 16-byte chunks applied to the
+//                SOURCE address of the DMA (its LDS image is lane-linear): K chunk c of row r holds logical chunk
+//                c ^ ((r >> 1) & 7) (16 rows of one ds_read_b128 pass -> 64 distinct banks), V chunk c holds
+//                c ^ (((r >> 1) & 1) << 2) (the 4 key rows x 64 B of a transpose-read pass -> 64 distinct banks).
+//   head_dim 72: K rows of 144 B (9 chunks: odd, conflict free), the k padding 72..79 of the QK^T reduction reads the next
+//                row's first chunk against Q fragments that are ZERO there; V rows of 160 B (9 chunks + one zero chunk), the
+//                third 32-row block of O^T reads 32 B into the next row: finite values feeding rows that are never stored.
+// Rows an item does not have keep finite leftovers (LDS is zeroed once per block) and are masked in the last step.
+template <int HD_, int NW_, int NP_>
+struct ResCfg {
+    static constexpr int HD = HD_, NW = NW_, NP = NP_, NT = (NW + NP) * 64, ROWS = NW * 32;   // NW query waves + NP producer waves
+    static constexpr int HDK = (HD + 15) / 16 * 16, NKK = HDK / 16, NDB = (HD + 31) / 32, CH = HD / 8;
+    static constexpr bool SWZ = HD == 64;
+    static constexpr int KPB = SWZ ? 128 : HD * 2, VPB = SWZ ? 128 : 160;      // bytes per LDS row
+    static constexpr int KCH = KPB / 16, VCH = VPB / 16;                        // 16-byte slots per row
+    static constexpr int K_BYTES = ROWS * KPB, V_BYTES = ROWS * VPB, BUF = V_BYTES + K_BYTES;   // V first: its overshoot lands in K
+    static constexpr int NKI = (ROWS * KCH + 63) / 64, NVI = (ROWS * VCH + 63) / 64, TOT = NKI + NVI, PT = (TOT + NW - 1) / NW;
+    static constexpr int SMEM = 2 * BUF + 64;
+    static constexpr int MINW = (NW + NP + 3) / 4;                              // one block per CU
+    static_assert(SMEM <= 160 * 1024 && HD % 8 == 0 && (HD == 64 || HD == 72), "LDS budget; layouts above");
+};
+
+#ifdef ATTN_LAB_TRACE
+__device__ unsigned long long g_attn_trace[16 * 12 * 8 * 8];   // [block L < 16][wave < 12][item < 8][stamp < 8]
+#define ATTN_STAMP(k) do { if (L < 16 && tr_it < 8 && lane == 0) g_attn_trace[((L * 12 + wave) * 8 + tr_it) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ATTN_STAMP(k) do { } while (0)
+#endif
+
+template <class RC>
+__global__ __launch_bounds__(RC::NT, RC::MINW) void emmax_attention_resident_kernel(AttnParams p, int per_xcd, int gx) {
+    constexpr int HD = RC::HD, NW = RC::NW, NT = RC::NT, ROWS = RC::ROWS, NKK = RC::NKK, NDB = RC::NDB, CH = RC::CH;
+    constexpr int KPB = RC::KPB, VPB = RC::VPB, KCH = RC::KCH, VCH = RC::VCH, NKI = RC::NKI, TOT = RC::TOT, PT = RC::PT;
+    constexpr bool SWZ = RC::SWZ;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, hi = lane >> 5, i16 = lane & 15, b4 = (lane >> 4) & 1;
+    const int L = (int)blockIdx.x, xcd = L & 7, kb = L >> 3;      // block L runs on XCD L % 8; items in contiguous runs per XCD
+    const int n_items = p.B * p.Hq;
+#ifdef ATTN_LAB_TRACE
+    int tr_it = 0;
+#endif
+
+    struct Item { int valid, h, start, len; };
+    auto item_at = [&](int it) {
+        Item w = {0, 0, 0, 0};
+        const int item = xcd * per_xcd + it;
+        if (it < per_xcd && item < n_items) {
+            const int b = item / p.Hq;
+            w.valid = 1;
+            w.h = item - b * p.Hq;
+            w.start = p.cu_seqlens[b];
+            w.len = max(0, min(p.cu_seqlens[b + 1] - w.start, ROWS));
+        }
+        return w;
+    };
+    Item cur = item_at(kb);
+    if (!cur.valid) return;
+
+    for (int i = tid * 16; i < RC::SMEM; i += NT * 16) *(u32x4_t*)(smem + i) = (u32x4_t){0u, 0u, 0u, 0u};
+
+    const float c = p.scale * 1.44269504088896340736f;
+    const unsigned int lds0 = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    const unsigned int row_bytes = (unsigned int)p.ld_qkv * 2u;
+    // lane-constant fragment offsets (bytes)
+    const int kx = SWZ ? ((hi ^ ((ql >> 1) & 7)) << 4) : (hi << 4);          // K chunk 2 kk + hi: SWZ -> kx ^ (kk << 5), else kx + (kk << 5)
+    const int k_row = RC::V_BYTES + ql * KPB;
+    const int v_row = (4 * hi + (i16 >> 2)) * VPB;                            // + key base * VPB; second read + 8 VPB
+    // V chunk 4 db + 2 b4 + ((i16 & 3) >> 1), byte 8 (i16 & 1) inside it; SWZ flips the db bit on rows with (row >> 1) & 1
+    const int v_in = (b4 << 5) + ((i16 & 3) << 3);
+    const int v_flip = SWZ ? (((i16 >> 3) & 1) << 6) : 0;
+
+    // requesting an item: its Q^T fragments (B operand: lane (ql, hi) holds Q[q_row][16 kk + 8 hi .. +8]; unconditional clamped
+    // loads, masked by `mask_q` once they have landed -- masking here would make the compiler wait for them, i.e. for everything
+    // requested behind them) by the query waves, its K / V slabs by the producer waves
+    auto request_q = [&](const Item& w, bf16x8_t (&q)[NKK]) {
+        if (w.len <= 0) return;
+        const bf16_t* base = (const bf16_t*)p.qkv + (size_t)w.start * p.ld_qkv;
+        const int q_row = wave * 32 + ql;
+        const bf16_t* qp = base + p.q_off + w.h * HD + (size_t)min(q_row, w.len - 1) * p.ld_qkv;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) q[kk] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(qp + min(kk * 16 + hi * 8, HD - 8)));
+    };
+    // DMA instructions 8 grp .. 8 grp + 7 of the K (isk) or V image of item w: instruction il fills the 64 slots 64 il ..; one M0
+    // per group, the slab by immediate offset
+    auto request_kv8 = [&](const Item& w, int buf, bool isk, int grp) {
+        const int xch = isk ? KCH : VCH, ni = isk ? NKI : RC::NVI;
+        const bf16_t* kvb = (const bf16_t*)p.qkv + (size_t)w.start * p.ld_qkv + (w.h / (p.Hq / p.Hkv)) * HD;
+        glds_base(lds0 + buf * RC::BUF + (isk ? RC::V_BYTES : 0) + grp * 8192 + 4096);
+        auto one = [&](auto jtag) {
+            constexpr int J = decltype(jtag)::value;
+            const int il = grp * 8 + J;
+            if (il >= ni || (il * 64) / xch >= w.len) return;          // past the image / the slab's first row does not exist (scalar)
+            const int n = il * 64 + lane;
+            const int row = n / xch, pc = n - row * xch;
+            int lc = pc;
+            if (SWZ) lc = isk ? pc ^ ((row >> 1) & 7) : pc ^ (((row >> 1) & 1) << 2);
+            const unsigned int off = (unsigned int)(((isk ? p.k_off : p.v_off) + lc * 8) * 2);
+            const int rg = min(row, w.len - 1);
+            if (pc < CH && row < ROWS) glds16_slab<J>((const char*)kvb + ((size_t)(unsigned int)rg * row_bytes + off));
+        };
+        one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{});
+        one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
+        one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
+    };
+    auto request_kv_all = [&](const Item& w, int buf) {   // producer waves: the groups of eight dealt round robin
+        if (w.len <= 0) return;
+        constexpr int GK = (NKI + 7) / 8, GV = (RC::NVI + 7) / 8;
+        for (int gi = RC::NP ? wave - NW : wave; gi < GK + GV; gi += (RC::NP ? RC::NP : NW)) {   // no producer waves: everybody
+            if (gi < GK) request_kv8(w, buf, true, gi);
+            else request_kv8(w, buf, false, gi - GK);
+        }
+    };
+    auto mask_q = [&](const Item& w, const bf16x8_t (&raw)[NKK], bf16x8_t (&q)[NKK]) {   // rows past the end and the k padding are zero
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            u32x4_t v = __builtin_bit_cast(u32x4_t, raw[kk]);
+            if (wave * 32 + ql >= w.len || kk * 16 + hi * 8 >= HD) v = (u32x4_t){0u, 0u, 0u, 0u};
+            q[kk] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    };
+    bf16x8_t qf[NKK], qn[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) qn[kk] = __builtin_bit_cast(bf16x8_t, (u32x4_t){0u, 0u, 0u, 0u});
+    __syncthreads();                      // the zero fill is complete
+    const bool producer = RC::NP > 0 && wave >= NW, issuer = RC::NP == 0 || producer;
+    if (producer) __builtin_amdgcn_s_setprio(3);   // its few instructions go ahead of the query waves sharing its SIMD
+    if (!producer) request_q(cur, qn);
+    if (issuer) request_kv_all(cur, 0);
+    Item nxt = item_at(kb + gx);
+    int it2 = kb + 2 * gx;                // the item after the next: its descriptor loads are issued one item ahead, raw
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), visible to the compiler: Q and this wave's slabs have landed
+    __syncthreads();                      // ... everybody's slabs
+    mask_q(cur, qn, qf);
+    int buf = 0;
+    while (true) {
+        ATTN_STAMP(0);
+        if (nxt.valid && !producer) request_q(nxt, qn);   // lands while this item is computed
+        if (RC::NP > 0) __syncthreads();                  // the Q requests are in the memory queue ahead of the slabs
+        if (nxt.valid && issuer)                          // everybody left that buffer at the barrier that ended the last item
+            request_kv_all(nxt, buf ^ 1);
+        const int item2 = xcd * per_xcd + it2;
+        const bool valid2 = it2 < per_xcd && item2 < n_items;
+        const int b2 = valid2 ? item2 / p.Hq : 0;
+        const int raw_lo = p.cu_seqlens[b2], raw_hi = p.cu_seqlens[b2 + 1];   // used after the barrier that ends this item
+        ATTN_STAMP(1);
+        const int len = cur.len;
+        if (wave * 32 < len && !producer) {
+            const unsigned char* sB = smem + buf * RC::BUF;
+            f32x16_t o[NDB];
+            float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+
+            // One softmax step over the 32 keys of group g (the ring kernel's algebra with NG = 1), software-pipelined on the LDS
+            // reads: MFMA and VALU instructions of one SIMD do not overlap (tools/mfma_valu_overlap.hip: an MFMA wave and a VALU
+            // wave sharing a SIMD take the SUM of their times), so what is left to hide is LDS latency -- the V^T fragments of the
+            // step are requested before its QK^T MFMAs, the K fragments of the NEXT step right behind them, and both land under
+            // the softmax arithmetic.
+            typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+            constexpr bool KPRE = NDB <= 2;   // head_dim 72 (three row blocks, 20 more registers of Q / K fragments) has no registers for it
+            bf16x8_t kf[NKK];
+            auto read_k = [&](int g) {
+                const unsigned char* Kg = sB + g * 32 * KPB + k_row;
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) kf[kk] = *(const bf16x8_t*)(Kg + (SWZ ? (kx ^ (kk << 5)) : (kx + (kk << 5))));
+            };
+            auto step = [&](auto edge_tag, int g, bool prefetch_k) {
+                constexpr bool EDGE = decltype(edge_tag)::value;
+                // V^T fragments of this step: two transpose reads each (head_dim 72: read right before their MFMAs instead)
+                constexpr int VPRE = NDB <= 2 ? 2 : 0;
+                if (!KPRE) read_k(g);
+                s16x4_t va[2][NDB][2];
+                auto read_v = [&](int mm) {
+                    const unsigned char* vb = sB + (g * 32 + mm * 16) * VPB + v_row;
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db) {
+                        const int vo = ((db << 6) ^ v_flip) + v_in;
+                        va[mm][db][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + vo));
+                        va[mm][db][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + 8 * VPB + vo));
+                    }
+                };
+#pragma unroll
+                for (int mm = 0; mm < VPRE; ++mm) read_v(mm);
+                f32x16_t st;
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) {
+                    const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], kk == 0 ? zero : st, 0, 0, 0);
+                }
+                if (KPRE && prefetch_k) read_k(g + 1);
+                if (EDGE) {
+                    const int lim = len - g * 32 - 4 * hi;   // key of register r: 32 g + (r & 3) + 8 (r >> 2) + 4 hi
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[r] = ((r & 3) + 8 * (r >> 2) < lim) ? st[r] : -INFINITY;
+                }
+                float m_tile = st[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m_tile = fmaxf(m_tile, st[r]);
+                m_tile = half_max(m_tile);
+                // LAZY reference maximum: m_run only moves when the step's maximum exceeds it by more than 2^LAZY in the exp2
+                // domain (always at the first step: m_run = -inf).  P then lies in (0, 2^LAZY] instead of (0, 1] -- the same
+                // relative precision in bf16, fp32 sums far from overflow -- and numerator and denominator use the same reference,
+                // so the quotient is unchanged; what it buys: the rescale of the O^T accumulators (NDB x 16 multiplies, a fifth
+                // of the step's VALU work) runs only when some row of the wave really moved (wave-uniform branch; not for
+                // head_dim 72, where the two register copies of the accumulators the branch makes hipcc keep do not fit)
+                constexpr float LAZY = 8.0f;
+                const bool move = m_tile * c > m_run * c + LAZY;   // finite m_tile: key 0 is visible to every query
+                if (NDB > 2 || __builtin_amdgcn_ballot_w64(move) != 0) {
+                    const float m_new = move ? m_tile : m_run;
+                    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);   // 1 for the rows that stay
+                    l_run *= alpha;
+                    m_run = m_new;
+#pragma unroll
+                    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+                }
+                const float mc = m_run * c;
+                float psum = 0.f;
+                u32x4_t pf[2];
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[8 * mm + 2 * t], c, -mc));
+                        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[8 * mm + 2 * t + 1], c, -mc));
+                        psum += p0 + p1;
+                        pf[mm][t] = pack_bf16x2(p0, p1);
+                    }
+                l_run += psum;
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) {
+                    if (mm >= VPRE) read_v(mm);
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db) {
+                        const u32x2_t w0 = __builtin_bit_cast(u32x2_t, va[mm][db][0]), w1 = __builtin_bit_cast(u32x2_t, va[mm][db][1]);
+                        const u32x4_t av = {w0[0], w0[1], w1[0], w1[1]};
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, pf[mm]), o[db], 0, 0, 0);
+                    }
+                }
+            };
+            const int n_full = len >> 5, n_steps = n_full + ((len & 31) ? 1 : 0);
+#ifdef ATTN_LAB_KO_COMPUTE
+            if (len < 0) step(std::true_type{}, 0, false);
+#else
+            if (KPRE) read_k(0);
+            for (int g = 0; g < n_full; ++g) step(std::false_type{}, g, g + 1 < n_steps);
+            if (len & 31) step(std::true_type{}, n_full, false);
+#endif
+            ATTN_STAMP(2);
+
+            // ---- write O[q][d]: lane (ql, hi) holds d = 32 db + 8 a + 4 hi + (0..3) in o[db][4 a .. 4 a + 3] ----
+            const float l_tot = half_sum(l_run);
+            const int q_row = wave * 32 + ql;
+            if (q_row < len) {
+                const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+                bf16_t* orow = (bf16_t*)p.out + (size_t)(cur.start + q_row) * p.ld_out + cur.h * HD;
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int d0 = db * 32 + a * 8 + hi * 4;
+                        if (d0 < HD) {
+                            u32x2_t w;
+                            w[0] = pack_bf16x2(o[db][4 * a] * inv, o[db][4 * a + 1] * inv);
+                            w[1] = pack_bf16x2(o[db][4 * a + 2] * inv, o[db][4 * a + 3] * inv);
+                            *(u32x2_t*)(orow + d0) = w;
+                        }
+                    }
+            }
+        }
+        ATTN_STAMP(3);
+        if (!nxt.valid) break;
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // the next item (and its Q) has landed ...
+        ATTN_STAMP(4);
+        __syncthreads();                      // ... for everybody, and everybody is done reading this one
+        ATTN_STAMP(5);
+#ifdef ATTN_LAB_TRACE
+        ++tr_it;
+#endif
+        mask_q(nxt, qn, qf);
+        cur = nxt;
+        nxt.valid = valid2;
+        nxt.h = item2 - b2 * p.Hq;
+        nxt.start = raw_lo;
+        nxt.len = max(0, min(raw_hi - raw_lo, ROWS));
+        it2 += gx;
+        buf ^= 1;
+    }
+}
+
 }  // namespace
 
 template <class DM>
@@ -381,10 +706,36 @@ static int launch_attention_t(const AttnParams& p, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
+template <class RC>
+static int launch_attention_resident(const AttnParams& p, hipStream_t stream) {
+    auto kern = emmax_attention_resident_kernel<RC>;
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, RC::SMEM) != hipSuccess) return -4;
+        attr_done = true;
+    }
+    const int per_xcd = cdiv(p.B * p.Hq, 8);               // (sequence, head) items per XCD
+    const int gx = per_xcd < 32 ? per_xcd : 32;            // blocks per XCD: persistent, one per CU
+    hipLaunchKernelGGL(kern, dim3(8 * gx), dim3(RC::NT), RC::SMEM, stream, p, per_xcd, gx);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
 int launch_attention(const AttnParams& p, int head_dim, hipStream_t stream) {
     if (p.B <= 0 || p.max_seqlen <= 0) return 0;
     if (p.Hq % p.Hkv != 0) return -1;
     if ((p.ld_qkv % 8) || (p.q_off % 8) || (p.k_off % 8) || (p.v_off % 8) || (p.ld_out % 4)) return -1;
+    static const bool no_resident = getenv("EMMAX_ATTN_RESIDENT") && atoi(getenv("EMMAX_ATTN_RESIDENT")) == 0;   // tuning hook
+    // short non-causal sequences with enough (sequence, head) items to keep persistent blocks busy: the resident form (see
+    // above).  Thresholds from tools/attn_lab.hip and the in-situ kernel trace: head_dim 64 wins from 32 frames on (190 vs 229 us
+    // at 256 frames), head_dim 72 -- no room for the pipelined step -- only at the largest batches (174 vs 182 us in situ)
+    static const int force = getenv("EMMAX_ATTN_RESIDENT") ? atoi(getenv("EMMAX_ATTN_RESIDENT")) : -1;   // tests: 2 = whenever it fits
+    const int items = p.B * p.Hq;
+    if (!p.causal && !no_resident) {
+        const bool big64 = force == 2 ? items >= 8 : items >= 512, big72 = force == 2 ? items >= 8 : items >= 2048;
+        if (head_dim == 64 && big64 && p.max_seqlen <= 256) return launch_attention_resident<ResCfg<64, 8, 2>>(p, stream);
+        if (head_dim == 64 && big64 && p.max_seqlen <= 288) return launch_attention_resident<ResCfg<64, 9, 2>>(p, stream);
+        if (head_dim == 72 && big72 && p.max_seqlen <= 256) return launch_attention_resident<ResCfg<72, 8, 2>>(p, stream);
+    }
     // Block shape: 4 waves (128 queries) unless 3 waves (96) waste fewer padded query rows -- DINOv2's 261 tokens are 3 x 96 - 27
     // against 3 x 128 - 123.  One 32-query block per wave and 2-4 light blocks per CU measured best on all three head sizes
     // (tools/attn_probe.py; two query blocks per wave halve the LDS fragment reads but need ~250 registers and lose to spills /

@@ -445,6 +445,46 @@ def test_decode_attention_done_rows_read_nothing(device):
     assert torch.isinf(b_[1, :, :, 128]).all() and (b_[1, :, :, 128] < 0).all() and (b_[1, :, :, 129] == 0).all() and (b_[1, :, :, :128] == 0).all()
 
 
+@pytest.mark.parametrize("hd,Hq,Hkv,top,boost", [(64, 16, 16, 261, 1), (64, 16, 16, 288, 1), (64, 16, 16, 256, 8), (72, 16, 16, 256, 1), (64, 32, 8, 200, 1),
+                                                 (72, 16, 4, 130, 8), (64, 16, 16, 261, 8)])
+def test_attention_resident_form_many_short_sequences(device, hd, Hq, Hkv, top, boost):
+    """>= 512 (head_dim 64) / 2048 (head_dim 72) (sequence, head) items of <= 288 / 256 tokens, non-causal, take the resident kernel
+    (whole K / V of an item in LDS, double buffered, producer waves, swizzled / unpadded images): ragged lengths around every
+    32-key step boundary, the production lengths 261 / 256, the maximum, single tokens, and grouped K / V heads.  boost = 8
+    scales the queries so that the row maxima keep moving by more than the lazy-rescale threshold in later steps."""
+    L, lib = _lib()
+    rng = np.random.default_rng(hd * 1000 + top + Hkv)
+    B = (512 if hd == 64 else 2048) // Hq + 3
+    lens = [top, 1, 31, 32, 33, 63, 64, 65, top - 1, max(1, top - 31), max(1, top - 32), 97, 160, 5][: B]
+    lens += [int(x) for x in rng.integers(1, top + 1, size=B - len(lens))]
+    g = torch.Generator().manual_seed(hd + top)
+    total = sum(lens)
+    qd, kvd = Hq * hd, Hkv * hd
+    ld = (qd + 2 * kvd + 127) // 128 * 128
+    qkv = torch.randn(total, ld, generator=g)
+    qkv[:, :qd] *= boost
+    qkv = bf(qkv)
+    cu = [0]
+    for n in lens:
+        cu.append(cu[-1] + n)
+    scale = hd ** -0.5
+    ref = _attn_ref(qkv, cu, Hq, Hkv, hd, 0, qd, qd + kvd, scale, 0)
+    ld_out = (qd + 127) // 128 * 128
+    out = torch.zeros(total, ld_out, dtype=torch.bfloat16, device=device)
+    cu_d = torch.tensor(cu, dtype=torch.int32, device=device)
+    qkv_d = qkv.to(device)
+    L.check(lib.emmax_op_attention(qkv_d.data_ptr(), ld, 0, qd, qd + kvd, out.data_ptr(), ld_out, cu_d.data_ptr(), len(lens), max(lens),
+                                   Hq, Hkv, hd, scale, 0, stream()), "attention")
+    torch.cuda.synchronize()
+    got = out[:, :qd].cpu()
+    assert torch.isfinite(got.float()).all()
+    assert relerr(got, ref) < TOL
+    for b in (0, 1, 2, len(lens) - 1):   # per sequence too: a wrong row of a short one disappears in the global norm
+        assert relerr(got[cu[b]:cu[b + 1]], ref[cu[b]:cu[b + 1]]) < 2 * TOL, (b, lens[b])
+    if ld_out > qd:
+        assert (out[:, qd:] == 0).all(), "attention must not write the padding columns"
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_attention_random_ragged_shapes(device, seed):
     """Seeded random ragged batches through the attention kernel (the LDS-DMA ring, the masked / 32-key tail steps, the
