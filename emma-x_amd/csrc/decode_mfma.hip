@@ -70,16 +70,19 @@ __global__ __launch_bounds__(256) void emmax_quant_fm8_kernel(const bf16_t* __re
     }
 }
 
-// 8 fp8 e4m3 (two dwords) -> 8 bf16 (exact: e4m3 fits bf16)
+// 8 fp8 e4m3 (two dwords) -> 8 bf16 (exact: e4m3 fits bf16): v_cvt_scalef32_pk_bf16_fp8 with scale 1, two values per
+// instruction.  (Through v_cvt_pk_f32_fp8 + repacking it was three to four instructions per pair, and VALU work is not free
+// next to the MFMAs -- MFMA and VALU instructions of one SIMD do not overlap, tools/mfma_valu_overlap.hip -- the fp8
+// projections were bound by this conversion, not by HBM.)
 __device__ __forceinline__ bf16x8_t fp8x8_to_bf16x8(uint32_t a, uint32_t b) {
-    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-    const f32x2_t f0 = __builtin_amdgcn_cvt_pk_f32_fp8(a, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(a, true);
-    const f32x2_t f2 = __builtin_amdgcn_cvt_pk_f32_fp8(b, false), f3 = __builtin_amdgcn_cvt_pk_f32_fp8(b, true);
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
+    const bf16x2v p0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a, 1.0f, false), p1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a, 1.0f, true);
+    const bf16x2v p2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b, 1.0f, false), p3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b, 1.0f, true);
     u32x4_t r;
-    r[0] = (__float_as_uint(f0[0]) >> 16) | (__float_as_uint(f0[1]) & 0xffff0000u);
-    r[1] = (__float_as_uint(f1[0]) >> 16) | (__float_as_uint(f1[1]) & 0xffff0000u);
-    r[2] = (__float_as_uint(f2[0]) >> 16) | (__float_as_uint(f2[1]) & 0xffff0000u);
-    r[3] = (__float_as_uint(f3[0]) >> 16) | (__float_as_uint(f3[1]) & 0xffff0000u);
+    r[0] = __builtin_bit_cast(uint32_t, p0);
+    r[1] = __builtin_bit_cast(uint32_t, p1);
+    r[2] = __builtin_bit_cast(uint32_t, p2);
+    r[3] = __builtin_bit_cast(uint32_t, p3);
     return __builtin_bit_cast(bf16x8_t, r);
 }
 

@@ -41,6 +41,18 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, int mode) {
                 a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a2, 0, 0, 0);
                 a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a3, 0, 0, 0);
             }
+    } else if (mode & 8) {   // LDS reads: 8 conflict-free ds_read_b128 per iteration
+        __shared__ __attribute__((aligned(16))) unsigned char sm[8192];
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        u32x4 acc = {0, 0, 0, 0};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const u32x4 r = *(volatile u32x4*)(sm + ((j & 7) * 1024 + (threadIdx.x & 63) * 16) % 8192);
+                acc[0] ^= r[0]; acc[1] ^= r[1]; acc[2] ^= r[2]; acc[3] ^= r[3];
+            }
+        }
+        v0 += (float)(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]);
     } else if (mode & 2) {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -77,6 +89,9 @@ int main() {
     printf("one MFMA wave per SIMD (4 x 32x32x16 per iteration):  %.3f ms = %.1f clk per MFMA @2.1 GHz\n", tm, tm * 1e-3 * 2.1e9 / (iters * 4.0));
     printf("one VALU wave per SIMD (32 v_fma_f32 per iteration):   %.3f ms = %.1f clk per fma\n", tv, tv * 1e-3 * 2.1e9 / (iters * 32.0));
     printf("both on the same SIMD:                                 %.3f ms  (max %.3f, sum %.3f)\n", tb, tm > tv ? tm : tv, tm + tv);
+    const float tl = run<8>(out, iters, 8), tlb = run<8>(out, iters, 9);
+    printf("one LDS wave per SIMD (8 ds_read_b128 per iteration):  %.3f ms = %.1f clk per read (4 waves share the CU's LDS)\n", tl, tl * 1e-3 * 2.1e9 / (iters * 8.0));
+    printf("MFMA wave + LDS wave on the same SIMD:                 %.3f ms  (max %.3f, sum %.3f)\n", tlb, tm > tl ? tm : tl, tm + tl);
     const float i0 = run<8>(out, iters, 4), i1 = run<16>(out, iters, 4), i2 = run<32>(out, iters, 4);
     printf("two waves per SIMD, each: MFMA then N independent fmas, per MFMA: N=8 %.1f clk, N=16 %.1f clk, N=32 %.1f clk (both waves together)\n",
            i0 * 1e-3 * 2.1e9 / (iters * 2.0), i1 * 1e-3 * 2.1e9 / (iters * 2.0), i2 * 1e-3 * 2.1e9 / (iters * 2.0));
