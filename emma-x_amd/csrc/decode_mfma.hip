@@ -105,8 +105,15 @@ __device__ __forceinline__ void stage_attn_rows(const float* __restrict__ attn_p
 
 // FP8: weights are the fp8 fragment-major copy (1 KiB tile = 16 rows x 64 k), de-quantised to bf16 in registers
 // (exact), per-row scale applied to the fp32 result; activations stay bf16.  A "k-step" is then 64 elements.
+#ifdef DECODE_LAB_TRACE
+__device__ unsigned long long g_dec_trace[256 * 8];   // [block][stamp]: s_memrealtime (100 MHz) of wave 0
+#define DEC_STAMP(k) do { if (threadIdx.x == 0) g_dec_trace[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define DEC_STAMP(k) do { } while (0)
+#endif
 template <int MODE, bool NORM, bool XATTN, bool FP8 = false>
 __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParams p) {
+    DEC_STAMP(0);
     constexpr int TILES = (MODE == MODE_QKV || MODE == MODE_GATEUP) ? 2 : 1;
     // k-steps per ring block: 8 KiB of weights in flight per wave (64 KiB per CU, 16 MiB on the chip) is the measured optimum
     // once the ring really rolls -- 16 KiB per wave costs 1-3 us per launch, 32 KiB up to 20 us (the first burst alone is then
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
                     off[j] = i < total ? (int)(b * pitch + c * 16) : -1;
                     v[j] = *((const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx + kc0) + c);
                 }
-                if (HEAD && base == 0) issue_head();
+                if (HEAD && base == 0) { DEC_STAMP(6); issue_head(); DEC_STAMP(7); }
 #pragma unroll
                 for (int j = 0; j < SX; ++j)
                     if (off[j] >= 0) *(u32x4_t*)(smem + off[j]) = v[j];
@@ -414,7 +421,9 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
         }
     };
     if (!one_pass) stage_x(0, std::true_type{});
+    DEC_STAMP(1);
     __syncthreads();
+    DEC_STAMP(2);
 
     // LMHEAD: per-thread running best of the (row slot, batch) it finalises
     float best = -INFINITY;
@@ -579,6 +588,9 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
             }
         };
         if (P.i < n_seg) run_block(std::true_type{}); else run_block(std::false_type{});
+#ifdef DECODE_LAB_TRACE
+        if (C.i == 0 && C.ph == 0 && C.kb == 0) DEC_STAMP(3);
+#endif
         const bool task_done = (C.ph == n_phase - 1) && (C.kb == nkb_of(C.sg, C.ph) - 1);
         const Seg cs = C.sg;
         const int t = cs.t;
@@ -605,10 +617,12 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
         pend_par = par;
         par ^= 1;
     }
+    DEC_STAMP(4);
     if (pend) {
         __syncthreads();
         reduce_epilogue(pend_sg, red + pend_par * RSZ);
     }
+    DEC_STAMP(5);
 
     if (MODE == MODE_LMHEAD) {
         __syncthreads();                      // the last reduction has read red[]
