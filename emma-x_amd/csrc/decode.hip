@@ -44,8 +44,15 @@ constexpr int GW = 8;   // waves per GEMV block
 // B <= 2: two resident blocks per CU (<= 128 VGPRs); larger batches keep more accumulators and run one block per CU
 // COH: chained launch (B <= 2 only) -- activations move with agent-scope accesses (common.h); a compile-time switch so that
 // the plain path keeps its exact code (a run-time flag cost 3 us per layer)
+#ifdef DECODE_LAB_TRACE
+__device__ unsigned long long g_gemv_trace[1024 * 8];   // [block][stamp]: s_memrealtime (100 MHz) of wave 0
+#define GEMV_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_gemv_trace[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define GEMV_STAMP(k) do { } while (0)
+#endif
 template <int B, int MODE, bool NORM, bool XATTN = false, bool COH = false>
 __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_kernel(GemvParams p) {
+    GEMV_STAMP(0);
     constexpr int NR = 2;   // weight rows per group
     constexpr int U = 8;    // 16-byte loads per row per chunk (8 * 64 lanes * 8 elems = 4096 elements)
     constexpr int NT = GW * 64;
@@ -141,7 +148,9 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
     // requested up front (branch-free, split count as a template argument -- only affordable while the weight block is not
     // occupying 64 registers) it is one round trip of ~1 us; as a loop BEHIND the weight stream it was sixteen dependent
     // round trips, ~5 of the 11 us of the launch.
-    const bool head_first = COH || !((one_pass && MODE == MODE_QKV) || XATTN);
+    // plain rows (down projection) that fit one round of four chunks per thread: activations first, see stage_x
+    const bool plain_first = !NORM && !XATTN && !COH && B <= 2 && !multi_phase && (K >> 3) <= 4 * NT;
+    const bool head_first = COH || !((one_pass && MODE == MODE_QKV) || XATTN || plain_first);
     if (head_first) issue_head(false);
     if (COH) dep_wait(p.dep);   // everything below reads data of the previous kernel
 
@@ -222,6 +231,28 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
     // stage x[:, kc0 : kc0 + 8*nch] into LDS (normalised if NORM, merged from the attention partials if XATTN)
     auto stage_x = [&](int kc0, int nch, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;   // the call in front of the main loop (no weight block live yet)
+        if (!XATTN && !NORM && FIRST && plain_first) {
+            // plain rows in front of the main loop (down projection: 22 KB per row): every chunk of a thread requested at once,
+            // UNCONDITIONALLY (clamped index, masked at the store), and the weight head right behind them -- the wait for the
+            // activations is then a counted one.  (Behind the head, with predicated loads, hipcc waited for vmcnt(0): phase
+            // stamps showed the prologue of a down launch ending 6 us in, when each wave's whole 16 KiB head had landed.)
+            u32x4_t v[B][4];
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const u32x4_t* xr = (const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx + kc0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[b][j] = ld_act16(xr + min(tid + j * NT, nch - 1), coh);
+            }
+            issue_head(true);
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (tid + j * NT < nch) xs[b * XS + tid + j * NT] = v[b][j];
+                if (tid == NT - 1) xs[b * XS + nch] = (u32x4_t){0u, 0u, 0u, 0u};
+            }
+            return;
+        }
         if (!XATTN && !NORM) {
             // plain rows (down projection: 22 KB per row): four loads in flight per thread, then the LDS writes
 #pragma unroll
@@ -296,7 +327,9 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
         }
     };
     if (!one_pass) stage_x(0, phase_nch(0), std::true_type{});
+    GEMV_STAMP(1);
     __syncthreads();
+    GEMV_STAMP(2);
 
     // LMHEAD: running best over this wave's rows
     float best[B];
@@ -378,6 +411,9 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
         // B = 2 (refill of step u between the dot products of steps u and u+1, counted waits) is 2 us slower per gate/up launch
 #pragma unroll
         for (int u = 0; u < U; ++u) issue_step(P, u, p_active);
+#ifdef DECODE_LAB_TRACE
+        if (Cc.rd == 0 && Cc.ph == 0 && Cc.blk == 0) GEMV_STAMP(3);
+#endif
         const bool group_done = (Cc.ph == n_phase - 1) && (Cc.blk == phase_nblk(Cc.ph) - 1);
         const int g = g_lo + Cc.rd * GW + wave;
         advance(Cc);
@@ -461,6 +497,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
         }
     }
 
+    GEMV_STAMP(4);
     if (MODE == MODE_LMHEAD) {
         // block best; first index wins ties (torch.argmax semantics); one partial per block
         __shared__ float bv[GW][B];
