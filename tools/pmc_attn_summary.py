@@ -12,8 +12,13 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/pmc*/pmc_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        i = k.find("AttnCfg<")
-        k = ("emmax_attention_kernel<" + k[i:k.find(">", i) + 1] + ">") if i >= 0 else k[k.find("emmax_attention_kernel"):][:32]
+        i, j = k.find("AttnCfg<"), k.find("ResCfg<")
+        if i >= 0:
+            k = "emmax_attention_kernel<" + k[i:k.find(">", i) + 1] + ">"
+        elif j >= 0:
+            k = "emmax_attention_resident_kernel<" + k[j:k.find(">", j) + 1] + ">"
+        else:
+            k = k[max(k.find("emmax_attention"), 0):][:48]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         agg[k]["_vgpr"] = [float(r["VGPR_Count"])]
         agg[k]["_lds"] = [float(r["LDS_Block_Size"])]
