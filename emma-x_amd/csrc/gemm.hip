@@ -62,15 +62,19 @@ using GeomSmall = Geom<2, 2, 4, 4>;
 
 // LDS-DMA, 16 bytes per lane: lane i's data lands at M0 + immediate + 16 i.  The LDS base goes to M0 ONCE per group of
 // slabs (`glds_base`); the slab inside the group is chosen by the instruction's immediate offset, which the hardware adds to
-// BOTH addresses (the global address is pre-decremented by it).  Issued as asm: hipcc's builtin form rewrites M0 before every
-// instruction.
-__device__ __forceinline__ void glds_base(const void* lds_base) {
-    const unsigned int b = __builtin_amdgcn_readfirstlane((unsigned int)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_base);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(b) : "m0", "memory");
+// BOTH addresses.  The global address is a wave-uniform 64-bit base in SGPRs (tile origin + K offset, advanced by scalar adds)
+// plus a per-lane 32-bit offset that does not change along K: no vector address arithmetic per request (as flat 64-bit
+// pointers every request cost two v_lshl_add_u64 -- and VALU instructions are not free next to the MFMAs of the same SIMD).
+// The lane offset carries the immediate's compensation and a bias DMA_BIAS >= 3072 so that it stays non-negative when an edge
+// tile clamps its rows; the scalar base is lowered by the same bias.  Issued as asm: hipcc's builtin form rewrites M0 before
+// every instruction and only takes flat pointers.
+constexpr int DMA_BIAS = 4096;
+__device__ __forceinline__ void glds_base(unsigned int lds_base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(__builtin_amdgcn_readfirstlane(lds_base)) : "m0", "memory");
 }
-template <int J>   // slab J (1 KiB) behind the base
-__device__ __forceinline__ void glds16_slab(const unsigned char* gsrc) {
-    asm volatile("global_load_lds_dwordx4 %0, off offset:%1" ::"v"(gsrc - J * 1024), "n"(J * 1024) : "memory");
+template <int J>   // slab J (1 KiB) behind the base; voff = lane offset - J * 1024 + DMA_BIAS, sbase = tile base + k offset - DMA_BIAS
+__device__ __forceinline__ void glds16_slab(unsigned int voff, unsigned long long sbase) {
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(sbase), "n"(J * 1024) : "memory");
 }
 
 // bf16 epilogue through LDS: a wave parks 64 rows of its result (64 columns; SwiGLU: 32) in its private 8 KiB window
@@ -284,37 +288,41 @@ __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams 
     };
 
     // ---- DMA sources: wave w fills 1 KiB slabs (8 rows each) SA*w .. of the A tile and SB*w .. of the W tile ----
-    const unsigned char* srcA[G::SA];
-    const unsigned char* srcB[G::SB];
+    unsigned int offA_l[G::SA], offB_l[G::SB];        // per lane: (row - tile origin) * ld * 2 + swizzled chunk - slab immediate + bias
+    unsigned long long baseA = 0, baseB = 0;          // wave-uniform: tile origin - bias (K offset added per step)
+    const unsigned int lds0 = __builtin_amdgcn_readfirstlane((unsigned int)(uintptr_t)(__attribute__((address_space(3))) void*)smem);
     auto set_sources = [&](int m0, int n0) {
         // logical chunk landing in physical chunk lane&7: (row >> 1) & 7 with row = 8 * slab + (lane >> 3)
+        baseA = (unsigned long long)(uintptr_t)((const bf16_t*)p.A + (size_t)m0 * p.lda) - DMA_BIAS;
+        baseB = (unsigned long long)(uintptr_t)((const bf16_t*)p.W + (size_t)n0 * p.ldw) - DMA_BIAS;
 #pragma unroll
         for (int j = 0; j < G::SA; ++j) {
             const int row = (wave * G::SA + j) * 8 + (lane >> 3);
-            const int gm = min(m0 + row, p.M - 1);   // edge tiles re-read the last row (never stored)
-            srcA[j] = (const unsigned char*)((const bf16_t*)p.A + (size_t)gm * p.lda + ((lane & 7) ^ ((row >> 1) & 7)) * 8);
+            const int gm = min(m0 + row, p.M - 1) - m0;   // edge tiles re-read the last row (never stored)
+            offA_l[j] = (unsigned int)gm * (unsigned int)(p.lda * 2) + ((lane & 7) ^ ((row >> 1) & 7)) * 16 + (DMA_BIAS - j * 1024);
         }
 #pragma unroll
         for (int j = 0; j < G::SB; ++j) {
             const int row = (wave * G::SB + j) * 8 + (lane >> 3);
-            const int gn = min(n0 + row, p.N - 1);
-            srcB[j] = (const unsigned char*)((const bf16_t*)p.W + (size_t)gn * p.ldw + ((lane & 7) ^ ((row >> 1) & 7)) * 8);
+            const int gn = min(n0 + row, p.N - 1) - n0;
+            offB_l[j] = (unsigned int)gn * (unsigned int)(p.ldw * 2) + ((lane & 7) ^ ((row >> 1) & 7)) * 16 + (DMA_BIAS - j * 1024);
         }
     };
     auto issue = [&](int kt) {
-        unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
-        const size_t koff = (size_t)(kbeg + kt) * (BK * 2);
-        static_assert(G::SA <= 4 && G::SB <= 4, "a wave's slabs of one operand share one M0 (immediates 0 .. 3072)");
+        const unsigned int st = lds0 + (kt & 1) * STAGE_BYTES;
+        const unsigned long long koff = (unsigned long long)(kbeg + kt) * (BK * 2);
+        static_assert(G::SA == 4 && G::SB == 4, "a wave's slabs of one operand share one M0 (immediates 0 .. 3072)");
+        const unsigned long long sa = baseA + koff, sb = baseB + koff;
         glds_base(st + wave * G::SA * 1024);
-        glds16_slab<0>(srcA[0] + koff);
-        if (G::SA > 1) glds16_slab<1>(srcA[G::SA > 1 ? 1 : 0] + koff);
-        if (G::SA > 2) glds16_slab<2>(srcA[G::SA > 2 ? 2 : 0] + koff);
-        if (G::SA > 3) glds16_slab<3>(srcA[G::SA > 3 ? 3 : 0] + koff);
+        glds16_slab<0>(offA_l[0], sa);
+        glds16_slab<1>(offA_l[1], sa);
+        glds16_slab<2>(offA_l[2], sa);
+        glds16_slab<3>(offA_l[3], sa);
         glds_base(st + OP_BYTES + wave * G::SB * 1024);
-        glds16_slab<0>(srcB[0] + koff);
-        if (G::SB > 1) glds16_slab<1>(srcB[G::SB > 1 ? 1 : 0] + koff);
-        if (G::SB > 2) glds16_slab<2>(srcB[G::SB > 2 ? 2 : 0] + koff);
-        if (G::SB > 3) glds16_slab<3>(srcB[G::SB > 3 ? 3 : 0] + koff);
+        glds16_slab<0>(offB_l[0], sb);
+        glds16_slab<1>(offB_l[1], sb);
+        glds16_slab<2>(offB_l[2], sb);
+        glds16_slab<3>(offB_l[3], sb);
     };
 
     // ---- fragment read offsets: row base + swizzled chunk; (row >> 1) & 7 == (li >> 1) & 7 for every 16-row tile ----
