@@ -204,8 +204,10 @@ def test_fullsize_vision_towers_match_oracle(device):
 def test_fullsize_vision_towers_large_batch_plans(device):
     """BASELINE configs[3] (ViT-only, batch 256): at B >= 16 `launch_gemm` takes the big-tile / row-split plans instead of the
     small-tile and split-K plans of B <= 2.  B = 16 at the real tower dimensions against the fp32 oracle (3e-2 * max|ref| as
-    above), then B = 256 (the 16 frames tiled 16x) against the B = 16 result of the same frames: a different launch plan may
-    change the fp32 summation order only (1e-2)."""
+    above), then B = 256 (the 16 frames tiled 16x) against the oracle and the B = 16 result of the same frames.  At B = 256 both
+    towers also take the RESIDENT attention kernel (4096 (frame, head) items: whole K / V of an item in LDS, producer waves,
+    lazy rescale) instead of the ring kernel of the small batches -- this is its end-to-end check against the fp32 oracle
+    (`test_attention_resident_form_many_short_sequences` is the op-level one)."""
     from emmax.config import EmmaXConfig
     from emmax.modeling import EmmaXForActionPrediction
     from emmax.weights import synthetic_state_dict
