@@ -183,7 +183,9 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
             ss = wave_sum(ss);
             if (lane == 0) red1p[wave][b] = ss;
         }
+        GEMV_STAMP(5);
         __syncthreads();
+        GEMV_STAMP(6);
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             float t = 0.f;
@@ -986,3 +988,11 @@ int launch_set_tokens(int32_t* cur_tok, const int32_t* toks, int B, int32_t* don
     hipLaunchKernelGGL(emmax_set_tokens_kernel, dim3(1), dim3(64), 0, stream, cur_tok, toks, B, done, stop_m, stop_after, max_new, budget);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
+
+#ifdef DECODE_LAB_TRACE
+// lab builds only (tools/decode_stage_trace.py): the phase stamps of the most recent GEMV launch, [block][8]
+extern "C" int emmax_debug_gemv_trace(unsigned long long* host_out, int n_words) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemv_trace), (size_t)n_words * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+

@@ -50,8 +50,10 @@ int main(int argc, char** argv) {
         for (int b = 0; b < nb; ++b) t0 = std::min(t0, tr[b * 8]);
         printf("%s N=%d K=%d B=%d grid %d: %.1f us per launch (%.0f MB, %.2f TB/s); us from the first block's entry (min / median / max over blocks):\n", s.name, s.N,
                s.K, B, grid, ms * 1e3 / NBUF, nw * 2 / 1e6, nw * 2 / (ms * 1e-3 / NBUF) / 1e12);
-        const char* names[] = {"entry", "prologue done", "x staged (barrier)", "first block consumed", "stream + epilogues done"};
-        for (int k = 0; k < 5; ++k) {
+        const char* names[] = {"entry", "prologue done", "x staged (barrier)", "first block consumed", "stream + epilogues done", "x arrived, stats done", "stats barrier passed"};
+        const int order[] = {0, 5, 6, 1, 2, 3, 4};
+        for (int kk = 0; kk < 7; ++kk) {
+            const int k = order[kk];
             std::vector<double> v;
             for (int b = 0; b < nb; ++b) v.push_back((double)(tr[b * 8 + k] - t0) * 0.01);
             std::sort(v.begin(), v.end());
