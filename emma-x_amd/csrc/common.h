@@ -92,17 +92,20 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // exact-erf GELU, 0.5 x (1 + erf(x / sqrt 2)), with erfc(z) = poly(t) exp(-z^2), t = 1 / (1 + p z) (Abramowitz-Stegun
 // 7.1.26, |error| <= 1.5e-7 in erf -- two orders below the bf16 rounding of the output) and no cancellation on the
-// negative side: x >= 0: x (1 - erfc(z)/2);  x < 0: x erfc(z)/2,  z = |x| / sqrt 2.  ~14 instructions instead of the
-// ~40 of ocml erff: the GELU epilogue of a K = 1024 ViT GEMM was as long as its main loop.
+// negative side: with h = erfc(z)/2, z = |x| / sqrt 2:  x >= 0: x - |x| h;  x < 0: -|x| h  ==  max(x, 0) - |x| h.
+// Written for the instruction count -- VALU work of a GEMM epilogue does not overlap the MFMAs of its SIMD: z carries the
+// sqrt(log2 e) of the exp2 (so exp(-z^2) is one v_exp_f32 of a product), the 1/2 sits in the polynomial, the sign select is a
+// max: 12 full-rate instructions + rcp + exp2 (the ocml erff is ~40, the first version of this one 17 + v_exp_f32's scale).
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float pl = fmaf(1.061405429f, t, -1.453152027f);
-    pl = fmaf(pl, t, 1.421413741f);
-    pl = fmaf(pl, t, -0.284496736f);
-    pl = fmaf(pl, t, 0.254829592f);
-    const float h = 0.5f * pl * t * __expf(-z * z);   // erfc(z) / 2
-    return x * (x >= 0.f ? 1.0f - h : h);
+    const float a = fabsf(x);
+    const float zs = a * 0.84932180028801904272f;                   // z sqrt(log2 e) = |x| sqrt(log2 e / 2)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.2727374809f, zs, 1.0f));   // 1 / (1 + p z),  p / sqrt(log2 e)
+    float pl = fmaf(0.5307027145f, t, -0.7265760135f);             // the A-S coefficients halved
+    pl = fmaf(pl, t, 0.7107068705f);
+    pl = fmaf(pl, t, -0.142248368f);
+    pl = fmaf(pl, t, 0.127414796f);
+    const float h = pl * t * __builtin_amdgcn_exp2f(-(zs * zs));   // erfc(z) / 2
+    return fmaxf(x, 0.f) - a * h;
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
