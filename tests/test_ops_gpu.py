@@ -455,7 +455,7 @@ def test_attention_resident_form_many_short_sequences(device, hd, Hq, Hkv, top, 
     L, lib = _lib()
     rng = np.random.default_rng(hd * 1000 + top + Hkv)
     B = (512 if hd == 64 else 2048) // Hq + 3
-    lens = [top, 1, 31, 32, 33, 63, 64, 65, top - 1, max(1, top - 31), max(1, top - 32), 97, 160, 5][: B]
+    lens = [top, 1, 31, 0, 32, 33, 63, 64, 65, top - 1, max(1, top - 31), max(1, top - 32), 97, 160, 5, 0][: B]   # incl. empty sequences
     lens += [int(x) for x in rng.integers(1, top + 1, size=B - len(lens))]
     g = torch.Generator().manual_seed(hd + top)
     total = sum(lens)
@@ -479,7 +479,7 @@ def test_attention_resident_form_many_short_sequences(device, hd, Hq, Hkv, top, 
     got = out[:, :qd].cpu()
     assert torch.isfinite(got.float()).all()
     assert relerr(got, ref) < TOL
-    for b in (0, 1, 2, len(lens) - 1):   # per sequence too: a wrong row of a short one disappears in the global norm
+    for b in (0, 1, 2, 4, len(lens) - 1):   # per sequence too: a wrong row of a short one disappears in the global norm
         assert relerr(got[cu[b]:cu[b + 1]], ref[cu[b]:cu[b + 1]]) < 2 * TOL, (b, lens[b])
     if ld_out > qd:
         assert (out[:, qd:] == 0).all(), "attention must not write the padding columns"
