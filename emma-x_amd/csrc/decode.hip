@@ -41,6 +41,46 @@ constexpr int PSTRIDE = EMMAX_PSTRIDE;   // floats per attention split partial: 
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int GW = 8;   // waves per GEMV block
 
+// two fp8 e4m3 (the low or the high half of a dword) -> two bf16, exact
+template <bool HI>
+__device__ __forceinline__ uint32_t fp8x2_to_bf16x2(uint32_t v) {
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, HI));
+}
+
+// row-major bf16 [N, ld] -> fp8 e4m3 (OCP) rows of K bytes in the GEMV's span order + one fp32 scale per row (amax / 448, the
+// values of emmax_quant_fm8_kernel).  A row is cut into spans of 128 chunks of 8 elements (the last one shorter: nc chunks, nc
+// even); the 16-byte granule l of a span holds chunk l (bytes 0-7) and chunk nc/2 + l (bytes 8-15).  One block per row; K % 16 == 0.
+__global__ __launch_bounds__(256) void emmax_quant_rm8_kernel(const bf16_t* __restrict__ src, int ld, uint8_t* __restrict__ dst,
+                                                             float* __restrict__ scales, int N, int K) {
+    const int n = blockIdx.x, tid = threadIdx.x;
+    __shared__ float red[4];
+    const bf16_t* row = src + (size_t)n * ld;
+    float amax = 0.f;
+    for (int c = tid; c < K / 8; c += 256) {
+        const u32x4_t v = *(const u32x4_t*)(row + c * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(bf_lo(v[j])), fabsf(bf_hi(v[j]))));
+    }
+    amax = wave_max(amax);
+    if ((tid & 63) == 0) red[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (tid == 0) scales[n] = scale;
+    for (int c = tid; c < K / 8; c += 256) {
+        const u32x4_t v = *(const u32x4_t*)(row + c * 8);
+        const int sp = c >> 7, ci = c & 127, nc2 = min(128, K / 8 - sp * 128) >> 1;
+        const int l = ci < nc2 ? ci : ci - nc2, half = ci < nc2 ? 0 : 1;
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[0]) / scale, bf_hi(v[0]) / scale, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[1]) / scale, bf_hi(v[1]) / scale, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[2]) / scale, bf_hi(v[2]) / scale, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[3]) / scale, bf_hi(v[3]) / scale, hi, true);
+        u32x2_t w = {(uint32_t)lo, (uint32_t)hi};
+        *(u32x2_t*)(dst + (size_t)n * K + sp * 1024 + l * 16 + half * 8) = w;
+    }
+}
+
 // B <= 2: two resident blocks per CU (<= 128 VGPRs); larger batches keep more accumulators and run one block per CU
 // COH: chained launch (B <= 2 only) -- activations move with agent-scope accesses (common.h); a compile-time switch so that
 // the plain path keeps its exact code (a run-time flag cost 3 us per layer)
@@ -50,11 +90,24 @@ __device__ unsigned long long g_gemv_trace[1024 * 8];   // [block][stamp]: s_mem
 #else
 #define GEMV_STAMP(k) do { } while (0)
 #endif
-template <int B, int MODE, bool NORM, bool XATTN = false, bool COH = false>
-__global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_kernel(GemvParams p) {
+// F8 > 0 (B <= 2): the weights are the row-major e4m3 copy of emmax_quant_rm8_kernel above + one fp32 scale per row.  A 16-byte
+// load is then 16 weights: a step covers a SPAN of up to 128 activation chunks (1024 elements), and lane l of the span holds the
+// weights of chunks (l, nc/2 + l) of it (nc = chunks in the span), so that the two LDS reads of a step are each consecutive
+// over the lanes, like the bf16 path's one.  Rows are half as long in bytes, so the block shape follows the matrix (the launcher
+// picks): F8 = 3 -- groups of FOUR rows (two pairs) x 4 steps, the bf16 path's 16 KiB per wave in flight, for matrices with
+// enough rows to give every wave a group (qkv, gate/up, lm-head); F8 = 1 / 2 -- two rows x 4 / 12 steps for the 4096-row
+// matrices, whose 2048 pairs are one per wave of a one-block-per-CU grid: the WHOLE pair is requested up front (o-proj: K = 4096
+// is four spans; down: K = 11008 is eleven -- 96 weight registers, which one block per CU affords).  De-quantisation is exact (e4m3 fits bf16:
+// v_cvt_scalef32_pk_bf16_fp8 with scale 1, two values per instruction, ~4.5 clocks), the products accumulate in fp32 and the row
+// scale multiplies the reduced sum.
+template <int B, int MODE, bool NORM, bool XATTN = false, bool COH = false, int F8 = 0>
+__global__ __launch_bounds__(GW * 64, (B <= 2 && F8 != 1 && F8 != 2 ? 4 : 2)) void emmax_decode_gemv_kernel(GemvParams p) {
     GEMV_STAMP(0);
-    constexpr int NR = 2;   // weight rows per group
-    constexpr int U = 8;    // 16-byte loads per row per chunk (8 * 64 lanes * 8 elems = 4096 elements)
+    constexpr bool FP8 = F8 > 0;
+    static_assert(!FP8 || (B <= 2 && !COH), "the fp8 GEMV serves batch 1-2 under plain stream ordering");
+    constexpr int NR = F8 == 3 ? 4 : 2;            // weight rows per group
+    constexpr int NP = NR / 2;                     // row PAIRS per group (the epilogues work on pairs)
+    constexpr int U = F8 == 2 ? 12 : F8 ? 4 : 8;   // 16-byte loads per row per block (bf16: 8 * 64 lanes * 8 elements = 4096 elements)
     constexpr int NT = GW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4_t* xs = (u32x4_t*)smem;   // [B][KC/8 + 1] 16-byte chunks; chunk nch of a row is zero (lanes past the end of K read it)
@@ -72,7 +125,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
     const int g_lo = bid * gq + min(bid, gr), g_hi = g_lo + gq + (bid < gr ? 1 : 0);
     const int rounds = (g_hi - g_lo + GW - 1) / GW;
 
-    auto group_rows = [&](int g, int& r0, int& r1) {
+    auto pair_rows = [&](int g, int& r0, int& r1) {   // g: pair index (= group index on the bf16 path)
         if (MODE == MODE_QKV) {
             const int half = p.head_dim >> 1;
             const int hb = g / half, d = g - hb * half;
@@ -94,7 +147,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
     const int n_phase = (K + KC - 1) / KC;
     struct Cursor { int rd, ph, blk; };
     auto phase_nch = [&](int ph) { return min(KC, K - ph * KC) >> 3; };           // 16-byte chunks in a phase
-    auto phase_nblk = [&](int ph) { return (phase_nch(ph) + 64 * U - 1) / (64 * U); };
+    auto phase_nblk = [&](int ph) { return FP8 ? ((phase_nch(ph) + 127) / 128 + U - 1) / U : (phase_nch(ph) + 64 * U - 1) / (64 * U); };
     auto advance = [&](Cursor& c) {
         if (++c.blk >= phase_nblk(c.ph)) {
             c.blk = 0;
@@ -104,18 +157,42 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
     u32x4_t wr[NR][U];
     const u32x4_t* w0p = nullptr;   // row pointers of the producer's current (group, phase)
     const u32x4_t* w1p = nullptr;
+    const u32x4_t* w8p[NR];         // fp8 rows
+#pragma unroll
+    for (int r = 0; r < NR; ++r) w8p[r] = nullptr;
     auto producer_rows = [&](const Cursor& c) {
         const int g = g_lo + c.rd * GW + wave;
         int r0, r1;
-        group_rows(min(g, g_hi - 1), r0, r1);
+        if (FP8) {   // (single phase; ldw = bytes per row)
+            const uint8_t* W8 = (const uint8_t*)p.W;
+            const int gg = min(g, g_hi - 1);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                pair_rows(min(gg * NP + i, p.n_pairs - 1), r0, r1);
+                w8p[2 * i] = (const u32x4_t*)(W8 + (size_t)r0 * p.ldw);
+                w8p[2 * i + 1] = (const u32x4_t*)(W8 + (size_t)r1 * p.ldw);
+            }
+            return;
+        }
+        pair_rows(min(g, g_hi - 1), r0, r1);
         w0p = (const u32x4_t*)(W + (size_t)r0 * p.ldw + c.ph * KC);
         w1p = (const u32x4_t*)(W + (size_t)r1 * p.ldw + c.ph * KC);
     };
+    // FP8: chunks of span s = step u of block blk, and whether this lane holds weights of it
+    auto span_nc = [&](int s) { return min(128, (K >> 3) - s * 128); };
     auto issue_step = [&](const Cursor& c, int u, bool active) {
-        const int ch = c.blk * 64 * U + u * 64 + lane;
-        const bool ok = active && ch < phase_nch(c.ph);
-        wr[0][u] = ok ? ld_nt(w0p + ch) : (u32x4_t){0u, 0u, 0u, 0u};
-        wr[1][u] = ok ? ld_nt(w1p + ch) : (u32x4_t){0u, 0u, 0u, 0u};
+        if constexpr (FP8) {
+            const int sp = c.blk * U + u;
+            const bool ok = active && lane < (span_nc(sp) >> 1);
+            const int at = sp * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) wr[r][u] = ok ? ld_nt(w8p[r] + at) : (u32x4_t){0u, 0u, 0u, 0u};
+        } else {
+            const int ch = c.blk * 64 * U + u * 64 + lane;
+            const bool ok = active && ch < phase_nch(c.ph);
+            wr[0][u] = ok ? ld_nt(w0p + ch) : (u32x4_t){0u, 0u, 0u, 0u};
+            wr[1][u] = ok ? ld_nt(w1p + ch) : (u32x4_t){0u, 0u, 0u, 0u};
+        }
     };
 
     // ---- head of the weight stream: it does not depend on x.  UNCONDITIONAL loads (clamped addresses; lanes and waves past
@@ -127,7 +204,14 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
     auto issue_head = [&](bool counted) {
         producer_rows(P);
         const int nch0 = phase_nch(0);
-        if (counted) {
+        if (counted && FP8) {   // (lanes past a span's end re-read the row's last granule and meet the zero chunk of x)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int at = min(u * 64 + lane, (nch0 >> 1) - 1);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) wr[r][u] = ld_nt(w8p[r] + at);
+            }
+        } else if (counted) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int ch = min(u * 64 + lane, nch0 - 1);
@@ -150,7 +234,9 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
     // round trips, ~5 of the 11 us of the launch.
     // plain rows (down projection) that fit one round of four chunks per thread: activations first, see stage_x
     const bool plain_first = !NORM && !XATTN && !COH && B <= 2 && !multi_phase && (K >> 3) <= 4 * NT;
-    const bool head_first = COH || !((one_pass && MODE == MODE_QKV) || XATTN || plain_first);
+    // fp8: every one-pass prologue goes first -- the first burst is most of the matrix, the refills cannot go out before x is
+    // staged, and x requested behind the burst arrived 7 us into a 19 us gate/up launch (tools/gemv_lab.hip)
+    const bool head_first = COH || !((one_pass && (MODE == MODE_QKV || FP8)) || XATTN || plain_first);
     if (head_first) issue_head(false);
     if (COH) dep_wait(p.dep);   // everything below reads data of the previous kernel
 
@@ -347,32 +433,51 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
 #pragma unroll
         for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
 
-    float red0[B], red1[B];
+    float red[NR][B];
     // Epilogue operands are fetched when a group STARTS, not when its dot products are done: the old residual values (RESID)
     // and the row's position / page id / cos-sin pair (QKV) are dependent global loads (~0.7-1.5 us from L2) that would
     // otherwise sit at the tail of every group with the wave's weight ring idle behind them.  Lane b serves batch row b.
     const int eb = lane < B ? lane : 0;
     int pre_pos = 0, pre_pg = 0;
-    float pre_a = 0.f, pre_b = 0.f;                      // RESID: h[r0], h[r1];  QKV: cos, sin
+    float pre_a[NP], pre_b[NP];                          // RESID: h[r0], h[r1];  QKV: cos, sin
+    float wsc[NR];                                       // FP8: the group's row scales
+#pragma unroll
+    for (int i = 0; i < NP; ++i) pre_a[i] = pre_b[i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) wsc[r] = 1.f;
     if (MODE == MODE_QKV) {
         pre_pos = p.ctx_len[eb];
         pre_pg = p.page_table[(size_t)eb * p.max_pages + pre_pos / p.page];
     }
     auto prefetch_epilogue = [&](int rd) {
         const int g = g_lo + rd * GW + wave;
-        if (g >= g_hi || lane >= B) return;
-        if (MODE == MODE_RESID) {
-            int r0, r1;
-            group_rows(g, r0, r1);
-            const bf16_t* hp = (const bf16_t*)p.y + (size_t)eb * p.ldy;
-            pre_a = bf2f(ld_act_bf16(hp + r0, coh));
-            pre_b = bf2f(ld_act_bf16(hp + r1, coh));
-        } else if (MODE == MODE_QKV) {
-            const int half = p.head_dim >> 1;
-            const int hb = g / half, d = g - hb * half;
-            if (hb < p.Hq + p.Hkv) {
-                pre_a = p.cos_t[(size_t)pre_pos * half + d];
-                pre_b = p.sin_t[(size_t)pre_pos * half + d];
+        if (g >= g_hi) return;
+        if constexpr (FP8) {   // every lane: the lm-head compares on all of them
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                int r0, r1;
+                pair_rows(min(g * NP + i, p.n_pairs - 1), r0, r1);
+                wsc[2 * i] = p.wscale[r0];
+                wsc[2 * i + 1] = p.wscale[r1];
+            }
+        }
+        if (lane >= B) return;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int pg = FP8 ? min(g * NP + i, p.n_pairs - 1) : g;
+            if (MODE == MODE_RESID) {
+                int r0, r1;
+                pair_rows(pg, r0, r1);
+                const bf16_t* hp = (const bf16_t*)p.y + (size_t)eb * p.ldy;
+                pre_a[i] = bf2f(ld_act_bf16(hp + r0, coh));
+                pre_b[i] = bf2f(ld_act_bf16(hp + r1, coh));
+            } else if (MODE == MODE_QKV) {
+                const int half = p.head_dim >> 1;
+                const int hb = pg / half, d = pg - hb * half;
+                if (hb < p.Hq + p.Hkv) {
+                    pre_a[i] = p.cos_t[(size_t)pre_pos * half + d];
+                    pre_b[i] = p.sin_t[(size_t)pre_pos * half + d];
+                }
             }
         }
     };
@@ -388,6 +493,46 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
         const bool p_active = P.rd < my_rounds;
         if (P.blk == 0) producer_rows(P);
         const int nch = phase_nch(Cc.ph);
+        if constexpr (FP8) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int sp = Cc.blk * U + u, base = sp * 128;
+                if (valid && base < nch) {   // wave-uniform
+                    const int nc2 = span_nc(sp) >> 1;
+                    const bool l_ok = lane < nc2;
+                    const int cc0 = l_ok ? base + lane : nch, cc1 = l_ok ? base + nc2 + lane : nch;   // past the end: the zero chunk
+                    u32x4_t xa[B], xb[B];
+#pragma unroll
+                    for (int b = 0; b < B; ++b) {
+                        xa[b] = xs[b * XS + cc0];
+                        xb[b] = xs[b * XS + cc1];
+                    }
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        // dwords 0-1 of the granule: the 8 weights of chunk cc0, dwords 2-3: of chunk cc1 (emmax_quant_rm8_kernel)
+                        uint32_t w[8];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            w[2 * j] = fp8x2_to_bf16x2<false>(wr[r][u][j]);
+                            w[2 * j + 1] = fp8x2_to_bf16x2<true>(wr[r][u][j]);
+                        }
+#pragma unroll
+                        for (int b = 0; b < B; ++b) {
+                            float a = acc[r][b];
+                            a = dot2_bf16(w[0], xa[b][0], a);
+                            a = dot2_bf16(w[1], xa[b][1], a);
+                            a = dot2_bf16(w[2], xa[b][2], a);
+                            a = dot2_bf16(w[3], xa[b][3], a);
+                            a = dot2_bf16(w[4], xb[b][0], a);
+                            a = dot2_bf16(w[5], xb[b][1], a);
+                            a = dot2_bf16(w[6], xb[b][2], a);
+                            a = dot2_bf16(w[7], xb[b][3], a);
+                            acc[r][b] = a;
+                        }
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int c = Cc.blk * 64 * U + u * 64 + lane;
@@ -407,6 +552,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
                     }
                 }
             }
+        }
         }
         // refill the whole block AFTER it is consumed: sixteen requests back to back (two rows x 8 KiB, consecutive addresses).
         // This is the order hipcc picked by itself at B = 1 and it is the fast one -- the per-step interleaving it chose at
@@ -428,33 +574,43 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
             for (int b = 0; b < B; ++b) {
                 const float t = wave_sum(acc[r][b]);
                 acc[r][b] = 0.f;
-                if (r == 0) red0[b] = t; else red1[b] = t;
+                red[r][b] = FP8 ? t * wsc[r] : t;
             }
 
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+        const int pg = FP8 ? g * NP + i : g;   // the pair's index
+        if (FP8 && pg >= p.n_pairs) continue;
+        float red0[B], red1[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            red0[b] = red[2 * i][b];
+            red1[b] = red[2 * i + 1][b];
+        }
         int r0, r1;
-        group_rows(g, r0, r1);
+        pair_rows(pg, r0, r1);
         if (MODE == MODE_PLAIN) {
 #pragma unroll
             for (int b = 0; b < B; ++b)
                 if (lane == b) {
                     st_act_bf16((bf16_t*)p.y + (size_t)b * p.ldy + r0, f2bf(red0[b]), coh);
-                    if (2 * g + 1 < p.n_rows) st_act_bf16((bf16_t*)p.y + (size_t)b * p.ldy + r1, f2bf(red1[b]), coh);
+                    if (2 * pg + 1 < p.n_rows) st_act_bf16((bf16_t*)p.y + (size_t)b * p.ldy + r1, f2bf(red1[b]), coh);
                 }
         } else if (MODE == MODE_RESID) {
 #pragma unroll
             for (int b = 0; b < B; ++b)
                 if (lane == b) {
                     bf16_t* hp = (bf16_t*)p.y + (size_t)b * p.ldy;
-                    st_act_bf16(hp + r0, f2bf(pre_a + red0[b]), coh);
-                    if (2 * g + 1 < p.n_rows) st_act_bf16(hp + r1, f2bf(pre_b + red1[b]), coh);
+                    st_act_bf16(hp + r0, f2bf(pre_a[i] + red0[b]), coh);
+                    if (2 * pg + 1 < p.n_rows) st_act_bf16(hp + r1, f2bf(pre_b[i] + red1[b]), coh);
                 }
         } else if (MODE == MODE_GATEUP) {
 #pragma unroll
             for (int b = 0; b < B; ++b)
-                if (lane == b) st_act_bf16((bf16_t*)p.y + (size_t)b * p.ldy + g, f2bf(silu(red0[b]) * red1[b]), coh);
+                if (lane == b) st_act_bf16((bf16_t*)p.y + (size_t)b * p.ldy + pg, f2bf(silu(red0[b]) * red1[b]), coh);
         } else if (MODE == MODE_QKV) {
             const int hd = p.head_dim, half = hd >> 1;
-            const int hb = g / half, d = g - hb * half;
+            const int hb = pg / half, d = pg - hb * half;
 #pragma unroll
             for (int b = 0; b < B; ++b)
                 if (lane == b) {
@@ -462,21 +618,21 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
                     // linear outputs are bf16 activations in the reference; RoPE acts on those
                     const float x0 = bf2f(f2bf(red0[b])), x1 = bf2f(f2bf(red1[b]));
                     if (hb < p.Hq + p.Hkv) {
-                        const float cs = pre_a, sn = pre_b;
+                        const float cs = pre_a[i], sn = pre_b[i];
                         const bf16_t y0 = f2bf(x0 * cs - x1 * sn), y1 = f2bf(x1 * cs + x0 * sn);
                         if (hb < p.Hq) {
                             bf16_t* q = (bf16_t*)p.y + (size_t)b * p.ldy + hb * hd;
                             st_act_bf16(q + d, y0, coh);
                             st_act_bf16(q + d + half, y1, coh);
                         } else {
-                            const int pg = pre_pg;
-                            bf16_t* kc = (bf16_t*)p.kcache + (((size_t)pg * p.Hkv + (hb - p.Hq)) * p.page + pos % p.page) * hd;
+                            const int pgid = pre_pg;
+                            bf16_t* kc = (bf16_t*)p.kcache + (((size_t)pgid * p.Hkv + (hb - p.Hq)) * p.page + pos % p.page) * hd;
                             st_act_bf16(kc + d, y0, coh);
                             st_act_bf16(kc + d + half, y1, coh);
                         }
                     } else {
-                        const int pg = pre_pg;
-                        bf16_t* vc = (bf16_t*)p.vcache + (((size_t)pg * p.Hkv + (hb - p.Hq - p.Hkv)) * p.page + pos % p.page) * hd;
+                        const int pgid = pre_pg;
+                        bf16_t* vc = (bf16_t*)p.vcache + (((size_t)pgid * p.Hkv + (hb - p.Hq - p.Hkv)) * p.page + pos % p.page) * hd;
                         st_act_bf16(vc + d, f2bf(x0), coh);
                         st_act_bf16(vc + d + half, f2bf(x1), coh);
                     }
@@ -485,9 +641,9 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
 #pragma unroll
             for (int b = 0; b < B; ++b) {
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
+                for (int r = 0; r < 2; ++r) {
                     const int row = r == 0 ? r0 : r1;
-                    if (r == 1 && 2 * g + 1 >= p.n_rows) continue;
+                    if (r == 1 && 2 * pg + 1 >= p.n_rows) continue;
                     const float v = r == 0 ? red0[b] : red1[b];
                     if (v > best[b] || (v == best[b] && row < besti[b])) {
                         best[b] = v;
@@ -496,6 +652,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 ? 4 : 2)) void emmax_decode_gemv_k
                     if (p.logits_out && lane == 0) p.logits_out[(size_t)b * p.n_rows + row] = v;
                 }
             }
+        }
         }
     }
 
@@ -833,14 +990,21 @@ static int gemv_grid(int B, size_t smem, int n_groups, int max_grid = 0) {
     if (max_grid > 0) grid = min(grid, max_grid);
     return min(grid, cdiv(n_groups, GW));
 }
-int decode_lmhead_grid(int B, int K, int n_rows, int max_parts, int max_grid) {
-    return min(gemv_grid(B, (size_t)B * K * 2, (n_rows + 1) / 2, max_grid), max_parts);
+// block shape of the fp8 GEMV (template argument F8): four-row groups when that still gives every wave of the 512-block grid one,
+// else two rows x 12 steps when the row has more than eight spans, else two rows x 4 steps
+static int gemv_fp8_shape(int n_rows, int K) {
+    if (n_rows >= 4 * 512 * GW * 3 / 4) return 3;
+    return K > 8 * 1024 ? 2 : 1;
+}
+int decode_lmhead_grid(int B, int K, int n_rows, int max_parts, int max_grid, bool fp8) {
+    const int pairs = (n_rows + 1) / 2;
+    return min(gemv_grid(B, (size_t)B * K * 2, fp8 && gemv_fp8_shape(n_rows, K) == 3 ? (pairs + 1) / 2 : pairs, max_grid), max_parts);
 }
 
-template <int B, int MODE, bool NORM, bool XATTN = false>
+template <int B, int MODE, bool NORM, bool XATTN = false, int F8 = 0>
 static int launch_gemv_t(const GemvParams& p, hipStream_t stream, int* grid_out) {
     const size_t smem = (size_t)B * (p.kc * 2 + 16);
-    int grid = gemv_grid(B, smem, p.n_groups, p.max_grid);
+    int grid = gemv_grid(B, smem, p.n_groups, (F8 == 1 || F8 == 2) ? 256 : p.max_grid);
     {   // tuning hook: EMMAX_GEMV_GRID="qkv,resid,gateup,lmhead,plain" (0 = default) overrides the persistent grid per mode
         static int forced[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         static bool parsed = false;
@@ -861,7 +1025,11 @@ static int launch_gemv_t(const GemvParams& p, hipStream_t stream, int* grid_out)
     if (grid_out) *grid_out = grid;
     GemvParams q = p;
     q.dep.n_blocks = (unsigned)grid;
-    if (dep_coherent(q.dep)) {   // chained launch
+    if constexpr (F8 > 0) {
+        if (dep_coherent(q.dep)) return -1;
+        auto kern = emmax_decode_gemv_kernel<B, MODE, NORM, XATTN, false, F8>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(GW * 64), smem, stream, q);
+    } else if (dep_coherent(q.dep)) {   // chained launch
         if constexpr (B <= 2) {
             auto kern = emmax_decode_gemv_kernel<B, MODE, NORM, XATTN, true>;
             hipLaunchKernelGGL(kern, dim3(grid), dim3(GW * 64), smem, stream, q);
@@ -884,6 +1052,16 @@ static int launch_gemv_mode(GemvParams p, int B, hipStream_t stream, int* grid_o
     if (MODE == MODE_QKV) p.n_groups = p.n_rows / 2;
     else if (MODE == MODE_GATEUP) p.n_groups = p.n_rows / 2;
     else p.n_groups = (p.n_rows + 1) / 2;
+    p.n_pairs = p.n_groups;
+    if (p.wscale) {   // fp8 rows (batch 1-2, one K phase)
+        if (p.kc != p.K || p.K % 16 || B > 2) return -1;
+        const int f8 = gemv_fp8_shape(p.n_rows, p.K);
+        if (f8 == 3) p.n_groups = (p.n_pairs + 1) / 2;   // groups of two pairs
+#define CASEF(BB, FF) if (B == BB && f8 == FF) return launch_gemv_t<BB, MODE, NORM, XATTN, FF>(p, stream, grid_out)
+        CASEF(1, 1); CASEF(1, 2); CASEF(1, 3); CASEF(2, 1); CASEF(2, 2); CASEF(2, 3);
+#undef CASEF
+        return -1;
+    }
     switch (B) {
 #define CASEB(BB) case BB: return launch_gemv_t<BB, MODE, NORM, XATTN>(p, stream, grid_out)
         CASEB(1); CASEB(2); CASEB(3); CASEB(4); CASEB(5); CASEB(6); CASEB(7); CASEB(8);
@@ -902,6 +1080,9 @@ static int gemv_init_mode() {
 #define SETC(BB) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_gemv_kernel<BB, MODE, NORM, XATTN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
     SETC(1); SETC(2);
 #undef SETC
+#define SETF(BB, FF) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_gemv_kernel<BB, MODE, NORM, XATTN, false, FF>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
+    SETF(1, 1); SETF(1, 2); SETF(1, 3); SETF(2, 1); SETF(2, 2); SETF(2, 3);
+#undef SETF
     return e == hipSuccess ? 0 : -4;
 }
 int decode_gemv_init() {
@@ -917,6 +1098,13 @@ int decode_gemv_init() {
     return r;
 }
 
+int launch_quant_rm8(const void* src, int ld, void* dst, float* scales, int N, int K, hipStream_t stream) {
+    if (N <= 0 || K <= 0 || K % 16 || ld % 8) return -1;
+    hipLaunchKernelGGL(emmax_quant_rm8_kernel, dim3(N), dim3(256), 0, stream, (const bf16_t*)src, ld, (uint8_t*)dst, scales, N, K);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// p.wscale set: p.W is the fp8 row copy of launch_quant_rm8 (ldw = bytes per row), batch 1-2
 int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
     if (p.K % 8 || p.ldw % 8 || p.ldx % 8) return -1;
     switch (mode) {

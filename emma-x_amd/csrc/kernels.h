@@ -107,7 +107,8 @@ struct GemvParams {
     // RESID with x = merged attention output: split partials f32 [B][Hq][nsplit][132] (null: x is a bf16 vector)
     const float* attn_part;
     int nsplit;
-    const float* wscale;    // MFMA path: per-row fp32 scales when W is the fp8 fragment-major copy (null: bf16 copy)
+    const float* wscale;    // per-row fp32 scales when W is an fp8 copy (MFMA path: fragment-major tiles; GEMV: rows in span order); null: bf16
+    int n_pairs;            // GEMV, set by the launcher: row pairs (fp8 groups hold two)
     unsigned long long* sk_ws;   // MFMA path: stream-K granules [256 blocks][2 tiles][256] of {f32, tag} (null: whole tasks per block)
     int sk_kt8, sk_q, sk_r;      // MFMA path, set by the launcher: super-steps per task (0: whole tasks), per-block share and remainder
     unsigned int sk_magic;       // ... and ceil(2^32 / sk_kt8)
@@ -116,7 +117,7 @@ struct GemvParams {
     DepInfo dep;            // chained-launch hand-off (all null: plain stream ordering)
 };
 int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
-int decode_lmhead_grid(int B, int K, int n_rows, int max_parts, int max_grid = 0);   // blocks (= argmax partials) the lm-head launch uses
+int decode_lmhead_grid(int B, int K, int n_rows, int max_parts, int max_grid = 0, bool fp8 = false);   // blocks (= argmax partials) the lm-head launch uses
 int decode_gemv_init();   // raise the dynamic-LDS limit of every GEMV instantiation (call once, outside graph capture)
 int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, const DepInfo& dep, hipStream_t stream);
 
@@ -165,6 +166,7 @@ int launch_set_tokens(int32_t* cur_tok, const int32_t* toks, int B, int32_t* don
 // ---- decode_mfma.hip: small-batch (B >= 3) projections on MFMA over the fragment-major weight copy ----
 int launch_repack_fm(const void* src, int ld, void* dst, int N, int K, hipStream_t stream);
 int launch_quant_fm8(const void* src, int ld, void* dst, float* scales, int N, int K, hipStream_t stream);   // fp8 e4m3 + per-row scale
+int launch_quant_rm8(const void* src, int ld, void* dst, float* scales, int N, int K, hipStream_t stream);   // same values, rows in the GEMV's span order
 int launch_decode_mfma(int mode, const GemvParams& p, int B, hipStream_t stream);   // p.W = fragment-major copy
 int decode_mfma_lmhead_grid(int n_rows, int max_parts);
 int decode_mfma_init();

@@ -71,6 +71,7 @@ struct LayerW {
     bf16 *ln1, *wqkv, *wo, *ln2, *wgu, *wdown;
     bf16 *wqkv_fm, *wo_fm, *wgu_fm, *wdown_fm;   // MFMA-fragment-major copies for the B >= 3 decode path (fp8 mode: e4m3 tiles)
     float *wqkv_sc, *wo_sc, *wgu_sc, *wdown_sc;  // fp8 mode: per-row scales (null otherwise)
+    bf16 *wqkv_r8, *wo_r8, *wgu_r8, *wdown_r8;   // fp8 mode: the same e4m3 values as rows in the GEMV's span order (batch 1-2)
 };
 
 struct emmax_model {
@@ -81,7 +82,7 @@ struct emmax_model {
     int H, inter, inter_p, q_dim, kv_dim, qkv_dim, vocab, vocab_p, V, Vp, P1, P1p;
     TowerW tw[2];
     bf16 *pj1_w, *pj1_b, *pj2_w, *pj2_b, *pj3_w, *pj3_b;
-    bf16 *embed, *final_norm, *lm_head, *lm_head_fm;
+    bf16 *embed, *final_norm, *lm_head, *lm_head_fm, *lm_head_r8 = nullptr;
     float* lm_head_sc = nullptr;
     bool fp8 = false;
     std::vector<LayerW> layers;
@@ -192,7 +193,12 @@ static void plan_arena(emmax_model* m, Bump& b) {
         L.wgu_fm = b.take((int64_t)2 * m->inter_p * m->H / d);
         L.wdown_fm = b.take((int64_t)m->H * m->inter_p / d);
         L.wqkv_sc = L.wo_sc = L.wgu_sc = L.wdown_sc = nullptr;
+        L.wqkv_r8 = L.wo_r8 = L.wgu_r8 = L.wdown_r8 = nullptr;
         if (m->fp8) {
+            L.wqkv_r8 = b.take((int64_t)m->qkv_dim * m->H / 2);
+            L.wo_r8 = b.take((int64_t)m->H * m->q_dim / 2);
+            L.wgu_r8 = b.take((int64_t)2 * m->inter_p * m->H / 2);
+            L.wdown_r8 = b.take((int64_t)m->H * m->inter_p / 2);
             L.wqkv_sc = (float*)b.take(2 * (int64_t)m->qkv_dim);
             L.wo_sc = (float*)b.take(2 * (int64_t)m->H);
             L.wgu_sc = (float*)b.take(4 * (int64_t)m->inter_p);
@@ -202,7 +208,10 @@ static void plan_arena(emmax_model* m, Bump& b) {
     m->final_norm = b.take(m->H);
     m->lm_head = b.take((int64_t)m->vocab_p * m->H);
     m->lm_head_fm = b.take((int64_t)m->vocab_p * m->H / (m->fp8 ? 2 : 1));
-    if (m->fp8) m->lm_head_sc = (float*)b.take(2 * (int64_t)m->vocab_p);
+    if (m->fp8) {
+        m->lm_head_sc = (float*)b.take(2 * (int64_t)m->vocab_p);
+        m->lm_head_r8 = b.take((int64_t)m->vocab_p * m->H / 2);
+    }
 }
 
 // copy a bound [rows, cols] bf16 matrix into dst (row pitch dst_ld elements) starting at dst row `row0`
@@ -426,10 +435,33 @@ static bool streamk_on() {
     return !(e && atoi(e) == 0);
 }
 
-// B <= 2: per-lane dot-product GEMV over the row-major weights; B >= 3: MFMA over the fragment-major copy
+// tuning hook: EMMAX_FP8_GEMV = bit mask of the batch 1-2 fp8 projections that run as dot-product GEMV over the e4m3 row copy
+// (1 qkv, 2 o-proj, 4 gate/up, 8 down, 16 lm-head); the others go through the MFMA kernel like every larger batch.  0 = round 1.
+// Default 23: per launch at B = 1 (rocprofv3, in situ) GEMV / MFMA = qkv 15.0 / 15.3, o-proj 8.0 / 9.5, gate/up 18.2 / 20.5,
+// lm-head 25.1 / 29.8 us -- and down 13.3 / 12.4: its 22 KB activation row is staged 8 us into the launch, by when the MFMA
+// kernel (K split over the waves, partial sums) is further along.
+enum { F8_QKV = 1, F8_OPROJ = 2, F8_GATEUP = 4, F8_DOWN = 8, F8_LMHEAD = 16 };
+static int fp8_gemv_mask() {
+    static int mask = -1;
+    if (mask < 0) {
+        const char* e = getenv("EMMAX_FP8_GEMV");
+        mask = e ? atoi(e) & 31 : 23;
+    }
+    return mask;
+}
+static bool fp8_rows(const emmax_model* m, int B, int bit) { return m->fp8 && B < EMMAX_MFMA_MIN_BATCH && (fp8_gemv_mask() & bit); }
+
+// B <= 2: per-lane dot-product GEMV over the row-major weights (fp8 mode: over the e4m3 row copy w_r8);
+// B >= 3: MFMA over the fragment-major copy
 static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_fm, int B, hipStream_t st, int* grid_out = nullptr,
-                       const float* w_scale = nullptr) {
-    if (B >= EMMAX_MFMA_MIN_BATCH || w_scale) {   // fp8 weights exist only as fragment-major tiles: every batch goes MFMA
+                       const float* w_scale = nullptr, const void* w_r8 = nullptr, int f8bit = 0) {
+    if (B < EMMAX_MFMA_MIN_BATCH && w_scale && w_r8 && !dep_coherent(p.dep) && (fp8_gemv_mask() & f8bit)) {
+        p.W = w_r8;
+        p.wscale = w_scale;
+        p.ldw = p.K;   // bytes per row
+        return launch_decode_gemv(mode, p, B, st, grid_out);
+    }
+    if (B >= EMMAX_MFMA_MIN_BATCH || w_scale) {
         p.W = w_fm;
         p.wscale = w_scale;
         return launch_decode_mfma(mode, p, B, st);
@@ -476,12 +508,13 @@ static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* log
     p.n_rows = m->vocab; p.max_parts = s->n_lm_blocks; p.part_val = s->part_val; p.part_idx = s->part_idx; p.logits_out = logits_out;
     int lm_grid = 0;
     if (ch) { p.dep = ch->dep(); p.max_grid = 256; st = ch->stream(); }
-    KCHK(launch_proj(GEMV_LMHEAD, p, m->lm_head, m->lm_head_fm, B, st, &lm_grid, m->lm_head_sc));
+    KCHK(launch_proj(GEMV_LMHEAD, p, m->lm_head, m->lm_head_fm, B, st, &lm_grid, m->lm_head_sc, m->lm_head_r8, F8_LMHEAD));
     if (ch) ch->launched();
     if (do_finish) {
         FinishParams f;
         memset(&f, 0, sizeof(f));
-        f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = (B >= EMMAX_MFMA_MIN_BATCH || m->fp8) ? decode_mfma_lmhead_grid(m->vocab, s->n_lm_blocks) : decode_lmhead_grid(B, m->H, m->vocab, s->n_lm_blocks, ch ? 256 : 0);
+        f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = (B >= EMMAX_MFMA_MIN_BATCH || (m->fp8 && !fp8_rows(m, B, F8_LMHEAD))) ? decode_mfma_lmhead_grid(m->vocab, s->n_lm_blocks)
+                                                                                  : decode_lmhead_grid(B, m->H, m->vocab, s->n_lm_blocks, ch ? 256 : 0, m->fp8);
         f.B = B;
         f.cur_tok = s->cur_tok + slot0; f.ctx_len = s->ctx_len + slot0; f.done = s->done + slot0; f.n_out = s->n_out + slot0;
         f.out_ids = s->out_ids + (size_t)slot0 * s->max_out;
@@ -587,7 +620,7 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             p.ctx_len = s->ctx_len; p.page_table = s->page_table; p.cos_t = s->cos_t; p.sin_t = s->sin_t;
             p.kcache = kcache_of(s, li); p.vcache = vcache_of(s, li);
             arm();
-            KCHK(launch_proj(GEMV_QKV, p, L.wqkv, L.wqkv_fm, B, st, &grid, L.wqkv_sc));
+            KCHK(launch_proj(GEMV_QKV, p, L.wqkv, L.wqkv_fm, B, st, &grid, L.wqkv_sc, L.wqkv_r8, F8_QKV));
             if (ch) ch->launched();
             return 0;
         case STAGE_ATTN: {
@@ -606,20 +639,20 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             p.x = s->datt; p.ldx = m->q_dim; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
             p.attn_part = s->part; p.nsplit = decode_attn_nsplit(B, c.n_kv_heads); p.Hq = c.n_heads;   // split merge fused into the staging
             arm();
-            KCHK(launch_proj(GEMV_RESID, p, L.wo, L.wo_fm, B, st, &grid, L.wo_sc));
+            KCHK(launch_proj(GEMV_RESID, p, L.wo, L.wo_fm, B, st, &grid, L.wo_sc, L.wo_r8, F8_OPROJ));
             if (ch) ch->launched();
             return 0;
         case STAGE_GATEUP:
             p.x = s->dh; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln2; p.eps = c.rms_eps;
             p.y = s->dact; p.ldy = m->inter_p; p.n_rows = 2 * m->inter_p;
             arm();
-            KCHK(launch_proj(GEMV_GATEUP, p, L.wgu, L.wgu_fm, B, st, &grid, L.wgu_sc));
+            KCHK(launch_proj(GEMV_GATEUP, p, L.wgu, L.wgu_fm, B, st, &grid, L.wgu_sc, L.wgu_r8, F8_GATEUP));
             if (ch) ch->launched();
             return 0;
         case STAGE_DOWN:
             p.x = s->dact; p.ldx = m->inter_p; p.ldw = m->inter_p; p.K = m->inter_p; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
             arm();
-            KCHK(launch_proj(GEMV_RESID, p, L.wdown, L.wdown_fm, B, st, &grid, L.wdown_sc));
+            KCHK(launch_proj(GEMV_RESID, p, L.wdown, L.wdown_fm, B, st, &grid, L.wdown_sc, L.wdown_r8, F8_DOWN));
             if (ch) ch->launched();
             return 0;
         default:
@@ -867,6 +900,10 @@ int emmax_model_finalize(emmax_model* m, void* arena, int64_t arena_bytes, emmax
             KCHK(launch_quant_fm8(L.wo, m->q_dim, L.wo_fm, L.wo_sc, m->H, m->q_dim, st));
             KCHK(launch_quant_fm8(L.wgu, m->H, L.wgu_fm, L.wgu_sc, 2 * m->inter_p, m->H, st));
             KCHK(launch_quant_fm8(L.wdown, m->inter_p, L.wdown_fm, L.wdown_sc, m->H, m->inter_p, st));
+            KCHK(launch_quant_rm8(L.wqkv, m->H, L.wqkv_r8, L.wqkv_sc, m->qkv_dim, m->H, st));   // (writes the same scales again)
+            KCHK(launch_quant_rm8(L.wo, m->q_dim, L.wo_r8, L.wo_sc, m->H, m->q_dim, st));
+            KCHK(launch_quant_rm8(L.wgu, m->H, L.wgu_r8, L.wgu_sc, 2 * m->inter_p, m->H, st));
+            KCHK(launch_quant_rm8(L.wdown, m->inter_p, L.wdown_r8, L.wdown_sc, m->H, m->inter_p, st));
         } else {
             KCHK(launch_repack_fm(L.wqkv, m->H, L.wqkv_fm, m->qkv_dim, m->H, st));
             KCHK(launch_repack_fm(L.wo, m->q_dim, L.wo_fm, m->H, m->q_dim, st));
@@ -876,8 +913,10 @@ int emmax_model_finalize(emmax_model* m, void* arena, int64_t arena_bytes, emmax
     }
     PUT1("language_model.model.norm.weight", m->H, m->final_norm);
     PUT2("language_model.lm_head.weight", m->vocab, m->H, m->lm_head, m->H, 0);
-    if (m->fp8) KCHK(launch_quant_fm8(m->lm_head, m->H, m->lm_head_fm, m->lm_head_sc, m->vocab_p, m->H, st));
-    else KCHK(launch_repack_fm(m->lm_head, m->H, m->lm_head_fm, m->vocab_p, m->H, st));
+    if (m->fp8) {
+        KCHK(launch_quant_fm8(m->lm_head, m->H, m->lm_head_fm, m->lm_head_sc, m->vocab_p, m->H, st));
+        KCHK(launch_quant_rm8(m->lm_head, m->H, m->lm_head_r8, m->lm_head_sc, m->vocab_p, m->H, st));
+    } else KCHK(launch_repack_fm(m->lm_head, m->H, m->lm_head_fm, m->vocab_p, m->H, st));
 #undef PUT2
 #undef PUT1
     HIPCHK(hipStreamSynchronize(st));
@@ -1374,6 +1413,22 @@ int emmax_op_resize_bicubic_u8(const uint8_t* src, int B, int H, int W, uint8_t*
 int emmax_op_quant_fm8(const void* W, int ld, void* W8, float* scales, int N, int K, emmax_stream st) {
     int r = launch_quant_fm8(W, ld, W8, scales, N, K, (hipStream_t)st);
     if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_quant_fm8: N %% 16, K %% 64, ld %% 8 required");
+    return 0;
+}
+int emmax_op_quant_rm8(const void* W, int ld, void* W8, float* scales, int N, int K, emmax_stream st) {
+    int r = launch_quant_rm8(W, ld, W8, scales, N, K, (hipStream_t)st);
+    if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_quant_rm8: K %% 16, ld %% 8 required");
+    return 0;
+}
+int emmax_op_gemv_fp8(const void* x, const void* W8, const float* scales, void* y, int B, int N, int K, emmax_stream st) {
+    if (B < 1 || B > 2) return fail(EMMAX_ERR_INVALID, "emmax_op_gemv_fp8: batch must be 1..2");
+    if (!scales) return fail(EMMAX_ERR_INVALID, "emmax_op_gemv_fp8: scales required");
+    if (decode_gemv_init()) return fail(EMMAX_ERR_HIP, "emmax_op_gemv_fp8: init failed");
+    GemvParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.ldx = K; p.W = W8; p.ldw = K; p.K = K; p.y = y; p.ldy = N; p.n_rows = N; p.wscale = scales;
+    int r = launch_decode_gemv(GEMV_PLAIN, p, B, (hipStream_t)st);
+    if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_gemv_fp8: unsupported shape (K %% 16, B * K * 2 bytes of LDS)");
     return 0;
 }
 int emmax_op_gemm_small_fp8(const void* x, const void* W8, const float* scales, void* y, int B, int N, int K, emmax_stream st) {

@@ -90,6 +90,8 @@ SIGNATURES = {
     "emmax_op_resize_bicubic_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "emmax_op_quant_fm8": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp]),
     "emmax_op_gemm_small_fp8": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "emmax_op_quant_rm8": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "emmax_op_gemv_fp8": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "emmax_op_repack_fm": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp]),
     "emmax_op_gemm_small": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
 }

@@ -213,6 +213,11 @@ int emmax_op_resize_bicubic_u8(const uint8_t* src_dev, int B, int H, int W, uint
 int emmax_op_quant_fm8(const void* W_dev, int ld, void* W8_fm_out_dev, float* scales_out_dev, int N, int K, emmax_stream stream);
 int emmax_op_gemm_small_fp8(const void* x_dev, const void* W8_fm_dev, const float* scales_dev, void* y_dev, int B, int N, int K,
                             emmax_stream stream);
+/* fp8 rows for batch 1-2: the same e4m3 values and scales as emmax_op_quant_fm8, laid out as N rows of K bytes in the span
+ * order the dot-product GEMV streams (decode.hip, emmax_quant_rm8_kernel; K % 16 == 0), and that GEMV (1 <= B <= 2). */
+int emmax_op_quant_rm8(const void* W_dev, int ld, void* W8_rows_out_dev, float* scales_out_dev, int N, int K, emmax_stream stream);
+int emmax_op_gemv_fp8(const void* x_dev, const void* W8_rows_dev, const float* scales_dev, void* y_dev, int B, int N, int K,
+                      emmax_stream stream);
 int emmax_op_repack_fm(const void* W_dev, int ld, void* W_fm_out_dev, int N, int K, emmax_stream stream);
 int emmax_op_gemm_small(const void* x_dev, const void* W_fm_dev, void* y_dev, int B, int N, int K, emmax_stream stream);
 

@@ -435,9 +435,9 @@ def test_fp8_weight_decode_vs_bf16(device):
         m8.engine.set_current_tokens(tok)                      # keep both models on the bf16 trajectory
     print(f"fp8 vs bf16: worst relative logit error {worst:.4f}, argmax mismatch {mism}/{2 * T}")
     assert worst < 0.15                                        # e4m3 weights: ~2^-4 relative per weight, averaged over K
-    # planted weights: ids exact incl. EOS, through the fp8 path at B = 1 and B = 3
+    # planted weights: ids exact incl. EOS, through the fp8 path at B = 1, 2 (dot-product GEMV over the e4m3 rows) and B = 3 (MFMA)
     p8, _ = _mk(cfg8, 5, True, device, max_batch=4, max_prompt=40)
-    for Bn in (1, 3):
+    for Bn in (1, 2, 3):
         fr2, rows2 = _inputs(cfg, Bn, 12, seed=40 + Bn)
         for b in range(Bn):
             rows2[b][-1] = planted_start_token(cfg, 4 + b)

@@ -349,6 +349,50 @@ def test_fp8_weight_projection(device, B, N, K):
     assert relerr(y, ref) < TOL
 
 
+def _rm8_rows_to_codes(W8, N, K):
+    """Undo the span order of emmax_quant_rm8_kernel: spans of 128 chunks of 8 bytes (the last one shorter, nc chunks);
+    granule l of a span = chunk l ++ chunk nc/2 + l."""
+    rows = W8.cpu().view(N, K)
+    back = torch.empty_like(rows)
+    nch = K // 8
+    for sp in range((nch + 127) // 128):
+        nc = min(128, nch - sp * 128)
+        span = rows[:, sp * 1024: sp * 1024 + nc * 8].reshape(N, nc // 2, 2, 8)      # granule, half, byte
+        back[:, sp * 1024: sp * 1024 + nc * 8] = span.permute(0, 2, 1, 3).reshape(N, nc * 8)
+    return back
+
+
+@pytest.mark.parametrize("B", [1, 2])
+@pytest.mark.parametrize("N,K", [(256, 256), (4096, 4096), (1008, 11008), (64, 704), (7, 64), (33, 1040), (4099, 2048),
+                                 (12290, 1040), (22016, 4096), (12293, 64)])
+def test_fp8_row_gemv(device, B, N, K):
+    """Batch 1-2 of the fp8 decode weights: the e4m3 ROW copy (span order, decode.hip) must hold torch.float8_e4m3fn's codes
+    bit for bit with the scales of the fragment-major quantiser, and the dot-product GEMV over it must match an fp32 matmul
+    over the de-quantised weights -- all three block shapes of the kernel (two rows x 4 or 8 steps, four-row groups from 12288
+    rows), row counts that are not a multiple of the group, K with a short last span (704, 1040, 11008) and K below one span (64)."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(B * 7 + N + K)
+    x = bf(torch.randn(B, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    W[3, 5] = 0.7
+    scale_ref = W.float().abs().amax(dim=1).clamp_min(1e-30) / 448.0
+    Wq_ref = (W.float() / scale_ref[:, None]).to(torch.float8_e4m3fn)
+    Wd, xd = W.to(device), x.to(device)
+    W8 = torch.empty(N * K, dtype=torch.uint8, device=device)
+    sc = torch.empty(N, dtype=torch.float32, device=device)
+    L.check(lib.emmax_op_quant_rm8(Wd.data_ptr(), K, W8.data_ptr(), sc.data_ptr(), N, K, stream()), "quant rows")
+    torch.cuda.synchronize()
+    assert torch.allclose(sc.cpu(), scale_ref, rtol=1e-6, atol=0)
+    diff = (_rm8_rows_to_codes(W8, N, K) != Wq_ref.view(torch.uint8))
+    assert not diff.any(), f"{int(diff.sum())} of {diff.numel()} fp8 codes differ from torch.float8_e4m3fn"
+    ref = x.float() @ (Wq_ref.float() * scale_ref[:, None]).t()
+    y = torch.full((B, N), float("nan"), dtype=torch.bfloat16, device=device)
+    L.check(lib.emmax_op_gemv_fp8(xd.data_ptr(), W8.data_ptr(), sc.data_ptr(), y.data_ptr(), B, N, K, stream()), "gemv fp8")
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all()
+    assert relerr(y, ref) < TOL
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Paged split-KV decode attention (emmax_decode_attn_kernel) at the benchmark's operating point: contexts 768..1280,
 # ragged batches, MHA and GQA, every split count the launcher can pick, page tables that are NOT the identity.

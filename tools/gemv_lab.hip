@@ -14,15 +14,17 @@
 
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 1;
+    const bool fp8 = argc > 2 && !strcmp(argv[2], "fp8");   // the e4m3 row copy (half the bytes), batch 1-2
     struct Shape { const char* name; int mode, N, K; };
     const Shape shapes[] = {{"gate/up (norm, SwiGLU)", MODE_GATEUP, 22016, 4096}, {"down (+residual)", MODE_RESID, 4096, 11008}, {"plain 4096 x 4096", MODE_PLAIN, 4096, 4096},
                             {"plain 12288 x 4096", MODE_PLAIN, 12288, 4096}};
     if (decode_gemv_init() != 0) { printf("init failed\n"); return 1; }
     for (const Shape& s : shapes) {
-        const size_t nw = (size_t)s.N * s.K;
+        const size_t nw = (size_t)s.N * s.K, wb = fp8 ? 1 : 2;
         const int NBUF = 5;
-        void *W[NBUF], *x, *y, *nwp;
-        for (int i = 0; i < NBUF; ++i) { CHECK(hipMalloc(&W[i], nw * 2)); CHECK(hipMemset(W[i], 0x11, nw * 2)); }
+        void *W[NBUF], *x, *y, *nwp, *wsc;
+        for (int i = 0; i < NBUF; ++i) { CHECK(hipMalloc(&W[i], nw * wb)); CHECK(hipMemset(W[i], 0x11, nw * wb)); }
+        CHECK(hipMalloc(&wsc, (size_t)s.N * 4)); CHECK(hipMemset(wsc, 0, (size_t)s.N * 4));
         CHECK(hipMalloc(&x, (size_t)8 * s.K * 2)); CHECK(hipMemset(x, 0x11, (size_t)8 * s.K * 2));
         CHECK(hipMalloc(&nwp, (size_t)s.K * 2)); CHECK(hipMemset(nwp, 0x11, (size_t)s.K * 2));
         CHECK(hipMalloc(&y, (size_t)8 * s.N * 2)); CHECK(hipMemset(y, 0, (size_t)8 * s.N * 2));
@@ -37,6 +39,7 @@ int main(int argc, char** argv) {
                 memset(&p, 0, sizeof(p));
                 p.x = x; p.ldx = s.K; p.W = W[i]; p.ldw = s.K; p.K = s.K; p.y = y; p.ldy = s.mode == MODE_GATEUP ? s.N / 2 : s.N; p.n_rows = s.N;
                 p.norm_w = nwp; p.eps = 1e-5f;
+                if (fp8) p.wscale = (const float*)wsc;
                 if (launch_decode_gemv(s.mode, p, B, 0, &grid) != 0) { printf("launch failed\n"); return 1; }
             }
             CHECK(hipEventRecord(e1, 0));
@@ -49,7 +52,7 @@ int main(int argc, char** argv) {
         unsigned long long t0 = ~0ull;
         for (int b = 0; b < nb; ++b) t0 = std::min(t0, tr[b * 8]);
         printf("%s N=%d K=%d B=%d grid %d: %.1f us per launch (%.0f MB, %.2f TB/s); us from the first block's entry (min / median / max over blocks):\n", s.name, s.N,
-               s.K, B, grid, ms * 1e3 / NBUF, nw * 2 / 1e6, nw * 2 / (ms * 1e-3 / NBUF) / 1e12);
+               s.K, B, grid, ms * 1e3 / NBUF, nw * wb / 1e6, nw * wb / (ms * 1e-3 / NBUF) / 1e12);
         const char* names[] = {"entry", "prologue done", "x staged (barrier)", "first block consumed", "stream + epilogues done", "x arrived, stats done", "stats barrier passed"};
         const int order[] = {0, 5, 6, 1, 2, 3, 4};
         for (int kk = 0; kk < 7; ++kk) {
@@ -60,7 +63,7 @@ int main(int argc, char** argv) {
             printf("  %-26s %6.2f / %6.2f / %6.2f\n", names[k], v[0], v[nb / 2], v[nb - 1]);
         }
         for (int i = 0; i < NBUF; ++i) CHECK(hipFree(W[i]));
-        CHECK(hipFree(x)); CHECK(hipFree(y)); CHECK(hipFree(nwp));
+        CHECK(hipFree(x)); CHECK(hipFree(y)); CHECK(hipFree(nwp)); CHECK(hipFree(wsc));
     }
     return 0;
 }
