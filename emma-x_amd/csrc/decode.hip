@@ -988,6 +988,9 @@ __global__ void emmax_set_tokens_kernel(int32_t* cur_tok, const int32_t* toks, i
 static int gemv_grid(int B, size_t smem, int n_groups, int max_grid = 0) {
     int grid = (B > 2 || smem > 72 * 1024) ? 256 : 512;
     if (max_grid > 0) grid = min(grid, max_grid);
+    // a partial second layer of blocks is worse than none: the CUs that hold two blocks finish ~4 us after the others (the fp8
+    // qkv rows are 384 blocks' worth of four-row groups: 16.6 us with 384 blocks, 15.0 with 256; tools/gemv_lab.hip)
+    if (grid == 512 && cdiv(n_groups, GW) < 512) grid = 256;
     return min(grid, cdiv(n_groups, GW));
 }
 // block shape of the fp8 GEMV (template argument F8): four-row groups when that still gives every wave of the 512-block grid one,

@@ -61,6 +61,21 @@ int main(int argc, char** argv) {
             std::sort(v.begin(), v.end());
             printf("  %-22s %6.2f / %6.2f / %6.2f\n", names[k], v[0], v[128], v[255]);
         }
+        {   // who finishes late?  "stream done" per XCD (block b runs on XCD b % 8) and per eighth of the block range
+            printf("  stream done by XCD (mean / max):");
+            for (int xc = 0; xc < 8; ++xc) {
+                double m = 0, mx = 0;
+                for (int b = xc; b < 256; b += 8) { const double t = (double)(tr[b * 8 + 4] - t0) * 0.01; m += t / 32; mx = std::max(mx, t); }
+                printf("  %5.1f/%5.1f", m, mx);
+            }
+            printf("\n  stream done by block range of 32 (mean / max):");
+            for (int r = 0; r < 8; ++r) {
+                double m = 0, mx = 0;
+                for (int b = r * 32; b < r * 32 + 32; ++b) { const double t = (double)(tr[b * 8 + 4] - t0) * 0.01; m += t / 32; mx = std::max(mx, t); }
+                printf("  %5.1f/%5.1f", m, mx);
+            }
+            printf("\n");
+        }
         for (int i = 0; i < NBUF; ++i) CHECK(hipFree(fm[i]));
         CHECK(hipFree(raw)); CHECK(hipFree(x)); CHECK(hipFree(y));
     }

@@ -62,6 +62,21 @@ int main(int argc, char** argv) {
             std::sort(v.begin(), v.end());
             printf("  %-26s %6.2f / %6.2f / %6.2f\n", names[k], v[0], v[nb / 2], v[nb - 1]);
         }
+        {   // who finishes late?  per XCD (block b runs on XCD b % 8) and per eighth of the block range
+            printf("  done by XCD (mean / max):");
+            for (int xc = 0; xc < 8; ++xc) {
+                double m = 0, mx = 0; int n = 0;
+                for (int b = xc; b < nb; b += 8) { const double t = (double)(tr[b * 8 + 4] - t0) * 0.01; m += t; mx = std::max(mx, t); ++n; }
+                printf("  %5.1f/%5.1f", m / n, mx);
+            }
+            printf("\n  done by eighth of the block range (mean / max):");
+            for (int r = 0; r < 8; ++r) {
+                double m = 0, mx = 0; int n = 0;
+                for (int b = r * nb / 8; b < (r + 1) * nb / 8; ++b) { const double t = (double)(tr[b * 8 + 4] - t0) * 0.01; m += t; mx = std::max(mx, t); ++n; }
+                printf("  %5.1f/%5.1f", m / n, mx);
+            }
+            printf("\n");
+        }
         for (int i = 0; i < NBUF; ++i) CHECK(hipFree(W[i]));
         CHECK(hipFree(x)); CHECK(hipFree(y)); CHECK(hipFree(nwp)); CHECK(hipFree(wsc));
     }
