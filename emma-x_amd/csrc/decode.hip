@@ -1101,6 +1101,12 @@ int decode_gemv_init() {
     return r;
 }
 
+// the fp8 row GEMV stages the whole activation rows in LDS (one K phase) and serves batch 1-2
+bool decode_gemv_fp8_fits(int B, int K) {
+    if (B < 1 || B > 2 || K <= 0 || K % 16) return false;
+    return K <= ((128 * 1024 / 2 / B) & ~511);
+}
+
 int launch_quant_rm8(const void* src, int ld, void* dst, float* scales, int N, int K, hipStream_t stream) {
     if (N <= 0 || K <= 0 || K % 16 || ld % 8) return -1;
     hipLaunchKernelGGL(emmax_quant_rm8_kernel, dim3(N), dim3(256), 0, stream, (const bf16_t*)src, ld, (uint8_t*)dst, scales, N, K);

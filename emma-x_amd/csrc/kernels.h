@@ -166,6 +166,7 @@ int launch_set_tokens(int32_t* cur_tok, const int32_t* toks, int B, int32_t* don
 // ---- decode_mfma.hip: small-batch (B >= 3) projections on MFMA over the fragment-major weight copy ----
 int launch_repack_fm(const void* src, int ld, void* dst, int N, int K, hipStream_t stream);
 int launch_quant_fm8(const void* src, int ld, void* dst, float* scales, int N, int K, hipStream_t stream);   // fp8 e4m3 + per-row scale
+bool decode_gemv_fp8_fits(int B, int K);   // the fp8 row GEMV takes this (batch, K); else the MFMA kernel serves it
 int launch_quant_rm8(const void* src, int ld, void* dst, float* scales, int N, int K, hipStream_t stream);   // same values, rows in the GEMV's span order
 int launch_decode_mfma(int mode, const GemvParams& p, int B, hipStream_t stream);   // p.W = fragment-major copy
 int decode_mfma_lmhead_grid(int n_rows, int max_parts);

@@ -449,13 +449,15 @@ static int fp8_gemv_mask() {
     }
     return mask;
 }
-static bool fp8_rows(const emmax_model* m, int B, int bit) { return m->fp8 && B < EMMAX_MFMA_MIN_BATCH && (fp8_gemv_mask() & bit); }
+static bool fp8_rows(const emmax_model* m, int B, int K, int bit) {
+    return m->fp8 && B < EMMAX_MFMA_MIN_BATCH && (fp8_gemv_mask() & bit) && decode_gemv_fp8_fits(B, K);
+}
 
 // B <= 2: per-lane dot-product GEMV over the row-major weights (fp8 mode: over the e4m3 row copy w_r8);
 // B >= 3: MFMA over the fragment-major copy
 static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_fm, int B, hipStream_t st, int* grid_out = nullptr,
                        const float* w_scale = nullptr, const void* w_r8 = nullptr, int f8bit = 0) {
-    if (B < EMMAX_MFMA_MIN_BATCH && w_scale && w_r8 && !dep_coherent(p.dep) && (fp8_gemv_mask() & f8bit)) {
+    if (B < EMMAX_MFMA_MIN_BATCH && w_scale && w_r8 && !dep_coherent(p.dep) && (fp8_gemv_mask() & f8bit) && decode_gemv_fp8_fits(B, p.K)) {
         p.W = w_r8;
         p.wscale = w_scale;
         p.ldw = p.K;   // bytes per row
@@ -513,7 +515,7 @@ static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* log
     if (do_finish) {
         FinishParams f;
         memset(&f, 0, sizeof(f));
-        f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = (B >= EMMAX_MFMA_MIN_BATCH || (m->fp8 && !fp8_rows(m, B, F8_LMHEAD))) ? decode_mfma_lmhead_grid(m->vocab, s->n_lm_blocks)
+        f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = (B >= EMMAX_MFMA_MIN_BATCH || (m->fp8 && !fp8_rows(m, B, m->H, F8_LMHEAD))) ? decode_mfma_lmhead_grid(m->vocab, s->n_lm_blocks)
                                                                                   : decode_lmhead_grid(B, m->H, m->vocab, s->n_lm_blocks, ch ? 256 : 0, m->fp8);
         f.B = B;
         f.cur_tok = s->cur_tok + slot0; f.ctx_len = s->ctx_len + slot0; f.done = s->done + slot0; f.n_out = s->n_out + slot0;

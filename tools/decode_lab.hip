@@ -30,6 +30,9 @@ int main(int argc, char** argv) {
         CHECK(hipMalloc(&x, (size_t)8 * s.K * 2));
         CHECK(hipMemset(x, 0x11, (size_t)8 * s.K * 2));
         CHECK(hipMalloc(&y, (size_t)8 * s.N * 2));
+        void* skws;   // stream-K granules, as the session provides them (all zero between launches); SK=0: whole tasks per block
+        CHECK(hipMalloc(&skws, (size_t)256 * 2 * 256 * 8));
+        CHECK(hipMemset(skws, 0, (size_t)256 * 2 * 256 * 8));
         hipEvent_t e0, e1;
         CHECK(hipEventCreate(&e0));
         CHECK(hipEventCreate(&e1));
@@ -40,6 +43,7 @@ int main(int argc, char** argv) {
                 GemvParams p;
                 memset(&p, 0, sizeof(p));
                 p.x = x; p.ldx = s.K; p.W = fm[i]; p.ldw = s.K; p.K = s.K; p.y = y; p.ldy = s.N; p.n_rows = s.N;
+                if (!(getenv("SK") && atoi(getenv("SK")) == 0)) p.sk_ws = (unsigned long long*)skws;
                 if (launch_decode_mfma(GEMV_PLAIN, p, B, 0) != 0) { printf("launch failed\n"); return 1; }
             }
             CHECK(hipEventRecord(e1, 0));
@@ -77,7 +81,7 @@ int main(int argc, char** argv) {
             printf("\n");
         }
         for (int i = 0; i < NBUF; ++i) CHECK(hipFree(fm[i]));
-        CHECK(hipFree(raw)); CHECK(hipFree(x)); CHECK(hipFree(y));
+        CHECK(hipFree(raw)); CHECK(hipFree(x)); CHECK(hipFree(y)); CHECK(hipFree(skws));
     }
     return 0;
 }
