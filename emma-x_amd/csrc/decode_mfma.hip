@@ -745,3 +745,10 @@ int decode_mfma_init() {
     done = (e == hipSuccess) ? 0 : -4;
     return done;
 }
+
+#ifdef DECODE_LAB_TRACE
+// lab builds only (tools/decode_stage_trace.py): the phase stamps of the most recent small-batch MFMA launch, [256 blocks][8]
+extern "C" int emmax_debug_mfma_trace(unsigned long long* host_out, int n_words) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dec_trace), (size_t)n_words * 8) == hipSuccess ? 0 : -1;
+}
+#endif

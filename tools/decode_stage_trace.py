@@ -30,6 +30,22 @@ lib.emmax_debug_gemv_trace.restype = C.c_int
 lib.emmax_debug_gemv_trace.argtypes = [C.c_void_p, C.c_int]
 names = ["qkv_gemv", "paged_attn", "oproj_gemv", "gateup_gemv", "down_gemv", "lmhead_argmax"]
 grids = {"qkv_gemv": 512, "oproj_gemv": 256, "gateup_gemv": 512, "down_gemv": 256, "lmhead_argmax": 512}
+if B >= 3:   # the small-batch MFMA projections: when is each block's stream done, by XCD (block b runs on XCD b % 8)
+    lib.emmax_debug_mfma_trace.restype = C.c_int
+    lib.emmax_debug_mfma_trace.argtypes = [C.c_void_p, C.c_int]
+    for rep in range(3):
+        for i, n in enumerate(names):
+            us = eng.profile_decode_stage(i, reps=2)
+            if n == "paged_attn":
+                continue
+            buf = (C.c_ulonglong * (256 * 8))()
+            assert lib.emmax_debug_mfma_trace(buf, 256 * 8) == 0
+            tr = np.frombuffer(buf, dtype=np.uint64).reshape(256, 8).astype(np.int64)
+            t0 = tr[:, 0].min()
+            done = (tr[:, 4] - t0) * 0.01
+            print(f"{n}: {us:.2f} us per launch; stream done min / median / max {done.min():.1f} / {np.median(done):.1f} / {done.max():.1f}; by XCD mean:",
+                  " ".join(f"{done[x::8].mean():5.1f}" for x in range(8)))
+    sys.exit(0)
 for i, n in enumerate(names):
     us = eng.profile_decode_stage(i, reps=2)
     if n == "paged_attn":
