@@ -276,8 +276,9 @@ def main():
         # HBM traffic of the same kernel from PMC counters (separate rocprofv3 --pmc passes over tools/pmc_probe.py, B=1;
         # FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); not collected during this run
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-        if B == 1 and not args.tiny and not args.fp8 and os.path.isfile(pmc_file):
+        pmc_name = {(1, False): "r02_pmc_traffic.json", (8, False): "r02_pmc_traffic_b8.json", (1, True): "r02_pmc_traffic_fp8.json"}.get((B, bool(args.fp8)))
+        pmc_file = os.path.join(ROOT, "profiles", pmc_name or "none")
+        if not args.tiny and pmc_name and os.path.isfile(pmc_file):
             with open(pmc_file) as f:
                 traffic = json.load(f)["stages"].get(dom, {}).get("hbm_bytes_per_launch")
         # whole decode step: algorithmic bytes / measured step time
@@ -308,7 +309,7 @@ def main():
             "roofline": {"kernel": ("emmax_decode_gemv_kernel<B=%d,GATEUP,NORM%s>" % (B, ",FP8 rows" if args.fp8 else "") if B <= 2 else "emmax_decode_mfma_kernel<GATEUP,NORM%s> (B=%d)" % (",FP8" if args.fp8 else "", B)) + " (gate/up projection + SiLU*mul)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "bytes_per_launch": stage_bytes[dom], "us_per_launch": round(stage_us[dom], 2), "traffic": traffic,
-                         "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc, offline)" if traffic else None},
+                         "traffic_source": "profiles/%s (rocprofv3 --pmc, offline)" % pmc_name if traffic else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, P, T)

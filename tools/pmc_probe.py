@@ -18,6 +18,8 @@ cfg.llm.num_layers = 2
 for t in cfg.towers:
     t.depth = 3
 B = int(os.environ.get("PROBE_BATCH", "1"))
+if os.environ.get("PROBE_FP8"):   # e4m3 decode weights (BASELINE configs[4])
+    cfg.decode_weight_dtype = "fp8"
 model = EmmaXForActionPrediction.from_synthetic(cfg, seed=0, device="cuda:0", max_batch=B, max_prompt=512, max_ctx=1281)
 rng = np.random.default_rng(0)
 frames = torch.from_numpy(rng.integers(0, 256, size=(B, 224, 224, 3), dtype=np.uint8)).cuda()
