@@ -42,6 +42,13 @@ __global__ __launch_bounds__(512, 4) void probe(const u32x4* __restrict__ W, con
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         acc = xv[0] ^ xv[1] ^ xv[2] ^ xv[3];
         if (tid == 0) t1 = wall();
+    } else if (MODE == 3) {   // no weight requests at all: what does the 8 KB cost by itself at the start of a launch?
+        const u32x4 xv = *((const u32x4*)x + tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        acc = xv[0] ^ xv[1] ^ xv[2] ^ xv[3];
+        if (tid == 0) t1 = wall();
+#pragma unroll
+        for (int u = 0; u < 16; ++u) w[u] = (u32x4){0u, 0u, 0u, 0u};
     } else {
         const uint32_t* xs = x + __builtin_amdgcn_readfirstlane(wave) * 256;   // this wave's 1 KB of x ...
         u32x16 s[8];                                                             // ... half of it here (8 x 64 B = 512 B keeps the SGPR budget)
@@ -73,15 +80,17 @@ int main() {
     uint32_t *x, *sink;
     unsigned long long* st;
     CHECK(hipMalloc(&x, 8192)); CHECK(hipMalloc(&sink, 4096)); CHECK(hipMalloc(&st, G * 4 * 8));
-    const char* names[] = {"vector x behind the head (vmcnt(0))", "vector x first, counted wait", "scalar x first (s_load_dwordx16)"};
-    for (int mode = 0; mode < 3; ++mode) {
+    const char* names[] = {"vector x behind the head (vmcnt(0))", "vector x first, counted wait", "scalar x first (s_load_dwordx16)",
+                           "x alone, no weight requests", "x alone, NOT rewritten before the launch"};
+    for (int mode = 0; mode < 5; ++mode) {
         std::vector<double> med;
         double mn = 1e9, mx = 0, all = 0;
         for (int rep = 0; rep < NB; ++rep) {
-            hipLaunchKernelGGL(write_x, dim3(8), dim3(256), 0, 0, x, (uint32_t)(rep * 977 + mode));
+            if (mode != 4) hipLaunchKernelGGL(write_x, dim3(8), dim3(256), 0, 0, x, (uint32_t)(rep * 977 + mode));
             if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(G), dim3(512), 0, 0, (const u32x4*)W[rep], x, st, sink);
             if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(G), dim3(512), 0, 0, (const u32x4*)W[rep], x, st, sink);
             if (mode == 2) hipLaunchKernelGGL(probe<2>, dim3(G), dim3(512), 0, 0, (const u32x4*)W[rep], x, st, sink);
+            if (mode >= 3) hipLaunchKernelGGL(probe<3>, dim3(G), dim3(512), 0, 0, (const u32x4*)W[rep], x, st, sink);
             CHECK(hipDeviceSynchronize());
             if (rep == 0) continue;   // warm-up
             std::vector<unsigned long long> h(G * 4);
@@ -93,7 +102,7 @@ int main() {
             med.push_back(v[G / 2]); mn = std::min(mn, v[0]); mx = std::max(mx, v[G - 1]); all += (double)(e1 - e0) * 0.01;
         }
         std::sort(med.begin(), med.end());
-        printf("%-40s x arrives min %.2f / median %.2f / max %.2f us after the block's entry; all 64 MB landed %.1f us after the first entry\n", names[mode], mn,
+        printf("%-40s x arrives min %.2f / median %.2f / max %.2f us after the block's entry; launch done %.1f us after the first entry\n", names[mode], mn,
                med[med.size() / 2], mx, all / (NB - 1));
     }
     return 0;
