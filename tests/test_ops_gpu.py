@@ -393,6 +393,22 @@ def test_fp8_row_gemv(device, B, N, K):
     assert relerr(y, ref) < TOL
 
 
+def test_fp8_row_gemv_refuses_what_it_cannot_stage(device):
+    """The fp8-row GEMV stages whole activation rows in LDS (one K phase) and serves batch 1-2: a third row, a K that is not a
+    multiple of 16 or rows beyond the LDS budget are refused with an error code and a message (the session then keeps such a
+    projection on the MFMA kernel, model.hip: launch_proj), never run wrong."""
+    L, lib = _lib()
+    x = torch.zeros(3, 65536, dtype=torch.bfloat16, device=device)
+    W8 = torch.zeros(16 * 65536, dtype=torch.uint8, device=device)
+    sc = torch.ones(16, dtype=torch.float32, device=device)
+    y = torch.zeros(3, 16, dtype=torch.bfloat16, device=device)
+    for B, N, K in [(3, 16, 256), (2, 16, 65536), (1, 16, 264)]:
+        rc = lib.emmax_op_gemv_fp8(x.data_ptr(), W8.data_ptr(), sc.data_ptr(), y.data_ptr(), B, N, K, stream())
+        assert rc != 0, (B, N, K)
+        assert b"emmax_op_gemv_fp8" in lib.emmax_last_error()
+    torch.cuda.synchronize()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Paged split-KV decode attention (emmax_decode_attn_kernel) at the benchmark's operating point: contexts 768..1280,
 # ragged batches, MHA and GQA, every split count the launcher can pick, page tables that are NOT the identity.
