@@ -80,60 +80,90 @@ def resize_area(image: np.ndarray, size: Sequence[int]) -> np.ndarray:
     return np.clip(np.rint(x), 0, 255).astype(np.uint8)
 
 
+# Per-embodiment constants of the SimplerEnv wrapper: the statistics key the model un-normalises with by default and the
+# number of control steps a google_robot gripper command is held for (openvla_model.py:24-34).
+_EMBODIMENTS = {
+    "widowx_bridge": {"unnorm_key": "bridge_orig", "hold_steps": 1, "gripper": "absolute"},
+    "google_robot": {"unnorm_key": "fractal20220817_data", "hold_steps": 15, "gripper": "sticky_delta"},
+}
+
+
+class StickyGripper:
+    """google_robot gripper post-processing (behaviour of openvla_model.py:104-131, pinned by tests/golden/simpler_env.json).
+
+    The model emits an absolute opening in [0, 1] (1 = open); the simulator wants the CHANGE of opening, and wants a large
+    change repeated for `hold_steps` consecutive control steps.  State: the previous opening, and -- while a command is being
+    held -- the held delta and how many steps it has been emitted for."""
+
+    def __init__(self, hold_steps: int) -> None:
+        self.hold_steps = int(hold_steps)
+        self.clear()
+
+    def clear(self) -> None:
+        self.last_opening: Optional[np.ndarray] = None
+        self.held: Optional[np.ndarray] = None   # delta being repeated, None when idle
+        self.emitted = 0
+
+    def __call__(self, opening: np.ndarray) -> np.ndarray:
+        delta = np.array([0]) if self.last_opening is None else self.last_opening - opening
+        self.last_opening = opening
+        if self.held is None and np.abs(delta) > 0.5:
+            self.held = delta
+        if self.held is not None:
+            delta = self.held
+            self.emitted += 1
+        if self.emitted == self.hold_steps:   # also true for an idle gripper when hold_steps == 0; harmless
+            self.held, self.emitted = None, 0
+        return delta
+
+
 class OpenVLAInference:
+    """Same constructor arguments, `reset`, `step` and result keys as the SimplerEnv wrapper (openvla_model.py:12-145)."""
+
+    ACTION_LABELS = ("x", "y", "z", "roll", "pitch", "yaw", "grasp")
+
     def __init__(self, saved_model_path: str = "openvla/openvla-7b", unnorm_key: Optional[str] = None,
                  policy_setup: str = "widowx_bridge", horizon: int = 1, pred_action_horizon: int = 1, exec_horizon: int = 1,
                  image_size: Sequence[int] = (224, 224), action_scale: float = 1.0, vla=None, processor=None,
                  device: str = "cuda:0") -> None:
         os.environ["TOKENIZERS_PARALLELISM"] = "false"
-        if policy_setup == "widowx_bridge":
-            unnorm_key = "bridge_orig" if unnorm_key is None else unnorm_key
-            self.sticky_gripper_num_repeat = 1
-        elif policy_setup == "google_robot":
-            unnorm_key = "fractal20220817_data" if unnorm_key is None else unnorm_key
-            self.sticky_gripper_num_repeat = 15
-        else:
-            raise NotImplementedError(
-                f"Policy setup {policy_setup} not supported for octo models. The other datasets can be found in the huggingface config.json file."
-            )
+        setup = _EMBODIMENTS.get(policy_setup)
+        if setup is None:
+            raise NotImplementedError(f"Policy setup {policy_setup!r} is not one of {sorted(_EMBODIMENTS)}; other embodiments "
+                                      "need their statistics key from the checkpoint's config.json")
         self.policy_setup = policy_setup
-        self.unnorm_key = unnorm_key
+        self.unnorm_key = setup["unnorm_key"] if unnorm_key is None else unnorm_key
+        self.sticky_gripper_num_repeat = setup["hold_steps"]
+        self._gripper = StickyGripper(setup["hold_steps"]) if setup["gripper"] == "sticky_delta" else None
         self.device = device
-        if processor is None or vla is None:
-            from .modeling import EmmaXForActionPrediction
+        self.image_size = [int(v) for v in image_size]
+        self.action_scale = action_scale
+        self.horizon, self.pred_action_horizon, self.exec_horizon = horizon, pred_action_horizon, exec_horizon
+        self.task = None
+        self.task_description: Optional[str] = None
+        self.num_image_history = 0
+        self.processor, self.vla = self._load(saved_model_path, processor, vla, device)
+
+    @staticmethod
+    def _load(path, processor, vla, device):
+        if processor is None:
             from .processing import EmmaXProcessor
 
-            processor = processor if processor is not None else EmmaXProcessor.from_pretrained(saved_model_path)
-            if vla is None:
-                import torch
+            processor = EmmaXProcessor.from_pretrained(path)
+        if vla is None:
+            import torch
 
-                vla = EmmaXForActionPrediction.from_pretrained(saved_model_path, torch_dtype=torch.bfloat16, low_cpu_mem_usage=True,
-                                                               trust_remote_code=True).to(device)
-        self.processor, self.vla = processor, vla
+            from .modeling import EmmaXForActionPrediction
 
-        self.image_size = list(image_size)
-        self.action_scale = action_scale
-        self.horizon = horizon
-        self.pred_action_horizon = pred_action_horizon
-        self.exec_horizon = exec_horizon
-
-        self.sticky_action_is_on = False
-        self.gripper_action_repeat = 0
-        self.sticky_gripper_action = 0.0
-        self.previous_gripper_action = None
-
-        self.task = None
-        self.task_description = None
-        self.num_image_history = 0
+            vla = EmmaXForActionPrediction.from_pretrained(path, torch_dtype=torch.bfloat16, low_cpu_mem_usage=True,
+                                                           trust_remote_code=True).to(device)
+        return processor, vla
 
     def reset(self, task_description: str) -> None:
         self.task_description = task_description
         self.num_image_history = 0
-
-        self.sticky_action_is_on = False
-        self.gripper_action_repeat = 0
-        self.sticky_gripper_action = 0.0
-        self.previous_gripper_action = None
+        if self._gripper is not None:
+            self._gripper.clear()
 
     def _predict(self, prompt: Optional[str], image: np.ndarray) -> np.ndarray:
         import torch
@@ -143,55 +173,56 @@ class OpenVLAInference:
 
     def step(self, image: np.ndarray, task_description: Optional[str] = None, *args, **kwargs) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
         """image uint8 [H,W,3] -> (raw_action {world_vector[3], rotation_delta[3], open_gripper[1]},
-        action {world_vector[3], rot_axangle[3], gripper[1], terminate_episode[1]}) -- openvla_model.py:72-145."""
-        if task_description is not None:
-            if task_description != self.task_description:
-                self.reset(task_description)
+        action {world_vector[3], rot_axangle[3], gripper[1], terminate_episode[1]}) -- contract of openvla_model.py:72-145.
+        A task description different from the current one starts a new episode; the bare description (None when omitted) is
+        the prompt, as in the reference."""
+        if task_description is not None and task_description != self.task_description:
+            self.reset(task_description)
+        if image.dtype != np.uint8:
+            raise AssertionError("step() takes a uint8 camera frame")
+        vec = np.asarray(self._predict(task_description, self._resize_image(image))).reshape(-1)
+        xyz, rpy, opening = np.array(vec[0:3]), np.array(vec[3:6]), np.array(vec[6:7])
+        raw_action = {"world_vector": xyz, "rotation_delta": rpy, "open_gripper": opening}
 
-        assert image.dtype == np.uint8
-        image = self._resize_image(image)
-        prompt = task_description   # the reference passes the bare description (None when omitted) as the prompt
-
-        raw_actions = np.asarray(self._predict(prompt, image))[None]
-        raw_action = {
-            "world_vector": np.array(raw_actions[0, :3]),
-            "rotation_delta": np.array(raw_actions[0, 3:6]),
-            "open_gripper": np.array(raw_actions[0, 6:7]),  # range [0, 1]; 1 = open; 0 = close
+        axis, angle = euler2axangle(*(float(v) for v in rpy))
+        if self._gripper is not None:
+            grip = self._gripper(opening)                    # change of opening, held over several steps
+        else:
+            grip = np.where(opening > 0.5, 1.0, -1.0)       # widowx: +1 open / -1 close
+        action = {
+            "world_vector": xyz * self.action_scale,
+            "rot_axangle": axis * angle * self.action_scale,
+            "gripper": grip,
+            "terminate_episode": np.array([0.0]),
         }
-
-        action = {}
-        action["world_vector"] = raw_action["world_vector"] * self.action_scale
-        roll, pitch, yaw = np.asarray(raw_action["rotation_delta"], dtype=np.float64)
-        ax, angle = euler2axangle(roll, pitch, yaw)
-        action["rot_axangle"] = ax * angle * self.action_scale
-
-        if self.policy_setup == "google_robot":
-            current_gripper_action = raw_action["open_gripper"]
-            if self.previous_gripper_action is None:
-                relative_gripper_action = np.array([0])
-            else:
-                relative_gripper_action = self.previous_gripper_action - current_gripper_action
-            self.previous_gripper_action = current_gripper_action
-
-            if np.abs(relative_gripper_action) > 0.5 and (not self.sticky_action_is_on):
-                self.sticky_action_is_on = True
-                self.sticky_gripper_action = relative_gripper_action
-
-            if self.sticky_action_is_on:
-                self.gripper_action_repeat += 1
-                relative_gripper_action = self.sticky_gripper_action
-
-            if self.gripper_action_repeat == self.sticky_gripper_num_repeat:
-                self.sticky_action_is_on = False
-                self.gripper_action_repeat = 0
-                self.sticky_gripper_action = 0.0
-
-            action["gripper"] = relative_gripper_action
-        elif self.policy_setup == "widowx_bridge":
-            action["gripper"] = 2.0 * (raw_action["open_gripper"] > 0.5) - 1.0
-
-        action["terminate_episode"] = np.array([0.0])
         return raw_action, action
 
     def _resize_image(self, image: np.ndarray) -> np.ndarray:
         return resize_area(image, tuple(self.image_size))
+
+    def visualize_epoch(self, predicted_raw_actions: Sequence[Dict[str, np.ndarray]], images: Sequence[np.ndarray], save_path: str) -> None:
+        """Episode summary the SimplerEnv evaluator asks for after a roll-out (maniskill2_evaluator.py:170): one trace per
+        action dimension over every third resized frame.  A figure when matplotlib is importable, else the traces as .npy."""
+        traces = np.stack([np.concatenate([np.ravel(a[k]) for k in ("world_vector", "rotation_delta", "open_gripper")])
+                           for a in predicted_raw_actions])
+        try:
+            import matplotlib
+
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+        except ImportError:
+            np.save(os.path.splitext(save_path)[0] + "_actions.npy", traces)
+            return
+        strip = np.concatenate([self._resize_image(im) for im in images[::3]], axis=1)
+        fig = plt.figure(figsize=(45, 10))
+        grid = fig.add_gridspec(2, len(self.ACTION_LABELS))
+        top = fig.add_subplot(grid[0, :])
+        top.imshow(strip)
+        top.set_xlabel("episode frames (every third)")
+        for d, name in enumerate(self.ACTION_LABELS):
+            ax = fig.add_subplot(grid[1, d])
+            ax.plot(traces[:, d])
+            ax.set_title(name)
+            ax.set_xlabel("step")
+        fig.savefig(save_path)
+        plt.close(fig)
