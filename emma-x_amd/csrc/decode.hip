@@ -999,10 +999,6 @@ static int gemv_fp8_shape(int n_rows, int K) {
     if (n_rows >= 4 * 512 * GW * 3 / 4) return 3;
     return K > 8 * 1024 ? 2 : 1;
 }
-int decode_lmhead_grid(int B, int K, int n_rows, int max_parts, int max_grid, bool fp8) {
-    const int pairs = (n_rows + 1) / 2;
-    return min(gemv_grid(B, (size_t)B * K * 2, fp8 && gemv_fp8_shape(n_rows, K) == 3 ? (pairs + 1) / 2 : pairs, max_grid), max_parts);
-}
 
 template <int B, int MODE, bool NORM, bool XATTN = false, int F8 = 0>
 static int launch_gemv_t(const GemvParams& p, hipStream_t stream, int* grid_out) {

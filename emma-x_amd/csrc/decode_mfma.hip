@@ -672,10 +672,8 @@ static int mfma_kc(int B, int K, int tiles, int kstep) {
     return cdiv(cdiv(K, nph), kstep) * kstep;
 }
 
-int decode_mfma_lmhead_grid(int n_rows, int max_parts) { return min(min(256, cdiv(n_rows, 16)), max_parts); }
-
 template <int MODE, bool NORM, bool XATTN, bool FP8>
-static int launch_mfma_t(GemvParams p, int B, hipStream_t stream) {
+static int launch_mfma_t(GemvParams p, int B, hipStream_t stream, int* grid_out) {
     constexpr int TILES = (MODE == MODE_QKV || MODE == MODE_GATEUP) ? 2 : 1;
     if (FP8 && !p.wscale) return -1;
     if (p.K % (FP8 ? 64 : 32) || p.n_rows % (16 * TILES)) {
@@ -687,6 +685,7 @@ static int launch_mfma_t(GemvParams p, int B, hipStream_t stream) {
     p.n_groups = p.n_rows / (16 * TILES);
     int grid = min(256, p.n_groups);
     if (MODE == MODE_LMHEAD) grid = min(grid, p.max_parts);
+    if (grid_out) *grid_out = grid;
     if (MODE == MODE_QKV) {
         p.qk_shift = 0;
         while ((32 << p.qk_shift) < p.head_dim) ++p.qk_shift;
@@ -708,21 +707,21 @@ static int launch_mfma_t(GemvParams p, int B, hipStream_t stream) {
 }
 
 template <bool FP8>
-static int launch_mfma_mode(int mode, const GemvParams& p, int B, hipStream_t stream) {
+static int launch_mfma_mode(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
     switch (mode) {
-        case MODE_QKV: return launch_mfma_t<MODE_QKV, true, false, FP8>(p, B, stream);
+        case MODE_QKV: return launch_mfma_t<MODE_QKV, true, false, FP8>(p, B, stream, grid_out);
         case MODE_RESID:
-            return p.attn_part ? launch_mfma_t<MODE_RESID, false, true, FP8>(p, B, stream) : launch_mfma_t<MODE_RESID, false, false, FP8>(p, B, stream);
-        case MODE_GATEUP: return launch_mfma_t<MODE_GATEUP, true, false, FP8>(p, B, stream);
-        case MODE_LMHEAD: return launch_mfma_t<MODE_LMHEAD, true, false, FP8>(p, B, stream);
-        case MODE_PLAIN: return launch_mfma_t<MODE_PLAIN, false, false, FP8>(p, B, stream);
+            return p.attn_part ? launch_mfma_t<MODE_RESID, false, true, FP8>(p, B, stream, grid_out) : launch_mfma_t<MODE_RESID, false, false, FP8>(p, B, stream, grid_out);
+        case MODE_GATEUP: return launch_mfma_t<MODE_GATEUP, true, false, FP8>(p, B, stream, grid_out);
+        case MODE_LMHEAD: return launch_mfma_t<MODE_LMHEAD, true, false, FP8>(p, B, stream, grid_out);
+        case MODE_PLAIN: return launch_mfma_t<MODE_PLAIN, false, false, FP8>(p, B, stream, grid_out);
         default: return -1;
     }
 }
 
-int launch_decode_mfma(int mode, const GemvParams& p, int B, hipStream_t stream) {
+int launch_decode_mfma(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
     if (B < 1 || B > EMMAX_MAX_DECODE_BATCH) return -1;
-    return p.wscale ? launch_mfma_mode<true>(mode, p, B, stream) : launch_mfma_mode<false>(mode, p, B, stream);
+    return p.wscale ? launch_mfma_mode<true>(mode, p, B, stream, grid_out) : launch_mfma_mode<false>(mode, p, B, stream, grid_out);
 }
 
 int launch_quant_fm8(const void* src, int ld, void* dst, float* scales, int N, int K, hipStream_t stream) {

@@ -117,7 +117,6 @@ struct GemvParams {
     DepInfo dep;            // chained-launch hand-off (all null: plain stream ordering)
 };
 int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
-int decode_lmhead_grid(int B, int K, int n_rows, int max_parts, int max_grid = 0, bool fp8 = false);   // blocks (= argmax partials) the lm-head launch uses
 int decode_gemv_init();   // raise the dynamic-LDS limit of every GEMV instantiation (call once, outside graph capture)
 int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, const DepInfo& dep, hipStream_t stream);
 
@@ -168,7 +167,6 @@ int launch_repack_fm(const void* src, int ld, void* dst, int N, int K, hipStream
 int launch_quant_fm8(const void* src, int ld, void* dst, float* scales, int N, int K, hipStream_t stream);   // fp8 e4m3 + per-row scale
 bool decode_gemv_fp8_fits(int B, int K);   // the fp8 row GEMV takes this (batch, K); else the MFMA kernel serves it
 int launch_quant_rm8(const void* src, int ld, void* dst, float* scales, int N, int K, hipStream_t stream);   // same values, rows in the GEMV's span order
-int launch_decode_mfma(int mode, const GemvParams& p, int B, hipStream_t stream);   // p.W = fragment-major copy
-int decode_mfma_lmhead_grid(int n_rows, int max_parts);
+int launch_decode_mfma(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);   // p.W = fragment-major copy
 int decode_mfma_init();
 #define EMMAX_MFMA_MIN_BATCH 3

@@ -269,6 +269,7 @@ struct emmax_session {
     int graph_B = 0;
     hipStream_t graph_stream = nullptr;
     int graph_failed = 0;
+    int last_step_graph = 0;   // the most recent decode step was a graph replay (what emmax_session_graph_active reports)
     hipEvent_t ev = nullptr;
     hipStream_t overlap_stream = nullptr;   // second stream of the chained launch
     unsigned int* dep_ctr = nullptr;         // device: one completion counter per kernel of the step (+ error word at [511])
@@ -466,7 +467,7 @@ static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_
     if (B >= EMMAX_MFMA_MIN_BATCH || w_scale) {
         p.W = w_fm;
         p.wscale = w_scale;
-        return launch_decode_mfma(mode, p, B, st);
+        return launch_decode_mfma(mode, p, B, st, grid_out);
     }
     p.W = w_rm;
     return launch_decode_gemv(mode, p, B, st, grid_out);
@@ -515,8 +516,10 @@ static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* log
     if (do_finish) {
         FinishParams f;
         memset(&f, 0, sizeof(f));
-        f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = (B >= EMMAX_MFMA_MIN_BATCH || (m->fp8 && !fp8_rows(m, B, m->H, F8_LMHEAD))) ? decode_mfma_lmhead_grid(m->vocab, s->n_lm_blocks)
-                                                                                  : decode_lmhead_grid(B, m->H, m->vocab, s->n_lm_blocks, ch ? 256 : 0, m->fp8);
+        // the partial count is the grid the launch really used (every launcher reports it): a count modelled separately went
+        // stale when a launcher capped its grid (fp8 row GEMV shapes 1/2, EMMAX_GEMV_GRID) and stale partials could win the argmax
+        if (lm_grid <= 0 || lm_grid > s->n_lm_blocks) return fail(EMMAX_ERR_STATE, "lm-head launch reported no partial count");
+        f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = lm_grid;
         f.B = B;
         f.cur_tok = s->cur_tok + slot0; f.ctx_len = s->ctx_len + slot0; f.done = s->done + slot0; f.n_out = s->n_out + slot0;
         f.out_ids = s->out_ids + (size_t)slot0 * s->max_out;
@@ -743,10 +746,8 @@ static int ensure_graph(emmax_session* s, int B, hipStream_t st) {
     // launch thread cannot be kept free); read per call so a process can switch.
     {
         const char* e = getenv("EMMAX_GRAPH");
-        if (!e || atoi(e) == 0) {
-            drop_graph(s);
-            return 1;
-        }
+        s->last_step_graph = 0;   // set again by launch_graph_step when a replay really runs
+        if (!e || atoi(e) == 0) return 1;   // eager step: a captured graph stays valid for the next caller that wants replay
     }
     const bool chain = chain_on(s, B);
     if (chain && !s->chain_graph) return 1;
@@ -788,6 +789,7 @@ static int ensure_graph(emmax_session* s, int B, hipStream_t st) {
 }
 
 static int launch_graph_step(emmax_session* s, int B, hipStream_t st) {
+    s->last_step_graph = 1;
     if (chain_on(s, B)) {
         int r = chain_step_begin(s, st);
         if (r) return r;
@@ -1103,7 +1105,7 @@ int emmax_decode_step(emmax_session* s, emmax_stream stream) {
         if (r) return r;
         return slot_leave(s, user, st);
     }
-    drop_graph(s);   // eager mode: emmax_session_graph_active() reports what the steps really do
+    s->last_step_graph = 0;   // eager mode: emmax_session_graph_active() reports what the steps really do; the graph is kept
     return run_decode_step(s, s->cur_B, (hipStream_t)stream);
 }
 
@@ -1296,7 +1298,7 @@ int emmax_session_chain_active(emmax_session* s) { return s && s->prefilled && c
 
 int emmax_session_graph_active(emmax_session* s) {
     if (s && !s->graph_exec && !s->graph_err.empty()) g_err = s->graph_err;   // why the capture was refused
-    return s && s->graph_exec ? 1 : 0;
+    return s && s->graph_exec && s->last_step_graph ? 1 : 0;
 }
 
 int emmax_profile_decode_stage(emmax_session* s, int stage, int reps, float* avg_us, emmax_stream stream) {

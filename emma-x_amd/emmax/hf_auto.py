@@ -98,3 +98,30 @@ def register_auto_classes(exist_ok: bool = True) -> Dict[str, str]:
     if report.get("AutoConfig") != "ok" or not any(report.get(k) == "ok" for k in ("AutoModelForVision2Seq", "AutoModelForImageTextToText")):
         raise RuntimeError(f"could not register the Emma-X classes with transformers {transformers.__version__}: {report}")
     return report
+
+
+def require_emmax(model):
+    """Fail loudly when an Auto class handed back anything but the MI355X model.  Real OpenVLA / Emma-X checkpoints carry an
+    `auto_map` plus bundled `modeling_prismatic.py`; on transformers 4.x `trust_remote_code=True` makes that remote code win
+    over locally registered classes, i.e. the README call would silently load the PyTorch reference."""
+    from .modeling import EmmaXForActionPrediction
+
+    if not isinstance(model, EmmaXForActionPrediction):
+        raise RuntimeError(f"AutoModel resolved to {type(model).__module__}.{type(model).__qualname__}, not emmax's "
+                           "EmmaXForActionPrediction: the checkpoint's auto_map / bundled code took precedence. Load with "
+                           "trust_remote_code=False (emmax.hf_auto.load_vision2seq does) or strip `auto_map` from config.json")
+    return model
+
+
+def load_vision2seq(path: str, **kwargs):
+    """`AutoModelForVision2Seq.from_pretrained(path, ...)` that is guaranteed to come back as the MI355X class: registers the
+    Auto classes, forces `trust_remote_code=False` (so a checkpoint's auto_map cannot route to its bundled PyTorch code) and
+    checks the resolved type.  Accepts the README's keyword arguments (torch_dtype / dtype, low_cpu_mem_usage, ...)."""
+    import transformers
+
+    report = register_auto_classes()
+    kwargs.pop("trust_remote_code", None)
+    auto = next(getattr(transformers, n) for n in ("AutoModelForVision2Seq", "AutoModelForImageTextToText") if report.get(n) == "ok")
+    if int(transformers.__version__.split(".")[0]) >= 5 and "torch_dtype" in kwargs:
+        kwargs["dtype"] = kwargs.pop("torch_dtype")
+    return require_emmax(auto.from_pretrained(path, trust_remote_code=False, **kwargs))

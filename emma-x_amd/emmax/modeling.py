@@ -243,8 +243,11 @@ class EmmaXForActionPrediction:
             raise NotImplementedError("loss / labels belong to training, outside the inference hot path")
         if output_attentions or output_hidden_states:
             raise NotImplementedError("attention maps / hidden states are not materialised by the fused kernels")
-        if inputs_embeds is not None:
-            raise NotImplementedError("`inputs_embeds` input is not supported; pass input_ids + pixel_values")
+        # `inputs_embeds` is never consumed as data by the reference either: the cached branch hands the language model
+        # inputs_embeds=None (modeling_prismatic.py:330-341), the multimodal branch embeds `input_ids` whatever else was passed
+        # (:381), and the language-only branch asserts it away (:345).  Same behaviour here.
+        if input_ids is None:
+            raise ValueError("forward() needs `input_ids`: every branch of the reference embeds them (`inputs_embeds` is not read)")
         rows = self._rows(input_ids, attention_mask)
         if isinstance(input_ids, torch.Tensor) and input_ids.shape[-1] == 1 and past_key_values is not None:
             assert len(rows) == len(past_key_values.lengths), "cached step must keep the batch of the prefill"
@@ -257,6 +260,7 @@ class EmmaXForActionPrediction:
             assert past_key_values is not None, "You must provide `past_key_values` during cached generation!"
         if pixel_values is None and frames_u8 is None:
             # unimodal forward (modeling_prismatic.py:343-359): text only, no patch rows
+            assert inputs_embeds is None, "Missing `input_ids` in language-only forward!"
             assert past_key_values is None, "Unexpected key `past_key_values` provided during language-only forward!"
             eng.ensure_capacity(len(rows), max(len(r) for r in rows), self.cache_reserve if use_cache else 1)
             eng.prefill(rows, None)
@@ -365,8 +369,8 @@ class EmmaXForActionPrediction:
         """
         args = list(args)
         inputs = kwargs.pop("inputs", None)
-        if inputs is None and args and isinstance(args[0], dict):
-            inputs = args.pop(0)
+        if inputs is None and args and hasattr(args[0], "keys") and "input_ids" in args[0]:
+            inputs = args.pop(0)   # dict, our BatchFeature, or transformers.BatchFeature (a UserDict: processing_prismatic.py:216)
         if kwargs.get("do_sample", False):
             raise NotImplementedError("only greedy decoding (do_sample=False) is on the hot path")
         if kwargs.get("num_beams", 1) != 1:

@@ -127,20 +127,35 @@ class EmmaXProcessor:
 
     def __init__(self, image_processor: EmmaXImageProcessor, tokenizer=None) -> None:
         self.image_processor = image_processor
-        self.tokenizer = tokenizer if tokenizer is not None else StubTokenizer()
+        if tokenizer is None:
+            raise ValueError("EmmaXProcessor needs a tokenizer (from_pretrained(dir) loads the checkpoint's; from_synthetic() names the stub)")
+        self.tokenizer = tokenizer
 
     @classmethod
     def from_pretrained(cls, path: Optional[str] = None, cfg: Optional[EmmaXConfig] = None, **_) -> "EmmaXProcessor":
-        """Reads config.json (+ tokenizer files when present) from a checkpoint directory; with no path (or no tokenizer
-        files there) the deterministic stub tokenizer is used -- text<->id parity is then unpinned."""
-        if cfg is None:
-            cfg = EmmaXConfig.from_pretrained(path) if path else EmmaXConfig.emma_x_7b()
-        tok = None
-        if path and any(os.path.isfile(os.path.join(path, f)) for f in ("tokenizer.json", "tokenizer.model")):
-            from transformers import AutoTokenizer  # host-side only, never on the device path
+        """Reads config.json and the tokenizer files from a checkpoint directory (processing_prismatic.py:216 surface).
 
-            tok = AutoTokenizer.from_pretrained(path, model_max_length=cfg.llm.max_position, padding_side="right")
+        A directory WITHOUT tokenizer files is an error: tokenising prompts with a stand-in would feed the model garbage ids
+        without any sign of it.  With no path at all this is `from_synthetic` (the stub tokenizer, named as such)."""
+        if not path:
+            return cls.from_synthetic(cfg)
+        if cfg is None:
+            cfg = EmmaXConfig.from_pretrained(path)
+        if not any(os.path.isfile(os.path.join(path, f)) for f in ("tokenizer.json", "tokenizer.model")):
+            raise FileNotFoundError(
+                f"{path!r} holds no tokenizer.json / tokenizer.model: refusing to tokenise prompts with a stand-in. Copy the "
+                "checkpoint's LLaMA tokenizer files there, or build the processor explicitly with "
+                "EmmaXProcessor.from_synthetic(cfg) for synthetic-weight runs.")
+        from transformers import AutoTokenizer  # host-side only, never on the device path
+
+        tok = AutoTokenizer.from_pretrained(path, model_max_length=cfg.llm.max_position, padding_side="right")
         return cls(EmmaXImageProcessor(cfg), tok)
+
+    @classmethod
+    def from_synthetic(cls, cfg: Optional[EmmaXConfig] = None) -> "EmmaXProcessor":
+        """Processor for synthetic-weight runs (tests, bench): the deterministic character-level `StubTokenizer`; text<->id
+        parity with the LLaMA tokenizer is unpinned there."""
+        return cls(EmmaXImageProcessor(cfg if cfg is not None else EmmaXConfig.emma_x_7b()), StubTokenizer())
 
     def __call__(self, text: Union[str, List[str]], images, padding: bool = False, truncation: Optional[bool] = None,
                  max_length: Optional[int] = None, return_tensors: str = "pt") -> BatchFeature:

@@ -380,7 +380,9 @@ def test_checkpoint_ingest_and_caller_shims(device, tmp_path):
     assert vla.config.llm.hidden_size == cfg.llm.hidden_size and vla.config.towers[1].mlp_hidden == cfg.towers[1].mlp_hidden
     assert list(vla.norm_stats) == ["bridge_orig"]
     assert vla.tokenizer is None          # the directory holds no tokenizer files: nothing is invented
-    proc = EmmaXProcessor.from_pretrained(ck)
+    with pytest.raises(FileNotFoundError):   # ... and the processor refuses to tokenise with a stand-in behind the caller's back
+        EmmaXProcessor.from_pretrained(ck)
+    proc = EmmaXProcessor.from_synthetic(vla.config)
     sd_ref = {k: v.to(torch.bfloat16).float() for k, v in synthetic_state_dict(cfg, seed=5, planted=True).items()}
     rng = np.random.default_rng(8)
     obs = {"full_image": rng.integers(0, 256, size=(224, 224, 3), dtype=np.uint8)}

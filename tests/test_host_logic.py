@@ -349,6 +349,84 @@ def test_register_auto_classes_resolves_to_the_mi355x_classes(tmp_path):
     kw = {"dtype": torch.bfloat16} if int(transformers.__version__.split(".")[0]) >= 5 else {"torch_dtype": torch.bfloat16}
     vla = auto.from_pretrained(ck, low_cpu_mem_usage=True, trust_remote_code=True, **kw)
     assert isinstance(vla, EmmaXForActionPrediction) and list(vla.norm_stats) == ["bridge_orig"]
-    assert isinstance(transformers.AutoProcessor.from_pretrained(ck, trust_remote_code=True), EmmaXProcessor)
+    with pytest.raises(FileNotFoundError):            # no tokenizer files in the directory: no silent stand-in
+        transformers.AutoProcessor.from_pretrained(ck, trust_remote_code=True)
+    _write_wordlevel_tokenizer(ck)
+    proc = transformers.AutoProcessor.from_pretrained(ck, trust_remote_code=True)
+    assert isinstance(proc, EmmaXProcessor) and type(proc.tokenizer).__name__ != "StubTokenizer"
     with pytest.raises(RuntimeError, match="MI355X"):
         vla.to("cpu")
+
+
+def _write_wordlevel_tokenizer(d):
+    tokenizers = pytest.importorskip("tokenizers")
+    import json
+    words = ["<unk>", "<s>", "</s>", "In:", "Out:", "What", "action", "should", "the", "robot", "take", "to", "pick", "up", "cup", "?"]
+    tk = tokenizers.Tokenizer(tokenizers.models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="<unk>"))
+    tk.pre_tokenizer = tokenizers.pre_tokenizers.WhitespaceSplit()
+    tk.save(os.path.join(d, "tokenizer.json"))
+    with open(os.path.join(d, "tokenizer_config.json"), "w") as f:
+        json.dump({"tokenizer_class": "PreTrainedTokenizerFast", "bos_token": "<s>", "eos_token": "</s>", "unk_token": "<unk>",
+                   "pad_token": "</s>"}, f)
+
+
+def test_checkpoint_with_auto_map_still_resolves_to_the_mi355x_class(tmp_path):
+    """Real checkpoints carry `auto_map` + bundled modeling code; with trust_remote_code=True transformers 4.x would load THAT.
+    `load_vision2seq` forces the local class and checks the resolved type; `require_emmax` is the check on its own."""
+    pytest.importorskip("transformers")
+    import sys
+
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    from emmax.hf_auto import load_vision2seq, require_emmax
+    from emmax.modeling import EmmaXForActionPrediction
+    from tools.make_synthetic_checkpoint import write_checkpoint
+
+    ck = str(tmp_path / "ckpt")
+    write_checkpoint(ck, EmmaXConfig.tiny(), seed=2, tiny_towers=True, auto_map=True)
+    import json
+    assert "auto_map" in json.load(open(os.path.join(ck, "config.json")))
+    vla = load_vision2seq(ck, torch_dtype=torch.bfloat16, low_cpu_mem_usage=True, trust_remote_code=True)
+    assert isinstance(vla, EmmaXForActionPrediction)
+    with pytest.raises(RuntimeError, match="auto_map"):
+        require_emmax(torch.nn.Linear(2, 2))
+
+
+def test_full_size_synthetic_checkpoint_config_carries_statistics(tmp_path, monkeypatch):
+    """tools/make_synthetic_checkpoint.py --full used to write empty norm_stats (config default) -> predict_action raised."""
+    import sys
+
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import tools.make_synthetic_checkpoint as mk
+
+    monkeypatch.setattr(mk, "synthetic_state_dict", lambda cfg, seed=0, planted=True: {"w": torch.zeros(2, 2)})
+    cfg = EmmaXConfig.emma_x_7b()
+    assert not cfg.norm_stats
+    mk.write_checkpoint(str(tmp_path), cfg, shards=1)
+    import json
+    assert list(json.load(open(tmp_path / "dataset_statistics.json"))) == ["bridge_orig"]
+    assert list(json.load(open(tmp_path / "config.json"))["norm_stats"]) == ["bridge_orig"]
+
+
+def test_generate_actions_accepts_a_userdict_batchfeature_and_processor_needs_a_tokenizer(tmp_path):
+    """transformers.BatchFeature is a UserDict, not a dict (processing_prismatic.py:216): the README form must still be taken.
+    No device here: the route is observed through the first thing each form touches."""
+    from collections import UserDict
+
+    from emmax.modeling import EmmaXForActionPrediction
+    from emmax.processing import EmmaXImageProcessor, EmmaXProcessor
+
+    m = EmmaXForActionPrediction(EmmaXConfig.tiny(), None)
+    feat = UserDict(input_ids=torch.tensor([[1, 5, 6]]), attention_mask=torch.ones(1, 3, dtype=torch.long), pixel_values=torch.zeros(1, 6, 224, 224))
+    with pytest.raises(ValueError, match="no tokenizer given"):     # README branch reached (native form would raise TypeError)
+        m.generate_actions(feat, do_sample=False, max_new_tokens=4)
+    with pytest.raises(TypeError):
+        m.generate_actions(torch.zeros(3), do_sample=False)          # not a mapping with input_ids: native form, arguments missing
+    with pytest.raises(ValueError, match="needs a tokenizer"):
+        EmmaXProcessor(EmmaXImageProcessor(EmmaXConfig.tiny()), None)
+    with pytest.raises(FileNotFoundError, match="tokenizer"):
+        (tmp_path / "config.json").write_text("{}")
+        EmmaXProcessor.from_pretrained(str(tmp_path), cfg=EmmaXConfig.tiny())
+    assert type(EmmaXProcessor.from_synthetic(EmmaXConfig.tiny()).tokenizer).__name__ == "StubTokenizer"
+    assert type(EmmaXProcessor.from_pretrained(cfg=EmmaXConfig.tiny()).tokenizer).__name__ == "StubTokenizer"   # no path = synthetic

@@ -12,12 +12,15 @@ sys.path[:0] = [os.path.join(ROOT, "emma-x_amd")]
 import torch
 from safetensors.torch import save_file
 
-from emmax.config import EmmaXConfig
+from emmax.config import EmmaXConfig, default_norm_stats
 from emmax.weights import synthetic_state_dict
 
 
-def write_checkpoint(out: str, cfg: EmmaXConfig, seed: int = 0, planted: bool = True, shards: int = 2, tiny_towers: bool = False) -> None:
+def write_checkpoint(out: str, cfg: EmmaXConfig, seed: int = 0, planted: bool = True, shards: int = 2, tiny_towers: bool = False,
+                     auto_map: bool = False) -> None:
     os.makedirs(out, exist_ok=True)
+    if not cfg.norm_stats:   # a synthetic checkpoint ships synthetic (made-up) statistics, like from_synthetic; never an empty dict
+        cfg.norm_stats = default_norm_stats()
     sd = {k: v.to(torch.bfloat16).contiguous() for k, v in synthetic_state_dict(cfg, seed=seed, planted=planted).items()}
     keys = sorted(sd)
     per = (len(keys) + shards - 1) // shards
@@ -43,6 +46,9 @@ def write_checkpoint(out: str, cfg: EmmaXConfig, seed: int = 0, planted: bool = 
                         "rms_norm_eps": L.rms_eps, "rope_theta": L.rope_theta, "pad_token_id": cfg.pad_token_id},
         "norm_stats": cfg.norm_stats, "torch_dtype": "bfloat16",
     }
+    if auto_map:   # what real OpenVLA / Emma-X checkpoints carry next to their bundled modeling code
+        conf["auto_map"] = {"AutoConfig": "configuration_prismatic.OpenVLAConfig",
+                            "AutoModelForVision2Seq": "modeling_prismatic.OpenVLAForActionPrediction"}
     if tiny_towers:   # non-standard: the real config carries no tower dims (they come from the timm ids)
         conf["emmax_tower_overrides"] = [{"embed_dim": t.embed_dim, "depth": t.depth, "num_heads": t.num_heads,
                                           "mlp_hidden": t.mlp_hidden} for t in cfg.towers]
