@@ -1112,6 +1112,10 @@ int launch_quant_rm8(const void* src, int ld, void* dst, float* scales, int N, i
 // p.wscale set: p.W is the fp8 row copy of launch_quant_rm8 (ldw = bytes per row), batch 1-2
 int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
     if (p.K % 8 || p.ldw % 8 || p.ldx % 8) return -1;
+    if (decode_ks_enabled()) {   // batch 1-2, bf16, K % 64 == 0: the K-split kernel (decode_ks.hip)
+        const int r = launch_decode_ks(mode, p, B, stream, grid_out);
+        if (r != -2) return r;
+    }
     switch (mode) {
         case MODE_QKV: return launch_gemv_mode<MODE_QKV, true>(p, B, stream, grid_out);
         case MODE_RESID:

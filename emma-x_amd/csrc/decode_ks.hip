@@ -1,0 +1,426 @@
+// decode_ks.hip -- batch 1-2 decode projections, K split across the waves of a block ("ks").
+// Replaces the q_len == 1 linears of HF `LlamaDecoderLayer` + the fused stages around them (cached branch of
+// prismatic/extern/hf/modeling_prismatic.py:325-341), like decode.hip's GEMV, with a structure that has NO block-wide
+// activation stage and NO barrier in front of the weight stream:
+//
+//   * a block is 8 waves; wave w owns the K slice [w K/8, (w+1) K/8) of EVERY row of the block.  Its slice of the activation
+//     row lives in registers for the whole launch (K = 4096: one 16-byte chunk per lane; the down projection's K = 11008:
+//     three), loaded straight from global memory -- no LDS round trip, nobody waits for another wave's loads;
+//   * weights go HBM -> VGPR with 16-byte non-temporal loads, a batch of RB rows (16 KiB per wave at K = 4096) in flight; a batch
+//     is consumed completely (v_dot2c_f32_bf16 against the register-resident slice), its successor requested back to back,
+//     and only then are the RB per-lane partial sums reduced -- with a TRANSPOSING butterfly (v_permlane32/16_swap, DPP
+//     row_ror / half_mirror / quad_perm: ~2 VALU instructions per row instead of ~7 for one wave_sum per row) that leaves
+//     row j's total in lane group j;
+//   * the eight K-slice sums of a row meet in LDS once, at the end of the block (one barrier per launch), where the fused
+//     epilogues run: RoPE + paged K/V append (qkv), + residual (o-proj, down), SiLU(gate) * up, greedy argmax partial;
+//   * RMSNorm is folded in without a statistics pass: y_r = rstd * sum_k W[r,k] bf16(x_k g_k); every wave adds up the squares
+//     of its own slice and the scalar 1/rms multiplies the reduced sums in the epilogue (one rounding fewer than HF's
+//     bf16(bf16(x rstd) g): closer to the fp32 reference, and nothing waits for a row statistic before the stream starts);
+//   * the o-proj's merge of the split-KV attention partials happens per lane, for the lane's own chunk only, in registers.
+#include <cstdlib>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int KS_WAVES = 8;
+constexpr int KS_NT = KS_WAVES * 64;
+constexpr int PSTRIDE = EMMAX_PSTRIDE;
+
+__device__ __forceinline__ u32x4_t ks_ld_nt(const u32x4_t* p) { return __builtin_nontemporal_load(p); }
+
+// ---- transposing reduction ------------------------------------------------------------------------------------------
+// In: v[j], j < RB = this lane's partial sum of row j.  Out: the total of row ks_row_of_lane<RB>(lane) (every lane of the
+// wave holds a valid total; lanes that differ only in bits the plain stages folded hold the same one).
+__device__ __forceinline__ void ks_fold32(float& a, float& b) {   // a = {a.lo + a.hi, b.lo + b.hi}
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a += b;
+}
+__device__ __forceinline__ void ks_fold16(float& a, float& b) {   // a = {a0 + a1, b0 + b1, a2 + a3, b2 + b3} over 16-lane rows
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a += b;
+}
+template <int RB>
+__device__ __forceinline__ float ks_reduce_rows(float (&v)[RB], int lane) {
+    static_assert(RB == 1 || RB == 2 || RB == 4 || RB == 8 || RB == 16, "batch of rows");
+    // transposing stages, high to low: 32 (RB = 16), 16 (RB >= 8), 8 (RB >= 4), 4 (RB >= 2); the other stages fold plainly
+    if constexpr (RB == 16) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ks_fold32(v[j], v[j + 8]);
+    }
+    if constexpr (RB >= 8) {
+        constexpr int H = 4;
+#pragma unroll
+        for (int j = 0; j < H; ++j) ks_fold16(v[j], v[j + H]);
+    }
+    if constexpr (RB >= 4) {
+        const bool hi = (lane & 8) != 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float keep = hi ? v[j + 2] : v[j], give = hi ? v[j] : v[j + 2];
+            v[j] = keep + dpp_move<0x128>(give);   // row_ror:8 = lane ^ 8 inside a row of 16
+        }
+    }
+    if constexpr (RB >= 2) {
+        const bool hi = (lane & 4) != 0;
+        const float keep = hi ? v[1] : v[0], give = hi ? v[0] : v[1];
+        v[0] = keep + dpp_move<0x141>(give);       // row_half_mirror: lane ^ 7 inside 8 lanes (pairs bit-2-clear with bit-2-set lanes)
+    }
+    float t = v[0];
+    t += dpp_move<0xB1>(t);    // quad_perm [1,0,3,2]
+    t += dpp_move<0x4E>(t);    // quad_perm [2,3,0,1]
+    if constexpr (RB < 2) t += dpp_move<0x141>(t);
+    if constexpr (RB < 4) t += dpp_move<0x128>(t);
+    if constexpr (RB < 8) { float a = t, b = t; ks_fold16(a, b); t = a; }   // {r0 + r1, r0 + r1, r2 + r3, r2 + r3}
+    if constexpr (RB < 16) { float a = t, b = t; ks_fold32(a, b); t = a; }
+    return t;
+}
+template <int RB>
+__device__ __forceinline__ int ks_row_of_lane(int lane) {
+    int r = 0, bit = RB >> 1;
+    if constexpr (RB == 16) { r += (lane >> 5) * bit; bit >>= 1; }
+    if constexpr (RB >= 8) { r += ((lane >> 4) & 1) * bit; bit >>= 1; }
+    if constexpr (RB >= 4) { r += ((lane >> 3) & 1) * bit; bit >>= 1; }
+    if constexpr (RB >= 2) { r += ((lane >> 2) & 1) * bit; }
+    return r;
+}
+// the lane that stores row ks_row_of_lane(lane): first lane of its quad, plain-folded bits clear
+template <int RB>
+__device__ __forceinline__ bool ks_lane_stores(int lane) {
+    int mask = 3;
+    if constexpr (RB < 2) mask |= 4;
+    if constexpr (RB < 4) mask |= 8;
+    if constexpr (RB < 8) mask |= 16;
+    if constexpr (RB < 16) mask |= 32;
+    return (lane & mask) == 0;
+}
+
+// rows in flight per wave: 16 loads of 16 B per lane at batch 1 (64 VGPRs), 8 at batch 2 (two accumulators per row)
+template <int B, int CPL> struct KsShape { static constexpr int RB = (B == 1 ? 16 : 8) / (CPL == 1 ? 1 : CPL == 2 ? 2 : 4); };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// grid: persistent, 2 blocks per CU; block b owns a contiguous range of row PAIRS (the epilogues work on pairs: (d, d + hd/2)
+// of a head for QKV, (gate_i, up_i) for GATEUP, two consecutive rows otherwise) and streams their 2 x npairs rows.
+// Dynamic LDS: float part[8 waves][B][rows_cap] + float sumsq[8][B].
+// ---------------------------------------------------------------------------------------------------------------------
+template <int B, int MODE, bool NORM, bool XATTN, int CPL>
+__global__ __launch_bounds__(KS_NT, 4) void emmax_decode_ks_kernel(GemvParams p) {
+    constexpr int RB = KsShape<B, CPL>::RB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = p.K;
+    const int NCW = K >> 6;                 // 16-byte chunks of a wave's K slice (K / 8 waves / 8 elements)
+    const int rows_cap = p.kc;              // launcher: LDS rows per (wave, batch row), a multiple of RB
+    float* part = (float*)ks_smem;          // [KS_WAVES][B][rows_cap]
+    float* sumsq = part + KS_WAVES * B * rows_cap;   // [KS_WAVES][B]
+
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int gq = p.n_groups / G, gr = p.n_groups % G;
+    const int g_lo = bid * gq + min(bid, gr), npairs = gq + (bid < gr ? 1 : 0);
+    const int nrows = 2 * npairs;
+
+    auto pair_rows = [&](int g, int& r0, int& r1) {
+        if (MODE == GEMV_QKV) {
+            const int half = p.head_dim >> 1;
+            const int hb = g >> p.ks_shift, d = g - hb * half;   // head_dim is a power of two (launcher)
+            r0 = hb * p.head_dim + d;
+            r1 = r0 + half;
+        } else if (MODE == GEMV_GATEUP) {
+            r0 = (g >> 4) * 32 + (g & 15);
+            r1 = r0 + 16;
+        } else {
+            r0 = 2 * g;
+            r1 = min(2 * g + 1, p.n_rows - 1);
+        }
+    };
+
+    // ---- epilogue operands of this thread's (pair, batch row), requested before anything else ----
+    // wave b (< B) serves batch row b, lane i the block's pair i (launcher: npairs <= 64)
+    const bool epi = wave < B && lane < npairs;
+    const int eb = wave < B ? wave : 0, epair = g_lo + min(lane, max(npairs - 1, 0));
+    int er0, er1;
+    pair_rows(epair, er0, er1);
+    float pre_a = 0.f, pre_b = 0.f;
+    int pre_pos = 0, pre_pg = 0;
+    if (epi) {
+        if (MODE == GEMV_RESID) {
+            const bf16_t* hp = (const bf16_t*)p.y + (size_t)eb * p.ldy;
+            pre_a = bf2f(hp[er0]);
+            pre_b = bf2f(hp[er1]);
+        } else if (MODE == GEMV_QKV) {
+            pre_pos = p.ctx_len[eb];
+            pre_pg = p.page_table[(size_t)eb * p.max_pages + pre_pos / p.page];
+            const int half = p.head_dim >> 1;
+            const int hb = epair >> p.ks_shift, d = epair - hb * half;
+            if (hb < p.Hq + p.Hkv) {
+                pre_a = p.cos_t[(size_t)pre_pos * half + d];
+                pre_b = p.sin_t[(size_t)pre_pos * half + d];
+            }
+        }
+    }
+
+    // ---- this lane's chunks of the wave's K slice ----
+    int coff[CPL];      // 16-byte chunk index inside a row
+    bool cok[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int c = j * 64 + lane;
+        cok[j] = c < NCW;
+        coff[j] = wave * NCW + min(c, NCW - 1);   // lanes past the slice re-read its last chunk and meet a zero activation
+    }
+
+    // ---- weight stream ----
+    // buffer loads: ONE descriptor for the matrix, the row's byte offset in an SGPR (soffset), the lane's chunk in a 32-bit VGPR --
+    // with flat pointers hipcc kept a 64-bit VGPR address per row in flight (32 registers, and spills at 16 rows).  Rows past the
+    // block's share get an out-of-range offset: the load returns zeros without touching memory, so every batch is RB
+    // unconditional loads (counted waits, no branches).
+    const unsigned w_bytes = (unsigned)p.n_rows * (unsigned)p.ldw * 2u;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)w_bytes, 0x00020000);
+    unsigned voff[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) voff[j] = (unsigned)coff[j] * 16u;
+    u32x4_t wr[RB][CPL];
+    auto row_off = [&](int i) -> unsigned {   // i: row of the block, uniform
+        int r0, r1;
+        pair_rows(g_lo + (i >> 1), r0, r1);
+        // rows past the share take row index n_rows = the first byte past the matrix; mask arithmetic, not a select: hipcc turned
+        // the select into a branch around the multiply, sixteen basic blocks per batch
+        const int m = (i - nrows) >> 31;   // all ones: valid
+        const int r = (((i & 1) ? r1 : r0) & m) | (p.n_rows & ~m);
+        return (unsigned)r * (unsigned)p.ldw * 2u;
+    };
+    auto issue = [&](int bb) {
+#pragma unroll
+        for (int jj = 0; jj < RB; ++jj) {
+            const unsigned so = row_off(bb * RB + jj);
+#pragma unroll
+            for (int j = 0; j < CPL; ++j)
+                wr[jj][j] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff[j], so, 2));   // aux 2 = nt
+        }
+    };
+
+    // ---- activations: the wave's slice, straight into registers ----
+    u32x4_t xr[B][CPL];
+    if constexpr (XATTN) {
+        // chunk cg of the merged attention output = head (cg >> 4), elements (cg & 15) * 8 .. + 8 of the split partials; each
+        // lane merges the chunks it will multiply with, every load of a chunk in flight at once; the weights go out behind them
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const int cg = coff[j];
+                const float* pp = p.attn_part + (size_t)(b * p.Hq + (cg >> 4)) * p.nsplit * PSTRIDE;
+                const u32x4_t v = p.nsplit == 8 ? attn_merge_chunk<8, 4>(pp, (cg & 15) * 8) : attn_merge_chunk_loop(pp, (cg & 15) * 8, p.nsplit);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xr[b][j][e] = cok[j] ? v[e] : 0u;
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        issue(0);
+    } else {
+        u32x4_t nw[CPL];
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) xr[b][j] = *((const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx) + coff[j]);
+        if constexpr (NORM) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) nw[j] = *((const u32x4_t*)p.norm_w + coff[j]);
+        }
+        issue(0);   // right behind the activations: they are waited for by count while the head of the stream is in flight
+        float ss[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            ss[b] = 0.f;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    uint32_t v = cok[j] ? xr[b][j][e] : 0u;
+                    if constexpr (NORM) {
+                        const float a = bf_lo(v), c = bf_hi(v);
+                        ss[b] += a * a + c * c;
+                        v = pack_bf16x2(a * bf_lo(nw[j][e]), c * bf_hi(nw[j][e]));
+                    }
+                    xr[b][j][e] = v;
+                }
+        }
+        if constexpr (NORM) {
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const float t = wave_sum(ss[b]);
+                if (lane == 0) sumsq[wave * B + b] = t;
+            }
+        }
+    }
+
+    // ---- main loop: consume a batch of RB rows, request the next one, then reduce ----
+    const int nbatch = (nrows + RB - 1) / RB;
+    for (int bb = 0; bb < nbatch; ++bb) {
+        float acc[B][RB];
+#pragma unroll
+        for (int jj = 0; jj < RB; ++jj)
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    a = dot2_bf16(wr[jj][j][0], xr[b][j][0], a);
+                    a = dot2_bf16(wr[jj][j][1], xr[b][j][1], a);
+                    a = dot2_bf16(wr[jj][j][2], xr[b][j][2], a);
+                    a = dot2_bf16(wr[jj][j][3], xr[b][j][3], a);
+                }
+                acc[b][jj] = a;
+            }
+        // the refill reuses the registers the dot products just freed: pinned, or hipcc hoists it into fresh ones (and spills)
+        __builtin_amdgcn_sched_barrier(0);
+        issue(bb + 1);   // past the last batch every row is out of range: sixteen free loads of zeros, no branch
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const float t = ks_reduce_rows<RB>(acc[b], lane);
+            if (ks_lane_stores<RB>(lane)) part[(wave * B + b) * rows_cap + bb * RB + ks_row_of_lane<RB>(lane)] = t;
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: wave b, lane i = (batch row b, pair i) ----
+    float red0 = 0.f, red1 = 0.f;
+    if (epi) {
+#pragma unroll
+        for (int w = 0; w < KS_WAVES; ++w) {
+            red0 += part[(w * B + eb) * rows_cap + 2 * lane];
+            red1 += part[(w * B + eb) * rows_cap + 2 * lane + 1];
+        }
+        if constexpr (NORM) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < KS_WAVES; ++w) t += sumsq[w * B + eb];
+            const float rstd = rsqrtf(t / (float)K + p.eps);
+            red0 *= rstd;
+            red1 *= rstd;
+        }
+    }
+    const bool has1 = MODE == GEMV_QKV || MODE == GEMV_GATEUP || 2 * epair + 1 < p.n_rows;   // the pair's second row exists
+    if (MODE == GEMV_PLAIN) {
+        if (epi) {
+            bf16_t* yp = (bf16_t*)p.y + (size_t)eb * p.ldy;
+            yp[er0] = f2bf(red0);
+            if (has1) yp[er1] = f2bf(red1);
+        }
+    } else if (MODE == GEMV_RESID) {
+        if (epi) {
+            bf16_t* hp = (bf16_t*)p.y + (size_t)eb * p.ldy;
+            hp[er0] = f2bf(pre_a + red0);
+            if (has1) hp[er1] = f2bf(pre_b + red1);
+        }
+    } else if (MODE == GEMV_GATEUP) {
+        if (epi) ((bf16_t*)p.y)[(size_t)eb * p.ldy + epair] = f2bf(silu(red0) * red1);
+    } else if (MODE == GEMV_QKV) {
+        if (epi) {
+            const int hd = p.head_dim, half = hd >> 1;
+            const int hb = epair >> p.ks_shift, d = epair - hb * half;
+            // linear outputs are bf16 activations in the reference; RoPE acts on those
+            const float x0 = bf2f(f2bf(red0)), x1 = bf2f(f2bf(red1));
+            if (hb < p.Hq + p.Hkv) {
+                const bf16_t y0 = f2bf(x0 * pre_a - x1 * pre_b), y1 = f2bf(x1 * pre_a + x0 * pre_b);
+                if (hb < p.Hq) {
+                    bf16_t* q = (bf16_t*)p.y + (size_t)eb * p.ldy + hb * hd;
+                    q[d] = y0;
+                    q[d + half] = y1;
+                } else {
+                    bf16_t* kc = (bf16_t*)p.kcache + (((size_t)pre_pg * p.Hkv + (hb - p.Hq)) * p.page + pre_pos % p.page) * hd;
+                    kc[d] = y0;
+                    kc[d + half] = y1;
+                }
+            } else {
+                bf16_t* vc = (bf16_t*)p.vcache + (((size_t)pre_pg * p.Hkv + (hb - p.Hq - p.Hkv)) * p.page + pre_pos % p.page) * hd;
+                vc[d] = f2bf(x0);
+                vc[d + half] = f2bf(x1);
+            }
+        }
+    } else if (MODE == GEMV_LMHEAD) {
+        if (wave < B) {   // whole waves: the argmax below is a wave reduction
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+            if (epi) {
+                bv = red0;
+                bi = er0;
+                if (has1 && red1 > bv) { bv = red1; bi = er1; }   // er1 > er0: the first index wins ties (torch.argmax)
+                if (p.logits_out) {
+                    p.logits_out[(size_t)eb * p.n_rows + er0] = red0;
+                    if (has1) p.logits_out[(size_t)eb * p.n_rows + er1] = red1;
+                }
+            }
+            const float m = wave_max(bv);
+            // vocabulary indices are exact in fp32: the smallest index among the maxima is a wave_max of its negation
+            const float mi = wave_max((epi && bv == m) ? -(float)bi : -INFINITY);
+            if (lane == 0) {
+                p.part_val[(size_t)bid * B + eb] = m;
+                p.part_idx[(size_t)bid * B + eb] = mi == -INFINITY ? 0x7fffffff : (int)(-mi);
+            }
+        }
+    }
+}
+
+template <int B, int MODE, bool NORM, bool XATTN, int CPL>
+int ks_launch_t(GemvParams p, hipStream_t stream, int* grid_out) {
+    constexpr int RB = KsShape<B, CPL>::RB;
+    int grid = min(512, p.n_groups);
+    if (p.max_grid > 0) grid = min(grid, p.max_grid);
+    if (MODE == GEMV_LMHEAD) grid = min(grid, p.max_parts);
+    if (grid < 1) return -2;
+    const int pairs_max = cdiv(p.n_groups, grid);
+    if (pairs_max > 64) return -2;   // the epilogue maps one lane to a pair
+    p.kc = cdiv(2 * pairs_max, RB) * RB;
+    const size_t smem = (size_t)(KS_WAVES * B * p.kc + KS_WAVES * B) * sizeof(float);
+    if (grid_out) *grid_out = grid;
+    hipLaunchKernelGGL((emmax_decode_ks_kernel<B, MODE, NORM, XATTN, CPL>), dim3(grid), dim3(KS_NT), smem, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+template <int MODE, bool NORM, bool XATTN>
+int ks_launch_mode(GemvParams p, int B, hipStream_t stream, int* grid_out) {
+    if (MODE == GEMV_QKV || MODE == GEMV_GATEUP) p.n_groups = p.n_rows / 2;
+    else p.n_groups = (p.n_rows + 1) / 2;
+    p.n_pairs = p.n_groups;
+    if (MODE == GEMV_QKV) {
+        p.ks_shift = 0;
+        while ((2 << p.ks_shift) < p.head_dim) ++p.ks_shift;
+        if ((2 << p.ks_shift) != p.head_dim) return -2;
+    }
+    const int cpl = cdiv(p.K >> 6, 64);
+#define KS_CASE(BB, CC) if (B == BB && cpl == CC) return ks_launch_t<BB, MODE, NORM, XATTN, CC>(p, stream, grid_out)
+    KS_CASE(1, 1); KS_CASE(1, 2); KS_CASE(1, 3); KS_CASE(2, 1); KS_CASE(2, 2); KS_CASE(2, 3);
+#undef KS_CASE
+    return -2;
+}
+
+}  // namespace
+
+// tuning hook: EMMAX_KS=0 keeps the batch 1-2 bf16 projections on decode.hip's LDS-staged GEMV (the A/B partner)
+bool decode_ks_enabled() {   // read per call (a getenv per launch is noise next to a >= 5 us kernel): tests switch it inside one process
+    const char* e = getenv("EMMAX_KS");
+    return !(e && atoi(e) == 0);
+}
+
+// -2: shape outside this kernel (the caller falls back to launch_decode_gemv's LDS-staged kernel); bf16 weights, batch 1-2,
+// plain stream ordering, K a multiple of 64 and at most 12288 (three 16-byte chunks per lane)
+int launch_decode_ks(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
+    if (B < 1 || B > 2 || p.wscale || dep_coherent(p.dep)) return -2;
+    if (p.K % 64 || p.K > 64 * 64 * 3 || p.ldw % 8 || p.ldx % 8 || p.K < 64) return -2;
+    switch (mode) {
+        case GEMV_QKV: return ks_launch_mode<GEMV_QKV, true, false>(p, B, stream, grid_out);
+        case GEMV_RESID:
+            if (p.attn_part && (p.K != p.Hq * 128)) return -2;   // the merge maps 16 chunks to a 128-wide head
+            // measured (B = 1, 7B): 12.2 us against 10.1 for decode.hip's kernel -- every WAVE re-merges its four heads, and with
+            // 512 blocks that is twice the L2 reads of the 256-block LDS-staged merge.  EMMAX_KS_OPROJ=1 forces it (lab).
+            if (p.attn_part && !(getenv("EMMAX_KS_OPROJ") && atoi(getenv("EMMAX_KS_OPROJ")) != 0)) return -2;
+            return p.attn_part ? ks_launch_mode<GEMV_RESID, false, true>(p, B, stream, grid_out)
+                               : ks_launch_mode<GEMV_RESID, false, false>(p, B, stream, grid_out);
+        case GEMV_GATEUP: return ks_launch_mode<GEMV_GATEUP, true, false>(p, B, stream, grid_out);
+        case GEMV_LMHEAD: return ks_launch_mode<GEMV_LMHEAD, true, false>(p, B, stream, grid_out);
+        case GEMV_PLAIN: return ks_launch_mode<GEMV_PLAIN, false, false>(p, B, stream, grid_out);
+        default: return -2;
+    }
+}

@@ -114,9 +114,14 @@ struct GemvParams {
     unsigned int sk_magic;       // ... and ceil(2^32 / sk_kt8)
     int qk_shift;                // MFMA QKV, set by the launcher: log2(head_dim / 32)
     int max_grid;           // 0: default persistent grid; chained launch caps it at 256 (two kernels co-resident)
+    int ks_shift;           // K-split kernel, QKV, set by its launcher: log2(head_dim / 2)
     DepInfo dep;            // chained-launch hand-off (all null: plain stream ordering)
 };
 int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
+// decode_ks.hip: the batch 1-2 bf16 projections with K split across the waves of a block (activation slice in registers, no
+// block-wide stage); returns -2 for a shape it does not take.  launch_decode_gemv tries it first (EMMAX_KS=0: never).
+int launch_decode_ks(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
+bool decode_ks_enabled();
 int decode_gemv_init();   // raise the dynamic-LDS limit of every GEMV instantiation (call once, outside graph capture)
 int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, const DepInfo& dep, hipStream_t stream);
 
