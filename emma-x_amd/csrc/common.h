@@ -171,6 +171,12 @@ __device__ __forceinline__ f32x4_t ld_act_f32x4(const float* p, bool coh) {
     return __builtin_bit_cast(f32x4_t, v);
 }
 
+// 16-byte write-through (agent-scope, sc1) store: acknowledged once it is past the XCD-private L2.  Compiler-visible (the data
+// registers are read before the statement ends: the trailing s_nop, cdna_hip_programming.md section 5.7 item 1).
+__device__ __forceinline__ void st_sc1_f32x4(float* p, f32x4_t v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ void dep_wait(const DepInfo& d) {
     if (d.wait_flag) {
         if (threadIdx.x == 0) {

@@ -712,7 +712,13 @@ __global__ __launch_bounds__(256) void emmax_decode_embed_kernel(const int32_t* 
 //   part[((b*Hq + h)*nsplit + s) * PSTRIDE] = { o[0..HD) un-normalised, m, l, pad }
 // The cross-split merge is fused into the staging prologue of the o-proj GEMV (XATTN).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int HD, int G, bool COH = false>
+// MERGE (batch 1-2 bf16 path, round 3): the cross-split merge happens HERE instead of in every block of the o-proj launch (135 KB
+// of partial reads per o-proj block; inside the persistent layer chain, where every WAVE would re-merge its heads, 10-25 us).
+// Every block writes its partial through (16-byte sc1 stores), drains, and bumps the (row, kv head)'s arrival counter; the block
+// that arrives LAST re-reads the nsplit partials past its XCD's L2 (sc1 loads), merges with attn_merge_chunk_loop -- the
+// arithmetic of the o-proj prologues, bit for bit -- writes bf16 o[G x 128] and re-arms the counter (MI355X_MICROARCH.md:
+// drained sc1 payload, then an agent-scope atomic as the flag; no spin anywhere, so nothing can hang).
+template <int HD, int G, bool COH = false, bool MERGE = false>
 __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams p) {
     static_assert(HD == 128, "decode attention maps 16 lanes x 8 elements onto one 128-wide K/V row");
     constexpr int KU = G <= 2 ? 4 : 2;    // keys per lane group per chunk (block chunk = 16 * KU keys), two chunks in flight
@@ -752,7 +758,36 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
     const int Hq = p.Hkv * G;
     float* part = p.part + ((size_t)(b * Hq + hk * G) * nsplit + split) * PSTRIDE;
 
+    // MERGE: arrival of this block at the (row, kv head)'s counter; the last arriver merges the splits of its G heads
+    __shared__ int s_last;
+    auto arrive_and_merge = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
+        __syncthreads();
+        unsigned int* ctr = p.merge_ctr + (size_t)b * p.Hkv + hk;
+        if (tid == 0) {
+            const unsigned int prev = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = prev == (unsigned)nsplit - 1u;
+            if (s_last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everyone has arrived: re-arm
+        }
+        __syncthreads();
+        if (!s_last) return;
+        if (tid < G * 16) {
+            const int gq = tid >> 4, c = tid & 15;
+            const float* pp = p.part + (size_t)(b * Hq + hk * G + gq) * nsplit * PSTRIDE;
+            const u32x4_t v = attn_merge_chunk_loop(pp, c * 8, nsplit, true);
+            *((u32x4_t*)((bf16_t*)p.o_out + (size_t)b * p.ldq + (hk * G + gq) * HD) + c) = v;
+        }
+    };
     if (k0 >= L || row_done) {   // empty split, or a row that no longer decodes: no K/V traffic
+        if constexpr (MERGE) {
+            for (int i = tid; i < G * (PSTRIDE / 4); i += 256) {
+                const int gq = i / (PSTRIDE / 4), j4 = i - gq * (PSTRIDE / 4);
+                const f32x4_t v = {j4 * 4 == HD ? -INFINITY : 0.f, 0.f, 0.f, 0.f};
+                st_sc1_f32x4(part + (size_t)gq * nsplit * PSTRIDE + j4 * 4, v);
+            }
+            arrive_and_merge();
+            return;
+        }
         for (int i = tid; i < G * PSTRIDE; i += 256) {
             const int gq = i / PSTRIDE, j = i - gq * PSTRIDE;
             st_act_f32(part + (size_t)gq * nsplit * PSTRIDE + j, (j == HD) ? -INFINITY : 0.f, coh);
@@ -866,8 +901,7 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
         }
     }
     __syncthreads();
-    for (int i = tid; i < G * PSTRIDE; i += 256) {
-        const int gq = i / PSTRIDE, j = i - gq * PSTRIDE;
+    auto part_value = [&](int gq, int j) {
         const float M = fmaxf(fmaxf(red_ml[0][gq][0], red_ml[1][gq][0]), fmaxf(red_ml[2][gq][0], red_ml[3][gq][0]));
         const float msafe = (M == -INFINITY) ? 0.f : M;
         float v = 0.f;
@@ -880,7 +914,20 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
 #pragma unroll
             for (int w = 0; w < 4; ++w) v += red_ml[w][gq][1] * __expf(red_ml[w][gq][0] - msafe);
         }
-        st_act_f32(part + (size_t)gq * nsplit * PSTRIDE + j, v, coh);
+        return v;
+    };
+    if constexpr (MERGE) {
+        for (int i = tid; i < G * (PSTRIDE / 4); i += 256) {   // 33 write-through stores of 16 bytes per head
+            const int gq = i / (PSTRIDE / 4), j4 = i - gq * (PSTRIDE / 4);
+            const f32x4_t v = {part_value(gq, j4 * 4), part_value(gq, j4 * 4 + 1), part_value(gq, j4 * 4 + 2), part_value(gq, j4 * 4 + 3)};
+            st_sc1_f32x4(part + (size_t)gq * nsplit * PSTRIDE + j4 * 4, v);
+        }
+        arrive_and_merge();
+        return;
+    }
+    for (int i = tid; i < G * PSTRIDE; i += 256) {
+        const int gq = i / PSTRIDE, j = i - gq * PSTRIDE;
+        st_act_f32(part + (size_t)gq * nsplit * PSTRIDE + j, part_value(gq, j), coh);
     }
     if (COH) dep_signal(p.dep);
 }
@@ -1158,12 +1205,14 @@ int launch_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_dim
     p.page_shift = 0;
     while ((1 << p.page_shift) < p.page) ++p.page_shift;
     p.dep.n_blocks = (unsigned)(nsplit * p.Hkv * B);
+    if (p.o_out && (!p.merge_ctr || dep_coherent(p.dep))) return -1;   // the in-kernel merge needs its arrival counters; not with the chained launch
     const int G = Hq / p.Hkv;
     dim3 grid(nsplit, p.Hkv, B), block(256);
     switch (G) {
 #define ATTN_CASE(GG)                                                                                                   \
     case GG:                                                                                                           \
         if (dep_coherent(p.dep)) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true>), grid, block, 0, stream, p); \
+        else if (p.o_out) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, false, true>), grid, block, 0, stream, p); \
         else hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG>), grid, block, 0, stream, p);                         \
         break
         ATTN_CASE(1); ATTN_CASE(2); ATTN_CASE(4); ATTN_CASE(8);

@@ -115,6 +115,7 @@ struct GemvParams {
     int qk_shift;                // MFMA QKV, set by the launcher: log2(head_dim / 32)
     int max_grid;           // 0: default persistent grid; chained launch caps it at 256 (two kernels co-resident)
     int ks_shift;           // K-split kernel, QKV, set by its launcher: log2(head_dim / 2)
+    int ks_unit;            // K-split kernel, set by its launcher: pairs per unit of the block shares (2: gate/up inside a chain)
     DepInfo dep;            // chained-launch hand-off (all null: plain stream ordering)
 };
 int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
@@ -122,6 +123,13 @@ int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream,
 // block-wide stage); returns -2 for a shape it does not take.  launch_decode_gemv tries it first (EMMAX_KS=0: never).
 int launch_decode_ks(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
 bool decode_ks_enabled();
+// persistent layer chain (decode_ks.hip): o-proj -> gate/up -> down -> tail (qkv of the next layer | lm-head) in one launch, the
+// activation vectors of the three edges handed over through mailboxes of data-tagged granules.  The four GemvParams are what the
+// stand-alone launches would get.  mbox: decode_chain_mbox_bytes() bytes, zeroed once; epoch / err: device words, zeroed once.
+// -2: outside the chain's shapes (the caller launches the stages one by one).
+size_t decode_chain_mbox_bytes(int B, int hidden, int inter);
+int launch_decode_chain(const GemvParams& oproj, const GemvParams& gateup, const GemvParams& down, const GemvParams& tail, int tail_mode,
+                        int B, void* mbox, unsigned int* epoch, unsigned int* err, hipStream_t stream, int* tail_grid_out);
 int decode_gemv_init();   // raise the dynamic-LDS limit of every GEMV instantiation (call once, outside graph capture)
 int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, const DepInfo& dep, hipStream_t stream);
 
@@ -133,6 +141,8 @@ struct DecodeAttnParams {
     const int32_t* ctx_len;
     const int32_t* done;    // int32 [B] or null: finished / idle rows read no K/V (their partials are written empty)
     float* part;            // f32 [B][Hq][nsplit][132] = { o[128] un-normalised, m, l, pad }
+    void* o_out;            // non-null: ALSO merge the splits in this launch (last-arriving block per (row, kv head)): bf16 [B, ldq]
+    unsigned int* merge_ctr;   // ... arrival counters [B][Hkv], zero between launches (the last arriver re-arms its counter)
     int ldq, Hkv, page, max_pages;
     int page_shift;         // log2(page), set by the launcher
     float scale;

@@ -273,6 +273,11 @@ struct emmax_session {
     hipEvent_t ev = nullptr;
     hipStream_t overlap_stream = nullptr;   // second stream of the chained launch
     unsigned int* dep_ctr = nullptr;         // device: one completion counter per kernel of the step (+ error word at [511])
+    unsigned int* merge_ctr = nullptr;       // device: arrival counters of the in-attention split merge, [max_batch][kv heads], zero between launches
+    unsigned long long* pc_mbox = nullptr;   // device: mailboxes of the persistent layer chain (decode_ks.hip), batch <= 2
+    int pc_lm_grid = 0;                      // argmax partials the last chain launch wrote (= its grid)
+    unsigned int* pc_words = nullptr;        // device: [0] epoch of the chain launches, [32] error word (a bounded poll gave up)
+    int pchain = 0;                          // persistent layer chain (batch 1-2, bf16), measured slower than the stage launches: EMMAX_PCHAIN=1 enables
     int chain = 0;                           // chained launch (B <= 2 only), experimental: EMMAX_CHAIN=1 enables
     int chain_graph = 0;                     // EMMAX_CHAIN_GRAPH=1: replay the chained step as two per-stream graphs
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -343,6 +348,9 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->stop_m = (int32_t*)b.take(Bd * 4);
     s->stop_after = (int32_t*)b.take(Bd * 4);
     s->dep_ctr = (unsigned int*)b.take((256 * 64 + 16) * 4);
+    s->pc_mbox = (unsigned long long*)b.take((int64_t)decode_chain_mbox_bytes(2, m->H, m->inter_p));
+    s->pc_words = (unsigned int*)b.take(64 * 4);
+    s->merge_ctr = (unsigned int*)b.take((int64_t)Bd * m->cfg.n_kv_heads * 4);
     s->page_table = (int32_t*)b.take((int64_t)Bd * s->max_pages * 4);
     s->sk_ws = (unsigned long long*)b.take((int64_t)256 * 2 * 256 * 8);
     s->splitk_bytes = (int64_t)64 << 20;   // e.g. 4 slices of a 768 x 4096 prefill GEMM = 50 MB; smaller budgets just split less
@@ -481,6 +489,7 @@ constexpr int DEP_WORDS = DEP_MAX_KERNELS * 64 + 16;
 struct Chain;
 static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, Chain* ch = nullptr,
                             int slot0 = 0);
+static int launch_finish_step(emmax_session* s, int B, bool is_prefill, int n_part, int slot0, hipStream_t st, Chain* ch = nullptr);
 
 // chained-launch bookkeeping: kernel k runs on stream[k & 1], waits for counter k-1 and bumps counter k
 struct Chain {
@@ -501,35 +510,38 @@ struct Chain {
     void launched() { ++k; }
 };
 
+// finish of a step over rows slot0 .. slot0 + B: argmax over the n_part lm-head partials, EOS / budget / stop rule, next token
+static int launch_finish_step(emmax_session* s, int B, bool is_prefill, int n_part, int slot0, hipStream_t st, Chain* ch) {
+    emmax_model* m = s->m;
+    FinishParams f;
+    memset(&f, 0, sizeof(f));
+    // the partial count is the grid the launch really used (every launcher reports it): a count modelled separately went
+    // stale when a launcher capped its grid (fp8 row GEMV shapes 1/2, EMMAX_GEMV_GRID) and stale partials could win the argmax
+    if (n_part <= 0 || n_part > s->n_lm_blocks) return fail(EMMAX_ERR_STATE, "lm-head launch reported no partial count");
+    f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = n_part;
+    f.B = B;
+    f.cur_tok = s->cur_tok + slot0; f.ctx_len = s->ctx_len + slot0; f.done = s->done + slot0; f.n_out = s->n_out + slot0;
+    f.out_ids = s->out_ids + (size_t)slot0 * s->max_out;
+    f.max_new_p = s->max_new_d + slot0; f.max_out = s->max_out; f.max_ctx = s->max_ctx;
+    f.stop_ids = s->stop_ids; f.stop_cfg = s->stop_cfg; f.stop_m = s->stop_m + slot0; f.stop_after = s->stop_after + slot0;
+    f.eos_id = m->cfg.eos_id; f.pad_id = m->cfg.pad_id; f.is_prefill = is_prefill ? 1 : 0;
+    if (ch) { f.dep = ch->dep(); st = ch->stream(); }
+    KCHK(launch_decode_finish(f, st));
+    if (ch) ch->launched();
+    return 0;
+}
+
+static void lmhead_params(emmax_session* s, int slot0, float* logits_out, GemvParams& p);
 // slot0: first row of the B rows this call covers (slot prefill: one row in the middle of a live batch)
 static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, Chain* ch, int slot0) {
     emmax_model* m = s->m;
     GemvParams p;
-    memset(&p, 0, sizeof(p));
-    p.sk_ws = streamk_on() ? s->sk_ws : nullptr;
-    p.x = s->dh + (size_t)slot0 * m->H; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = m->final_norm; p.eps = m->cfg.rms_eps;
-    p.n_rows = m->vocab; p.max_parts = s->n_lm_blocks; p.part_val = s->part_val; p.part_idx = s->part_idx; p.logits_out = logits_out;
+    lmhead_params(s, slot0, logits_out, p);
     int lm_grid = 0;
     if (ch) { p.dep = ch->dep(); p.max_grid = 256; st = ch->stream(); }
     KCHK(launch_proj(GEMV_LMHEAD, p, m->lm_head, m->lm_head_fm, B, st, &lm_grid, m->lm_head_sc, m->lm_head_r8, F8_LMHEAD));
     if (ch) ch->launched();
-    if (do_finish) {
-        FinishParams f;
-        memset(&f, 0, sizeof(f));
-        // the partial count is the grid the launch really used (every launcher reports it): a count modelled separately went
-        // stale when a launcher capped its grid (fp8 row GEMV shapes 1/2, EMMAX_GEMV_GRID) and stale partials could win the argmax
-        if (lm_grid <= 0 || lm_grid > s->n_lm_blocks) return fail(EMMAX_ERR_STATE, "lm-head launch reported no partial count");
-        f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = lm_grid;
-        f.B = B;
-        f.cur_tok = s->cur_tok + slot0; f.ctx_len = s->ctx_len + slot0; f.done = s->done + slot0; f.n_out = s->n_out + slot0;
-        f.out_ids = s->out_ids + (size_t)slot0 * s->max_out;
-        f.max_new_p = s->max_new_d + slot0; f.max_out = s->max_out; f.max_ctx = s->max_ctx;
-        f.stop_ids = s->stop_ids; f.stop_cfg = s->stop_cfg; f.stop_m = s->stop_m + slot0; f.stop_after = s->stop_after + slot0;
-        f.eos_id = m->cfg.eos_id; f.pad_id = m->cfg.pad_id; f.is_prefill = is_prefill ? 1 : 0;
-        if (ch) { f.dep = ch->dep(); st = ch->stream(); }
-        KCHK(launch_decode_finish(f, st));
-        if (ch) ch->launched();
-    }
+    if (do_finish) return launch_finish_step(s, B, is_prefill, lm_grid, slot0, st, ch);
     return 0;
 }
 
@@ -604,19 +616,26 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
     return 0;
 }
 
-enum { STAGE_QKV = 0, STAGE_ATTN = 1, STAGE_OPROJ = 2, STAGE_GATEUP = 3, STAGE_DOWN = 4, STAGE_LMHEAD = 5 };
+enum { STAGE_QKV = 0, STAGE_ATTN = 1, STAGE_OPROJ = 2, STAGE_GATEUP = 3, STAGE_DOWN = 4, STAGE_LMHEAD = 5, STAGE_CHAIN = 6 };
 
-// one stage of decoder layer `li` (the unit the profiler times); the step is stages 0..4 of every layer + lm head
-static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStream_t st, Chain* ch = nullptr) {
+// batch 1-2 on bf16 weights: the attention launch merges its own splits (last-arriving block per head) and the o-proj reads a
+// plain bf16 row; every other path (MFMA batch >= 3, fp8, the two-stream chained launch) merges in the o-proj prologue
+// Measured (7B, B = 1): the merging attention launch takes 12.6 us against 5.7 (write-through stores, drain, atomic, re-read: four
+// dependent trips through the fabric) and the plain o-proj 8.9 against 10.1 -- a loss of 5.7 us per layer, so it is ON only where
+// it is needed (inside the persistent layer chain, whose o-proj cannot afford the per-wave merge) or asked for (EMMAX_ATTN_MERGE=1).
+static bool attn_merge_on(const emmax_session* s, int B) {
+    if (!(B < EMMAX_MFMA_MIN_BATCH && !s->m->fp8 && !s->chain && decode_ks_enabled())) return false;
+    const char* e = getenv("EMMAX_ATTN_MERGE");
+    return s->pchain || (e && atoi(e) != 0);
+}
+
+// GemvParams of a projection stage of decoder layer `li` (qkv / o-proj / gate-up / down), as every launcher takes them
+static void stage_params(emmax_session* s, int B, int li, int stage, GemvParams& p) {
     emmax_model* m = s->m;
     const auto& c = m->cfg;
     const LayerW& L = m->layers[li];
-    GemvParams p;
     memset(&p, 0, sizeof(p));
     p.sk_ws = streamk_on() ? s->sk_ws : nullptr;
-    int grid = 0;
-    if (ch) st = ch->stream();
-    auto arm = [&]() { if (ch) { p.dep = ch->dep(); p.max_grid = 256; } };
     switch (stage) {
         case STAGE_QKV:
             p.x = s->dh; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln1; p.eps = c.rms_eps;
@@ -624,6 +643,43 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             p.head_dim = c.head_dim; p.Hq = c.n_heads; p.Hkv = c.n_kv_heads; p.page = PAGE; p.max_pages = s->max_pages;
             p.ctx_len = s->ctx_len; p.page_table = s->page_table; p.cos_t = s->cos_t; p.sin_t = s->sin_t;
             p.kcache = kcache_of(s, li); p.vcache = vcache_of(s, li);
+            break;
+        case STAGE_OPROJ:
+            p.x = s->datt; p.ldx = m->q_dim; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
+            if (!attn_merge_on(s, B)) {   // split merge fused into the staging
+                p.attn_part = s->part; p.nsplit = decode_attn_nsplit(B, c.n_kv_heads); p.Hq = c.n_heads;
+            }
+            break;
+        case STAGE_GATEUP:
+            p.x = s->dh; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln2; p.eps = c.rms_eps;
+            p.y = s->dact; p.ldy = m->inter_p; p.n_rows = 2 * m->inter_p;
+            break;
+        case STAGE_DOWN:
+            p.x = s->dact; p.ldx = m->inter_p; p.ldw = m->inter_p; p.K = m->inter_p; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
+            break;
+        default: break;
+    }
+}
+static void lmhead_params(emmax_session* s, int slot0, float* logits_out, GemvParams& p) {
+    emmax_model* m = s->m;
+    memset(&p, 0, sizeof(p));
+    p.sk_ws = streamk_on() ? s->sk_ws : nullptr;
+    p.x = s->dh + (size_t)slot0 * m->H; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = m->final_norm; p.eps = m->cfg.rms_eps;
+    p.n_rows = m->vocab; p.max_parts = s->n_lm_blocks; p.part_val = s->part_val; p.part_idx = s->part_idx; p.logits_out = logits_out;
+}
+
+// one stage of decoder layer `li` (the unit the profiler times); the step is stages 0..4 of every layer + lm head
+static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStream_t st, Chain* ch = nullptr) {
+    emmax_model* m = s->m;
+    const auto& c = m->cfg;
+    const LayerW& L = m->layers[li];
+    GemvParams p;
+    int grid = 0;
+    if (ch) st = ch->stream();
+    auto arm = [&]() { if (ch) { p.dep = ch->dep(); p.max_grid = 256; } };
+    switch (stage) {
+        case STAGE_QKV:
+            stage_params(s, B, li, stage, p);
             arm();
             KCHK(launch_proj(GEMV_QKV, p, L.wqkv, L.wqkv_fm, B, st, &grid, L.wqkv_sc, L.wqkv_r8, F8_QKV));
             if (ch) ch->launched();
@@ -634,28 +690,28 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             a.page_table = s->page_table; a.ctx_len = s->ctx_len; a.done = s->done; a.part = s->part; a.Hkv = c.n_kv_heads; a.page = PAGE;
             a.max_pages = s->max_pages; a.scale = 1.0f / sqrtf((float)c.head_dim);
             memset(&a.dep, 0, sizeof(a.dep));
+            a.o_out = nullptr; a.merge_ctr = nullptr;
             if (ch) a.dep = ch->dep();
+            else if (attn_merge_on(s, B)) { a.o_out = s->datt; a.merge_ctr = s->merge_ctr; }
             const int ns = decode_attn_nsplit(B, c.n_kv_heads);
             KCHK(launch_decode_attn(a, B, c.n_heads, c.head_dim, ns, st));
             if (ch) ch->launched();
             return 0;
         }
         case STAGE_OPROJ:
-            p.x = s->datt; p.ldx = m->q_dim; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
-            p.attn_part = s->part; p.nsplit = decode_attn_nsplit(B, c.n_kv_heads); p.Hq = c.n_heads;   // split merge fused into the staging
+            stage_params(s, B, li, stage, p);
             arm();
             KCHK(launch_proj(GEMV_RESID, p, L.wo, L.wo_fm, B, st, &grid, L.wo_sc, L.wo_r8, F8_OPROJ));
             if (ch) ch->launched();
             return 0;
         case STAGE_GATEUP:
-            p.x = s->dh; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln2; p.eps = c.rms_eps;
-            p.y = s->dact; p.ldy = m->inter_p; p.n_rows = 2 * m->inter_p;
+            stage_params(s, B, li, stage, p);
             arm();
             KCHK(launch_proj(GEMV_GATEUP, p, L.wgu, L.wgu_fm, B, st, &grid, L.wgu_sc, L.wgu_r8, F8_GATEUP));
             if (ch) ch->launched();
             return 0;
         case STAGE_DOWN:
-            p.x = s->dact; p.ldx = m->inter_p; p.ldw = m->inter_p; p.K = m->inter_p; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
+            stage_params(s, B, li, stage, p);
             arm();
             KCHK(launch_proj(GEMV_RESID, p, L.wdown, L.wdown_fm, B, st, &grid, L.wdown_sc, L.wdown_r8, F8_DOWN));
             if (ch) ch->launched();
@@ -663,6 +719,65 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
         default:
             return fail(EMMAX_ERR_INVALID, "unknown decode stage %d", stage);
     }
+}
+
+// Persistent layer chain (decode_ks.hip): batch 1-2, bf16 weights, plain stream ordering.  The step is then
+//   embed, qkv(0), { attention(l), chain(l) = o-proj + gate/up + down + [qkv(l + 1) | lm-head] } x layers, finish
+// = 2 + 2 x layers + 1 launches instead of 3 + 5 x layers; -2 from the launcher (shape outside the chain) falls back for good.
+extern "C" int emmax_session_pchain_fault(emmax_session* s, emmax_stream stream);
+static bool pchain_on(const emmax_session* s, int B) {
+    return s->pchain && B < EMMAX_MFMA_MIN_BATCH && !s->m->fp8 && !s->chain && decode_ks_enabled();
+}
+// tail_out: 1 = the launch included the tail (next layer's qkv / the lm-head: s->pc_lm_grid partials), 0 = the caller launches it
+static int run_layer_chain(emmax_session* s, int B, int li, hipStream_t st, int* tail_out) {
+    emmax_model* m = s->m;
+    const LayerW& L = m->layers[li];
+    GemvParams po, pg, pd, pt;
+    stage_params(s, B, li, STAGE_OPROJ, po); po.W = L.wo;
+    stage_params(s, B, li, STAGE_GATEUP, pg); pg.W = L.wgu;
+    stage_params(s, B, li, STAGE_DOWN, pd); pd.W = L.wdown;
+    const bool last = li + 1 == m->cfg.n_layers;
+    if (last) { lmhead_params(s, 0, nullptr, pt); pt.W = m->lm_head; }
+    else { stage_params(s, B, li + 1, STAGE_QKV, pt); pt.W = m->layers[li + 1].wqkv; }
+    int tail_grid = 0;
+    int r = launch_decode_chain(po, pg, pd, pt, last ? GEMV_LMHEAD : GEMV_QKV, B, s->pc_mbox, s->pc_words, s->pc_words + 32, st, &tail_grid);
+    *tail_out = 1;
+    if (r == -2) {   // e.g. a small grid leaves more lm-head rows per block than the epilogue maps: the three layer stages alone
+        r = launch_decode_chain(po, pg, pd, pt, -1, B, s->pc_mbox, s->pc_words, s->pc_words + 32, st, nullptr);
+        *tail_out = 0;
+    }
+    if (r == 0 && last && *tail_out) s->pc_lm_grid = tail_grid;
+    return r;
+}
+static int run_decode_step_pchain(emmax_session* s, int B, hipStream_t st) {
+    emmax_model* m = s->m;
+    const int nl = m->cfg.n_layers;
+    DepInfo nodep;
+    memset(&nodep, 0, sizeof(nodep));
+    KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, nodep, st));
+    int r = run_decode_stage(s, B, 0, STAGE_QKV, st);
+    if (r) return r;
+    for (int li = 0; li < nl; ++li) {
+        if ((r = run_decode_stage(s, B, li, STAGE_ATTN, st))) return r;
+        int with_tail = 0;
+        r = run_layer_chain(s, B, li, st, &with_tail);
+        if (r == -2) {   // a shape the chain does not take at all (first layer: nothing of the step has been skipped yet)
+            if (li != 0) return fail(EMMAX_ERR_STATE, "persistent chain refused layer %d after accepting layer 0", li);
+            s->pchain = 0;
+            for (int stage = STAGE_OPROJ; stage <= STAGE_DOWN; ++stage)
+                if ((r = run_decode_stage(s, B, 0, stage, st))) return r;
+            for (int l2 = 1; l2 < nl; ++l2)
+                for (int stage = STAGE_QKV; stage <= STAGE_DOWN; ++stage)
+                    if ((r = run_decode_stage(s, B, l2, stage, st))) return r;
+            return run_lm_head_step(s, B, false, nullptr, true, st);
+        }
+        if (r) return fail(EMMAX_ERR_HIP, "persistent chain launch failed (layer %d, code %d)", li, r);
+        if (!with_tail) {
+            if (li + 1 == nl) return run_lm_head_step(s, B, false, nullptr, true, st);
+            if ((r = run_decode_stage(s, B, li + 1, STAGE_QKV, st))) return r;
+        }
+    }
+    return launch_finish_step(s, B, false, s->pc_lm_grid, 0, st);
 }
 
 static bool chain_on(const emmax_session* s, int B) { return s->chain && B < EMMAX_MFMA_MIN_BATCH && !s->m->fp8; }
@@ -698,6 +813,7 @@ static int chain_step_end(emmax_session* s, hipStream_t st) {
 
 static int run_decode_step(emmax_session* s, int B, hipStream_t st) {
     emmax_model* m = s->m;
+    if (pchain_on(s, B)) return run_decode_step_pchain(s, B, st);
     if (chain_on(s, B)) {
         int r = chain_step_begin(s, st);
         if (!r) r = chain_step_kernels(s, B, st);
@@ -998,6 +1114,7 @@ int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_
     // OFF by default: measured 5.3 ms/token vs 3.1 ms for plain stream ordering -- an all-to-all in-kernel hand-off costs
     // ~13 us under streaming load (MI355X_MICROARCH.md "fanin"), far more than the ~1.5 us kernel boundary it replaces.
     s->chain = getenv("EMMAX_CHAIN") && atoi(getenv("EMMAX_CHAIN")) != 0;
+    s->pchain = getenv("EMMAX_PCHAIN") && atoi(getenv("EMMAX_PCHAIN")) != 0;
     // static page assignment: row b owns pages [b*max_pages, (b+1)*max_pages)
     {
         std::vector<int32_t> pt((size_t)max_batch * s->max_pages);
@@ -1165,6 +1282,10 @@ int emmax_generate(emmax_session* s, int max_new, int stop_on_eos, int32_t* out_
     HIPCHK(hipMemcpy2DAsync(out_ids, (size_t)max_new * 4, s->out_ids, (size_t)s->max_out * 4, (size_t)max_new * 4, B,
                             hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(out_lens, s->n_out, B * 4, hipMemcpyDeviceToDevice, st));
+    if (pchain_on(s, B)) {   // a hand-off poll of the persistent chain that gave up is an error, never a silent wrong answer
+        int r = emmax_session_pchain_fault(s, (emmax_stream)st);
+        if (r) return r;
+    }
     if (s->chain && B < EMMAX_MFMA_MIN_BATCH) {   // a bounded dependency wait that gave up is an error, never a silent wrong answer
         HIPCHK(hipMemcpyAsync(s->pinned + 1024, s->dep_ctr + DEP_WORDS - 1, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -1294,6 +1415,20 @@ int emmax_slot_release(emmax_session* s, int slot, emmax_stream stream) {
     return slot_leave(s, user, st);
 }
 
+int emmax_session_pchain_active(emmax_session* s) { return s && s->prefilled && pchain_on(s, s->cur_B) ? 1 : 0; }
+
+int emmax_session_pchain_fault(emmax_session* s, emmax_stream stream) {
+    if (!s) return fail(EMMAX_ERR_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(s->pinned + 1025, s->pc_words + 32, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (s->pinned[1025] == 0) return 0;
+    s->pchain = 0;
+    HIPCHK(hipMemsetAsync(s->pc_words + 32, 0, 4, st));
+    return fail(EMMAX_ERR_HIP, "persistent layer chain: a hand-off wait timed out -- is the GPU shared? (results since the last check are "
+                               "invalid; the chain is now off for this session; EMMAX_PCHAIN=0 disables it up front)");
+}
+
 int emmax_session_chain_active(emmax_session* s) { return s && s->prefilled && chain_on(s, s->cur_B) ? 1 : 0; }
 
 int emmax_session_graph_active(emmax_session* s) {
@@ -1320,6 +1455,14 @@ int emmax_profile_decode_stage(emmax_session* s, int stage, int reps, float* avg
             if (stage == STAGE_LMHEAD) {
                 r = run_lm_head_step(s, B, false, nullptr, false, st);
                 launches += pass;
+            } else if (stage == STAGE_CHAIN) {   // the persistent layer chain: o-proj + gate/up + down + next qkv (last layer: lm-head)
+                if (!pchain_on(s, B)) return fail(EMMAX_ERR_STATE, "stage 6 (persistent layer chain) is not active for this session / batch");
+                for (int li = 0; li < nl && r == 0; ++li) {
+                    int with_tail = 0;
+                    r = run_layer_chain(s, B, li, st, &with_tail);
+                    if (r) return fail(EMMAX_ERR_INVALID, "persistent chain refused layer %d (code %d)", li, r);
+                    launches += pass;
+                }
             } else {
                 for (int li = 0; li < nl && r == 0; ++li) {
                     r = run_decode_stage(s, B, li, stage, st);
@@ -1392,6 +1535,24 @@ int emmax_op_decode_attention(const void* q, const void* kcache, const void* vca
     if (ns > 16) return fail(EMMAX_ERR_INVALID, "emmax_op_decode_attention: nsplit %d > 16", ns);
     int r = launch_decode_attn(a, B, Hq, 128, ns, (hipStream_t)st);
     if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_decode_attention: unsupported (GQA group in {1,2,4,8}, page = 2^k, max_pages <= 512, nsplit = 2^k)");
+    return 0;
+}
+int emmax_op_decode_attention_merged(const void* q, const void* kcache, const void* vcache, const int32_t* page_table, const int32_t* ctx_len,
+                                     const int32_t* done, float* part_ws, void* o_out, uint32_t* arrival_ctr, int B, int Hq, int Hkv, int page,
+                                     int max_pages, int nsplit, float scale, int* nsplit_out, emmax_stream st) {
+    if (!q || !kcache || !vcache || !page_table || !ctx_len || !part_ws || !o_out || !arrival_ctr)
+        return fail(EMMAX_ERR_INVALID, "emmax_op_decode_attention_merged: null argument");
+    if (B < 1 || B > EMMAX_MAX_DECODE_BATCH || Hkv < 1 || Hq % Hkv) return fail(EMMAX_ERR_INVALID, "emmax_op_decode_attention_merged: bad B / heads");
+    DecodeAttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.q = q; a.ldq = Hq * 128; a.kcache = kcache; a.vcache = vcache; a.page_table = page_table; a.ctx_len = ctx_len; a.done = done;
+    a.part = part_ws; a.Hkv = Hkv; a.page = page; a.max_pages = max_pages; a.scale = scale;
+    a.o_out = o_out; a.merge_ctr = arrival_ctr;
+    const int ns = nsplit > 0 ? nsplit : decode_attn_nsplit(B, Hkv);
+    if (nsplit_out) *nsplit_out = ns;
+    if (ns > 16) return fail(EMMAX_ERR_INVALID, "emmax_op_decode_attention_merged: nsplit %d > 16", ns);
+    int r = launch_decode_attn(a, B, Hq, 128, ns, (hipStream_t)st);
+    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_decode_attention_merged: unsupported (GQA group in {1,2,4,8}, page = 2^k, max_pages <= 512, nsplit = 2^k)");
     return 0;
 }
 int emmax_op_gemv(const void* x, const void* W, void* y, int B, int N, int K, emmax_stream st) {

@@ -68,6 +68,8 @@ SIGNATURES = {
     "emmax_generate": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "emmax_session_graph_active": (C.c_int, [_vp]),
     "emmax_session_chain_active": (C.c_int, [_vp]),
+    "emmax_session_pchain_active": (C.c_int, [_vp]),
+    "emmax_session_pchain_fault": (C.c_int, [_vp, _vp]),
     "emmax_profile_decode_stage": (C.c_int, [_vp, C.c_int, C.c_int, _c_f32p, _vp]),
     "emmax_session_set_stop": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "emmax_slots_open": (C.c_int, [_vp, C.c_int, _vp]),
@@ -86,6 +88,8 @@ SIGNATURES = {
                                      C.c_int, C.c_int, C.c_float, C.c_int, _vp]),
     "emmax_op_decode_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_float, C.POINTER(C.c_int), _vp]),
+    "emmax_op_decode_attention_merged": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                   C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), _vp]),
     "emmax_op_gemv": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "emmax_op_resize_bicubic_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "emmax_op_quant_fm8": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp]),

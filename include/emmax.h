@@ -131,10 +131,19 @@ int emmax_generate(emmax_session* s, int max_new_tokens, int stop_on_eos, int32_
 
 /* 1 when emmax_generate is replaying a captured hipGraph of the step (0: eager launches). */
 int emmax_session_graph_active(emmax_session* s);
+/* 1 when the decode steps of the active batch run the PERSISTENT LAYER CHAIN (batch 1-2, bf16 weights; default on, EMMAX_PCHAIN=0
+ * at session creation disables): o-proj + gate/up + down + the next layer's qkv (last layer: lm-head) are ONE launch whose
+ * blocks hand the activation vectors over in-kernel; replaces the same HF `LlamaDecoderLayer` math as the per-stage launches
+ * (prismatic/extern/hf/modeling_prismatic.py:325-341), bit for bit. */
+int emmax_session_pchain_active(emmax_session* s);
+/* Synchronises `stream` and reports whether an in-kernel hand-off of the persistent chain gave up waiting since the last check
+ * (EMMAX_ERR_HIP: the results since then are invalid and the chain is switched off for the session; 0: fine).  emmax_generate
+ * checks by itself; callers that drive emmax_decode_step / the slot API call this where they would trust the ids. */
+int emmax_session_pchain_fault(emmax_session* s, emmax_stream stream);
 /* 1 when the decode steps of the active batch run as a chained two-stream launch (batch <= 2). */
 int emmax_session_chain_active(emmax_session* s);
 /* Measurement hook (bench.py `roofline`): launch decode stage `stage` (0 qkv GEMV, 1 paged attention, 2 o-proj GEMV,
- * 3 gate/up GEMV, 4 down GEMV: once per layer; 5 lm-head GEMV+argmax) `reps` sweeps on `stream`, bracketed by HIP
+ * 3 gate/up GEMV, 4 down GEMV: once per layer; 5 lm-head GEMV+argmax; 6 the persistent layer chain, once per layer) `reps` sweeps on `stream`, bracketed by HIP
  * events on that stream; returns the mean duration of one launch in microseconds.  Needs a prefilled session; the
  * residual stream it leaves behind is garbage (run a new prefill afterwards). */
 int emmax_profile_decode_stage(emmax_session* s, int stage, int reps, float* avg_us_out, emmax_stream stream);
@@ -196,6 +205,14 @@ int emmax_op_decode_attention(const void* q_dev, const void* kcache_dev, const v
                               const int32_t* ctx_len_dev, const int32_t* done_dev, float* part_out_dev, int B, int Hq, int Hkv,
                               int page, int max_pages, int nsplit, float scale, int* nsplit_out, emmax_stream stream);
 /* Decode-path weight-streaming GEMV: y[b,n] = sum_k x[b,k] W[n,k]  (bf16 in, fp32 accumulate, bf16 out), B <= 8. */
+/* The same launch with the cross-split merge INSIDE it (what emmax_decode_step runs at batch 1-2 on bf16 weights): the block that
+ * arrives last at a (row, kv head)'s counter merges the splits and writes o_out_dev bf16 [B, Hq*128] -- the row the o-proj reads.
+ * part_ws_dev: f32 [B][Hq][nsplit][132] scratch; arrival_ctr_dev: uint32 [B][Hkv], ZERO before the first launch (every launch
+ * leaves it zero again). */
+int emmax_op_decode_attention_merged(const void* q_dev, const void* kcache_dev, const void* vcache_dev, const int32_t* page_table_dev,
+                                     const int32_t* ctx_len_dev, const int32_t* done_dev, float* part_ws_dev, void* o_out_dev,
+                                     uint32_t* arrival_ctr_dev, int B, int Hq, int Hkv, int page, int max_pages, int nsplit, float scale,
+                                     int* nsplit_out, emmax_stream stream);
 int emmax_op_gemv(const void* x_dev, const void* W_dev, void* y_dev, int B, int N, int K, emmax_stream stream);
 
 /* Pillow-exact antialiased bicubic resize of uint8 RGB frames [B,H,W,3] -> [B,OH,OW,3] on the device (the `resize-naive`

@@ -359,6 +359,40 @@ def test_chained_launch_equals_sequential(device, tiny_random, monkeypatch):
     eng.new_session(eng.max_batch, eng.max_prompt, eng.max_ctx)
 
 
+def test_persistent_layer_chain_equals_stage_launches(device, tiny_random, monkeypatch):
+    """The persistent layer chain (decode_ks.hip: o-proj + gate/up + down + next qkv / lm-head in one launch, activation vectors
+    handed over in-kernel through data-tagged granules) must give bit-identical logits and ids to the same K-split kernels
+    launched stage by stage, step after step, at batch 1 and 2 (a stale or torn hand-off shows up here), and must report no
+    hand-off time-out."""
+    cfg, model, _ = tiny_random
+    eng = model.engine
+    monkeypatch.setenv("EMMAX_ATTN_MERGE", "1")   # stage launches: the split merge inside the attention launch, as the chain needs it
+    for nb, plens in ((2, [9, 21]), (1, [17])):
+        frames, rows = _inputs(cfg, nb, plens, seed=31 + nb)
+        fr = torch.from_numpy(frames).to(device)
+
+        def run(chain):
+            monkeypatch.setenv("EMMAX_PCHAIN", "1" if chain else "0")
+            eng.new_session(eng.max_batch, eng.max_prompt, eng.max_ctx)     # the switch is read at session creation
+            model._prefill(rows, None, fr, max_new=40)
+            assert eng.pchain_active() == chain
+            outs = []
+            for _ in range(24):
+                outs.append(eng.last_logits().clone())
+                eng.decode_step()
+            eng.pchain_check()
+            _, ids, lens = model.generate_actions_batch(fr, rows, max_new_tokens=24, stop_on_eos=False)
+            return torch.stack(outs), ids.clone(), lens.clone()
+
+        a, ids_a, lens_a = run(True)
+        b, ids_b, lens_b = run(False)
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), float((a - b).abs().max())
+        assert torch.equal(ids_a, ids_b) and torch.equal(lens_a, lens_b)
+    monkeypatch.delenv("EMMAX_PCHAIN")
+    eng.new_session(eng.max_batch, eng.max_prompt, eng.max_ctx)
+
+
 def test_checkpoint_ingest_and_caller_shims(device, tmp_path):
     """HF-format directory (config.json + sharded safetensors + dataset_statistics.json) -> from_pretrained -> the
     reference's caller functions (experiments/robot/openvla_utils.py get_vla_action / get_seq_action), each compared with the

@@ -1,14 +1,20 @@
 #!/bin/bash
-# round 3: op tests of the K-split GEMV, then the headline bench with it on / off (EMMAX_KS)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "gemv or decode_attention" 2>&1 | tail -5
-timeout 1200 python -m pytest tests/test_e2e_gpu.py tests/test_operating_point_gpu.py -x -q -m gpu 2>&1 | tail -5
-for ks in 1 0; do
-  EMMAX_KS=$ks timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/r3_bench_ks$ks.json
+run() { # label, env...
+  label=$1; shift
+  env "$@" timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/r3_bench_$label.json
   python - <<PY
 import json
-d=json.loads(open("gpurun_out/r3_bench_ks$ks.json").read())
-print("KS=$ks", d["value"], d["ms_per_step"], d.get("stage_us"), d.get("roofline"))
+try:
+    d=json.loads(open("gpurun_out/r3_bench_$label.json").read())
+    print("$label", d["value"], d["ms_per_step"], d["decode_ms_per_token"], d.get("stage_us"))
+except Exception as e:
+    print("$label failed", e, open("gpurun_out/r3_bench_$label.json").read()[:500])
 PY
-done
+}
+run default A=1
+run nsplit4 EMMAX_ATTN_NSPLIT=4
+run ksoproj EMMAX_KS_OPROJ=1
+run ksoproj256 EMMAX_KS_OPROJ=1 EMMAX_KS_OPROJ_GRID=256
+run ksoproj256n4 EMMAX_KS_OPROJ=1 EMMAX_KS_OPROJ_GRID=256 EMMAX_ATTN_NSPLIT=4
