@@ -276,7 +276,7 @@ def main():
         # HBM traffic of the same kernel from PMC counters (separate rocprofv3 --pmc passes over tools/pmc_probe.py, B=1;
         # FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); not collected during this run
         traffic = None
-        pmc_name = {(1, False): "r02_pmc_traffic.json", (8, False): "r02_pmc_traffic_b8.json", (1, True): "r02_pmc_traffic_fp8.json"}.get((B, bool(args.fp8)))
+        pmc_name = {(1, False): "r03_pmc_traffic.json", (8, False): "r02_pmc_traffic_b8.json", (1, True): "r02_pmc_traffic_fp8.json"}.get((B, bool(args.fp8)))
         pmc_file = os.path.join(ROOT, "profiles", pmc_name or "none")
         if not args.tiny and pmc_name and os.path.isfile(pmc_file):
             with open(pmc_file) as f:
@@ -297,7 +297,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not args.fp8 else "bf16 activations / fp8-e4m3 decode weights", "data": "synthetic",
             "config": {"workload": _workload(args, world, B, P, T),
                        "batch_per_gpu": B, "global_batch": B * world, "prompt_tokens": P, "new_tokens": T, "context": ctx + T,
-                       "parallelism": f"dp{world}", "hipgraph": eng.graph_active(), "chained_launch": eng.chain_active()},
+                       "parallelism": f"dp{world}", "hipgraph": eng.graph_active(), "chained_launch": eng.chain_active(), "persistent_layer_chain": eng.pchain_active()},
             "value_per_gpu": round(actions_per_s / world, 4), "single_gpu_same_workload": _profiled_single_gpu(args, B),
             "rccl_ranks": rccl_ranks, "dist_backend": edist.backend_name(),
             "gather_ms": round(gather_ms, 4), "gather_share": round(gather_ms / ms_per_step, 6),
@@ -306,7 +306,7 @@ def main():
             "decode_step_hbm_gbs": round(step_gbs, 1), "decode_step_hbm_frac": round(step_gbs / HBM_PEAK_GBS, 4),
             "stage_us": {k: round(v, 2) for k, v in stage_us.items()},
             "stage_gbs": {k: round(stage_bytes[k] / (stage_us[k] * 1e-6) / 1e9, 1) for k in stage_names},
-            "roofline": {"kernel": ("emmax_decode_gemv_kernel<B=%d,GATEUP,NORM%s>" % (B, ",FP8 rows" if args.fp8 else "") if B <= 2 else "emmax_decode_mfma_kernel<GATEUP,NORM%s> (B=%d)" % (",FP8" if args.fp8 else "", B)) + " (gate/up projection + SiLU*mul)", "bound": "hbm",
+            "roofline": {"kernel": (("emmax_decode_gemv_kernel<B=%d,GATEUP,NORM,FP8 rows>" % B if args.fp8 else "emmax_decode_ks_kernel<B=%d,GATEUP,NORM,CPL=1>" % B) if B <= 2 else "emmax_decode_mfma_kernel<GATEUP,NORM%s> (B=%d)" % (",FP8" if args.fp8 else "", B)) + " (gate/up projection + SiLU*mul)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "bytes_per_launch": stage_bytes[dom], "us_per_launch": round(stage_us[dom], 2), "traffic": traffic,
                          "traffic_source": "profiles/%s (rocprofv3 --pmc, offline)" % pmc_name if traffic else None},

@@ -84,7 +84,7 @@ def param_shapes(cfg: EmmaXConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
 
 
 def synthetic_state_dict(cfg: EmmaXConfig, seed: int = 0, device: str = "cpu", dtype: torch.dtype = torch.float32,
-                         planted: bool = False, std: float = 0.02) -> Dict[str, torch.Tensor]:
+                         planted: bool = False, std: float = 0.02, succ_override: Optional[Dict[int, int]] = None) -> Dict[str, torch.Tensor]:
     """Seeded random weights with the real key names / shapes.
 
     Values: matrices ~ N(0, std); LayerNorm / RMSNorm weights = 1 + 0.1*N; biases 0.01*N; LayerScale 0.1*(1+0.1*N);
@@ -93,7 +93,9 @@ def synthetic_state_dict(cfg: EmmaXConfig, seed: int = 0, device: str = "cpu", d
 
     planted=True builds the *margin-boosted* variant used for bit-exact token-id parity: embeddings are unit-scale,
     the residual branches are damped, and `lm_head[succ(t)]` is aligned with `embed[t]` for a fixed successor map
-    (`planted_successor`), so greedy decoding has a top-1 margin of many sigma and a known answer.
+    (`planted_successor`), so greedy decoding has a top-1 margin of many sigma and a known answer.  `succ_override`
+    {token: successor} re-routes single entries of that map (tests plant a scripted continuation, e.g. a complete
+    "MOVEMENT: .. POLICIES: .." answer, this way).
     """
     sd: Dict[str, torch.Tensor] = {}
     L = cfg.llm
@@ -120,6 +122,8 @@ def synthetic_state_dict(cfg: EmmaXConfig, seed: int = 0, device: str = "cpu", d
         emb = sd["language_model.model.embed_tokens.weight"].to(torch.float32)
         head = sd["language_model.lm_head.weight"].to(torch.float32)
         succ = planted_successor(cfg)
+        for t, nxt in (succ_override or {}).items():
+            succ[int(t)] = int(nxt)
         # logits[succ(t)] ~= |embed[t]|^2 * gain / rms  >>  sqrt(hidden)-scale background
         gain = 4.0 * std
         head.index_add_(0, succ.to(emb.device), gain * emb)   # row succ[t] += gain * embed[t]

@@ -263,6 +263,99 @@ def test_generate_actions_readme_form(device, tiny_planted):
     assert rel(f_orig[0, -1], f_pix[0, -1].float().cpu()) < 1e-2      # fused uint8 route == pixel_values route
 
 
+class _GrammarTokenizer:
+    """StubTokenizer + the two section markers and four distinct line breaks as single ids -- what a sub-word vocabulary gives the
+    real model ("POLICIES:" is a handful of LLaMA tokens, never nine separate characters): lets a planted successor MAP script a
+    complete grounded answer (a per-token map cannot walk through a text that repeats a character)."""
+
+    MOVEMENT, POLICIES, NL = 300, 301, (302, 303, 304, 305)
+
+    def __init__(self):
+        from emmax.tokenizer_stub import StubTokenizer
+
+        self._t = StubTokenizer()
+        self._text = {self.MOVEMENT: "MOVEMENT:", self.POLICIES: "POLICIES:", **{i: "\n" for i in self.NL}}
+
+    def __getattr__(self, k):
+        return getattr(self._t, k)
+
+    def __call__(self, *a, **k):
+        return self._t(*a, **k)
+
+    def decode(self, ids, skip_special_tokens=False, **kw):
+        ids = ids.tolist() if isinstance(ids, torch.Tensor) else list(ids)
+        out, run = [], []
+        for i in ids:
+            if int(i) in self._text:
+                out.append(self._t.decode(run, skip_special_tokens=skip_special_tokens))
+                out.append(self._text[int(i)])
+                run = []
+            else:
+                run.append(int(i))
+        out.append(self._t.decode(run, skip_special_tokens=skip_special_tokens))
+        return "".join(out)
+
+
+def test_generate_actions_parses_a_real_policies_and_movement_answer(device):
+    """the Solver's SUCCESS branches end to end on the GPU.  The planted successor map is re-routed so that the
+    model answers  MOVEMENT:\n<8 action tokens>\nPOLICIES:\n<8 action tokens>\n</s>  (the grammar of
+    /root/reference/prismatic/vla/solver.py:108-137); `generate_actions(type="act")` must return the 7 un-normalised policy values
+    and `type="pos"` the un-normalised movement plan -- non-trivial numbers, equal to the oracle's (ids bit-exact, values <= 1e-3),
+    through both call forms of /root/reference/prismatic/models/vlms/prismatic.py:627-696 and the README form."""
+    from emmax.config import EmmaXConfig
+    from emmax.modeling import EmmaXForActionPrediction
+    from emmax.processing import EmmaXImageProcessor, EmmaXProcessor
+    from emmax.weights import synthetic_state_dict
+
+    cfg = EmmaXConfig.tiny()
+    tok = _GrammarTokenizer()
+    lo = cfg.action_vocab_size - cfg.n_action_bins
+    # 16 distinct action-range ids: every token has ONE successor.  (Chosen among the bins whose embedding is least aligned with the
+    # lm-head row of 29871 -- the planted map sends 68 special / padding ids there, and at hidden 256 that row's noise can beat a
+    # single planted transition; with these the fp32 oracle follows the script with a top-2 margin >= 2.8 at every step.)
+    move = [lo + v for v in (6, 71, 213, 135, 23, 122, 75, 41)]
+    pol = [lo + v for v in (184, 101, 117, 177, 52, 118, 73, 49)]
+    rng = np.random.default_rng(12)
+    image = rng.integers(0, 256, size=(224, 224, 3), dtype=np.uint8)
+    builder_prompt = "In: What action should the robot take to achieve the instruction\nINSTRUCTION: \nput it down\n\nOut: "
+    ids_prompt = tok(builder_prompt, truncation=True, return_tensors="pt").input_ids[0].tolist()
+    script = [tok.MOVEMENT, tok.NL[0], *move, tok.NL[1], tok.POLICIES, tok.NL[2], *pol, tok.NL[3], cfg.eos_token_id]
+    assert len(set(script)) == len(script) and ids_prompt[-1] not in script
+    succ = {ids_prompt[-1]: script[0], **{a: b for a, b in zip(script[:-1], script[1:])}}
+    sd = synthetic_state_dict(cfg, seed=5, planted=True, succ_override=succ)
+    sd_bf = {k: v.to(torch.bfloat16) for k, v in sd.items()}
+    model = EmmaXForActionPrediction(cfg, dict(sd_bf)).to(device, max_batch=2, max_prompt=len(ids_prompt) + 8)
+    sd_ref = {k: v.float() for k, v in sd_bf.items()}
+    model.tokenizer = tok
+    T = len(script) + 6
+    want_text = "MOVEMENT:\n" + tok._t.decode(move) + "\nPOLICIES:\n" + tok._t.decode(pol)
+    for kind in ("act", "pos"):
+        new_ref, text_ref, want = _oracle_actions(cfg, sd_ref, ids_prompt, image, tok, T, kind)
+        assert new_ref == script, "the oracle itself must follow the planted script"
+        assert text_ref == want_text
+        got, text = model.generate_actions(image=image, prompt_text=builder_prompt, type=kind, temperature=0.0, max_new_tokens=T,
+                                           min_length=1, do_sample=False)
+        assert text == text_ref
+        if kind == "act":
+            assert len(got) == len(want) == 1
+            a, b = np.asarray(got[0], dtype=np.float64), np.asarray(want[0], dtype=np.float64)
+            assert a.shape == (7,) and np.abs(a - b).max() <= 1e-3
+            assert np.abs(a).sum() > 0 and len(set(np.round(a, 6))) > 3, "the fall-back answer is all zeros: this must be a parsed policy"
+            act_vals = a
+        else:
+            a, b = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+            assert a.shape == (7,) and np.abs(a - b).max() <= 1e-3
+            assert not np.any(a == -100), "-100 is the Solver's parse-failure answer"
+    # README form over the same request: (action[7], reasoning) with the first policy
+    proc = EmmaXProcessor(EmmaXImageProcessor(cfg), tok)
+    inputs = proc(builder_prompt, image).to(device, dtype=torch.bfloat16)
+    assert inputs["input_ids"][0].tolist() == ids_prompt
+    action, reasoning = model.generate_actions(inputs, tok, do_sample=False, max_new_tokens=T)
+    assert reasoning == want_text and np.abs(np.asarray(action, dtype=np.float64) - act_vals).max() <= 1e-6
+    got_ids = model.generate(inputs["input_ids"], frames_u8=inputs["frames_u8"], max_new_tokens=T)[0, len(ids_prompt):].tolist()
+    assert got_ids == script
+
+
 def test_generate_actions_native_keyword_form_matches_oracle(device, tiny_planted):
     """The reference's own call, by keyword (experiments/robot/openvla_utils.py:215-217 -> prismatic.py:628):
     `vla.generate_actions(image=..., prompt_text=..., type=..., temperature=0.0, max_new_tokens=.., min_length=1, do_sample=False)`

@@ -29,6 +29,27 @@ def relerr(got, ref):
     return ((got.float().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item()
 
 
+def assert_elementwise(got, ref, rtol=1e-2, atol_frac=4e-3, what=""):
+    """Per-ELEMENT bound |err| <= atol + rtol * |ref| with atol = atol_frac * rms(ref): the global `relerr` (max|err| / max|ref|)
+    cannot see a kernel that is wrong only on small-magnitude outputs -- an error of 1 % of max|ref| on an element whose true
+    value is 0.1 % of it passes there and fails here.  rtol 1e-2 = a bf16 output rounding (2^-9) plus a rounded epilogue operand;
+    atol = what fp32 accumulation order and one bf16 rounding of a typical-magnitude term leave on an output that cancels to ~0
+    (atol_frac 4e-3: two bf16 ulps of the rms)."""
+    g, r = got.float().cpu(), ref.float().cpu()
+    assert torch.isfinite(g).all(), what
+    bound = atol_frac * r.pow(2).mean().sqrt().item() + rtol * r.abs()
+    bad = (g - r).abs() > bound
+    if bad.any():
+        i = int(((g - r).abs() - bound).argmax())
+        raise AssertionError(f"{what}: {int(bad.sum())} of {bad.numel()} elements outside atol + rtol|ref|; worst at flat index {i}: "
+                             f"got {g.flatten()[i].item():.6g} ref {r.flatten()[i].item():.6g} bound {bound.flatten()[i].item():.3g}")
+
+
+# prefill / ViT attention: P is rounded to bf16 for the PV MFMA (as in the reference's bf16 SDPA), so an output that cancels to ~0
+# carries 2^-9 x the magnitude of its terms: measured up to 1.0e-2 x rms(ref) -- still 5x tighter than 1e-2 x max|ref|
+ATTN_ATOL = 2e-2
+
+
 def stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -62,6 +83,7 @@ def test_gemm(device, M, N, K, variant):
     torch.cuda.synchronize()
     assert torch.isfinite(Cd.float()).all()
     assert relerr(Cd, ref) < (1e-4 if out_f32 else TOL)
+    assert_elementwise(Cd, ref, rtol=1e-4 if out_f32 else 1e-2, atol_frac=1e-4 if out_f32 else 4e-3)
 
 
 def test_gemm_swiglu(device):
@@ -80,6 +102,7 @@ def test_gemm_swiglu(device):
                               stream()), "gemm swiglu")
     torch.cuda.synchronize()
     assert relerr(Cd, ref) < TOL
+    assert_elementwise(Cd, ref)
 
 
 @pytest.mark.parametrize("variant", ["plain", "gelu", "scale_res", "f32", "swiglu"])
@@ -102,6 +125,7 @@ def test_gemm_big_tile(device, variant):
         torch.cuda.synchronize()
         assert torch.isfinite(Cd.float()).all()
         assert relerr(Cd, ref) < TOL
+        assert_elementwise(Cd, ref)
         return
     bias = bf(torch.randn(N, generator=g)).to(device) if variant != "plain" else None
     scale = bf(torch.rand(N, generator=g) + 0.5).to(device) if variant == "scale_res" else None
@@ -119,6 +143,7 @@ def test_gemm_big_tile(device, variant):
     torch.cuda.synchronize()
     assert torch.isfinite(Cd.float()).all()
     assert relerr(Cd, ref) < (1e-4 if out_f32 else TOL)
+    assert_elementwise(Cd, ref, rtol=1e-4 if out_f32 else 1e-2, atol_frac=1e-4 if out_f32 else 4e-3)
 
 
 @pytest.mark.parametrize("variant", ["plain", "scale_res", "f32"])
@@ -145,6 +170,7 @@ def test_gemm_column_split_plan(device, variant):
     torch.cuda.synchronize()
     assert torch.isfinite(Cd.float()).all()
     assert relerr(Cd, ref) < (1e-4 if out_f32 else TOL)
+    assert_elementwise(Cd, ref, rtol=1e-4 if out_f32 else 1e-2, atol_frac=1e-4 if out_f32 else 4e-3)
 
 
 @pytest.mark.parametrize("M,N,K,ks", [(768, 4096, 4096, 2), (768, 4096, 11008, 4), (261, 1024, 4352, 8), (300, 384, 640, 3)])
@@ -178,6 +204,7 @@ def test_gemm_splitk(device, M, N, K, ks, variant):
     torch.cuda.synchronize()
     assert torch.isfinite(Cd.float()).all()
     assert relerr(Cd, ref) < (1e-4 if out_f32 else TOL)
+    assert_elementwise(Cd, ref, rtol=1e-4 if out_f32 else 1e-2, atol_frac=1e-4 if out_f32 else 4e-3)
     # too small a workspace / too many slices are errors, not silent fallbacks
     assert lib.emmax_op_gemm_splitk(A.data_ptr(), K, W.data_ptr(), K, Cd.data_ptr(), N, M, N, K, None, 0, None, None, N, 0, ks,
                                     ws.data_ptr(), 1024, stream()) != 0
@@ -204,6 +231,7 @@ def test_layernorm_rmsnorm(device, rows, D):
     L.check(lib.emmax_op_layernorm(xd.data_ptr(), y.data_ptr(), wd.data_ptr(), bd.data_ptr(), rows, D, 1e-6, stream()), "ln")
     ref = F.layer_norm(x.float(), (D,), w.float(), b.float(), eps=1e-6)
     assert relerr(y, ref) < TOL
+    assert_elementwise(y, ref)
     from oracle import emmax_oracle as orc
 
     L.check(lib.emmax_op_rmsnorm(xd.data_ptr(), y.data_ptr(), wd.data_ptr(), rows, D, 1e-5, stream()), "rms")
@@ -251,6 +279,7 @@ def test_attention(device, hd, Hq, Hkv, lens, causal):
     got = out[:, :qd]
     assert torch.isfinite(got.float()).all()
     assert relerr(got, ref) < TOL
+    assert_elementwise(got, ref, atol_frac=ATTN_ATOL)
     if ld_out > qd:
         assert (out[:, qd:] == 0).all(), "attention must not write the padding columns"
 
@@ -270,6 +299,7 @@ def test_gemv(device, B, N, K):
     L.check(lib.emmax_op_gemv(xd.data_ptr(), Wd.data_ptr(), y.data_ptr(), B, N, K, stream()), "gemv")
     torch.cuda.synchronize()
     assert relerr(y, ref) < TOL
+    assert_elementwise(y, ref)
 
 
 @pytest.mark.parametrize("B", [1, 3, 4, 8])
@@ -293,6 +323,7 @@ def test_gemm_small_mfma(device, B, N, K):
     torch.cuda.synchronize()
     assert torch.isfinite(y.float()).all()
     assert relerr(y, ref) < TOL
+    assert_elementwise(y, ref)
 
 
 @pytest.mark.parametrize("H,W", [(256, 256), (480, 640), (224, 300), (100, 180), (500, 224)])
@@ -347,6 +378,7 @@ def test_fp8_weight_projection(device, B, N, K):
     L.check(lib.emmax_op_gemm_small_fp8(xd.data_ptr(), W8.data_ptr(), sc.data_ptr(), y.data_ptr(), B, N, K, stream()), "gemm fp8")
     torch.cuda.synchronize()
     assert relerr(y, ref) < TOL
+    assert_elementwise(y, ref)
 
 
 def _rm8_rows_to_codes(W8, N, K):
@@ -391,6 +423,7 @@ def test_fp8_row_gemv(device, B, N, K):
     torch.cuda.synchronize()
     assert torch.isfinite(y.float()).all()
     assert relerr(y, ref) < TOL
+    assert_elementwise(y, ref)
 
 
 def test_fp8_row_gemv_refuses_what_it_cannot_stage(device):
@@ -476,6 +509,7 @@ def test_decode_attention_paged_matches_oracle(device, Hq, Hkv, ctxs):
         got = _merge_partials(part.view(-1)[: B * Hq * ns * 132].view(B, Hq, ns, 132).cpu(), ns)
         assert torch.isfinite(got).all(), (nsplit, ns)
         assert relerr(got, ref) < 5e-3, (nsplit, ns, relerr(got, ref))   # inputs are exact bf16, math fp32: only exp/ordering noise
+        assert_elementwise(got, ref)
         # the same launch with the split merge inside it (last-arriving block per head; what batch 1-2 decode runs): launched
         # three times over the same counters -- every launch must leave them re-armed -- and compared with the bf16 rounding of
         # the merge above (same partials, fp32 merge: the two agree to the last bf16 bit except across an exp() rounding)
@@ -491,6 +525,7 @@ def test_decode_attention_paged_matches_oracle(device, Hq, Hkv, ctxs):
             om = o.float().cpu().view(B, Hq, 128)
             assert torch.isfinite(om).all(), (nsplit, rep)
             assert relerr(om, ref) < 8e-3, (nsplit, rep, relerr(om, ref))
+            assert_elementwise(om, ref)
             assert (om - got).abs().max() <= 2 ** -7 * got.abs().max(), (nsplit, rep)   # one bf16 ulp of the largest value
 
 
@@ -555,6 +590,7 @@ def test_attention_resident_form_many_short_sequences(device, hd, Hq, Hkv, top, 
     got = out[:, :qd].cpu()
     assert torch.isfinite(got.float()).all()
     assert relerr(got, ref) < TOL
+    assert_elementwise(got, ref, atol_frac=ATTN_ATOL)
     for b in (0, 1, 2, 4, len(lens) - 1):   # per sequence too: a wrong row of a short one disappears in the global norm
         assert relerr(got[cu[b]:cu[b + 1]], ref[cu[b]:cu[b + 1]]) < 2 * TOL, (b, lens[b])
     if ld_out > qd:
@@ -596,6 +632,7 @@ def test_attention_random_ragged_shapes(device, seed):
         got = out[:, :qd]
         assert torch.isfinite(got.float()).all()
         assert relerr(got, ref) < TOL, (hd, Hq, Hkv, lens, causal, relerr(got, ref))
+        assert_elementwise(got, ref, atol_frac=ATTN_ATOL)
         # per-row check as well: a wrong row with small values hides under the max-norm
         err_row = (got.float().cpu() - ref).abs().amax(dim=1) / ref.abs().amax(dim=1).clamp_min(1e-3)
         assert err_row.max().item() < 5e-2, (hd, lens, causal, err_row.max().item())
