@@ -297,7 +297,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not args.fp8 else "bf16 activations / fp8-e4m3 decode weights", "data": "synthetic",
             "config": {"workload": _workload(args, world, B, P, T),
                        "batch_per_gpu": B, "global_batch": B * world, "prompt_tokens": P, "new_tokens": T, "context": ctx + T,
-                       "parallelism": f"dp{world}", "hipgraph": eng.graph_active(), "chained_launch": eng.chain_active(), "persistent_layer_chain": eng.pchain_active()},
+                       "parallelism": f"dp{world}", "hipgraph": eng.graph_active(), "persistent_layer_chain": eng.pchain_active()},
             "value_per_gpu": round(actions_per_s / world, 4), "single_gpu_same_workload": _profiled_single_gpu(args, B),
             "rccl_ranks": rccl_ranks, "dist_backend": edist.backend_name(),
             "gather_ms": round(gather_ms, 4), "gather_share": round(gather_ms / ms_per_step, 6),

@@ -110,30 +110,9 @@ __device__ __forceinline__ float gelu_erf(float x) {
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Chained launch: consecutive decode kernels run on two alternating streams, so kernel k+1 becomes resident and requests
-// its (x-independent) weights while kernel k drains; the DATA dependency k -> k+1 is enforced inside the kernel WITHOUT
-// cache-maintenance fences (a release fence is a full L2 write-back walk per block -- 32 of them queue up per XCD -- and
-// measured ~13 us per edge under streaming load):
-//   producer block: every activation store is an agent-scope write-through store (sc1: acknowledged once it is past the
-//                   XCD-private L2); every wave drains its stores (vmcnt(0)) -> barrier -> lane 0: relaxed counter
-//                   increment; the last arriver raises the flag
-//   consumer block: lane 0 polls the flag with agent-scope (sc1) loads (bounded), barrier, then reads the activations
-//                   with agent-scope loads, which never hit a stale line of the XCD-private L2.
-// (MI355X_MICROARCH.md, "handoff-flag": drained sc1 payload, then the flag.)  The `coh` argument of the helpers below is
-// block-uniform: plain accesses under ordinary stream ordering, agent-scope accesses under the chained launch.
-// Stream order still serialises k and k+2, so at most two kernels are in flight and both fit the chip (grids <= 256
-// blocks, <= 128 VGPRs): the spinning consumer can never starve its producer.
+// Activation accesses with a block-uniform `coh` switch: plain under ordinary stream ordering; agent-scope (sc1: past the
+// XCD-private L2) where a kernel reads what ANOTHER block of the same launch wrote (the in-attention split merge, decode.hip).
 // ---------------------------------------------------------------------------------------------------------------------
-struct DepInfo {
-    unsigned int* wait_flag;    // null: ordinary stream ordering, no in-kernel wait.  Polled word: != 0 once the producer is done
-    unsigned int* signal_ctr;   // null: nobody waits on this kernel.  Arrival counter of THIS kernel's blocks ...
-    unsigned int* signal_flag;  // ... and the flag its last-arriving block raises (a different 128-byte line than the counter,
-                                // so the consumer's pollers never contend with the producers' atomics)
-    unsigned int n_blocks;      // blocks of this kernel (the last arriver sees n_blocks - 1)
-    unsigned int* err;          // set to 1 when a wait gave up (bounded spin)
-};
-__host__ __device__ __forceinline__ bool dep_coherent(const DepInfo& d) { return d.wait_flag != nullptr || d.signal_ctr != nullptr; }
-
 __device__ __forceinline__ u32x4_t ld_act16(const u32x4_t* p, bool coh) {
     if (!coh) return *p;
     const unsigned long long* q = (const unsigned long long*)p;
@@ -175,37 +154,6 @@ __device__ __forceinline__ f32x4_t ld_act_f32x4(const float* p, bool coh) {
 // registers are read before the statement ends: the trailing s_nop, cdna_hip_programming.md section 5.7 item 1).
 __device__ __forceinline__ void st_sc1_f32x4(float* p, f32x4_t v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-}
-
-__device__ __forceinline__ void dep_wait(const DepInfo& d) {
-    if (d.wait_flag) {
-        if (threadIdx.x == 0) {
-            // bounded: a legitimate wait lasts one producer kernel (tens of us); ~0.1 s of polling means the protocol
-            // is broken -> flag it (the host turns the flag into an error) and let every later wait fall through
-            unsigned int spins = 0;
-            if (__hip_atomic_load(d.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                while (__hip_atomic_load(d.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                    __builtin_amdgcn_s_sleep(4);
-                    if (++spins > (1u << 19)) {
-                        __hip_atomic_store(d.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
-__device__ __forceinline__ void dep_signal(const DepInfo& d) {
-    if (d.signal_ctr) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own write-through stores
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned int prev = __hip_atomic_fetch_add(d.signal_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (prev == d.n_blocks - 1u) __hip_atomic_store(d.signal_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -82,8 +82,6 @@ __global__ __launch_bounds__(256) void emmax_quant_rm8_kernel(const bf16_t* __re
 }
 
 // B <= 2: two resident blocks per CU (<= 128 VGPRs); larger batches keep more accumulators and run one block per CU
-// COH: chained launch (B <= 2 only) -- activations move with agent-scope accesses (common.h); a compile-time switch so that
-// the plain path keeps its exact code (a run-time flag cost 3 us per layer)
 #ifdef DECODE_LAB_TRACE
 __device__ unsigned long long g_gemv_trace[1024 * 8];   // [block][stamp]: s_memrealtime (100 MHz) of wave 0
 #define GEMV_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_gemv_trace[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
@@ -100,11 +98,11 @@ __device__ unsigned long long g_gemv_trace[1024 * 8];   // [block][stamp]: s_mem
 // is four spans; down: K = 11008 is eleven -- 96 weight registers, which one block per CU affords).  De-quantisation is exact (e4m3 fits bf16:
 // v_cvt_scalef32_pk_bf16_fp8 with scale 1, two values per instruction, ~4.5 clocks), the products accumulate in fp32 and the row
 // scale multiplies the reduced sum.
-template <int B, int MODE, bool NORM, bool XATTN = false, bool COH = false, int F8 = 0>
+template <int B, int MODE, bool NORM, bool XATTN = false, int F8 = 0>
 __global__ __launch_bounds__(GW * 64, (B <= 2 && F8 != 1 && F8 != 2 ? 4 : 2)) void emmax_decode_gemv_kernel(GemvParams p) {
     GEMV_STAMP(0);
     constexpr bool FP8 = F8 > 0;
-    static_assert(!FP8 || (B <= 2 && !COH), "the fp8 GEMV serves batch 1-2 under plain stream ordering");
+    static_assert(!FP8 || B <= 2, "the fp8 GEMV serves batch 1-2");
     constexpr int NR = F8 == 3 ? 4 : 2;            // weight rows per group
     constexpr int NP = NR / 2;                     // row PAIRS per group (the epilogues work on pairs)
     constexpr int U = F8 == 2 ? 12 : F8 ? 4 : 8;   // 16-byte loads per row per block (bf16: 8 * 64 lanes * 8 elements = 4096 elements)
@@ -224,7 +222,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 && F8 != 1 && F8 != 2 ? 4 : 2)) vo
         }
         advance(P);
     };
-    constexpr bool coh = COH;
+    constexpr bool coh = false;   // activations move with plain accesses (stream ordering)
     const bool one_pass = NORM && !XATTN && !multi_phase && (K >> 3) <= NT;
     // x first pays for the qkv projection only (-0.9 us); gate/up and lm-head lose 1.5 us with it, the plain rows of the down
     // projection gain nothing.  The chained launch waits for its producer first, so there the stream always goes out ahead.
@@ -233,12 +231,11 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 && F8 != 1 && F8 != 2 ? 4 : 2)) vo
     // occupying 64 registers) it is one round trip of ~1 us; as a loop BEHIND the weight stream it was sixteen dependent
     // round trips, ~5 of the 11 us of the launch.
     // plain rows (down projection) that fit one round of four chunks per thread: activations first, see stage_x
-    const bool plain_first = !NORM && !XATTN && !COH && B <= 2 && !multi_phase && (K >> 3) <= 4 * NT;
+    const bool plain_first = !NORM && !XATTN && B <= 2 && !multi_phase && (K >> 3) <= 4 * NT;
     // fp8: every one-pass prologue goes first -- the first burst is most of the matrix, the refills cannot go out before x is
     // staged, and x requested behind the burst arrived 7 us into a 19 us gate/up launch (tools/gemv_lab.hip)
-    const bool head_first = COH || !((one_pass && (MODE == MODE_QKV || FP8)) || XATTN || plain_first);
+    const bool head_first = !((one_pass && (MODE == MODE_QKV || FP8)) || XATTN || plain_first);
     if (head_first) issue_head(false);
-    if (COH) dep_wait(p.dep);   // everything below reads data of the previous kernel
 
     // ---- RMSNorm statistics ----
     float rstd[B];
@@ -358,7 +355,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 && F8 != 1 && F8 != 2 ? 4 : 2)) vo
             }
             return;
         }
-        if (XATTN && !COH) {
+        if (XATTN) {
             // chunk cg = head (cg>>4), elements (cg&15)*8..+8 of the split partials.  A thread's FIRST chunk is merged with
             // every load in flight at once (needs ~60 registers: before the weight block exists); the weight stream is
             // requested right behind it; any further chunk (K > 4096) takes the low-register loop.
@@ -685,22 +682,20 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 && F8 != 1 && F8 != 2 ? 4 : 2)) vo
             st_act_i32(p.part_idx + (size_t)blockIdx.x * B + tid, i0, coh);
         }
     }
-    if (COH) dep_signal(p.dep);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // h[b] = E[cur_tok[b]]
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void emmax_decode_embed_kernel(const int32_t* __restrict__ cur_tok, const bf16_t* __restrict__ E,
-                                                                bf16_t* __restrict__ h, int hidden, int vocab, DepInfo dep) {
+                                                                bf16_t* __restrict__ h, int hidden, int vocab) {
     const int b = blockIdx.x;
     int id = cur_tok[b];
     id = min(max(id, 0), vocab - 1);
     const u32x4_t* s = (const u32x4_t*)(E + (size_t)id * hidden);
     u32x4_t* o = (u32x4_t*)(h + (size_t)b * hidden);
-    const bool coh = dep_coherent(dep);
+    constexpr bool coh = false;
     for (int c = threadIdx.x; c < hidden / 8; c += blockDim.x) st_act16(o + c, s[c], coh);
-    dep_signal(dep);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -718,7 +713,7 @@ __global__ __launch_bounds__(256) void emmax_decode_embed_kernel(const int32_t* 
 // that arrives LAST re-reads the nsplit partials past its XCD's L2 (sc1 loads), merges with attn_merge_chunk_loop -- the
 // arithmetic of the o-proj prologues, bit for bit -- writes bf16 o[G x 128] and re-arms the counter (MI355X_MICROARCH.md:
 // drained sc1 payload, then an agent-scope atomic as the flag; no spin anywhere, so nothing can hang).
-template <int HD, int G, bool COH = false, bool MERGE = false>
+template <int HD, int G, bool MERGE = false>
 __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams p) {
     static_assert(HD == 128, "decode attention maps 16 lanes x 8 elements onto one 128-wide K/V row");
     constexpr int KU = G <= 2 ? 4 : 2;    // keys per lane group per chunk (block chunk = 16 * KU keys), two chunks in flight
@@ -731,8 +726,7 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
     const int kg = lane >> 4, ch = lane & 15;       // key group within the wave, 16-byte chunk within the row
     const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
     const int nsplit = gridDim.x;
-    constexpr bool coh = COH;
-    if (COH) dep_wait(p.dep);   // q, ctx_len and the freshly appended K/V row come from the kernels before
+    constexpr bool coh = false;   // activations move with plain accesses (stream ordering)
     // ONE memory round trip for everything in front of the K/V loads: the context length and the done flag (scalar loads,
     // requested first), the row's whole page table (<= SP entries, two per thread, kept in registers until all requests are
     // out, then written to LDS) and q.  (A loop that waited for each table load, then a dependent scalar load for the length,
@@ -792,7 +786,6 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
             const int gq = i / PSTRIDE, j = i - gq * PSTRIDE;
             st_act_f32(part + (size_t)gq * nsplit * PSTRIDE + j, (j == HD) ? -INFINITY : 0.f, coh);
         }
-        if (COH) dep_signal(p.dep);
         return;
     }
 
@@ -929,7 +922,6 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
         const int gq = i / PSTRIDE, j = i - gq * PSTRIDE;
         st_act_f32(part + (size_t)gq * nsplit * PSTRIDE + j, part_value(gq, j), coh);
     }
-    if (COH) dep_signal(p.dep);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -937,8 +929,7 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void emmax_decode_finish_kernel(FinishParams p) {
     const int b = blockIdx.x, tid = threadIdx.x;
-    const bool coh = dep_coherent(p.dep);
-    dep_wait(p.dep);
+    constexpr bool coh = false;
     __shared__ float sv[256];
     __shared__ int si[256];
     float best = -INFINITY;
@@ -1009,7 +1000,6 @@ __global__ __launch_bounds__(256) void emmax_decode_finish_kernel(FinishParams p
         }
         p.cur_tok[b] = tok;
     }
-    dep_signal(p.dep);
 }
 
 // caller-supplied continuation (teacher forcing / the HF cached forward step): the row decodes again whatever the engine's own
@@ -1069,23 +1059,8 @@ static int launch_gemv_t(const GemvParams& p, hipStream_t stream, int* grid_out)
     }
     if (MODE == MODE_LMHEAD) grid = min(grid, p.max_parts);
     if (grid_out) *grid_out = grid;
-    GemvParams q = p;
-    q.dep.n_blocks = (unsigned)grid;
-    if constexpr (F8 > 0) {
-        if (dep_coherent(q.dep)) return -1;
-        auto kern = emmax_decode_gemv_kernel<B, MODE, NORM, XATTN, false, F8>;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(GW * 64), smem, stream, q);
-    } else if (dep_coherent(q.dep)) {   // chained launch
-        if constexpr (B <= 2) {
-            auto kern = emmax_decode_gemv_kernel<B, MODE, NORM, XATTN, true>;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(GW * 64), smem, stream, q);
-        } else {
-            return -1;
-        }
-    } else {
-        auto kern = emmax_decode_gemv_kernel<B, MODE, NORM, XATTN>;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(GW * 64), smem, stream, q);
-    }
+    auto kern = emmax_decode_gemv_kernel<B, MODE, NORM, XATTN, F8>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(GW * 64), smem, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
@@ -1123,10 +1098,7 @@ static int gemv_init_mode() {
 #define SETB(BB) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_gemv_kernel<BB, MODE, NORM, XATTN>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
     SETB(1); SETB(2); SETB(3); SETB(4); SETB(5); SETB(6); SETB(7); SETB(8);
 #undef SETB
-#define SETC(BB) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_gemv_kernel<BB, MODE, NORM, XATTN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
-    SETC(1); SETC(2);
-#undef SETC
-#define SETF(BB, FF) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_gemv_kernel<BB, MODE, NORM, XATTN, false, FF>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
+#define SETF(BB, FF) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_gemv_kernel<BB, MODE, NORM, XATTN, FF>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
     SETF(1, 1); SETF(1, 2); SETF(1, 3); SETF(2, 1); SETF(2, 2); SETF(2, 3);
 #undef SETF
     return e == hipSuccess ? 0 : -4;
@@ -1175,10 +1147,8 @@ int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream,
     }
 }
 
-int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, const DepInfo& dep_in, hipStream_t stream) {
-    DepInfo dep = dep_in;
-    dep.n_blocks = (unsigned)B;
-    hipLaunchKernelGGL(emmax_decode_embed_kernel, dim3(B), dim3(256), 0, stream, cur_tok, (const bf16_t*)E, (bf16_t*)h, hidden, vocab, dep);
+int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, hipStream_t stream) {
+    hipLaunchKernelGGL(emmax_decode_embed_kernel, dim3(B), dim3(256), 0, stream, cur_tok, (const bf16_t*)E, (bf16_t*)h, hidden, vocab);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
@@ -1204,15 +1174,13 @@ int launch_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_dim
     if (nsplit < 1 || (nsplit & (nsplit - 1))) return -1;   // the kernel divides the keys among the splits by shifting
     p.page_shift = 0;
     while ((1 << p.page_shift) < p.page) ++p.page_shift;
-    p.dep.n_blocks = (unsigned)(nsplit * p.Hkv * B);
-    if (p.o_out && (!p.merge_ctr || dep_coherent(p.dep))) return -1;   // the in-kernel merge needs its arrival counters; not with the chained launch
+    if (p.o_out && !p.merge_ctr) return -1;   // the in-kernel merge needs its arrival counters
     const int G = Hq / p.Hkv;
     dim3 grid(nsplit, p.Hkv, B), block(256);
     switch (G) {
 #define ATTN_CASE(GG)                                                                                                   \
     case GG:                                                                                                           \
-        if (dep_coherent(p.dep)) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true>), grid, block, 0, stream, p); \
-        else if (p.o_out) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, false, true>), grid, block, 0, stream, p); \
+        if (p.o_out) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true>), grid, block, 0, stream, p);          \
         else hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG>), grid, block, 0, stream, p);                         \
         break
         ATTN_CASE(1); ATTN_CASE(2); ATTN_CASE(4); ATTN_CASE(8);
@@ -1224,7 +1192,6 @@ int launch_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_dim
 
 int launch_decode_finish(const FinishParams& p_in, hipStream_t stream) {
     FinishParams p = p_in;
-    p.dep.n_blocks = (unsigned)p.B;
     hipLaunchKernelGGL(emmax_decode_finish_kernel, dim3(p.B), dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }

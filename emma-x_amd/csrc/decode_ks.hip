@@ -469,7 +469,7 @@ __global__ __launch_bounds__(KS_NT, 4) void emmax_decode_ks_kernel(GemvParams p)
     float keep[2] = {0.f, 0.f};
     KsLink lk;
     lk.in = nullptr; lk.out = nullptr; lk.in_tag = lk.out_tag = 0u; lk.err = nullptr;
-    ks_run_op<B, MODE, NORM, XATTN ? XS_ATTN : XS_GLOBAL, CPL, false, false, true, true>(p, lk, wr, part, sumsq, rows_cap, keep, [] {});
+    ks_run_op<B, MODE, NORM, XATTN ? XS_ATTN : XS_GLOBAL, CPL, false, false, true, true>(p, lk, wr, part, sumsq, rows_cap, keep, [] {}, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -604,7 +604,7 @@ bool decode_ks_enabled() {   // read per call (a getenv per launch is noise next
 // -2: shape outside this kernel (the caller falls back to launch_decode_gemv's LDS-staged kernel); bf16 weights, batch 1-2,
 // plain stream ordering, K a multiple of 64 and at most 12288 (three 16-byte chunks per lane)
 int launch_decode_ks(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
-    if (B < 1 || B > 2 || p.wscale || dep_coherent(p.dep)) return -2;
+    if (B < 1 || B > 2 || p.wscale) return -2;
     if (p.K % 64 || p.K > 64 * 64 * 3 || p.ldw % 8 || p.ldx % 8 || p.K < 64) return -2;
     switch (mode) {
         case GEMV_QKV: return ks_launch_mode<GEMV_QKV, true, false>(p, B, stream, grid_out);
@@ -652,7 +652,7 @@ int launch_decode_chain(const GemvParams& oproj, const GemvParams& gateup, const
     if (H % 64 || H > 4096 || I % 64 || I > 64 * 64 * 3 || H % 2 || (I / 2) % 2) return -2;   // H: one chunk per lane; even shares of gate/up
     if (oproj.attn_part) return -2;   // the attention launch merges its splits (DecodeAttnParams::o_out): the o-proj reads a bf16 row
     for (const GemvParams* q : {&oproj, &gateup, &down, &tail})
-        if ((q != &tail || nops == 4) && (q->wscale || dep_coherent(q->dep) || q->ldw % 8)) return -2;
+        if ((q != &tail || nops == 4) && (q->wscale || q->ldw % 8)) return -2;
     KsChainParams c;
     c.op[0] = oproj; c.op[1] = gateup; c.op[2] = down; c.op[3] = tail;
     if (ks_prepare<GEMV_RESID>(c.op[0]) || ks_prepare<GEMV_GATEUP>(c.op[1]) || ks_prepare<GEMV_RESID>(c.op[2])) return -2;

@@ -113,10 +113,9 @@ struct GemvParams {
     int sk_kt8, sk_q, sk_r;      // MFMA path, set by the launcher: super-steps per task (0: whole tasks), per-block share and remainder
     unsigned int sk_magic;       // ... and ceil(2^32 / sk_kt8)
     int qk_shift;                // MFMA QKV, set by the launcher: log2(head_dim / 32)
-    int max_grid;           // 0: default persistent grid; chained launch caps it at 256 (two kernels co-resident)
+    int max_grid;           // 0: default persistent grid; > 0: cap (the K-split o-proj with the split merge runs one block per CU)
     int ks_shift;           // K-split kernel, QKV, set by its launcher: log2(head_dim / 2)
     int ks_unit;            // K-split kernel, set by its launcher: pairs per unit of the block shares (2: gate/up inside a chain)
-    DepInfo dep;            // chained-launch hand-off (all null: plain stream ordering)
 };
 int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
 // decode_ks.hip: the batch 1-2 bf16 projections with K split across the waves of a block (activation slice in registers, no
@@ -131,7 +130,7 @@ size_t decode_chain_mbox_bytes(int B, int hidden, int inter);
 int launch_decode_chain(const GemvParams& oproj, const GemvParams& gateup, const GemvParams& down, const GemvParams& tail, int tail_mode,
                         int B, void* mbox, unsigned int* epoch, unsigned int* err, hipStream_t stream, int* tail_grid_out);
 int decode_gemv_init();   // raise the dynamic-LDS limit of every GEMV instantiation (call once, outside graph capture)
-int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, const DepInfo& dep, hipStream_t stream);
+int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, hipStream_t stream);
 
 struct DecodeAttnParams {
     const void* q;          // bf16 [B, ldq] rotated queries
@@ -146,7 +145,6 @@ struct DecodeAttnParams {
     int ldq, Hkv, page, max_pages;
     int page_shift;         // log2(page), set by the launcher
     float scale;
-    DepInfo dep;
 };
 int decode_attn_nsplit(int B, int Hkv);
 int launch_decode_attn(const DecodeAttnParams& p, int B, int Hq, int head_dim, int nsplit, hipStream_t stream);
@@ -170,7 +168,6 @@ struct FinishParams {
     int max_out, max_ctx;
     int eos_id, pad_id;
     int is_prefill;
-    DepInfo dep;
 };
 int launch_decode_finish(const FinishParams& p, hipStream_t stream);
 int launch_set_tokens(int32_t* cur_tok, const int32_t* toks, int B, int32_t* done, int32_t* stop_m, int32_t* stop_after, int32_t* max_new,

@@ -263,24 +263,17 @@ struct emmax_session {
     int32_t* pinned = nullptr;  // small pinned host buffer for control uploads / done read-backs
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
-    hipGraph_t graph2 = nullptr;             // chained launch: the second stream's half of the step
-    hipGraphExec_t graph_exec2 = nullptr;
     hipStream_t graph_stream_cap = nullptr;  // stream the graphs were captured on
     int graph_B = 0;
     hipStream_t graph_stream = nullptr;
     int graph_failed = 0;
     int last_step_graph = 0;   // the most recent decode step was a graph replay (what emmax_session_graph_active reports)
     hipEvent_t ev = nullptr;
-    hipStream_t overlap_stream = nullptr;   // second stream of the chained launch
-    unsigned int* dep_ctr = nullptr;         // device: one completion counter per kernel of the step (+ error word at [511])
     unsigned int* merge_ctr = nullptr;       // device: arrival counters of the in-attention split merge, [max_batch][kv heads], zero between launches
     unsigned long long* pc_mbox = nullptr;   // device: mailboxes of the persistent layer chain (decode_ks.hip), batch <= 2
     int pc_lm_grid = 0;                      // argmax partials the last chain launch wrote (= its grid)
     unsigned int* pc_words = nullptr;        // device: [0] epoch of the chain launches, [32] error word (a bounded poll gave up)
     int pchain = 0;                          // persistent layer chain (batch 1-2, bf16), measured slower than the stage launches: EMMAX_PCHAIN=1 enables
-    int chain = 0;                           // chained launch (B <= 2 only), experimental: EMMAX_CHAIN=1 enables
-    int chain_graph = 0;                     // EMMAX_CHAIN_GRAPH=1: replay the chained step as two per-stream graphs
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t own_stream = nullptr;   // used by emmax_generate when the caller's stream is the (uncapturable) legacy stream
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     std::string graph_err;
@@ -347,7 +340,6 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->stop_cfg = (int32_t*)b.take(2 * 4);
     s->stop_m = (int32_t*)b.take(Bd * 4);
     s->stop_after = (int32_t*)b.take(Bd * 4);
-    s->dep_ctr = (unsigned int*)b.take((256 * 64 + 16) * 4);
     s->pc_mbox = (unsigned long long*)b.take((int64_t)decode_chain_mbox_bytes(2, m->H, m->inter_p));
     s->pc_words = (unsigned int*)b.take(64 * 4);
     s->merge_ctr = (unsigned int*)b.take((int64_t)Bd * m->cfg.n_kv_heads * 4);
@@ -466,7 +458,7 @@ static bool fp8_rows(const emmax_model* m, int B, int K, int bit) {
 // B >= 3: MFMA over the fragment-major copy
 static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_fm, int B, hipStream_t st, int* grid_out = nullptr,
                        const float* w_scale = nullptr, const void* w_r8 = nullptr, int f8bit = 0) {
-    if (B < EMMAX_MFMA_MIN_BATCH && w_scale && w_r8 && !dep_coherent(p.dep) && (fp8_gemv_mask() & f8bit) && decode_gemv_fp8_fits(B, p.K)) {
+    if (B < EMMAX_MFMA_MIN_BATCH && w_scale && w_r8 && (fp8_gemv_mask() & f8bit) && decode_gemv_fp8_fits(B, p.K)) {
         p.W = w_r8;
         p.wscale = w_scale;
         p.ldw = p.K;   // bytes per row
@@ -484,34 +476,11 @@ static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_
 static bf16* kcache_of(emmax_session* s, int layer) { return s->kv + (size_t)layer * s->kv_layer_stride; }
 static bf16* vcache_of(emmax_session* s, int layer) { return s->kv + (size_t)layer * s->kv_layer_stride + s->kv_layer_stride / 2; }
 
-constexpr int DEP_MAX_KERNELS = 256;
-constexpr int DEP_WORDS = DEP_MAX_KERNELS * 64 + 16;
-struct Chain;
-static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, Chain* ch = nullptr,
-                            int slot0 = 0);
-static int launch_finish_step(emmax_session* s, int B, bool is_prefill, int n_part, int slot0, hipStream_t st, Chain* ch = nullptr);
-
-// chained-launch bookkeeping: kernel k runs on stream[k & 1], waits for counter k-1 and bumps counter k
-struct Chain {
-    emmax_session* s;
-    hipStream_t st[2];
-    int k = 0;
-    hipStream_t stream() const { return st[k & 1]; }
-    // kernel k: arrival counter at word 64k, done flag at word 64k+32 (separate 128-byte lines); error word at the end
-    DepInfo dep() const {   // n_blocks is filled in by the launcher, which knows its grid
-        DepInfo d;
-        d.wait_flag = k > 0 ? s->dep_ctr + 64 * (k - 1) + 32 : nullptr;
-        d.signal_ctr = s->dep_ctr + 64 * k;
-        d.signal_flag = s->dep_ctr + 64 * k + 32;
-        d.n_blocks = 0;
-        d.err = s->dep_ctr + DEP_WORDS - 1;
-        return d;
-    }
-    void launched() { ++k; }
-};
+static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, int slot0 = 0);
+static int launch_finish_step(emmax_session* s, int B, bool is_prefill, int n_part, int slot0, hipStream_t st);
 
 // finish of a step over rows slot0 .. slot0 + B: argmax over the n_part lm-head partials, EOS / budget / stop rule, next token
-static int launch_finish_step(emmax_session* s, int B, bool is_prefill, int n_part, int slot0, hipStream_t st, Chain* ch) {
+static int launch_finish_step(emmax_session* s, int B, bool is_prefill, int n_part, int slot0, hipStream_t st) {
     emmax_model* m = s->m;
     FinishParams f;
     memset(&f, 0, sizeof(f));
@@ -525,23 +494,19 @@ static int launch_finish_step(emmax_session* s, int B, bool is_prefill, int n_pa
     f.max_new_p = s->max_new_d + slot0; f.max_out = s->max_out; f.max_ctx = s->max_ctx;
     f.stop_ids = s->stop_ids; f.stop_cfg = s->stop_cfg; f.stop_m = s->stop_m + slot0; f.stop_after = s->stop_after + slot0;
     f.eos_id = m->cfg.eos_id; f.pad_id = m->cfg.pad_id; f.is_prefill = is_prefill ? 1 : 0;
-    if (ch) { f.dep = ch->dep(); st = ch->stream(); }
     KCHK(launch_decode_finish(f, st));
-    if (ch) ch->launched();
     return 0;
 }
 
 static void lmhead_params(emmax_session* s, int slot0, float* logits_out, GemvParams& p);
 // slot0: first row of the B rows this call covers (slot prefill: one row in the middle of a live batch)
-static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, Chain* ch, int slot0) {
+static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, int slot0) {
     emmax_model* m = s->m;
     GemvParams p;
     lmhead_params(s, slot0, logits_out, p);
     int lm_grid = 0;
-    if (ch) { p.dep = ch->dep(); p.max_grid = 256; st = ch->stream(); }
     KCHK(launch_proj(GEMV_LMHEAD, p, m->lm_head, m->lm_head_fm, B, st, &lm_grid, m->lm_head_sc, m->lm_head_r8, F8_LMHEAD));
-    if (ch) ch->launched();
-    if (do_finish) return launch_finish_step(s, B, is_prefill, lm_grid, slot0, st, ch);
+    if (do_finish) return launch_finish_step(s, B, is_prefill, lm_grid, slot0, st);
     return 0;
 }
 
@@ -610,7 +575,7 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
         KCHK(launch_gemm(g, st));
     }
     KCHK(launch_gather_last_rows(s->ph, s->dh + (size_t)r0 * m->H, s->cu, B, m->H, st));
-    int r = run_lm_head_step(s, B, true, nullptr, true, st, nullptr, r0);
+    int r = run_lm_head_step(s, B, true, nullptr, true, st, r0);
     if (r) return r;
     s->prefilled = true;
     return 0;
@@ -624,7 +589,7 @@ enum { STAGE_QKV = 0, STAGE_ATTN = 1, STAGE_OPROJ = 2, STAGE_GATEUP = 3, STAGE_D
 // dependent trips through the fabric) and the plain o-proj 8.9 against 10.1 -- a loss of 5.7 us per layer, so it is ON only where
 // it is needed (inside the persistent layer chain, whose o-proj cannot afford the per-wave merge) or asked for (EMMAX_ATTN_MERGE=1).
 static bool attn_merge_on(const emmax_session* s, int B) {
-    if (!(B < EMMAX_MFMA_MIN_BATCH && !s->m->fp8 && !s->chain && decode_ks_enabled())) return false;
+    if (!(B < EMMAX_MFMA_MIN_BATCH && !s->m->fp8 && decode_ks_enabled())) return false;
     const char* e = getenv("EMMAX_ATTN_MERGE");
     return s->pchain || (e && atoi(e) != 0);
 }
@@ -669,52 +634,39 @@ static void lmhead_params(emmax_session* s, int slot0, float* logits_out, GemvPa
 }
 
 // one stage of decoder layer `li` (the unit the profiler times); the step is stages 0..4 of every layer + lm head
-static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStream_t st, Chain* ch = nullptr) {
+static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStream_t st) {
     emmax_model* m = s->m;
     const auto& c = m->cfg;
     const LayerW& L = m->layers[li];
     GemvParams p;
     int grid = 0;
-    if (ch) st = ch->stream();
-    auto arm = [&]() { if (ch) { p.dep = ch->dep(); p.max_grid = 256; } };
     switch (stage) {
         case STAGE_QKV:
             stage_params(s, B, li, stage, p);
-            arm();
             KCHK(launch_proj(GEMV_QKV, p, L.wqkv, L.wqkv_fm, B, st, &grid, L.wqkv_sc, L.wqkv_r8, F8_QKV));
-            if (ch) ch->launched();
             return 0;
         case STAGE_ATTN: {
             DecodeAttnParams a;
             a.q = s->dq; a.ldq = m->q_dim; a.kcache = kcache_of(s, li); a.vcache = vcache_of(s, li);
             a.page_table = s->page_table; a.ctx_len = s->ctx_len; a.done = s->done; a.part = s->part; a.Hkv = c.n_kv_heads; a.page = PAGE;
             a.max_pages = s->max_pages; a.scale = 1.0f / sqrtf((float)c.head_dim);
-            memset(&a.dep, 0, sizeof(a.dep));
             a.o_out = nullptr; a.merge_ctr = nullptr;
-            if (ch) a.dep = ch->dep();
-            else if (attn_merge_on(s, B)) { a.o_out = s->datt; a.merge_ctr = s->merge_ctr; }
+            if (attn_merge_on(s, B)) { a.o_out = s->datt; a.merge_ctr = s->merge_ctr; }
             const int ns = decode_attn_nsplit(B, c.n_kv_heads);
             KCHK(launch_decode_attn(a, B, c.n_heads, c.head_dim, ns, st));
-            if (ch) ch->launched();
             return 0;
         }
         case STAGE_OPROJ:
             stage_params(s, B, li, stage, p);
-            arm();
             KCHK(launch_proj(GEMV_RESID, p, L.wo, L.wo_fm, B, st, &grid, L.wo_sc, L.wo_r8, F8_OPROJ));
-            if (ch) ch->launched();
             return 0;
         case STAGE_GATEUP:
             stage_params(s, B, li, stage, p);
-            arm();
             KCHK(launch_proj(GEMV_GATEUP, p, L.wgu, L.wgu_fm, B, st, &grid, L.wgu_sc, L.wgu_r8, F8_GATEUP));
-            if (ch) ch->launched();
             return 0;
         case STAGE_DOWN:
             stage_params(s, B, li, stage, p);
-            arm();
             KCHK(launch_proj(GEMV_RESID, p, L.wdown, L.wdown_fm, B, st, &grid, L.wdown_sc, L.wdown_r8, F8_DOWN));
-            if (ch) ch->launched();
             return 0;
         default:
             return fail(EMMAX_ERR_INVALID, "unknown decode stage %d", stage);
@@ -726,7 +678,7 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
 // = 2 + 2 x layers + 1 launches instead of 3 + 5 x layers; -2 from the launcher (shape outside the chain) falls back for good.
 extern "C" int emmax_session_pchain_fault(emmax_session* s, emmax_stream stream);
 static bool pchain_on(const emmax_session* s, int B) {
-    return s->pchain && B < EMMAX_MFMA_MIN_BATCH && !s->m->fp8 && !s->chain && decode_ks_enabled();
+    return s->pchain && B < EMMAX_MFMA_MIN_BATCH && !s->m->fp8 && decode_ks_enabled();
 }
 // tail_out: 1 = the launch included the tail (next layer's qkv / the lm-head: s->pc_lm_grid partials), 0 = the caller launches it
 static int run_layer_chain(emmax_session* s, int B, int li, hipStream_t st, int* tail_out) {
@@ -752,9 +704,7 @@ static int run_layer_chain(emmax_session* s, int B, int li, hipStream_t st, int*
 static int run_decode_step_pchain(emmax_session* s, int B, hipStream_t st) {
     emmax_model* m = s->m;
     const int nl = m->cfg.n_layers;
-    DepInfo nodep;
-    memset(&nodep, 0, sizeof(nodep));
-    KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, nodep, st));
+    KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st));
     int r = run_decode_stage(s, B, 0, STAGE_QKV, st);
     if (r) return r;
     for (int li = 0; li < nl; ++li) {
@@ -780,49 +730,10 @@ static int run_decode_step_pchain(emmax_session* s, int B, hipStream_t st) {
     return launch_finish_step(s, B, false, s->pc_lm_grid, 0, st);
 }
 
-static bool chain_on(const emmax_session* s, int B) { return s->chain && B < EMMAX_MFMA_MIN_BATCH && !s->m->fp8; }
-
-// chained launch (see common.h): the kernels of a step alternate between `st` and the session's second stream
-static int chain_step_begin(emmax_session* s, hipStream_t st) {
-    HIPCHK(hipMemsetAsync(s->dep_ctr, 0, (DEP_WORDS - 1) * 4, st));          // counters of this step (the error word survives)
-    HIPCHK(hipEventRecord(s->ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(s->overlap_stream, s->ev_fork, 0));
-    return 0;
-}
-static int chain_step_kernels(emmax_session* s, int B, hipStream_t st) {
-    emmax_model* m = s->m;
-    Chain ch;
-    ch.s = s; ch.st[0] = st; ch.st[1] = s->overlap_stream;
-    KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, ch.dep(), ch.stream()));
-    ch.launched();
-    for (int li = 0; li < m->cfg.n_layers; ++li)
-        for (int stage = STAGE_QKV; stage <= STAGE_DOWN; ++stage) {
-            int r = run_decode_stage(s, B, li, stage, st, &ch);
-            if (r) return r;
-        }
-    int r = run_lm_head_step(s, B, false, nullptr, true, st, &ch);
-    if (r) return r;
-    if (ch.k >= DEP_MAX_KERNELS) return fail(EMMAX_ERR_INVALID, "too many kernels per step for the chained launch (%d)", ch.k);
-    return 0;
-}
-static int chain_step_end(emmax_session* s, hipStream_t st) {
-    HIPCHK(hipEventRecord(s->ev_join, s->overlap_stream));
-    HIPCHK(hipStreamWaitEvent(st, s->ev_join, 0));
-    return 0;
-}
-
 static int run_decode_step(emmax_session* s, int B, hipStream_t st) {
     emmax_model* m = s->m;
     if (pchain_on(s, B)) return run_decode_step_pchain(s, B, st);
-    if (chain_on(s, B)) {
-        int r = chain_step_begin(s, st);
-        if (!r) r = chain_step_kernels(s, B, st);
-        if (!r) r = chain_step_end(s, st);
-        return r;
-    }
-    DepInfo nodep;
-    memset(&nodep, 0, sizeof(nodep));
-    KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, nodep, st));
+    KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st));
     for (int li = 0; li < m->cfg.n_layers; ++li)
         for (int stage = STAGE_QKV; stage <= STAGE_DOWN; ++stage) {
             int r = run_decode_stage(s, B, li, stage, st);
@@ -834,10 +745,6 @@ static int run_decode_step(emmax_session* s, int B, hipStream_t st) {
 static void drop_graph(emmax_session* s) {
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
     if (s->graph) (void)hipGraphDestroy(s->graph);
-    if (s->graph_exec2) (void)hipGraphExecDestroy(s->graph_exec2);
-    if (s->graph2) (void)hipGraphDestroy(s->graph2);
-    s->graph_exec2 = nullptr;
-    s->graph2 = nullptr;
     s->graph_exec = nullptr;
     s->graph = nullptr;
     s->graph_B = 0;
@@ -850,13 +757,9 @@ static int graph_fail(emmax_session* s, const std::string& why) {
     return 1;
 }
 
-// Capture one decode step into a hipGraph (plain single-stream mode only).  The chained launch is NOT captured: its
-// in-kernel waits need the host's alternating submission order -- if the two streams happen to share a hardware queue,
-// a replayed graph would queue a whole stream's kernels ahead of their producers and dead-lock the waits, whereas eager
-// alternating launches degrade to plain sequential execution.  Eager launching costs ~0.6 ms of host time per 2.5 ms
-// step, fully overlapped with the GPU.
+// Capture one decode step into a hipGraph.
 static int ensure_graph(emmax_session* s, int B, hipStream_t st) {
-    // Default: eager launch-ahead.  One step is 163 launches for >= 2.9 ms of GPU time, so a single host thread stays far
+    // Default: eager launch-ahead.  One step is 163 launches for >= 2.6 ms of GPU time, so a single host thread stays far
     // ahead of the device, and measured on MI355X / ROCm 7.2 the replayed graph is the SLOWER option: 3.05 vs 2.95 ms/token
     // at B = 1 (~0.6 us more per kernel node than a same-stream launch).  EMMAX_GRAPH=1 selects graph replay (a host whose
     // launch thread cannot be kept free); read per call so a process can switch.
@@ -865,54 +768,30 @@ static int ensure_graph(emmax_session* s, int B, hipStream_t st) {
         s->last_step_graph = 0;   // set again by launch_graph_step when a replay really runs
         if (!e || atoi(e) == 0) return 1;   // eager step: a captured graph stays valid for the next caller that wants replay
     }
-    const bool chain = chain_on(s, B);
-    if (chain && !s->chain_graph) return 1;
     if (s->graph_exec && s->graph_B == B && s->graph_stream_cap == st) return 0;
     drop_graph(s);
     if (s->graph_failed) return 1;
-    hipStream_t sb = s->overlap_stream;
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) return graph_fail(s, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e));
-    if (chain) {   // two LINEAR graphs, one per stream; memset + fork/join stay outside (launch_graph_step)
-        e = hipStreamBeginCapture(sb, hipStreamCaptureModeThreadLocal);
-        if (e != hipSuccess) {
-            hipGraph_t tmp = nullptr;
-            (void)hipStreamEndCapture(st, &tmp);
-            if (tmp) (void)hipGraphDestroy(tmp);
-            return graph_fail(s, std::string("hipStreamBeginCapture(second stream): ") + hipGetErrorString(e));
-        }
-    }
-    const int r = chain ? chain_step_kernels(s, B, st) : run_decode_step(s, B, st);
-    hipGraph_t g = nullptr, g2 = nullptr;
+    const int r = run_decode_step(s, B, st);
+    hipGraph_t g = nullptr;
     e = hipStreamEndCapture(st, &g);
-    hipError_t e2 = chain ? hipStreamEndCapture(sb, &g2) : hipSuccess;
-    if (r != 0 || e != hipSuccess || e2 != hipSuccess || !g || (chain && !g2)) {
+    if (r != 0 || e != hipSuccess || !g) {
         if (g) (void)hipGraphDestroy(g);
-        if (g2) (void)hipGraphDestroy(g2);
-        return graph_fail(s, r != 0 ? ("launch during capture: " + g_err) : (std::string("hipStreamEndCapture: ") + hipGetErrorString(e != hipSuccess ? e : e2)));
+        return graph_fail(s, r != 0 ? ("launch during capture: " + g_err) : (std::string("hipStreamEndCapture: ") + hipGetErrorString(e)));
     }
-    hipGraphExec_t ge = nullptr, ge2 = nullptr;
+    hipGraphExec_t ge = nullptr;
     e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-    if (e == hipSuccess && chain) e = hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0);
     if (e != hipSuccess) {
-        if (ge) (void)hipGraphExecDestroy(ge);
         (void)hipGraphDestroy(g);
-        if (g2) (void)hipGraphDestroy(g2);
         return graph_fail(s, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
     }
-    s->graph = g; s->graph_exec = ge; s->graph2 = g2; s->graph_exec2 = ge2; s->graph_B = B; s->graph_stream_cap = st;
+    s->graph = g; s->graph_exec = ge; s->graph_B = B; s->graph_stream_cap = st;
     return 0;
 }
 
 static int launch_graph_step(emmax_session* s, int B, hipStream_t st) {
     s->last_step_graph = 1;
-    if (chain_on(s, B)) {
-        int r = chain_step_begin(s, st);
-        if (r) return r;
-        HIPCHK(hipGraphLaunch(s->graph_exec, st));
-        HIPCHK(hipGraphLaunch(s->graph_exec2, s->overlap_stream));
-        return chain_step_end(s, st);
-    }
     HIPCHK(hipGraphLaunch(s->graph_exec, st));
     return 0;
 }
@@ -1100,20 +979,6 @@ int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_
     HIPCHK(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
-    {   // a different priority class gives the second stream its own hardware queue
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&s->overlap_stream, hipStreamNonBlocking, hi) != hipSuccess) {
-            (void)hipGetLastError();
-            HIPCHK(hipStreamCreateWithFlags(&s->overlap_stream, hipStreamNonBlocking));
-        }
-    }
-    s->chain_graph = getenv("EMMAX_CHAIN_GRAPH") && atoi(getenv("EMMAX_CHAIN_GRAPH")) != 0;
-    HIPCHK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
-    // OFF by default: measured 5.3 ms/token vs 3.1 ms for plain stream ordering -- an all-to-all in-kernel hand-off costs
-    // ~13 us under streaming load (MI355X_MICROARCH.md "fanin"), far more than the ~1.5 us kernel boundary it replaces.
-    s->chain = getenv("EMMAX_CHAIN") && atoi(getenv("EMMAX_CHAIN")) != 0;
     s->pchain = getenv("EMMAX_PCHAIN") && atoi(getenv("EMMAX_PCHAIN")) != 0;
     // static page assignment: row b owns pages [b*max_pages, (b+1)*max_pages)
     {
@@ -1151,9 +1016,6 @@ void emmax_session_destroy(emmax_session* s) {
     if (s->ev_in) (void)hipEventDestroy(s->ev_in);
     if (s->ev_out) (void)hipEventDestroy(s->ev_out);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
-    if (s->overlap_stream) (void)hipStreamDestroy(s->overlap_stream);
-    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     delete s;
 }
 
@@ -1285,11 +1147,6 @@ int emmax_generate(emmax_session* s, int max_new, int stop_on_eos, int32_t* out_
     if (pchain_on(s, B)) {   // a hand-off poll of the persistent chain that gave up is an error, never a silent wrong answer
         int r = emmax_session_pchain_fault(s, (emmax_stream)st);
         if (r) return r;
-    }
-    if (s->chain && B < EMMAX_MFMA_MIN_BATCH) {   // a bounded dependency wait that gave up is an error, never a silent wrong answer
-        HIPCHK(hipMemcpyAsync(s->pinned + 1024, s->dep_ctr + DEP_WORDS - 1, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (s->pinned[1024] != 0) return fail(EMMAX_ERR_HIP, "chained launch: a dependency wait timed out (results invalid)");
     }
     if (special) {
         HIPCHK(hipEventRecord(s->ev_out, st));
@@ -1428,8 +1285,6 @@ int emmax_session_pchain_fault(emmax_session* s, emmax_stream stream) {
     return fail(EMMAX_ERR_HIP, "persistent layer chain: a hand-off wait timed out -- is the GPU shared? (results since the last check are "
                                "invalid; the chain is now off for this session; EMMAX_PCHAIN=0 disables it up front)");
 }
-
-int emmax_session_chain_active(emmax_session* s) { return s && s->prefilled && chain_on(s, s->cur_B) ? 1 : 0; }
 
 int emmax_session_graph_active(emmax_session* s) {
     if (s && !s->graph_exec && !s->graph_err.empty()) g_err = s->graph_err;   // why the capture was refused

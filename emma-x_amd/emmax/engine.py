@@ -259,9 +259,6 @@ class EmmaxEngine:
     def graph_active(self) -> bool:
         return bool(self.lib.emmax_session_graph_active(self._session))
 
-    def chain_active(self) -> bool:
-        return bool(self.lib.emmax_session_chain_active(self._session))
-
     def pchain_active(self) -> bool:
         """True when the decode steps of the active batch run the persistent layer chain (batch 1-2, bf16)."""
         return bool(self.lib.emmax_session_pchain_active(self._session))

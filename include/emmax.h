@@ -140,8 +140,6 @@ int emmax_session_pchain_active(emmax_session* s);
  * (EMMAX_ERR_HIP: the results since then are invalid and the chain is switched off for the session; 0: fine).  emmax_generate
  * checks by itself; callers that drive emmax_decode_step / the slot API call this where they would trust the ids. */
 int emmax_session_pchain_fault(emmax_session* s, emmax_stream stream);
-/* 1 when the decode steps of the active batch run as a chained two-stream launch (batch <= 2). */
-int emmax_session_chain_active(emmax_session* s);
 /* Measurement hook (bench.py `roofline`): launch decode stage `stage` (0 qkv GEMV, 1 paged attention, 2 o-proj GEMV,
  * 3 gate/up GEMV, 4 down GEMV: once per layer; 5 lm-head GEMV+argmax; 6 the persistent layer chain, once per layer) `reps` sweeps on `stream`, bracketed by HIP
  * events on that stream; returns the mean duration of one launch in microseconds.  Needs a prefilled session; the

@@ -421,37 +421,6 @@ def test_graph_replay_equals_eager(device, tiny_planted, monkeypatch):
     assert ids_l.cpu().tolist() == ids_g.cpu().tolist() and lens_l.cpu().tolist() == lens_g.cpu().tolist()
 
 
-def test_chained_launch_equals_sequential(device, tiny_random, monkeypatch):
-    """The experimental two-stream chained launch (EMMAX_CHAIN=1; in-kernel fence-free hand-off between consecutive decode
-    kernels -- write-through stores, counter, agent-scope loads; off by default because it is slower) must give
-    bit-identical logits to plain single-stream ordering, step after step (a stale hand-off would show up here)."""
-    cfg, model, _ = tiny_random
-    eng = model.engine
-    frames, rows = _inputs(cfg, 2, [9, 21], seed=21)
-    fr = torch.from_numpy(frames).to(device)
-    # the chained launch exists for decode.hip's LDS-staged GEMV only: compare like with like (the K-split kernel of
-    # decode_ks.hip sums in another order)
-    monkeypatch.setenv("EMMAX_KS", "0")
-
-    def run(chain):
-        monkeypatch.setenv("EMMAX_CHAIN", "1" if chain else "0")
-        eng.new_session(eng.max_batch, eng.max_prompt, eng.max_ctx)     # the switch is read at session creation
-        model._prefill(rows, None, fr, max_new=40)
-        outs = []
-        for _ in range(24):
-            outs.append(eng.last_logits().clone())
-            eng.decode_step()
-        _, ids, lens = model.generate_actions_batch(fr, rows, max_new_tokens=24, stop_on_eos=False)
-        return torch.stack(outs), ids.clone(), lens.clone()
-
-    a, ids_a, lens_a = run(True)
-    b, ids_b, lens_b = run(False)
-    assert torch.equal(a, b)
-    assert torch.equal(ids_a, ids_b) and torch.equal(lens_a, lens_b)
-    monkeypatch.delenv("EMMAX_CHAIN")
-    eng.new_session(eng.max_batch, eng.max_prompt, eng.max_ctx)
-
-
 def test_persistent_layer_chain_equals_stage_launches(device, tiny_random, monkeypatch):
     """The persistent layer chain (decode_ks.hip: o-proj + gate/up + down + next qkv / lm-head in one launch, activation vectors
     handed over in-kernel through data-tagged granules) must give bit-identical logits and ids to the same K-split kernels

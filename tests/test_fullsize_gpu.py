@@ -77,7 +77,7 @@ def test_fullsize_graph_equals_eager(device, big, monkeypatch):
     fr = frames.to(device)
     T = 32
     _, ids_g, lens_g = model.generate_actions_batch(fr, rows, max_new_tokens=T)
-    assert model.engine.graph_active() or model.engine.chain_active()
+    assert model.engine.graph_active()
     model._prefill(rows, None, fr, max_new=T)
     for _ in range(T - 1):
         model.engine.decode_step()
@@ -139,29 +139,6 @@ def test_fullsize_prefill_logits_consistent_with_decode_head(device, big):
     assert err < 1e-2
     assert int(full[-1].argmax()) == int(last.argmax())
     assert torch.isfinite(full).all()
-
-
-def test_fullsize_chained_launch_equals_sequential(device, big, monkeypatch):
-    """7B shapes, 48 steps: chained two-stream launch == single-stream ordering, bit for bit (logits and ids)."""
-    cfg, model = big
-    eng = model.engine
-    frames, rows = _rows(cfg, [300], [45], seed=13)
-    fr = frames.to(device)
-
-    def run(chain):
-        monkeypatch.setenv("EMMAX_CHAIN", "1" if chain else "0")
-        eng.new_session(eng.max_batch, eng.max_prompt, eng.max_ctx)
-        _, ids, lens = model.generate_actions_batch(fr, rows, max_new_tokens=48, stop_on_eos=False)
-        model._prefill(rows, None, fr, max_new=48)
-        for _ in range(8):
-            eng.decode_step()
-        return ids.clone(), lens.clone(), eng.last_logits().clone()
-
-    ia, la, ga = run(True)
-    ib, lb, gb = run(False)
-    assert torch.equal(ia, ib) and torch.equal(la, lb) and torch.equal(ga, gb)
-    monkeypatch.delenv("EMMAX_CHAIN")
-    eng.new_session(eng.max_batch, eng.max_prompt, eng.max_ctx)
 
 
 def test_fullsize_vision_towers_match_oracle(device):

@@ -152,7 +152,14 @@ def section_model(path, cfg, sd, tok, device, n_prompts, new_tokens, oracle_dtyp
     if not cfg.norm_stats:
         report["model"] = {"status": "SKIPPED", "why": "no dataset statistics in the checkpoint directory"}
         return
-    proc = EmmaXProcessor.from_pretrained(path, cfg=cfg)
+    try:
+        proc = EmmaXProcessor.from_pretrained(path, cfg=cfg)
+        tok_kind = "checkpoint tokenizer"
+    except FileNotFoundError:
+        # no tokenizer files (synthetic checkpoints; a real one always ships them): the model section is an ids-level check --
+        # prompts go through the deterministic stub, on both sides alike -- and says so in the report
+        proc = EmmaXProcessor.from_synthetic(cfg)
+        tok_kind = "StubTokenizer (no tokenizer files in the directory: ids-level check only)"
     unnorm_key = "bridge_orig" if "bridge_orig" in cfg.norm_stats else next(iter(cfg.norm_stats))
     vla = EmmaXForActionPrediction(cfg, {k: v.to(torch.bfloat16) for k, v in sd.items()}).to(device, max_batch=1, max_prompt=128)
     dt = torch.float32 if oracle_dtype == "fp32" else torch.bfloat16
@@ -180,7 +187,8 @@ def section_model(path, cfg, sd, tok, device, n_prompts, new_tokens, oracle_dtyp
         err = float(np.abs(action - want).max())
         ok = ok and same and err <= 1e-3
         rows.append({"prompt": i, "ids_equal": same, "action_err": err, "min_margin": min(margins), "hip_seconds": round(dt_hip, 4)})
-    report["model"] = {"status": "PASS" if ok else "FAIL", "oracle_dtype": oracle_dtype, "unnorm_key": unnorm_key, "prompts": rows}
+    report["model"] = {"status": "PASS" if ok else "FAIL", "oracle_dtype": oracle_dtype, "unnorm_key": unnorm_key, "tokenizer": tok_kind,
+                       "prompts": rows}
 
 
 def main(argv=None) -> int:
