@@ -249,6 +249,10 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
     // are a fixed handful (one-pass): loads return in order, so x queued behind 16 KiB of weights per wave would keep the
     // whole prologue waiting for HBM
     auto issue_head = [&]() {
+        // x_bar: every wave of the block (one block per CU) has REQUESTED its activation loads before any wave requests weights --
+        // the CU's vector-memory path serves requests in arrival order, so activations queued behind other waves' 8 KiB heads
+        // arrived 3-4 us into the launch (a bare s_barrier: it orders the requests, it does not wait for data)
+        if (p.x_bar) __builtin_amdgcn_s_barrier();
         producer_setup(P);
 #pragma unroll
         for (int u = 0; u < U; ++u) issue_step(P, u);
@@ -680,6 +684,10 @@ static int launch_mfma_t(GemvParams p, int B, hipStream_t stream, int* grid_out)
         if (!(MODE == MODE_LMHEAD && p.n_rows % 16 == 0)) return -1;
     }
     p.batch = B;
+    {   // tuning hook EMMAX_MFMA_XBAR (default on for the prologues that load activations ahead of the head)
+        static const int xbar = [] { const char* e = getenv("EMMAX_MFMA_XBAR"); return e ? atoi(e) : 1; }();
+        p.x_bar = XATTN ? 0 : xbar;
+    }
     p.kc = mfma_kc(B, p.K, TILES, FP8 ? 64 : 32);
     if (NORM && p.kc != p.K) return -1;
     p.n_groups = p.n_rows / (16 * TILES);

@@ -113,6 +113,7 @@ struct GemvParams {
     int sk_kt8, sk_q, sk_r;      // MFMA path, set by the launcher: super-steps per task (0: whole tasks), per-block share and remainder
     unsigned int sk_magic;       // ... and ceil(2^32 / sk_kt8)
     int qk_shift;                // MFMA QKV, set by the launcher: log2(head_dim / 32)
+    int x_bar;                   // MFMA path, set by the launcher: block barrier between the activation requests and the weight head
     int max_grid;           // 0: default persistent grid; > 0: cap (the K-split o-proj with the split merge runs one block per CU)
     int ks_shift;           // K-split kernel, QKV, set by its launcher: log2(head_dim / 2)
     int ks_unit;            // K-split kernel, set by its launcher: pairs per unit of the block shares (2: gate/up inside a chain)

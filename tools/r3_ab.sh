@@ -1,9 +1,9 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-run() { # label, env...
+run() { # label, bench args..., env via ENVV
   label=$1; shift
-  env "$@" timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/r3_bench_$label.json
+  env $ENVV timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" 2>&1 | tail -1 > gpurun_out/r3_bench_$label.json
   python - <<PY
 import json
 try:
@@ -13,8 +13,8 @@ except Exception as e:
     print("$label failed", e, open("gpurun_out/r3_bench_$label.json").read()[:500])
 PY
 }
-run default A=1
-run nsplit4 EMMAX_ATTN_NSPLIT=4
-run ksoproj EMMAX_KS_OPROJ=1
-run ksoproj256 EMMAX_KS_OPROJ=1 EMMAX_KS_OPROJ_GRID=256
-run ksoproj256n4 EMMAX_KS_OPROJ=1 EMMAX_KS_OPROJ_GRID=256 EMMAX_ATTN_NSPLIT=4
+ENVV="EMMAX_MFMA_XBAR=1" run b8_xbar1 --batch-per-gpu 8
+ENVV="EMMAX_MFMA_XBAR=0" run b8_xbar0 --batch-per-gpu 8
+ENVV="EMMAX_MFMA_XBAR=1" run f8b8_xbar1 --batch-per-gpu 8 --fp8
+ENVV="EMMAX_MFMA_XBAR=0" run f8b8_xbar0 --batch-per-gpu 8 --fp8
+timeout 900 python -m pytest tests/test_operating_point_gpu.py tests/test_ops_gpu.py -q -m gpu -k "B8 or mfma or fp8" 2>&1 | tail -3
