@@ -228,5 +228,20 @@ __device__ __forceinline__ u32x4_t attn_merge_chunk_loop(const float* __restrict
     return v;
 }
 
+// row of the SOURCE matrix (row-major, decode.hip's orders) that row r of tile t of the permuted copy holds
+//   perm 0: natural;  1: qkv -- head hb = t / (hd/16), block j = t % (hd/16): rows 8j..8j+7 and hd/2 + 8j .. of the head;
+//   2: gate/up -- gate_g, up_g of g = 8t + r (source: 16-row interleaved groups, gate_g at (g>>4)*32 + (g&15), up_g 16 below)
+__host__ __device__ __forceinline__ int km_src_row(int perm, int head_dim, int t, int r) {
+    if (perm == 1) {
+        const int tph = head_dim / 16, hb = t / tph, j = t - hb * tph;
+        return hb * head_dim + (r < 8 ? 8 * j + r : head_dim / 2 + 8 * j + r - 8);
+    }
+    if (perm == 2) {
+        const int g = 8 * t + (r & 7);
+        return (g >> 4) * 32 + (g & 15) + (r < 8 ? 0 : 16);
+    }
+    return t * 16 + r;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t align_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }

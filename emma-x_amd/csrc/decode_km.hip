@@ -1,0 +1,409 @@
+// decode_km.hip -- batch 3-8 decode projections with K <= 4096 on MFMA, K split across the waves of a block ("km").
+// Replaces the q_len == 1 linears of HF `LlamaDecoderLayer` at small batch (cached branch of
+// prismatic/extern/hf/modeling_prismatic.py:325-341; the configs[2] per-GPU shard), like decode_mfma.hip, with the structure
+// that made the batch-1 kernel of decode_ks.hip faster:
+//
+//   * one block of 8 waves per CU; wave w owns the k-steps [w KT/8, (w+1) KT/8) of EVERY 16-row tile of the block.  Its slice of
+//     the activations lives in registers for the whole launch, already in MFMA B-operand form (16 fragments of 8 bf16 per lane:
+//     batch row = lane & 15, rows past the batch are zero) -- no LDS stage, no barrier in front of the weight stream, no LDS
+//     read per MFMA;
+//   * weights stream from a fragment-major copy (one 1 KiB tile = the A operand of one v_mfma_f32_16x16x32_bf16) with
+//     non-temporal buffer loads, the tile in an SGPR offset: TWO tiles (32 KiB) per wave in flight, i.e. 64 MB on the chip like
+//     the batch-1 kernel (decode_mfma.hip keeps 16 MB in flight: at ~3 us of loaded latency that alone bounds it near 5.3 TB/s);
+//     every load is unconditional (tiles / steps past the end carry an out-of-range offset and return zeros for free), so the
+//     waits are counted;
+//   * the eight K-slice partial tiles meet in LDS once, at the end of the block, where the fused epilogues run;
+//   * the pairs the epilogues need live INSIDE a tile: the qkv and gate/up copies are row-permuted when they are built (rows
+//     0-7 of a tile = elements d .. d+7 of a head / gate rows, rows 8-15 = d+64 .. d+71 / the matching up rows), so the work
+//     unit is ONE tile for every matrix: 768 qkv tiles are 3 per block (as 384 two-tile tasks they were 1.5 and needed the
+//     stream-K split of decode_mfma.hip);
+//   * RMSNorm folded in as in decode_ks.hip: y = rstd * W (x .* g), the sum of squares per wave slice, 1/rms in the epilogue.
+// The down projection (K = 11008: 43 k-steps per wave would need 172 activation registers) stays on decode_mfma.hip.
+#include <cstdlib>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int KM_WAVES = 8;
+constexpr int KM_NT = KM_WAVES * 64;
+constexpr int KM_STEPS = 16;      // bf16 k-steps (32 elements) per tile and wave: K <= 8 * 16 * 32 = 4096
+constexpr int KM_MAX_TILES = 8;   // tiles per block the LDS partial sums hold
+constexpr int PSTRIDE = EMMAX_PSTRIDE;
+
+// two fp8 e4m3 pairs (the low / high half of a dword) -> two bf16, exact
+template <bool HI>
+__device__ __forceinline__ uint32_t km_fp8x2(uint32_t v) {
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, HI));
+}
+__device__ __forceinline__ bf16x8_t km_fp8x8(uint32_t lo, uint32_t hi) {
+    const u32x4_t v = {km_fp8x2<false>(lo), km_fp8x2<true>(lo), km_fp8x2<false>(hi), km_fp8x2<true>(hi)};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// row-major [N, ld] -> fragment-major tiles in the km row order (N % 16 == 0, K % 32 == 0)
+__global__ __launch_bounds__(256) void emmax_repack_km_kernel(const bf16_t* __restrict__ src, int ld, u32x4_t* __restrict__ dst, int N, int K,
+                                                             int perm, int head_dim) {
+    const size_t total = (size_t)N * K / 8;
+    for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < total; c += (size_t)gridDim.x * 256) {
+        const int lane = (int)(c & 63);
+        const size_t tile = c >> 6;
+        const int kt = (int)(tile % (K / 32)), nt = (int)(tile / (K / 32));
+        const int n = km_src_row(perm, head_dim, nt, lane & 15), k = kt * 32 + (lane >> 4) * 8;
+        dst[c] = *(const u32x4_t*)(src + (size_t)n * ld + k);
+    }
+}
+
+// o-proj prologue: merge the NS split partials of head (cg >> 4) for every batch row into the staged rows [B][K] bf16, two rows per
+// iteration so that the loads of both are in flight together (branch-free merge: attn_merge_chunk, common.h)
+template <int NS>
+__device__ __forceinline__ void km_merge_rows(const float* __restrict__ attn_part, unsigned char* dst, int pitch, int B, int Hq, int cg) {
+    const float* pp0 = attn_part + (size_t)(cg >> 4) * NS * PSTRIDE;
+    const size_t row = (size_t)Hq * NS * PSTRIDE;
+    const int d0 = (cg & 15) * 8;
+    int b = 0;
+    for (; b + 1 < B; b += 2) {
+        const u32x4_t v0 = attn_merge_chunk<NS>(pp0 + (size_t)b * row, d0);
+        const u32x4_t v1 = attn_merge_chunk<NS>(pp0 + (size_t)(b + 1) * row, d0);
+        *(u32x4_t*)(dst + (size_t)b * pitch) = v0;
+        *(u32x4_t*)(dst + (size_t)(b + 1) * pitch) = v1;
+    }
+    if (b < B) *(u32x4_t*)(dst + (size_t)b * pitch) = attn_merge_chunk<NS>(pp0 + (size_t)b * row, d0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// grid: one block per CU; block b owns a contiguous range of tiles (launcher: at most KM_MAX_TILES).
+// Dynamic LDS: float part[8 waves][tiles_cap][64][4] + float sumsq[8][16] + the activation staging (XATTN: the merged rows, bf16
+// [B][K]; else one window of 8 row slices per wave).
+// FP8: the tiles are e4m3 (16 rows x 64 k per KiB, decode_mfma.hip's emmax_quant_fm8_kernel layout) + one fp32 scale per row,
+// de-quantised in registers (exact), two MFMAs per load.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MODE, bool NORM, bool XATTN, bool FP8>
+__global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char km_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g4 = lane >> 4, c16 = lane & 15;
+    const int B = p.batch, K = p.K;
+    constexpr int KS = FP8 ? 64 : 32;             // elements per load step
+    constexpr int NSTEP = FP8 ? KM_STEPS / 2 : KM_STEPS;   // load steps per tile and wave
+    const int KT = K / KS;                        // load steps of a whole row
+    const int KTW = KT / KM_WAVES;                // ... of this wave's slice (launcher: K % (8 * KS) == 0, KTW <= NSTEP)
+    const int tiles_cap = p.kc;                   // launcher
+    float* part = (float*)km_smem;                                   // [KM_WAVES][tiles_cap][64][4]
+    float* sumsq = part + (size_t)KM_WAVES * tiles_cap * 256;        // [KM_WAVES][16]
+    unsigned char* xlds = (unsigned char*)(sumsq + KM_WAVES * 16);   // XATTN: the merged rows [B][K] bf16; else 8 wave-private windows
+
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int n_tiles = p.n_groups;
+    const int tq = n_tiles / G, tr = n_tiles % G;
+    const int t_lo = bid * tq + min(bid, tr), ntb = tq + (bid < tr ? 1 : 0);
+
+    // ---- epilogue operands of this thread's (tile, lane) slot, requested before anything else ----
+    // thread (tl = tid >> 6, l = tid & 63) finalises tile tl of the block: rows 4 (l >> 4) + j, batch column l & 15
+    const int e_tl = tid >> 6, e_l = lane, e_c = e_l & 15, e_rq = e_l >> 4;
+    const bool e_pairs = MODE == GEMV_QKV || MODE == GEMV_GATEUP;          // rows r, r + 8 of a tile belong together
+    const bool e_on = e_tl < ntb && e_c < B && (!e_pairs || e_rq < 2);
+    const int e_tile = t_lo + min(e_tl, max(ntb - 1, 0));
+    float pre_a[4] = {0.f, 0.f, 0.f, 0.f}, pre_b[4] = {0.f, 0.f, 0.f, 0.f};
+    int pre_pos = 0, pre_pg = 0;
+    if (e_on) {
+        if (MODE == GEMV_RESID) {
+            const bf16_t* hp = (const bf16_t*)p.y + (size_t)e_c * p.ldy + e_tile * 16 + 4 * e_rq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pre_a[j] = bf2f(hp[j]);
+        } else if (MODE == GEMV_QKV) {
+            pre_pos = p.ctx_len[e_c];
+            pre_pg = p.page_table[(size_t)e_c * p.max_pages + pre_pos / p.page];
+            const int hd = p.head_dim, half = hd >> 1, tph = hd / 16;
+            const int hb = e_tile / tph, d0 = 8 * (e_tile - hb * tph) + 4 * e_rq;
+            if (hb < p.Hq + p.Hkv) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pre_a[j] = p.cos_t[(size_t)pre_pos * half + d0 + j];
+                    pre_b[j] = p.sin_t[(size_t)pre_pos * half + d0 + j];
+                }
+            }
+        }
+    }
+
+    // ---- weight stream: buffer loads, the (tile, step) offset in an SGPR, the lane's 16 bytes in the VGPR offset ----
+    const unsigned w_bytes = (unsigned)((size_t)p.n_groups * 16 * (size_t)K * (FP8 ? 1 : 2));
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)w_bytes, 0x00020000);
+    const unsigned voff = (unsigned)lane * 16u;
+    u32x4_t wa[NSTEP], wb[NSTEP];   // two tiles in flight
+    auto issue = [&](u32x4_t (&w)[NSTEP], int tl) {   // tile tl of the block (uniform); past the end: out of range = zeros, no traffic
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const int ok = (tl < ntb && s < KTW) ? -1 : 0;
+            const unsigned so = ((unsigned)(((t_lo + tl) * KT + wave * KTW + s) * 1024) & (unsigned)ok) | (w_bytes & (unsigned)~ok);
+            w[s] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, so, 2));   // aux 2 = nt
+        }
+    };
+
+    // ---- activations: this wave's K slice as MFMA B fragments (batch row = lane & 15, k = 8 (lane >> 4) .. + 8 of a 32-step) ----
+    // Fetched ROW-shaped -- one contiguous 1 KiB request per batch row, lane l the 8 elements [8 l, 8 l + 8) of the slice -- and
+    // turned into fragments through a wave-private LDS window (no barrier: only this wave writes and reads it).  Fetched
+    // fragment-shaped (every instruction 16 bytes from each of B rows x 4 k-groups) the 32 requests of a wave touched 4x the cache
+    // lines and held the CU's address path for ~3 us: qkv 28.8 us against 22.4 for decode_mfma.hip at B = 8.
+    bf16x8_t xf[KM_STEPS];
+    const int ksl = K / KM_WAVES / 32;   // 32-element fragments in the wave's slice
+    constexpr int XPITCH = KM_STEPS * 64 + 16;   // bytes per staged row slice (+16: the four k-groups of a fragment read hit different banks)
+    if constexpr (XATTN) {
+        // o-proj: the block merges the attention split partials once (every thread one 8-element chunk per row), through LDS
+        issue(wa, 0);
+        const int nch = K >> 3;
+        for (int c = tid; c < nch; c += KM_NT) {
+            unsigned char* dst = xlds + (size_t)c * 16;
+            switch (p.nsplit) {
+                case 1: km_merge_rows<1>(p.attn_part, dst, K * 2, B, p.Hq, c); break;
+                case 2: km_merge_rows<2>(p.attn_part, dst, K * 2, B, p.Hq, c); break;
+                case 4: km_merge_rows<4>(p.attn_part, dst, K * 2, B, p.Hq, c); break;
+                case 8: km_merge_rows<8>(p.attn_part, dst, K * 2, B, p.Hq, c); break;
+                default:
+                    for (int b = 0; b < B; ++b)
+                        *(u32x4_t*)(dst + (size_t)b * K * 2) =
+                            attn_merge_chunk_loop(p.attn_part + (size_t)(b * p.Hq + (c >> 4)) * p.nsplit * PSTRIDE, (c & 15) * 8, p.nsplit);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < KM_STEPS; ++s) {
+            const int k0 = (wave * ksl + s) * 32 + g4 * 8;
+            const u32x4_t v = (s < ksl && c16 < B) ? *(const u32x4_t*)(xlds + ((size_t)c16 * K + k0) * 2) : (u32x4_t){0u, 0u, 0u, 0u};
+            xf[s] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    } else {
+        unsigned char* xw = xlds + (size_t)wave * EMMAX_MAX_DECODE_BATCH * XPITCH;   // this wave's window: [8 rows][XPITCH]
+        const bool mine = lane < ksl * 4;                                            // 16-byte chunks of the slice
+        const int ch = min(lane, ksl * 4 - 1);
+        u32x4_t xr[EMMAX_MAX_DECODE_BATCH];
+#pragma unroll
+        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b)
+            xr[b] = *((const u32x4_t*)((const bf16_t*)p.x + (size_t)min(b, B - 1) * p.ldx + wave * ksl * 32) + ch);
+        u32x4_t nwv = {0u, 0u, 0u, 0u};
+        if constexpr (NORM) nwv = *((const u32x4_t*)((const bf16_t*)p.norm_w + wave * ksl * 32) + ch);
+        issue(wa, 0);   // behind the activation requests: those are waited for by count while the first tile is in flight
+#pragma unroll
+        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b) {
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t v = (mine && b < B) ? xr[b][e] : 0u;
+                if constexpr (NORM) {
+                    const float a = bf_lo(v), c = bf_hi(v);
+                    ss += a * a + c * c;
+                    v = pack_bf16x2(a * bf_lo(nwv[e]), c * bf_hi(nwv[e]));
+                }
+                xr[b][e] = v;
+            }
+            if constexpr (NORM) {
+                const float t = wave_sum(ss);
+                if (lane == 0) sumsq[wave * 16 + b] = t;
+            }
+            *(u32x4_t*)(xw + (size_t)b * XPITCH + (size_t)lane * 16) = xr[b];   // lanes past the slice write zeros (never read)
+        }
+        // wave-private: the reads below only need this wave's own LDS writes to have landed (hipcc's lgkmcnt), no barrier
+#pragma unroll
+        for (int s = 0; s < KM_STEPS; ++s) {
+            const u32x4_t v = (s < ksl && c16 < B) ? *(const u32x4_t*)(xw + (size_t)c16 * XPITCH + (size_t)(s * 4 + g4) * 16) : (u32x4_t){0u, 0u, 0u, 0u};
+            xf[s] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+    issue(wb, 1);   // the second tile once the prologue's temporaries are dead (all of them next to two tiles would not fit 256 VGPRs)
+
+    // ---- main loop: two tiles per trip (register sets a / b); a set is consumed MFMA by MFMA and refilled with the tile two ahead ----
+    auto run_tile = [&](u32x4_t (&w)[NSTEP], int tl) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            if constexpr (FP8) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(km_fp8x8(w[s][0], w[s][1]), xf[2 * s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(km_fp8x8(w[s][2], w[s][3]), xf[2 * s + 1], acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[s]), xf[s], acc, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        issue(w, tl + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tl < ntb) *(f32x4_t*)(part + ((size_t)(wave * tiles_cap + tl) * 64 + lane) * 4) = acc;
+    };
+    for (int tl = 0; tl < ntb; tl += 2) {
+        run_tile(wa, tl);
+        run_tile(wb, tl + 1);
+    }
+    __syncthreads();
+
+    // ---- epilogue: thread (tl, l): rows 4 (l >> 4) + j of tile tl, batch column l & 15 ----
+    float v[4] = {0.f, 0.f, 0.f, 0.f}, u[4] = {0.f, 0.f, 0.f, 0.f};   // u: the partner rows r + 8 (qkv, gate/up)
+    if (e_on) {
+#pragma unroll
+        for (int w = 0; w < KM_WAVES; ++w) {
+            const f32x4_t a = *(const f32x4_t*)(part + ((size_t)(w * tiles_cap + e_tl) * 64 + e_l) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += a[j];
+            if (e_pairs) {
+                const f32x4_t b2 = *(const f32x4_t*)(part + ((size_t)(w * tiles_cap + e_tl) * 64 + e_l + 32) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) u[j] += b2[j];
+            }
+        }
+        float sc = 1.f;
+        if constexpr (NORM) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < KM_WAVES; ++w) t += sumsq[w * 16 + e_c];
+            sc = rsqrtf(t / (float)K + p.eps);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float sv = sc, su = sc;
+            if constexpr (FP8) {
+                sv *= p.wscale[e_tile * 16 + 4 * e_rq + j];
+                if (e_pairs) su *= p.wscale[e_tile * 16 + 8 + 4 * e_rq + j];
+            }
+            v[j] *= sv;
+            u[j] *= su;
+        }
+    }
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    if (e_on) {
+        const int row0 = e_tile * 16 + 4 * e_rq;   // natural-order matrices
+        if (MODE == GEMV_PLAIN) {
+            bf16_t* yp = (bf16_t*)p.y + (size_t)e_c * p.ldy + row0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) yp[j] = f2bf(v[j]);
+        } else if (MODE == GEMV_RESID) {
+            bf16_t* hp = (bf16_t*)p.y + (size_t)e_c * p.ldy + row0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hp[j] = f2bf(pre_a[j] + v[j]);
+        } else if (MODE == GEMV_GATEUP) {
+            bf16_t* yp = (bf16_t*)p.y + (size_t)e_c * p.ldy + 8 * e_tile + 4 * e_rq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) yp[j] = f2bf(silu(v[j]) * u[j]);
+        } else if (MODE == GEMV_QKV) {
+            const int hd = p.head_dim, half = hd >> 1, tph = hd / 16;
+            const int hb = e_tile / tph, d0 = 8 * (e_tile - hb * tph) + 4 * e_rq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = d0 + j;
+                // linear outputs are bf16 activations in the reference; RoPE acts on those
+                const float x0 = bf2f(f2bf(v[j])), x1 = bf2f(f2bf(u[j]));
+                if (hb < p.Hq + p.Hkv) {
+                    const bf16_t y0 = f2bf(x0 * pre_a[j] - x1 * pre_b[j]), y1 = f2bf(x1 * pre_a[j] + x0 * pre_b[j]);
+                    if (hb < p.Hq) {
+                        bf16_t* q = (bf16_t*)p.y + (size_t)e_c * p.ldy + hb * hd;
+                        q[d] = y0;
+                        q[d + half] = y1;
+                    } else {
+                        bf16_t* kc = (bf16_t*)p.kcache + (((size_t)pre_pg * p.Hkv + (hb - p.Hq)) * p.page + pre_pos % p.page) * hd;
+                        kc[d] = y0;
+                        kc[d + half] = y1;
+                    }
+                } else {
+                    bf16_t* vc = (bf16_t*)p.vcache + (((size_t)pre_pg * p.Hkv + (hb - p.Hq - p.Hkv)) * p.page + pre_pos % p.page) * hd;
+                    vc[d] = f2bf(x0);
+                    vc[d + half] = f2bf(x1);
+                }
+            }
+        } else if (MODE == GEMV_LMHEAD) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = row0 + j;
+                if (row < p.n_rows) {
+                    if (v[j] > best) { best = v[j]; besti = row; }   // rows ascend: the first index wins ties
+                    if (p.logits_out) p.logits_out[(size_t)e_c * p.n_rows + row] = v[j];
+                }
+            }
+        }
+    }
+    if (MODE == GEMV_LMHEAD) {
+        // block best per batch column: the 32 slots (tile, row quarter) of a column through LDS; first index wins ties
+        __syncthreads();                      // every thread has read its partial sums
+        float* bv = part;                     // [512]
+        int* bi = (int*)(part + KM_NT);       // [512]
+        bv[tid] = best;
+        bi[tid] = besti;
+        __syncthreads();
+        if (tid < B) {
+            float v0 = -INFINITY;
+            int i0 = 0x7fffffff;
+            for (int tl = 0; tl < KM_WAVES; ++tl)
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int e = tl * 64 + rq * 16 + tid;
+                    const float x = bv[e];
+                    const int ii = bi[e];
+                    if (x > v0 || (x == v0 && ii < i0)) { v0 = x; i0 = ii; }
+                }
+            p.part_val[(size_t)bid * B + tid] = v0;
+            p.part_idx[(size_t)bid * B + tid] = i0;
+        }
+    }
+}
+
+template <int MODE, bool NORM, bool XATTN, bool FP8>
+int km_launch_t(GemvParams p, int B, hipStream_t stream, int* grid_out) {
+    constexpr int KS = FP8 ? 64 : 32;
+    if (p.K % (KM_WAVES * KS) || p.K > KM_WAVES * KM_STEPS * 32 || p.n_rows % 16) return -2;
+    if (MODE == GEMV_QKV && (p.head_dim % 16 || p.head_dim < 16)) return -2;
+    p.batch = B;
+    p.n_groups = p.n_rows / 16;   // tiles
+    int grid = min(256, p.n_groups);
+    if (MODE == GEMV_LMHEAD) grid = min(grid, p.max_parts);
+    if (grid < 1) return -2;
+    p.kc = cdiv(p.n_groups, grid);
+    if (p.kc > KM_MAX_TILES) return -2;
+    if (p.kc & 1) p.kc += 1;   // the loop runs tiles in pairs
+    const size_t smem = (size_t)KM_WAVES * p.kc * 1024 + KM_WAVES * 16 * 4 +
+                        (XATTN ? (size_t)B * p.K * 2 : (size_t)KM_WAVES * EMMAX_MAX_DECODE_BATCH * (KM_STEPS * 64 + 16));
+    if (smem > 150 * 1024) return -2;
+    auto kern = emmax_decode_km_kernel<MODE, NORM, XATTN, FP8>;
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return -4;
+        raised = true;
+    }
+    if (grid_out) *grid_out = grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(KM_NT), smem, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+template <bool FP8>
+int km_launch_mode(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
+    switch (mode) {
+        case GEMV_QKV: return km_launch_t<GEMV_QKV, true, false, FP8>(p, B, stream, grid_out);
+        case GEMV_RESID:
+            if (p.attn_part && p.K != p.Hq * 128) return -2;
+            return p.attn_part ? km_launch_t<GEMV_RESID, false, true, FP8>(p, B, stream, grid_out) : km_launch_t<GEMV_RESID, false, false, FP8>(p, B, stream, grid_out);
+        case GEMV_GATEUP: return km_launch_t<GEMV_GATEUP, true, false, FP8>(p, B, stream, grid_out);
+        case GEMV_LMHEAD: return km_launch_t<GEMV_LMHEAD, true, false, FP8>(p, B, stream, grid_out);
+        case GEMV_PLAIN: return km_launch_t<GEMV_PLAIN, false, false, FP8>(p, B, stream, grid_out);
+        default: return -2;
+    }
+}
+
+}  // namespace
+
+// tuning hook: EMMAX_KM=0 keeps every batch >= 3 projection on decode_mfma.hip (the A/B partner)
+bool decode_km_enabled() {
+    const char* e = getenv("EMMAX_KM");
+    return !(e && atoi(e) == 0);
+}
+
+// perm: 0 natural row order, 1 qkv (head_dim given), 2 gate/up (source in decode.hip's 16-row interleaved order)
+int launch_repack_km(const void* src, int ld, void* dst, int N, int K, int perm, int head_dim, hipStream_t stream) {
+    if (N % 16 || K % 32 || ld % 8) return -1;
+    if (perm == 1 && (head_dim % 16 || N % head_dim)) return -1;
+    if (perm == 2 && N % 32) return -1;
+    hipLaunchKernelGGL(emmax_repack_km_kernel, dim3(2048), dim3(256), 0, stream, (const bf16_t*)src, ld, (u32x4_t*)dst, N, K, perm, head_dim);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// p.W: the km copy of the matrix (launch_repack_km; fp8: decode_mfma.hip's e4m3 tiles of the permuted rows + p.wscale in the same
+// row order).  -2: shape outside this kernel (K % 256, K > 4096, more than 8 tiles per block) -- the caller uses decode_mfma.hip.
+int launch_decode_km(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
+    if (B < 1 || B > EMMAX_MAX_DECODE_BATCH) return -2;
+    return p.wscale ? km_launch_mode<true>(mode, p, B, stream, grid_out) : km_launch_mode<false>(mode, p, B, stream, grid_out);
+}

@@ -207,6 +207,7 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, const KsLink lk, 
                                           int rows_cap, float (&keep)[2], NextHead&& next_head, int trace_op = -1) {
     constexpr int RB = KsShape<B, CPL>::RB;
     KS_STAMP(trace_op, 0, wall_clock64());
+    if ((p.ks_flags & 1) && blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = p.K, bid = blockIdx.x;
     int g_lo, npairs;
@@ -300,7 +301,10 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, const KsLink lk, 
                 for (int j = 0; j < CPL; ++j) xr[b][j] = *((const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx) + coff[j]);
         }
         // right behind the activations: they are waited for by count while the head of the stream is in flight
-        if constexpr (OWN_HEAD) ks_issue<B, MODE, CPL>(p, g_lo, nrows, 0, voff, wr);
+        if constexpr (OWN_HEAD) {
+            if (p.ks_flags & 2) __builtin_amdgcn_s_barrier();
+            ks_issue<B, MODE, CPL>(p, g_lo, nrows, 0, voff, wr);
+        }
         float ss[B];
 #pragma unroll
         for (int b = 0; b < B; ++b) {
@@ -543,6 +547,7 @@ int ks_launch_t(GemvParams p, hipStream_t stream, int* grid_out) {
     if (pairs_max > 64) return -2;   // the epilogue maps one lane to a pair
     p.kc = cdiv(2 * pairs_max, RB) * RB;
     p.ks_unit = 1;
+    p.ks_flags = getenv("EMMAX_KS_FLAGS") ? atoi(getenv("EMMAX_KS_FLAGS")) : 0;
     const size_t smem = (size_t)(KS_WAVES * B * p.kc + KS_WAVES * B) * sizeof(float);
     if (grid_out) *grid_out = grid;
     hipLaunchKernelGGL((emmax_decode_ks_kernel<B, MODE, NORM, XATTN, CPL>), dim3(grid), dim3(KS_NT), smem, stream, p);

@@ -39,11 +39,12 @@ __global__ __launch_bounds__(256) void emmax_repack_fm_kernel(const bf16_t* __re
 //   fm8[((n/16)*(K/64) + k/64) * 64 + lane] = 16 bytes: W8[row][64*(k/64) + 8g .. +8] ++ W8[row][64*(k/64) + 32 + 8g .. +8]
 //   with row = 16*(n/16) + (lane & 15), g = lane >> 4: one 16-byte load feeds two v_mfma_f32_16x16x32_bf16 k-steps.
 // One block per row.  N % 16 == 0, K % 64 == 0.
+// perm / head_dim: row order of the copy (km_src_row, common.h; 0 = natural): dst row n holds source row km_src_row(.., n / 16, n % 16)
 __global__ __launch_bounds__(256) void emmax_quant_fm8_kernel(const bf16_t* __restrict__ src, int ld, uint8_t* __restrict__ dst,
-                                                             float* __restrict__ scales, int N, int K) {
+                                                             float* __restrict__ scales, int N, int K, int perm, int head_dim) {
     const int n = blockIdx.x, tid = threadIdx.x;
     __shared__ float red[4];
-    const bf16_t* row = src + (size_t)n * ld;
+    const bf16_t* row = src + (size_t)km_src_row(perm, head_dim, n >> 4, n & 15) * ld;
     float amax = 0.f;
     for (int c = tid; c < K / 8; c += 256) {
         const u32x4_t v = *(const u32x4_t*)(row + c * 8);
@@ -732,9 +733,10 @@ int launch_decode_mfma(int mode, const GemvParams& p, int B, hipStream_t stream,
     return p.wscale ? launch_mfma_mode<true>(mode, p, B, stream, grid_out) : launch_mfma_mode<false>(mode, p, B, stream, grid_out);
 }
 
-int launch_quant_fm8(const void* src, int ld, void* dst, float* scales, int N, int K, hipStream_t stream) {
+int launch_quant_fm8(const void* src, int ld, void* dst, float* scales, int N, int K, hipStream_t stream, int perm, int head_dim) {
     if (N % 16 || K % 64 || ld % 8) return -1;
-    hipLaunchKernelGGL(emmax_quant_fm8_kernel, dim3(N), dim3(256), 0, stream, (const bf16_t*)src, ld, (uint8_t*)dst, scales, N, K);
+    if ((perm == 1 && (head_dim % 16 || head_dim < 16 || N % head_dim)) || (perm == 2 && N % 32) || perm < 0 || perm > 2) return -1;
+    hipLaunchKernelGGL(emmax_quant_fm8_kernel, dim3(N), dim3(256), 0, stream, (const bf16_t*)src, ld, (uint8_t*)dst, scales, N, K, perm, head_dim);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

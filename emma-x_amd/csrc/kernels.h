@@ -117,6 +117,8 @@ struct GemvParams {
     int max_grid;           // 0: default persistent grid; > 0: cap (the K-split o-proj with the split merge runs one block per CU)
     int ks_shift;           // K-split kernel, QKV, set by its launcher: log2(head_dim / 2)
     int ks_unit;            // K-split kernel, set by its launcher: pairs per unit of the block shares (2: gate/up inside a chain)
+    int ks_flags;           // K-split kernel, lab (EMMAX_KS_FLAGS): 1 = raise the wave priority of the blocks dispatched second,
+                            // 2 = block barrier between the activation requests and the weight head
 };
 int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
 // decode_ks.hip: the batch 1-2 bf16 projections with K split across the waves of a block (activation slice in registers, no
@@ -175,9 +177,16 @@ int launch_set_tokens(int32_t* cur_tok, const int32_t* toks, int B, int32_t* don
                       int budget, hipStream_t stream);
 
 
+// ---- decode_km.hip: batch 3-8 projections with K <= 4096 on MFMA, K split across the waves, activations as register fragments ----
+// p.W = the km copy (launch_repack_km: fragment-major tiles; perm 1 / 2 = the row orders that put the qkv RoPE pairs / the
+// (gate, up) pairs inside one 16-row tile).  -2: shape outside the kernel, the caller falls back to launch_decode_mfma.
+int launch_repack_km(const void* src, int ld, void* dst, int N, int K, int perm, int head_dim, hipStream_t stream);
+int launch_decode_km(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
+bool decode_km_enabled();
+
 // ---- decode_mfma.hip: small-batch (B >= 3) projections on MFMA over the fragment-major weight copy ----
 int launch_repack_fm(const void* src, int ld, void* dst, int N, int K, hipStream_t stream);
-int launch_quant_fm8(const void* src, int ld, void* dst, float* scales, int N, int K, hipStream_t stream);   // fp8 e4m3 + per-row scale
+int launch_quant_fm8(const void* src, int ld, void* dst, float* scales, int N, int K, hipStream_t stream, int perm = 0, int head_dim = 0);   // fp8 e4m3 + per-row scale
 bool decode_gemv_fp8_fits(int B, int K);   // the fp8 row GEMV takes this (batch, K); else the MFMA kernel serves it
 int launch_quant_rm8(const void* src, int ld, void* dst, float* scales, int N, int K, hipStream_t stream);   // same values, rows in the GEMV's span order
 int launch_decode_mfma(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);   // p.W = fragment-major copy

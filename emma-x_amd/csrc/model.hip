@@ -70,6 +70,8 @@ struct TowerW {
 struct LayerW {
     bf16 *ln1, *wqkv, *wo, *ln2, *wgu, *wdown;
     bf16 *wqkv_fm, *wo_fm, *wgu_fm, *wdown_fm;   // MFMA-fragment-major copies for the B >= 3 decode path (fp8 mode: e4m3 tiles)
+    bf16 *wqkv_km, *wgu_km;                      // ... in the row orders of decode_km.hip (RoPE pairs / (gate, up) pairs inside a 16-row tile)
+    float *wqkv_km_sc, *wgu_km_sc;               // fp8 mode: their per-row scales, in the same row order
     float *wqkv_sc, *wo_sc, *wgu_sc, *wdown_sc;  // fp8 mode: per-row scales (null otherwise)
     bf16 *wqkv_r8, *wo_r8, *wgu_r8, *wdown_r8;   // fp8 mode: the same e4m3 values as rows in the GEMV's span order (batch 1-2)
 };
@@ -192,6 +194,9 @@ static void plan_arena(emmax_model* m, Bump& b) {
         L.wo_fm = b.take((int64_t)m->H * m->q_dim / d);
         L.wgu_fm = b.take((int64_t)2 * m->inter_p * m->H / d);
         L.wdown_fm = b.take((int64_t)m->H * m->inter_p / d);
+        L.wqkv_km = b.take((int64_t)m->qkv_dim * m->H / d);
+        L.wgu_km = b.take((int64_t)2 * m->inter_p * m->H / d);
+        L.wqkv_km_sc = L.wgu_km_sc = nullptr;
         L.wqkv_sc = L.wo_sc = L.wgu_sc = L.wdown_sc = nullptr;
         L.wqkv_r8 = L.wo_r8 = L.wgu_r8 = L.wdown_r8 = nullptr;
         if (m->fp8) {
@@ -203,6 +208,8 @@ static void plan_arena(emmax_model* m, Bump& b) {
             L.wo_sc = (float*)b.take(2 * (int64_t)m->H);
             L.wgu_sc = (float*)b.take(4 * (int64_t)m->inter_p);
             L.wdown_sc = (float*)b.take(2 * (int64_t)m->H);
+            L.wqkv_km_sc = (float*)b.take(2 * (int64_t)m->qkv_dim);
+            L.wgu_km_sc = (float*)b.take(4 * (int64_t)m->inter_p);
         }
     }
     m->final_norm = b.take(m->H);
@@ -456,8 +463,10 @@ static bool fp8_rows(const emmax_model* m, int B, int K, int bit) {
 
 // B <= 2: per-lane dot-product GEMV over the row-major weights (fp8 mode: over the e4m3 row copy w_r8);
 // B >= 3: MFMA over the fragment-major copy
+// w_km / km_scale: the matrix in decode_km.hip's layout (null: that kernel does not serve this projection)
 static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_fm, int B, hipStream_t st, int* grid_out = nullptr,
-                       const float* w_scale = nullptr, const void* w_r8 = nullptr, int f8bit = 0) {
+                       const float* w_scale = nullptr, const void* w_r8 = nullptr, int f8bit = 0, const void* w_km = nullptr,
+                       const float* km_scale = nullptr) {
     if (B < EMMAX_MFMA_MIN_BATCH && w_scale && w_r8 && (fp8_gemv_mask() & f8bit) && decode_gemv_fp8_fits(B, p.K)) {
         p.W = w_r8;
         p.wscale = w_scale;
@@ -465,6 +474,13 @@ static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_
         return launch_decode_gemv(mode, p, B, st, grid_out);
     }
     if (B >= EMMAX_MFMA_MIN_BATCH || w_scale) {
+        if (B >= EMMAX_MFMA_MIN_BATCH && w_km && decode_km_enabled()) {   // K <= 4096: the K-split MFMA kernel (decode_km.hip)
+            GemvParams q = p;
+            q.W = w_km;
+            q.wscale = w_scale ? km_scale : nullptr;
+            const int r = launch_decode_km(mode, q, B, st, grid_out);
+            if (r != -2) return r;
+        }
         p.W = w_fm;
         p.wscale = w_scale;
         return launch_decode_mfma(mode, p, B, st, grid_out);
@@ -505,7 +521,7 @@ static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* log
     GemvParams p;
     lmhead_params(s, slot0, logits_out, p);
     int lm_grid = 0;
-    KCHK(launch_proj(GEMV_LMHEAD, p, m->lm_head, m->lm_head_fm, B, st, &lm_grid, m->lm_head_sc, m->lm_head_r8, F8_LMHEAD));
+    KCHK(launch_proj(GEMV_LMHEAD, p, m->lm_head, m->lm_head_fm, B, st, &lm_grid, m->lm_head_sc, m->lm_head_r8, F8_LMHEAD, m->lm_head_fm, m->lm_head_sc));
     if (do_finish) return launch_finish_step(s, B, is_prefill, lm_grid, slot0, st);
     return 0;
 }
@@ -643,7 +659,7 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
     switch (stage) {
         case STAGE_QKV:
             stage_params(s, B, li, stage, p);
-            KCHK(launch_proj(GEMV_QKV, p, L.wqkv, L.wqkv_fm, B, st, &grid, L.wqkv_sc, L.wqkv_r8, F8_QKV));
+            KCHK(launch_proj(GEMV_QKV, p, L.wqkv, L.wqkv_fm, B, st, &grid, L.wqkv_sc, L.wqkv_r8, F8_QKV, L.wqkv_km, L.wqkv_km_sc));
             return 0;
         case STAGE_ATTN: {
             DecodeAttnParams a;
@@ -658,11 +674,13 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
         }
         case STAGE_OPROJ:
             stage_params(s, B, li, stage, p);
-            KCHK(launch_proj(GEMV_RESID, p, L.wo, L.wo_fm, B, st, &grid, L.wo_sc, L.wo_r8, F8_OPROJ));
+            // o-proj at batch >= 3: the K-split MFMA kernel with fp8 weights (10.3 against 10.8 us at B = 8), decode_mfma.hip with bf16
+            // (12.5 against 15.4: the split merge of 8 rows queues behind the 16 KiB weight heads of the K-split kernel)
+            KCHK(launch_proj(GEMV_RESID, p, L.wo, L.wo_fm, B, st, &grid, L.wo_sc, L.wo_r8, F8_OPROJ, m->fp8 ? L.wo_fm : nullptr, L.wo_sc));
             return 0;
         case STAGE_GATEUP:
             stage_params(s, B, li, stage, p);
-            KCHK(launch_proj(GEMV_GATEUP, p, L.wgu, L.wgu_fm, B, st, &grid, L.wgu_sc, L.wgu_r8, F8_GATEUP));
+            KCHK(launch_proj(GEMV_GATEUP, p, L.wgu, L.wgu_fm, B, st, &grid, L.wgu_sc, L.wgu_r8, F8_GATEUP, L.wgu_km, L.wgu_km_sc));
             return 0;
         case STAGE_DOWN:
             stage_params(s, B, li, stage, p);
@@ -903,7 +921,11 @@ int emmax_model_finalize(emmax_model* m, void* arena, int64_t arena_bytes, emmax
             KCHK(launch_quant_rm8(L.wo, m->q_dim, L.wo_r8, L.wo_sc, m->H, m->q_dim, st));
             KCHK(launch_quant_rm8(L.wgu, m->H, L.wgu_r8, L.wgu_sc, 2 * m->inter_p, m->H, st));
             KCHK(launch_quant_rm8(L.wdown, m->inter_p, L.wdown_r8, L.wdown_sc, m->H, m->inter_p, st));
+            KCHK(launch_quant_fm8(L.wqkv, m->H, L.wqkv_km, L.wqkv_km_sc, m->qkv_dim, m->H, st, 1, m->cfg.head_dim));
+            KCHK(launch_quant_fm8(L.wgu, m->H, L.wgu_km, L.wgu_km_sc, 2 * m->inter_p, m->H, st, 2, 0));
         } else {
+            KCHK(launch_repack_km(L.wqkv, m->H, L.wqkv_km, m->qkv_dim, m->H, 1, m->cfg.head_dim, st));
+            KCHK(launch_repack_km(L.wgu, m->H, L.wgu_km, 2 * m->inter_p, m->H, 2, 0, st));
             KCHK(launch_repack_fm(L.wqkv, m->H, L.wqkv_fm, m->qkv_dim, m->H, st));
             KCHK(launch_repack_fm(L.wo, m->q_dim, L.wo_fm, m->H, m->q_dim, st));
             KCHK(launch_repack_fm(L.wgu, m->H, L.wgu_fm, 2 * m->inter_p, m->H, st));
@@ -1464,6 +1486,19 @@ int emmax_op_gemm_small_fp8(const void* x, const void* W8, const float* scales, 
 int emmax_op_repack_fm(const void* W, int ld, void* W_fm, int N, int K, emmax_stream st) {
     int r = launch_repack_fm(W, ld, W_fm, N, K, (hipStream_t)st);
     if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_repack_fm: N %% 16, K %% 32, ld %% 8 required");
+    return 0;
+}
+int emmax_op_repack_km(const void* W, int ld, void* W_km, int N, int K, int perm, int head_dim, emmax_stream st) {
+    int r = launch_repack_km(W, ld, W_km, N, K, perm, head_dim, (hipStream_t)st);
+    if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_repack_km: N %% 16, K %% 32, ld %% 8 (perm 1: N %% head_dim, head_dim %% 16; perm 2: N %% 32) required");
+    return 0;
+}
+int emmax_op_gemm_small_km(const void* x, const void* W_km, void* y, int B, int N, int K, emmax_stream st) {
+    GemvParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.ldx = K; p.W = W_km; p.ldw = K; p.K = K; p.y = y; p.ldy = N; p.n_rows = N;
+    int r = launch_decode_km(GEMV_PLAIN, p, B, (hipStream_t)st);
+    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_gemm_small_km: unsupported shape (1 <= B <= 8, N %% 16, K %% 256, K <= 4096, N <= 32768)");
     return 0;
 }
 int emmax_op_gemm_small(const void* x, const void* W_fm, void* y, int B, int N, int K, emmax_stream st) {

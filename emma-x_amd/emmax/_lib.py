@@ -97,6 +97,8 @@ SIGNATURES = {
     "emmax_op_gemv_fp8": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "emmax_op_repack_fm": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp]),
     "emmax_op_gemm_small": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "emmax_op_repack_km": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "emmax_op_gemm_small_km": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

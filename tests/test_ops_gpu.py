@@ -326,6 +326,36 @@ def test_gemm_small_mfma(device, B, N, K):
     assert_elementwise(y, ref)
 
 
+@pytest.mark.parametrize("B", [3, 5, 8])
+@pytest.mark.parametrize("N,K", [(256, 256), (4096, 4096), (12288, 4096), (32064, 4096), (1008, 1024), (48, 2048)])
+def test_gemm_small_km(device, B, N, K):
+    """Batch 3-8 decode projection on the K-split MFMA kernel (decode_km.hip): activations as register fragments, two tiles in
+    flight per wave, partial tiles of the eight K slices meeting in LDS.  N covers 1 .. 8 tiles per block and ragged shares."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(B * 11 + N + K)
+    x = bf(torch.randn(B, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    ref = x.float() @ W.float().t()
+    xd, Wd = x.to(device), W.to(device)
+    Wk = torch.empty_like(Wd)
+    y = torch.full((B, N), float("nan"), dtype=torch.bfloat16, device=device)
+    L.check(lib.emmax_op_repack_km(Wd.data_ptr(), K, Wk.data_ptr(), N, K, 0, 0, stream()), "repack km")
+    L.check(lib.emmax_op_gemm_small_km(xd.data_ptr(), Wk.data_ptr(), y.data_ptr(), B, N, K, stream()), "gemm small km")
+    torch.cuda.synchronize()
+    assert relerr(y, ref) < TOL
+    assert_elementwise(y, ref)
+
+
+def test_gemm_small_km_refuses_shapes_outside_it(device):
+    L, lib = _lib()
+    x = torch.zeros(8, 11008, dtype=torch.bfloat16, device=device)
+    W = torch.zeros(64 * 11008, dtype=torch.bfloat16, device=device)
+    y = torch.zeros(8, 64, dtype=torch.bfloat16, device=device)
+    for B, N, K in [(4, 64, 11008), (4, 64, 320), (9, 64, 256), (4, 40, 256)]:
+        assert lib.emmax_op_gemm_small_km(x.data_ptr(), W.data_ptr(), y.data_ptr(), B, N, K, stream()) != 0, (B, N, K)
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("H,W", [(256, 256), (480, 640), (224, 300), (100, 180), (500, 224)])
 def test_device_resize_matches_pillow(device, H, W):
     """Device-side resize-naive == PIL.Image.resize((224,224), BICUBIC) bit for bit (uint8)."""

@@ -1,6 +1,8 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "small_km" 2>&1 | tail -5
+timeout 900 python -m pytest tests/test_operating_point_gpu.py tests/test_fullsize_gpu.py -x -q -m gpu 2>&1 | tail -5
 run() { # label, bench args..., env via ENVV
   label=$1; shift
   env $ENVV timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" 2>&1 | tail -1 > gpurun_out/r3_bench_$label.json
@@ -13,8 +15,7 @@ except Exception as e:
     print("$label failed", e, open("gpurun_out/r3_bench_$label.json").read()[:500])
 PY
 }
-ENVV="EMMAX_MFMA_XBAR=1" run b8_xbar1 --batch-per-gpu 8
-ENVV="EMMAX_MFMA_XBAR=0" run b8_xbar0 --batch-per-gpu 8
-ENVV="EMMAX_MFMA_XBAR=1" run f8b8_xbar1 --batch-per-gpu 8 --fp8
-ENVV="EMMAX_MFMA_XBAR=0" run f8b8_xbar0 --batch-per-gpu 8 --fp8
-timeout 900 python -m pytest tests/test_operating_point_gpu.py tests/test_ops_gpu.py -q -m gpu -k "B8 or mfma or fp8" 2>&1 | tail -3
+ENVV="EMMAX_KM=1" run b8_km1 --batch-per-gpu 8
+ENVV="EMMAX_KM=0" run b8_km0 --batch-per-gpu 8
+ENVV="EMMAX_KM=1" run f8b8_km1 --batch-per-gpu 8 --fp8
+ENVV="EMMAX_KM=0" run f8b8_km0 --batch-per-gpu 8 --fp8
