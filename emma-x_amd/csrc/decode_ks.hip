@@ -296,9 +296,17 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, const KsLink lk, 
             }
         } else {
 #pragma unroll
-            for (int b = 0; b < B; ++b)
+            for (int b = 0; b < B; ++b) {
+                // layer 0: the row is the embedding of the current token (the embed launch folded in); block 0 leaves a copy in the
+                // residual stream for the o-proj's "+ residual"
+                size_t row = (size_t)b;
+                if (p.x_tok) row = (size_t)min(max(p.x_tok[b], 0), p.x_vocab - 1);
 #pragma unroll
-                for (int j = 0; j < CPL; ++j) xr[b][j] = *((const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx) + coff[j]);
+                for (int j = 0; j < CPL; ++j) {
+                    xr[b][j] = *((const u32x4_t*)((const bf16_t*)p.x + row * p.ldx) + coff[j]);
+                    if (p.x_tok && blockIdx.x == 0 && cok[j]) *((u32x4_t*)((bf16_t*)p.x_copy + (size_t)b * p.ldx) + coff[j]) = xr[b][j];
+                }
+            }
         }
         // right behind the activations: they are waited for by count while the head of the stream is in flight
         if constexpr (OWN_HEAD) {

@@ -117,6 +117,9 @@ struct GemvParams {
     int max_grid;           // 0: default persistent grid; > 0: cap (the K-split o-proj with the split merge runs one block per CU)
     int ks_shift;           // K-split kernel, QKV, set by its launcher: log2(head_dim / 2)
     int ks_unit;            // K-split kernel, set by its launcher: pairs per unit of the block shares (2: gate/up inside a chain)
+    const int32_t* x_tok;   // K-split kernel, non-null: x row b = x[x_tok[b]] (p.x = embedding table, ids clamped to x_vocab): the embed launch
+    void* x_copy;           //   folded into layer 0's qkv; block 0 also copies the rows to x_copy [B, ldx] (the residual stream)
+    int x_vocab;
     int ks_flags;           // K-split kernel, lab (EMMAX_KS_FLAGS): 1 = raise the wave priority of the blocks dispatched second,
                             // 2 = block barrier between the activation requests and the weight head
 };

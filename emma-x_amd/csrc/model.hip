@@ -675,7 +675,8 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
         case STAGE_OPROJ:
             stage_params(s, B, li, stage, p);
             // o-proj at batch >= 3: the K-split MFMA kernel with fp8 weights (10.3 against 10.8 us at B = 8), decode_mfma.hip with bf16
-            // (12.5 against 15.4: the split merge of 8 rows queues behind the 16 KiB weight heads of the K-split kernel)
+            // (12.5 against 15.4: the split merge of 8 rows queues behind the 16 KiB weight heads of the K-split kernel; merging all
+            // rows at once AHEAD of the heads: 14.3, and 11.8 for fp8 -- not kept)
             KCHK(launch_proj(GEMV_RESID, p, L.wo, L.wo_fm, B, st, &grid, L.wo_sc, L.wo_r8, F8_OPROJ, m->fp8 ? L.wo_fm : nullptr, L.wo_sc));
             return 0;
         case STAGE_GATEUP:
@@ -748,13 +749,31 @@ static int run_decode_step_pchain(emmax_session* s, int B, hipStream_t st) {
     return launch_finish_step(s, B, false, s->pc_lm_grid, 0, st);
 }
 
+// layer 0's qkv with the embedding gather folded in (K-split kernel; anything else: embed launch + the plain stage)
+static int run_qkv0_with_embed(emmax_session* s, int B, hipStream_t st) {
+    emmax_model* m = s->m;
+    GemvParams p;
+    stage_params(s, B, 0, STAGE_QKV, p);
+    p.W = m->layers[0].wqkv;
+    p.x = m->embed; p.x_tok = s->cur_tok; p.x_copy = s->dh; p.x_vocab = m->vocab;
+    int r = launch_decode_ks(GEMV_QKV, p, B, st, nullptr);
+    if (r == -2) {
+        KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st));
+        return run_decode_stage(s, B, 0, STAGE_QKV, st);
+    }
+    return r ? fail(EMMAX_ERR_HIP, "qkv launch of layer 0 failed (code %d)", r) : 0;
+}
+
 static int run_decode_step(emmax_session* s, int B, hipStream_t st) {
     emmax_model* m = s->m;
     if (pchain_on(s, B)) return run_decode_step_pchain(s, B, st);
-    KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st));
+    // batch 1-2 on bf16 weights: the embedding row is read by layer 0's qkv launch itself (K-split kernel) -- one launch fewer
+    const bool fold_embed = B < EMMAX_MFMA_MIN_BATCH && !m->fp8 && decode_ks_enabled() && m->H % 64 == 0 && m->H <= 12288 &&
+                            !(getenv("EMMAX_FOLD_EMBED") && atoi(getenv("EMMAX_FOLD_EMBED")) == 0);
+    if (!fold_embed) KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st));
     for (int li = 0; li < m->cfg.n_layers; ++li)
         for (int stage = STAGE_QKV; stage <= STAGE_DOWN; ++stage) {
-            int r = run_decode_stage(s, B, li, stage, st);
+            int r = (li == 0 && stage == STAGE_QKV && fold_embed) ? run_qkv0_with_embed(s, B, st) : run_decode_stage(s, B, li, stage, st);
             if (r) return r;
         }
     return run_lm_head_step(s, B, false, nullptr, true, st);
