@@ -142,12 +142,12 @@ def cpu_baseline(cfg, prompt_tokens, new_tokens, seed=0, decode_steps=16, distin
 
 
 def _profiled_single_gpu(args, B):
-    """The committed 1-GPU rate of the SAME per-GPU workload (profiles/r02_bench_variants.jsonl), so that an N > 1 line (8
+    """The committed 1-GPU rate of the SAME per-GPU workload (profiles/r03_bench_variants.jsonl), so that an N > 1 line (8
     frames per GPU) can be read against the right N = 1 number -- the N = 1 default of this script is configs[1] (1 frame)."""
     if args.tiny or args.prompt_tokens != 512 or args.new_tokens != 512:
         return None
     try:
-        lines = list(open(os.path.join(ROOT, "profiles", "r02_bench_variants.jsonl"))) + list(open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")))
+        lines = list(open(os.path.join(ROOT, "profiles", "r03_bench_variants.jsonl"))) + list(open(os.path.join(ROOT, "profiles", "r03_bench_n1.json")))
         for line in lines:
             if not line.strip().startswith("{"):
                 continue
@@ -155,7 +155,7 @@ def _profiled_single_gpu(args, B):
             c = d.get("config", {})
             if (d.get("n_gpus") == 1 and c.get("batch_per_gpu") == B and bool(c.get("hipgraph")) == bool(args.graph)
                     and ("fp8" in d.get("dtype", "")) == bool(args.fp8)):
-                return {"value": d["value"], "unit": d["unit"], "source": "profiles/r02_bench_variants.jsonl / r02_bench_n1.json"}
+                return {"value": d["value"], "unit": d["unit"], "source": "profiles/r03_bench_variants.jsonl / r03_bench_n1.json"}
     except OSError:
         pass
     return None
@@ -306,7 +306,7 @@ def main():
             "decode_step_hbm_gbs": round(step_gbs, 1), "decode_step_hbm_frac": round(step_gbs / HBM_PEAK_GBS, 4),
             "stage_us": {k: round(v, 2) for k, v in stage_us.items()},
             "stage_gbs": {k: round(stage_bytes[k] / (stage_us[k] * 1e-6) / 1e9, 1) for k in stage_names},
-            "roofline": {"kernel": (("emmax_decode_gemv_kernel<B=%d,GATEUP,NORM,FP8 rows>" % B if args.fp8 else "emmax_decode_ks_kernel<B=%d,GATEUP,NORM,CPL=1>" % B) if B <= 2 else "emmax_decode_mfma_kernel<GATEUP,NORM%s> (B=%d)" % (",FP8" if args.fp8 else "", B)) + " (gate/up projection + SiLU*mul)", "bound": "hbm",
+            "roofline": {"kernel": (("emmax_decode_gemv_kernel<B=%d,GATEUP,NORM,FP8 rows>" % B if args.fp8 else "emmax_decode_ks_kernel<B=%d,GATEUP,NORM,CPL=1>" % B) if B <= 2 else "emmax_decode_km_kernel<GATEUP,NORM%s> (B=%d)" % (",FP8" if args.fp8 else "", B)) + " (gate/up projection + SiLU*mul)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "bytes_per_launch": stage_bytes[dom], "us_per_launch": round(stage_us[dom], 2), "traffic": traffic,
                          "traffic_source": "profiles/%s (rocprofv3 --pmc, offline)" % pmc_name if traffic else None},

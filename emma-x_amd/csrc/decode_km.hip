@@ -360,11 +360,6 @@ int km_launch_t(GemvParams p, int B, hipStream_t stream, int* grid_out) {
                         (XATTN ? (size_t)B * p.K * 2 : (size_t)KM_WAVES * EMMAX_MAX_DECODE_BATCH * (KM_STEPS * 64 + 16));
     if (smem > 150 * 1024) return -2;
     auto kern = emmax_decode_km_kernel<MODE, NORM, XATTN, FP8>;
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return -4;
-        raised = true;
-    }
     if (grid_out) *grid_out = grid;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(KM_NT), smem, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -386,6 +381,22 @@ int km_launch_mode(int mode, const GemvParams& p, int B, hipStream_t stream, int
 
 }  // namespace
 
+// raise the dynamic-LDS limit of every instantiation (call once, outside graph capture)
+int decode_km_init() {
+    static int done = -1;
+    if (done == 0) return 0;
+    const int lim = 150 * 1024;
+    hipError_t e = hipSuccess;
+#define KM_SET(M, N_, X)                                                                                                                   \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_km_kernel<M, N_, X, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim); \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_km_kernel<M, N_, X, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
+    KM_SET(GEMV_QKV, true, false); KM_SET(GEMV_RESID, false, true); KM_SET(GEMV_RESID, false, false); KM_SET(GEMV_GATEUP, true, false);
+    KM_SET(GEMV_LMHEAD, true, false); KM_SET(GEMV_PLAIN, false, false);
+#undef KM_SET
+    done = (e == hipSuccess) ? 0 : -4;
+    return done;
+}
+
 // tuning hook: EMMAX_KM=0 keeps every batch >= 3 projection on decode_mfma.hip (the A/B partner)
 bool decode_km_enabled() {
     const char* e = getenv("EMMAX_KM");
@@ -405,5 +416,6 @@ int launch_repack_km(const void* src, int ld, void* dst, int N, int K, int perm,
 // row order).  -2: shape outside this kernel (K % 256, K > 4096, more than 8 tiles per block) -- the caller uses decode_mfma.hip.
 int launch_decode_km(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
     if (B < 1 || B > EMMAX_MAX_DECODE_BATCH) return -2;
+    if (decode_km_init() != 0) return -4;
     return p.wscale ? km_launch_mode<true>(mode, p, B, stream, grid_out) : km_launch_mode<false>(mode, p, B, stream, grid_out);
 }

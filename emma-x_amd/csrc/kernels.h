@@ -186,6 +186,7 @@ int launch_set_tokens(int32_t* cur_tok, const int32_t* toks, int B, int32_t* don
 int launch_repack_km(const void* src, int ld, void* dst, int N, int K, int perm, int head_dim, hipStream_t stream);
 int launch_decode_km(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
 bool decode_km_enabled();
+int decode_km_init();   // raise the dynamic-LDS limit of every instantiation (call once, outside graph capture)
 
 // ---- decode_mfma.hip: small-batch (B >= 3) projections on MFMA over the fragment-major weight copy ----
 int launch_repack_fm(const void* src, int ld, void* dst, int N, int K, hipStream_t stream);

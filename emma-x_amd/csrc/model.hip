@@ -1001,7 +1001,7 @@ int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_
         return fail(EMMAX_ERR_NOMEM, "session memory too small: workspace %lld/%lld, kv %lld/%lld", (long long)ws_bytes,
                     (long long)need_ws, (long long)kvb, (long long)need_kv);
     if (((uintptr_t)ws % 256) || ((uintptr_t)kv % 256)) return fail(EMMAX_ERR_INVALID, "workspace / kv must be 256-byte aligned");
-    if (decode_mfma_init() != 0) return fail(EMMAX_ERR_HIP, "could not raise the dynamic LDS limit of the MFMA decode kernels");
+    if (decode_mfma_init() != 0 || decode_km_init() != 0) return fail(EMMAX_ERR_HIP, "could not raise the dynamic LDS limit of the MFMA decode kernels");
     emmax_session* s = new emmax_session();
     s->m = m;
     s->max_batch = max_batch; s->max_prompt = max_prompt; s->max_ctx = max_ctx;
