@@ -489,6 +489,11 @@ __global__ __launch_bounds__(RC::NT, RC::MINW) void emmax_attention_resident_ker
     auto request_kv8 = [&](const Item& w, int buf, bool isk, int grp) {
         const int xch = isk ? KCH : VCH, ni = isk ? NKI : RC::NVI;
         const bf16_t* kvb = (const bf16_t*)p.qkv + (size_t)w.start * p.ld_qkv + (w.h / (p.Hq / p.Hkv)) * HD;
+        // M0 is written once for the eight requests below, in separate asm statements (their per-lane predicates differ, so they
+        // cannot be one statement as in gemm.hip): nothing between them may touch M0.  What sits between them is scalar / vector
+        // address arithmetic only (no dynamic register indexing, no LDS-DMA builtin); the scheduling fences keep unrelated code
+        // from being moved into the group.
+        __builtin_amdgcn_sched_barrier(0);
         glds_base(lds0 + buf * RC::BUF + (isk ? RC::V_BYTES : 0) + grp * 8192 + 4096);
         auto one = [&](auto jtag) {
             constexpr int J = decltype(jtag)::value;
@@ -505,6 +510,7 @@ __global__ __launch_bounds__(RC::NT, RC::MINW) void emmax_attention_resident_ker
         one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{});
         one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
         one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
+        __builtin_amdgcn_sched_barrier(0);
     };
     auto request_kv_all = [&](const Item& w, int buf) {   // producer waves: the groups of eight dealt round robin
         if (w.len <= 0) return;

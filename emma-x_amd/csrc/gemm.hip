@@ -61,7 +61,7 @@ using GeomBig = Geom<2, 4, 8, 4>;
 using GeomSmall = Geom<2, 2, 4, 4>;
 
 // LDS-DMA, 16 bytes per lane: lane i's data lands at M0 + immediate + 16 i.  The LDS base goes to M0 ONCE per group of
-// slabs (`glds_base`); the slab inside the group is chosen by the instruction's immediate offset, which the hardware adds to
+// slabs; the slab inside the group is chosen by the instruction's immediate offset, which the hardware adds to
 // BOTH addresses.  The global address is a wave-uniform 64-bit base in SGPRs (tile origin + K offset, advanced by scalar adds)
 // plus a per-lane 32-bit offset that does not change along K: no vector address arithmetic per request (as flat 64-bit
 // pointers every request cost two v_lshl_add_u64 -- and VALU instructions are not free next to the MFMAs of the same SIMD).
@@ -69,12 +69,17 @@ using GeomSmall = Geom<2, 2, 4, 4>;
 // tile clamps its rows; the scalar base is lowered by the same bias.  Issued as asm: hipcc's builtin form rewrites M0 before
 // every instruction and only takes flat pointers.
 constexpr int DMA_BIAS = 4096;
-__device__ __forceinline__ void glds_base(unsigned int lds_base) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(__builtin_amdgcn_readfirstlane(lds_base)) : "m0", "memory");
-}
-template <int J>   // slab J (1 KiB) behind the base; voff = lane offset - J * 1024 + DMA_BIAS, sbase = tile base + k offset - DMA_BIAS
-__device__ __forceinline__ void glds16_slab(unsigned int voff, unsigned long long sbase) {
-    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(sbase), "n"(J * 1024) : "memory");
+// ONE asm statement per group: M0 is compiler-reserved and not preserved between statements, so the write of M0 and the four
+// requests that read it must not be separable by anything hipcc might schedule in between
+__device__ __forceinline__ void glds16_group4(unsigned int lds_base, unsigned int v0, unsigned int v1, unsigned int v2, unsigned int v3,
+                                              unsigned long long sbase) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %5 offset:0\n\t"
+                 "global_load_lds_dwordx4 %2, %5 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %3, %5 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %4, %5 offset:3072"
+                 ::"s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase)
+                 : "m0", "memory");
 }
 
 // bf16 epilogue through LDS: a wave parks 64 rows of its result (64 columns; SwiGLU: 32) in its private 8 KiB window
@@ -313,16 +318,8 @@ __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams 
         const unsigned long long koff = (unsigned long long)(kbeg + kt) * (BK * 2);
         static_assert(G::SA == 4 && G::SB == 4, "a wave's slabs of one operand share one M0 (immediates 0 .. 3072)");
         const unsigned long long sa = baseA + koff, sb = baseB + koff;
-        glds_base(st + wave * G::SA * 1024);
-        glds16_slab<0>(offA_l[0], sa);
-        glds16_slab<1>(offA_l[1], sa);
-        glds16_slab<2>(offA_l[2], sa);
-        glds16_slab<3>(offA_l[3], sa);
-        glds_base(st + OP_BYTES + wave * G::SB * 1024);
-        glds16_slab<0>(offB_l[0], sb);
-        glds16_slab<1>(offB_l[1], sb);
-        glds16_slab<2>(offB_l[2], sb);
-        glds16_slab<3>(offB_l[3], sb);
+        glds16_group4(st + wave * G::SA * 1024, offA_l[0], offA_l[1], offA_l[2], offA_l[3], sa);
+        glds16_group4(st + OP_BYTES + wave * G::SB * 1024, offB_l[0], offB_l[1], offB_l[2], offB_l[3], sb);
     };
 
     // ---- fragment read offsets: row base + swizzled chunk; (row >> 1) & 7 == (li >> 1) & 7 for every 16-row tile ----
