@@ -231,7 +231,10 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 && F8 != 1 && F8 != 2 ? 4 : 2)) vo
     // occupying 64 registers) it is one round trip of ~1 us; as a loop BEHIND the weight stream it was sixteen dependent
     // round trips, ~5 of the 11 us of the launch.
     // plain rows (down projection) that fit one round of four chunks per thread: activations first, see stage_x
-    const bool plain_first = !NORM && !XATTN && B <= 2 && !multi_phase && (K >> 3) <= 4 * NT;
+    // (round 3: off -- the four-chunk burst next to the 64-register weight head spilled 44-84 registers at the 128-VGPR cap of
+    // two blocks per CU, i.e. the wave stored its own weight head to scratch right after requesting it; the down projection this
+    // was built for runs on decode_ks.hip now, this kernel only keeps shapes with K % 64 != 0 and the fp8 rows)
+    const bool plain_first = false;
     // fp8: every one-pass prologue goes first -- the first burst is most of the matrix, the refills cannot go out before x is
     // staged, and x requested behind the burst arrived 7 us into a 19 us gate/up launch (tools/gemv_lab.hip)
     const bool head_first = !((one_pass && (MODE == MODE_QKV || FP8)) || XATTN || plain_first);

@@ -674,10 +674,8 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
         }
         case STAGE_OPROJ:
             stage_params(s, B, li, stage, p);
-            // o-proj at batch >= 3: the K-split MFMA kernel with fp8 weights (10.3 against 10.8 us at B = 8), decode_mfma.hip with bf16
-            // (12.5 against 15.4: the split merge of 8 rows queues behind the 16 KiB weight heads of the K-split kernel; merging all
-            // rows at once AHEAD of the heads: 14.3, and 11.8 for fp8 -- not kept)
-            KCHK(launch_proj(GEMV_RESID, p, L.wo, L.wo_fm, B, st, &grid, L.wo_sc, L.wo_r8, F8_OPROJ, m->fp8 ? L.wo_fm : nullptr, L.wo_sc));
+            // (batch >= 3: the K-split MFMA kernel takes the o-proj with fp8 weights only, see decode_km.hip)
+            KCHK(launch_proj(GEMV_RESID, p, L.wo, L.wo_fm, B, st, &grid, L.wo_sc, L.wo_r8, F8_OPROJ, L.wo_fm, L.wo_sc));
             return 0;
         case STAGE_GATEUP:
             stage_params(s, B, li, stage, p);

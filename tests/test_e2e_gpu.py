@@ -429,6 +429,7 @@ def test_persistent_layer_chain_equals_stage_launches(device, tiny_random, monke
     cfg, model, _ = tiny_random
     eng = model.engine
     monkeypatch.setenv("EMMAX_ATTN_MERGE", "1")   # stage launches: the split merge inside the attention launch, as the chain needs it
+    monkeypatch.setenv("EMMAX_KS", "1")           # the chain is built from the K-split kernels
     for nb, plens in ((2, [9, 21]), (1, [17])):
         frames, rows = _inputs(cfg, nb, plens, seed=31 + nb)
         fr = torch.from_numpy(frames).to(device)
