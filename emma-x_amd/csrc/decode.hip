@@ -716,14 +716,15 @@ __global__ __launch_bounds__(256) void emmax_decode_embed_kernel(const int32_t* 
 // that arrives LAST re-reads the nsplit partials past its XCD's L2 (sc1 loads), merges with attn_merge_chunk_loop -- the
 // arithmetic of the o-proj prologues, bit for bit -- writes bf16 o[G x 128] and re-arms the counter (MI355X_MICROARCH.md:
 // drained sc1 payload, then an agent-scope atomic as the flag; no spin anywhere, so nothing can hang).
-template <int HD, int G, bool MERGE = false>
-__global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams p) {
+template <int HD, int G, bool MERGE = false, int NW = 4>   // NW: waves per block (4, or 8: twice the K/V requests in flight per block)
+__global__ __launch_bounds__(NW * 64) void emmax_decode_attn_kernel(DecodeAttnParams p) {
+    constexpr int NT = NW * 64;
     static_assert(HD == 128, "decode attention maps 16 lanes x 8 elements onto one 128-wide K/V row");
     constexpr int KU = G <= 2 ? 4 : 2;    // keys per lane group per chunk (block chunk = 16 * KU keys), two chunks in flight
     constexpr int SP = 512;  // page ids kept in LDS = the longest page table the launcher accepts (32 K tokens at 64 per page)
     __shared__ int s_pages[SP];
-    __shared__ float red_o[4][G][HD];
-    __shared__ float red_ml[4][G][2];
+    __shared__ float red_o[NW][G][HD];
+    __shared__ float red_ml[NW][G][2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kg = lane >> 4, ch = lane & 15;       // key group within the wave, 16-byte chunk within the row
@@ -743,10 +744,10 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
 #pragma unroll
     for (int gq = 0; gq < G; ++gq)
         q[gq] = ld_act16((const u32x4_t*)((const bf16_t*)p.q + (size_t)b * p.ldq + (hk * G + gq) * HD + ch * 8), coh);
-    const int pt0 = ptab[min(tid, p.max_pages - 1)], pt1 = ptab[min(tid + 256, p.max_pages - 1)];
+    const int pt0 = ptab[min(tid, p.max_pages - 1)], pt1 = ptab[min(tid + NT, p.max_pages - 1)];
     __builtin_amdgcn_sched_barrier(0);   // every request above is out before the first wait (hipcc sinks the q load below the LDS write otherwise)
     s_pages[tid] = pt0;
-    s_pages[tid + 256] = pt1;
+    if (NT < SP) s_pages[tid + NT] = pt1;
     const int L = ctx_now + 1;                      // keys including the one appended by the qkv kernel of this step
     int kps = (L + nsplit - 1) >> __builtin_ctz(nsplit);   // the split count is a power of two (launcher)
     kps = (kps + 15) & ~15;
@@ -777,7 +778,7 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
     };
     if (k0 >= L || row_done) {   // empty split, or a row that no longer decodes: no K/V traffic
         if constexpr (MERGE) {
-            for (int i = tid; i < G * (PSTRIDE / 4); i += 256) {
+            for (int i = tid; i < G * (PSTRIDE / 4); i += NT) {
                 const int gq = i / (PSTRIDE / 4), j4 = i - gq * (PSTRIDE / 4);
                 const f32x4_t v = {j4 * 4 == HD ? -INFINITY : 0.f, 0.f, 0.f, 0.f};
                 st_sc1_f32x4(part + (size_t)gq * nsplit * PSTRIDE + j4 * 4, v);
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
             arrive_and_merge();
             return;
         }
-        for (int i = tid; i < G * PSTRIDE; i += 256) {
+        for (int i = tid; i < G * PSTRIDE; i += NT) {
             const int gq = i / PSTRIDE, j = i - gq * PSTRIDE;
             st_act_f32(part + (size_t)gq * nsplit * PSTRIDE + j, (j == HD) ? -INFINITY : 0.f, coh);
         }
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
     auto load_chunk = [&](int kb, u32x4_t (&kv)[KU], u32x4_t (&vv)[KU], bool (&ok)[KU]) {
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
-            const int key = kb + u * 16 + wave * 4 + kg;
+            const int key = kb + u * (4 * NW) + wave * 4 + kg;
             ok[u] = key < k1;
             const int kk = ok[u] ? key : k0;
             // the page id ALWAYS comes from LDS (the launcher rejects tables longer than SP): a select between the LDS copy and
@@ -869,11 +870,11 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
         u32x4_t kvA[KU], vvA[KU], kvB[KU], vvB[KU];
         bool okA[KU], okB[KU];
         load_chunk(k0, kvA, vvA, okA);
-        for (int kb = k0; kb < k1; kb += 2 * 16 * KU) {
-            const bool hasB = kb + 16 * KU < k1;          // block-uniform
-            if (hasB) load_chunk(kb + 16 * KU, kvB, vvB, okB);
+        for (int kb = k0; kb < k1; kb += 2 * (4 * NW) * KU) {
+            const bool hasB = kb + (4 * NW) * KU < k1;          // block-uniform
+            if (hasB) load_chunk(kb + (4 * NW) * KU, kvB, vvB, okB);
             consume_chunk(kvA, vvA, okA);
-            if (kb + 2 * 16 * KU < k1) load_chunk(kb + 2 * 16 * KU, kvA, vvA, okA);
+            if (kb + 2 * (4 * NW) * KU < k1) load_chunk(kb + 2 * (4 * NW) * KU, kvA, vvA, okA);
             if (hasB) consume_chunk(kvB, vvB, okB);
         }
     }
@@ -898,22 +899,24 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
     }
     __syncthreads();
     auto part_value = [&](int gq, int j) {
-        const float M = fmaxf(fmaxf(red_ml[0][gq][0], red_ml[1][gq][0]), fmaxf(red_ml[2][gq][0], red_ml[3][gq][0]));
+        float M = red_ml[0][gq][0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) M = fmaxf(M, red_ml[w][gq][0]);
         const float msafe = (M == -INFINITY) ? 0.f : M;
         float v = 0.f;
         if (j < HD) {
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += red_o[w][gq][j] * __expf(red_ml[w][gq][0] - msafe);
+            for (int w = 0; w < NW; ++w) v += red_o[w][gq][j] * __expf(red_ml[w][gq][0] - msafe);
         } else if (j == HD) {
             v = M;
         } else if (j == HD + 1) {
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += red_ml[w][gq][1] * __expf(red_ml[w][gq][0] - msafe);
+            for (int w = 0; w < NW; ++w) v += red_ml[w][gq][1] * __expf(red_ml[w][gq][0] - msafe);
         }
         return v;
     };
     if constexpr (MERGE) {
-        for (int i = tid; i < G * (PSTRIDE / 4); i += 256) {   // 33 write-through stores of 16 bytes per head
+        for (int i = tid; i < G * (PSTRIDE / 4); i += NT) {   // 33 write-through stores of 16 bytes per head
             const int gq = i / (PSTRIDE / 4), j4 = i - gq * (PSTRIDE / 4);
             const f32x4_t v = {part_value(gq, j4 * 4), part_value(gq, j4 * 4 + 1), part_value(gq, j4 * 4 + 2), part_value(gq, j4 * 4 + 3)};
             st_sc1_f32x4(part + (size_t)gq * nsplit * PSTRIDE + j4 * 4, v);
@@ -921,7 +924,7 @@ __global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams
         arrive_and_merge();
         return;
     }
-    for (int i = tid; i < G * PSTRIDE; i += 256) {
+    for (int i = tid; i < G * PSTRIDE; i += NT) {
         const int gq = i / PSTRIDE, j = i - gq * PSTRIDE;
         st_act_f32(part + (size_t)gq * nsplit * PSTRIDE + j, part_value(gq, j), coh);
     }
@@ -1180,10 +1183,13 @@ int launch_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_dim
     if (p.o_out && !p.merge_ctr) return -1;   // the in-kernel merge needs its arrival counters
     const int G = Hq / p.Hkv;
     dim3 grid(nsplit, p.Hkv, B), block(256);
+    // lab: EMMAX_ATTN_WAVES=8 -- 8-wave blocks (twice the K/V requests in flight per block)
+    static const bool nw8 = getenv("EMMAX_ATTN_WAVES") && atoi(getenv("EMMAX_ATTN_WAVES")) == 8;
     switch (G) {
 #define ATTN_CASE(GG)                                                                                                   \
     case GG:                                                                                                           \
         if (p.o_out) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true>), grid, block, 0, stream, p);          \
+        else if (nw8) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, false, 8>), grid, dim3(512), 0, stream, p);  \
         else hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG>), grid, block, 0, stream, p);                         \
         break
         ATTN_CASE(1); ATTN_CASE(2); ATTN_CASE(4); ATTN_CASE(8);
