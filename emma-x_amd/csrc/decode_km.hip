@@ -18,7 +18,8 @@
 //     unit is ONE tile for every matrix: 768 qkv tiles are 3 per block (as 384 two-tile tasks they were 1.5 and needed the
 //     stream-K split of decode_mfma.hip);
 //   * RMSNorm folded in as in decode_ks.hip: y = rstd * W (x .* g), the sum of squares per wave slice, 1/rms in the epilogue.
-// The down projection (K = 11008: 43 k-steps per wave would need 172 activation registers) stays on decode_mfma.hip.
+// The down projection (K = 11008: 43 k-steps per wave would need 172 activation registers) has its own two-phase kernel below
+// (emmax_decode_kmd_kernel).
 #include <cstdlib>
 
 #include "common.h"
@@ -375,6 +376,141 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The down projection at batch 3-8 (K = 11008: 43 k-steps per wave -- 172 registers of activation fragments, or 176 KB of LDS for
+// eight rows, neither exists).  One 16-row tile per block; the wave's K slice runs in TWO phases of <= 22 fragments: the row slices
+// of a phase go through the wave-private LDS window (row-shaped requests, no barrier), the fragments are read just in time, one
+// ds_read_b128 per MFMA; the second phase's row slices wait in registers and replace the first's in the window when its MFMAs are
+// done.  Weights: the phase-A steps in flight from the start (22 KiB per wave, 176 KB per CU), every register refilled with the
+// phase-B step as soon as its MFMA has issued.  y = h + W x in place (+ the per-row scale with fp8 weights).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int KD_FRAGS = 22;                    // fragments (32 elements) per phase and wave
+constexpr int KD_XP = KD_FRAGS * 64 + 16;       // bytes per staged row slice
+template <bool FP8>
+__global__ __launch_bounds__(KM_NT, 2) void emmax_decode_kmd_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char km_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g4 = lane >> 4, c16 = lane & 15;
+    const int B = p.batch, K = p.K;
+    constexpr int KS = FP8 ? 64 : 32, FPS = FP8 ? 2 : 1;   // elements / fragments per load step
+    constexpr int NST = KD_FRAGS / FPS;                      // load steps per phase
+    const int KT = K / KS;
+    const int kq = KT / KM_WAVES, kr = KT % KM_WAVES;
+    const int k_lo = wave * kq + min(wave, kr), k_n = kq + (wave < kr ? 1 : 0);   // this wave's load steps
+    const int nA = min(NST, k_n), nB = k_n - nA;                                   // launcher: k_n <= 2 NST
+    float* part = (float*)km_smem;                                                 // [KM_WAVES][64][4]
+    unsigned char* xw = km_smem + KM_WAVES * 1024 + (size_t)wave * EMMAX_MAX_DECODE_BATCH * KD_XP;   // this wave's window
+    const int tile = blockIdx.x;
+
+    // epilogue operands of thread (lane l of wave 0): rows 4 (l >> 4) + j, batch column l & 15
+    const bool e_on = tid < 64 && c16 < B;
+    float pre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e_on) {
+        const bf16_t* hp = (const bf16_t*)p.y + (size_t)c16 * p.ldy + tile * 16 + 4 * g4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pre[j] = bf2f(hp[j]);
+    }
+
+    // ---- activation row slices of both phases: lane l holds chunks l and l + 64 of the phase's slice, for every batch row ----
+    auto load_rows = [&](int step0, int nstep, u32x4_t (&r)[EMMAX_MAX_DECODE_BATCH][2]) {
+        const int nch = nstep * (KS / 8);                       // 16-byte chunks in the slice
+        const bf16_t* base = (const bf16_t*)p.x + (size_t)(k_lo + step0) * KS;
+#pragma unroll
+        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = min(lane + 64 * h, max(nch - 1, 0));
+                r[b][h] = *((const u32x4_t*)(base + (size_t)min(b, B - 1) * p.ldx) + c);
+            }
+    };
+    auto store_rows = [&](int nstep, const u32x4_t (&r)[EMMAX_MAX_DECODE_BATCH][2]) {
+        const int nch = nstep * (KS / 8);
+#pragma unroll
+        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = lane + 64 * h;
+                if (c < KD_FRAGS * 4) {   // chunks past the slice / rows past the batch: zeros
+                    const bool live = c < nch && b < B;
+                    *(u32x4_t*)(xw + (size_t)b * KD_XP + (size_t)c * 16) = live ? r[b][h] : (u32x4_t){0u, 0u, 0u, 0u};
+                }
+            }
+    };
+    u32x4_t xa[EMMAX_MAX_DECODE_BATCH][2], xb[EMMAX_MAX_DECODE_BATCH][2];
+    load_rows(0, nA, xa);
+    load_rows(nA, nB, xb);
+
+    // ---- weights: phase A in flight now, phase B refilled register by register ----
+    const unsigned w_bytes = (unsigned)((size_t)p.n_groups * 16 * (size_t)K * (FP8 ? 1 : 2));
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)w_bytes, 0x00020000);
+    const unsigned voff = (unsigned)lane * 16u;
+    u32x4_t w[NST];
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        const int ok = s < nA ? -1 : 0;
+        const unsigned so = ((unsigned)((tile * KT + k_lo + s) * 1024) & (unsigned)ok) | (w_bytes & (unsigned)~ok);
+        w[s] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, so, 2));
+    }
+    store_rows(nA, xa);   // waits for the phase-A rows only (counted: the phase-B rows and the weights stay in flight)
+
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    // batch column = lane & 15; columns past the batch are zero (their window rows hold zeros; columns 8-15 have no row at all)
+    const unsigned char* xcol = xw + (size_t)min(c16, EMMAX_MAX_DECODE_BATCH - 1) * KD_XP + (size_t)g4 * 16;
+    auto frag = [&](int f) {
+        const u32x4_t v = *(const u32x4_t*)(xcol + (size_t)f * 64);
+        return __builtin_bit_cast(bf16x8_t, c16 < B ? v : (u32x4_t){0u, 0u, 0u, 0u});
+    };
+    auto mfma_step = [&](int s) {
+        if constexpr (FP8) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(km_fp8x8(w[s][0], w[s][1]), frag(2 * s), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(km_fp8x8(w[s][2], w[s][3]), frag(2 * s + 1), acc, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[s]), frag(s), acc, 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        mfma_step(s);
+        const int ok = s < nB ? -1 : 0;   // the register's phase-B step
+        const unsigned so = ((unsigned)((tile * KT + k_lo + nA + s) * 1024) & (unsigned)ok) | (w_bytes & (unsigned)~ok);
+        w[s] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, so, 2));
+    }
+    store_rows(nB, xb);   // same wave, in order behind the fragment reads above
+#pragma unroll
+    for (int s = 0; s < NST; ++s) mfma_step(s);
+
+    *(f32x4_t*)(part + ((size_t)wave * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (e_on) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int wv = 0; wv < KM_WAVES; ++wv) {
+            const f32x4_t a = *(const f32x4_t*)(part + ((size_t)wv * 64 + lane) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += a[j];
+        }
+        bf16_t* hp = (bf16_t*)p.y + (size_t)c16 * p.ldy + tile * 16 + 4 * g4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (FP8) v[j] *= p.wscale[tile * 16 + 4 * g4 + j];
+            hp[j] = f2bf(pre[j] + v[j]);
+        }
+    }
+}
+
+template <bool FP8>
+int kmd_launch(GemvParams p, int B, hipStream_t stream) {
+    constexpr int KS = FP8 ? 64 : 32, FPS = FP8 ? 2 : 1;
+    if (p.K % KS || p.n_rows % 16 || p.attn_part) return -2;
+    p.batch = B;
+    p.n_groups = p.n_rows / 16;
+    if (cdiv(p.K / KS, KM_WAVES) > 2 * (KD_FRAGS / FPS)) return -2;   // two phases of 22 fragments per wave: K <= 11264
+    if (p.K / KS < KM_WAVES) return -2;
+    const size_t smem = (size_t)KM_WAVES * 1024 + (size_t)KM_WAVES * EMMAX_MAX_DECODE_BATCH * KD_XP;
+    hipLaunchKernelGGL((emmax_decode_kmd_kernel<FP8>), dim3(p.n_groups), dim3(KM_NT), smem, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
 template <int MODE, bool NORM, bool XATTN, bool FP8>
 int km_launch_t(GemvParams p, int B, hipStream_t stream, int* grid_out) {
     constexpr int KS = FP8 ? 64 : 32;
@@ -443,6 +579,8 @@ int decode_km_init() {
     KM_SET(GEMV_LMHEAD, true, false); KM_SET(GEMV_PLAIN, false, false);
 #undef KM_SET
 #undef KM_SET1
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_kmd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_kmd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     done = (e == hipSuccess) ? 0 : -4;
     return done;
 }
@@ -467,5 +605,10 @@ int launch_repack_km(const void* src, int ld, void* dst, int N, int K, int perm,
 int launch_decode_km(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
     if (B < 1 || B > EMMAX_MAX_DECODE_BATCH) return -2;
     if (decode_km_init() != 0) return -4;
+    if (mode == GEMV_RESID && !p.attn_part && p.K > KM_WAVES * KM_STEPS * 32) {   // the down projection: two K phases (natural row order copy)
+        static const bool off = getenv("EMMAX_KM_DOWN") && atoi(getenv("EMMAX_KM_DOWN")) == 0;   // A/B partner: decode_mfma.hip
+        if (off) return -2;
+        return p.wscale ? kmd_launch<true>(p, B, stream) : kmd_launch<false>(p, B, stream);
+    }
     return p.wscale ? km_launch_mode<true>(mode, p, B, stream, grid_out) : km_launch_mode<false>(mode, p, B, stream, grid_out);
 }

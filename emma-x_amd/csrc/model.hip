@@ -683,7 +683,7 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             return 0;
         case STAGE_DOWN:
             stage_params(s, B, li, stage, p);
-            KCHK(launch_proj(GEMV_RESID, p, L.wdown, L.wdown_fm, B, st, &grid, L.wdown_sc, L.wdown_r8, F8_DOWN));
+            KCHK(launch_proj(GEMV_RESID, p, L.wdown, L.wdown_fm, B, st, &grid, L.wdown_sc, L.wdown_r8, F8_DOWN, L.wdown_fm, L.wdown_sc));
             return 0;
         default:
             return fail(EMMAX_ERR_INVALID, "unknown decode stage %d", stage);
