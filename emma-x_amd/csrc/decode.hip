@@ -1166,7 +1166,10 @@ int decode_attn_nsplit(int B, int Hkv) {
         while (f & (f - 1)) f &= f - 1;
         return f;
     }
-    int ns = 512 / (B * Hkv);
+    // batch 1-2: ~512 blocks of 4 waves (8 splits at 32 heads).  Batch >= 3: one block per CU is enough and every split less
+    // halves the partials the o-proj has to merge for 8 rows -- at B = 8 (32 heads) ONE split: attention 20.5 -> 20.0 us, o-proj
+    // 12.6 -> 11.0 us, step 3.373 -> 3.297 ms (4 splits: 22.3 / 15.5 us)
+    int ns = (B >= 3 ? 256 : 512) / (B * Hkv);
     if (ns < 1) ns = 1;
     if (ns > 8) ns = 8;
     while (ns & (ns - 1)) ns &= ns - 1;   // power of two: the o-proj prologue merges with a branch-free unrolled loop
