@@ -778,6 +778,11 @@ __global__ __launch_bounds__(NW * 64) void emmax_decode_attn_kernel(DecodeAttnPa
     };
     if (k0 >= L || row_done) {   // empty split, or a row that no longer decodes: no K/V traffic
         if constexpr (MERGE) {
+            if (nsplit == 1) {   // a row that no longer decodes: zeros (what the merge of an empty partial gives)
+                for (int i = tid; i < G * (HD / 8); i += NT)
+                    *((u32x4_t*)((bf16_t*)p.o_out + (size_t)b * p.ldq + hk * G * HD) + i) = (u32x4_t){0u, 0u, 0u, 0u};
+                return;
+            }
             for (int i = tid; i < G * (PSTRIDE / 4); i += NT) {
                 const int gq = i / (PSTRIDE / 4), j4 = i - gq * (PSTRIDE / 4);
                 const f32x4_t v = {j4 * 4 == HD ? -INFINITY : 0.f, 0.f, 0.f, 0.f};
@@ -916,6 +921,18 @@ __global__ __launch_bounds__(NW * 64) void emmax_decode_attn_kernel(DecodeAttnPa
         return v;
     };
     if constexpr (MERGE) {
+        if (nsplit == 1) {   // nothing to merge: this block holds the head's whole result -- normalise and write the bf16 row directly
+            for (int i = tid; i < G * (HD / 8); i += NT) {
+                const int gq = i / (HD / 8), c = i - gq * (HD / 8);
+                const float den = part_value(gq, HD + 1);
+                const float inv = den > 0.f ? 1.0f / den : 0.f;   // the arithmetic of attn_merge_chunk<1> (weight exp(m - M) = 1)
+                u32x4_t v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = pack_bf16x2(part_value(gq, c * 8 + 2 * j) * inv, part_value(gq, c * 8 + 2 * j + 1) * inv);
+                *((u32x4_t*)((bf16_t*)p.o_out + (size_t)b * p.ldq + (hk * G + gq) * HD) + c) = v;
+            }
+            return;
+        }
         for (int i = tid; i < G * (PSTRIDE / 4); i += NT) {   // 33 write-through stores of 16 bytes per head
             const int gq = i / (PSTRIDE / 4), j4 = i - gq * (PSTRIDE / 4);
             const f32x4_t v = {part_value(gq, j4 * 4), part_value(gq, j4 * 4 + 1), part_value(gq, j4 * 4 + 2), part_value(gq, j4 * 4 + 3)};
@@ -1183,7 +1200,7 @@ int launch_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_dim
     if (nsplit < 1 || (nsplit & (nsplit - 1))) return -1;   // the kernel divides the keys among the splits by shifting
     p.page_shift = 0;
     while ((1 << p.page_shift) < p.page) ++p.page_shift;
-    if (p.o_out && !p.merge_ctr) return -1;   // the in-kernel merge needs its arrival counters
+    if (p.o_out && nsplit > 1 && !p.merge_ctr) return -1;   // the in-kernel merge needs its arrival counters (one split: nothing to merge)
     const int G = Hq / p.Hkv;
     dim3 grid(nsplit, p.Hkv, B), block(256);
     // lab: EMMAX_ATTN_WAVES=8 -- 8-wave blocks (twice the K/V requests in flight per block)

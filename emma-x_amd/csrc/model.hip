@@ -605,6 +605,8 @@ enum { STAGE_QKV = 0, STAGE_ATTN = 1, STAGE_OPROJ = 2, STAGE_GATEUP = 3, STAGE_D
 // dependent trips through the fabric) and the plain o-proj 8.9 against 10.1 -- a loss of 5.7 us per layer, so it is ON only where
 // it is needed (inside the persistent layer chain, whose o-proj cannot afford the per-wave merge) or asked for (EMMAX_ATTN_MERGE=1).
 static bool attn_merge_on(const emmax_session* s, int B) {
+    // one KV split per (row, head) (batch >= 5 at 32 heads): nothing to merge, the attention launch writes the bf16 row itself
+    if (decode_attn_nsplit(B, s->m->cfg.n_kv_heads) == 1 && !(getenv("EMMAX_ATTN_DIRECT") && atoi(getenv("EMMAX_ATTN_DIRECT")) == 0)) return true;
     if (!(B < EMMAX_MFMA_MIN_BATCH && !s->m->fp8 && decode_ks_enabled())) return false;
     const char* e = getenv("EMMAX_ATTN_MERGE");
     return s->pchain || (e && atoi(e) != 0);
