@@ -590,11 +590,13 @@ int ks_launch_mode(GemvParams p, int B, hipStream_t stream, int* grid_out) {
 template <int B, int CPLD, int TAIL>
 int chain_launch_t(KsChainParams& c, int grid, size_t smem, hipStream_t stream) {
     auto kern = emmax_decode_chain_kernel<B, CPLD, TAIL>;
-    static int resident = -1;   // blocks per CU the runtime admits for this instantiation (queried once)
-    if (resident < 0) {
+    static int resident = -1;   // blocks per CU the runtime admits for this instantiation at this LDS size (queried when it changes)
+    static size_t resident_smem = 0;
+    if (resident < 0 || resident_smem != smem) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, KS_NT, smem) != hipSuccess) n = 0;
         resident = n;
+        resident_smem = smem;
     }
     static int cus = 0;
     if (cus == 0) {
@@ -635,8 +637,7 @@ int launch_decode_ks(int mode, const GemvParams& p, int B, hipStream_t stream, i
                 q.max_grid = g ? atoi(g) : 256;
                 return ks_launch_mode<GEMV_RESID, false, true>(q, B, stream, grid_out);
             }
-            return p.attn_part ? ks_launch_mode<GEMV_RESID, false, true>(p, B, stream, grid_out)
-                               : ks_launch_mode<GEMV_RESID, false, false>(p, B, stream, grid_out);
+            return ks_launch_mode<GEMV_RESID, false, false>(p, B, stream, grid_out);
         case GEMV_GATEUP: return ks_launch_mode<GEMV_GATEUP, true, false>(p, B, stream, grid_out);
         case GEMV_LMHEAD: return ks_launch_mode<GEMV_LMHEAD, true, false>(p, B, stream, grid_out);
         case GEMV_PLAIN: return ks_launch_mode<GEMV_PLAIN, false, false>(p, B, stream, grid_out);
