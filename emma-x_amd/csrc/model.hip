@@ -474,7 +474,8 @@ static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_
         return launch_decode_gemv(mode, p, B, st, grid_out);
     }
     if (B >= EMMAX_MFMA_MIN_BATCH || w_scale) {
-        if (B >= EMMAX_MFMA_MIN_BATCH && w_km && decode_km_enabled()) {   // K <= 4096: the K-split MFMA kernel (decode_km.hip)
+        // K-split MFMA kernel (decode_km.hip): batch >= 3, and with fp8 weights every batch the row GEMV above did not take
+        if ((B >= EMMAX_MFMA_MIN_BATCH || w_scale) && w_km && decode_km_enabled()) {
             GemvParams q = p;
             q.W = w_km;
             q.wscale = w_scale ? km_scale : nullptr;

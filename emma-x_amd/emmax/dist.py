@@ -17,12 +17,22 @@ import torch
 import torch.distributed as dist
 
 
+def _singleton() -> bool:
+    """EMMAX_DIST_SINGLETON=1: a one-rank launch still initialises the process group and runs every collective for real -- the
+    way the RCCL code path (communicator set-up, all_gather / all_reduce on device buffers) is exercised on a one-GPU box."""
+    return os.environ.get("EMMAX_DIST_SINGLETON", "0") == "1"
+
+
+def _collectives_on() -> bool:
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _singleton())
+
+
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """(rank, world, local_rank) from torchrun's env; initialises the default group when WORLD_SIZE > 1."""
+    """(rank, world, local_rank) from torchrun's env; initialises the default group when WORLD_SIZE > 1 (or EMMAX_DIST_SINGLETON=1)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or (_singleton() and "MASTER_PORT" in os.environ)) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
             # EMMAX_DIST_BACKEND=gloo lets the multi-process control flow be exercised on a single-GPU box
@@ -48,7 +58,7 @@ def gather_results(actions: torch.Tensor, ids: torch.Tensor, lens: torch.Tensor,
     actions f32 [b,7], ids i32 [b,T], lens i32 [b] -> ([B,7], [B,T], [B]).  Shards may be ragged in b (`counts` =
     per-rank shard sizes; default: all equal): rows are packed into one fixed-size i32 buffer per rank so a single
     all_gather moves everything."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collectives_on():
         return actions, ids, lens
     world = dist.get_world_size()
     b, T = ids.shape
@@ -72,12 +82,12 @@ def gather_results(actions: torch.Tensor, ids: torch.Tensor, lens: torch.Tensor,
 
 
 def barrier() -> None:
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_on():
         dist.barrier()
 
 
 def max_over_ranks(x: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collectives_on():
         return x
     t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -118,7 +128,7 @@ def backend_name() -> str:
 
 def collective_world_size(device) -> int:
     """Ranks that took part in an ACTUAL collective (all_reduce of ones): what `bench.py` reports as `rccl_ranks`."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collectives_on():
         return 1
     t = torch.ones(1, dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -41,3 +41,48 @@ def test_bench_two_ranks_tiny_gloo(device):
     assert d["gather_ms"] > 0 and 0 < d["gather_share"] < 0.5
     assert "cpu_baseline" not in d                 # rank 0 at N = 1 only
     assert d["roofline"]["bound"] == "hbm"
+
+
+def test_bench_one_rank_rccl_singleton(device):
+    """RCCL itself on the box: the driver's launch line with ONE rank and EMMAX_DIST_SINGLETON=1 -- the `nccl` (= RCCL) process group is
+    created on the device, and the result all_gather, the barrier and the max-over-ranks / rank-count all_reduces run through it on
+    device buffers.  (Two ranks cannot share one GPU under RCCL; with one rank the communicator set-up, the packing of
+    {actions, ids, lens} into the int32 gather buffer and its unpacking are the code the 8-GPU run executes.)"""
+    env = dict(os.environ, EMMAX_DIST_SINGLETON="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("EMMAX_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--tiny",
+           "--prompt-tokens", "24", "--new-tokens", "12", "--batch-per-gpu", "3", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["dist_backend"] == "nccl" and d["rccl_ranks"] == 1 and d["n_gpus"] == 1
+    assert d["gather_ms"] > 0            # the all_gather ran (a world-1 short cut would report no gather time)
+
+
+def test_gather_results_through_rccl_is_the_identity_at_world_one(device):
+    """`gather_results` on device buffers through the nccl backend, one rank: pack -> all_gather_into_tensor -> unpack returns the
+    inputs bit for bit (fp32 actions travel as int32 words)."""
+    code = r"""
+import os, sys, torch
+sys.path[:0] = [%r, %r]
+os.environ.update(EMMAX_DIST_SINGLETON="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=%r)
+from emmax import dist as ed
+rank, world, local = ed.init_from_env()
+assert ed.backend_name() == "nccl", ed.backend_name()
+g = torch.Generator().manual_seed(5)
+a = torch.randn(5, 7, generator=g).cuda(); ids = torch.randint(0, 32000, (5, 19), generator=g, dtype=torch.int32).cuda()
+lens = torch.randint(1, 19, (5,), generator=g, dtype=torch.int32).cuda()
+A, I, N = ed.gather_results(a, ids, lens)
+assert A.data_ptr() != a.data_ptr()          # went through the gather buffer
+assert torch.equal(A.view(torch.int32), a.view(torch.int32)) and torch.equal(I, ids) and torch.equal(N, lens)
+assert ed.collective_world_size("cuda:0") == 1 and ed.max_over_ranks(1.5, "cuda:0") == 1.5
+ed.barrier()
+torch.distributed.destroy_process_group()
+print("rccl-singleton-ok")
+""" % (ROOT, os.path.join(ROOT, "emma-x_amd"), str(_free_port()))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
+    assert out.returncode == 0 and "rccl-singleton-ok" in out.stdout, out.stderr[-3000:]
