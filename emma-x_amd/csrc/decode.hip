@@ -1208,7 +1208,8 @@ int launch_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_dim
     switch (G) {
 #define ATTN_CASE(GG)                                                                                                   \
     case GG:                                                                                                           \
-        if (p.o_out) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true>), grid, block, 0, stream, p);          \
+        if (p.o_out && nw8) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true, 8>), grid, dim3(512), 0, stream, p); \
+        else if (p.o_out) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true>), grid, block, 0, stream, p);     \
         else if (nw8) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, false, 8>), grid, dim3(512), 0, stream, p);  \
         else hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG>), grid, block, 0, stream, p);                         \
         break

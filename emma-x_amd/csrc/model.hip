@@ -444,21 +444,20 @@ static bool streamk_on() {
 }
 
 // tuning hook: EMMAX_FP8_GEMV = bit mask of the batch 1-2 fp8 projections that run as dot-product GEMV over the e4m3 row copy
-// (1 qkv, 2 o-proj, 4 gate/up, 8 down, 16 lm-head); the others go through the MFMA kernel like every larger batch.  0 = round 1.
-// Default 23: per launch at B = 1 (rocprofv3, in situ) GEMV / MFMA = qkv 15.0 / 15.3, o-proj 8.0 / 9.5, gate/up 18.2 / 20.5,
-// lm-head 25.1 / 29.8 us -- and down 13.3 / 12.4: its 22 KB activation row is staged 8 us into the launch, by when the MFMA
-// kernel (K split over the waves, partial sums) is further along.
+// (1 qkv, 2 o-proj, 4 gate/up, 8 down, 16 lm-head); the others go through the MFMA kernels like every larger batch.
+// Default (round 3, once the K-split MFMA kernels of decode_km.hip existed): the o-proj, and at batch 1 the lm-head.  Per launch
+// at B = 1 / B = 2, row GEMV against decode_km.hip (one box, tools/ab_bench.sh): qkv 14.1 / 17.3 against 12.5 / 12.7 us, gate/up
+// 17.9 / 20.3 against 17.1 / 17.1, down (always MFMA) 11.9, o-proj 7.7 / 9.8 against 8.4 / 10.7, lm-head 25.0 / 28.7 against
+// 25.7 / 24.4: step 1.939 -> 1.886 ms/token at B = 1 with everything on the MFMA kernels, 2.287 -> 2.028 at B = 2.
 enum { F8_QKV = 1, F8_OPROJ = 2, F8_GATEUP = 4, F8_DOWN = 8, F8_LMHEAD = 16 };
-static int fp8_gemv_mask() {
-    static int mask = -1;
-    if (mask < 0) {
+static int fp8_gemv_mask(int B) {
+    static int mask = -2;
+    if (mask == -2) {
         const char* e = getenv("EMMAX_FP8_GEMV");
-        mask = e ? atoi(e) & 31 : 23;
+        mask = e ? atoi(e) & 31 : -1;
     }
-    return mask;
-}
-static bool fp8_rows(const emmax_model* m, int B, int K, int bit) {
-    return m->fp8 && B < EMMAX_MFMA_MIN_BATCH && (fp8_gemv_mask() & bit) && decode_gemv_fp8_fits(B, K);
+    if (mask >= 0) return mask;
+    return B == 1 ? (F8_OPROJ | F8_LMHEAD) : F8_OPROJ;
 }
 
 // B <= 2: per-lane dot-product GEMV over the row-major weights (fp8 mode: over the e4m3 row copy w_r8);
@@ -467,7 +466,7 @@ static bool fp8_rows(const emmax_model* m, int B, int K, int bit) {
 static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_fm, int B, hipStream_t st, int* grid_out = nullptr,
                        const float* w_scale = nullptr, const void* w_r8 = nullptr, int f8bit = 0, const void* w_km = nullptr,
                        const float* km_scale = nullptr) {
-    if (B < EMMAX_MFMA_MIN_BATCH && w_scale && w_r8 && (fp8_gemv_mask() & f8bit) && decode_gemv_fp8_fits(B, p.K)) {
+    if (B < EMMAX_MFMA_MIN_BATCH && w_scale && w_r8 && (fp8_gemv_mask(B) & f8bit) && decode_gemv_fp8_fits(B, p.K)) {
         p.W = w_r8;
         p.wscale = w_scale;
         p.ldw = p.K;   // bytes per row
