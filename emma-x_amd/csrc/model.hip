@@ -818,10 +818,16 @@ static int ensure_graph(emmax_session* s, int B, hipStream_t st) {
         return graph_fail(s, r != 0 ? ("launch during capture: " + g_err) : (std::string("hipStreamEndCapture: ") + hipGetErrorString(e)));
     }
     hipGraphExec_t ge = nullptr;
-    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    {   // lab: EMMAX_GRAPH_FLAGS = hipGraphInstantiateWithFlags flags, EMMAX_GRAPH_UPLOAD=1 = hipGraphUpload before the first replay
+        const char* gf = getenv("EMMAX_GRAPH_FLAGS");
+        e = gf ? hipGraphInstantiateWithFlags(&ge, g, (unsigned long long)atoll(gf)) : hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    }
     if (e != hipSuccess) {
         (void)hipGraphDestroy(g);
         return graph_fail(s, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    }
+    if (const char* gu = getenv("EMMAX_GRAPH_UPLOAD")) {
+        if (atoi(gu) != 0) (void)hipGraphUpload(ge, st);
     }
     s->graph = g; s->graph_exec = ge; s->graph_B = B; s->graph_stream_cap = st;
     return 0;
