@@ -798,8 +798,9 @@ static int graph_fail(emmax_session* s, const std::string& why) {
 static int ensure_graph(emmax_session* s, int B, hipStream_t st) {
     // Default: eager launch-ahead.  One step is 163 launches for >= 2.6 ms of GPU time, so a single host thread stays far
     // ahead of the device, and measured on MI355X / ROCm 7.2 the replayed graph is the SLOWER option: 3.05 vs 2.95 ms/token
-    // at B = 1 (~0.6 us more per kernel node than a same-stream launch).  EMMAX_GRAPH=1 selects graph replay (a host whose
-    // launch thread cannot be kept free); read per call so a process can switch.
+    // at B = 1 (~0.6 us more per kernel node than a same-stream launch; round 3: 2.73 vs 2.62, and neither hipGraphUpload, the
+    // instantiate flags, DEBUG_HIP_GRAPH_BATCH_SIZE / DEBUG_HIP_FORCE_GRAPH_QUEUES nor the kernarg placement move it).
+    // EMMAX_GRAPH=1 selects graph replay (a host whose launch thread cannot be kept free); read per call so a process can switch.
     {
         const char* e = getenv("EMMAX_GRAPH");
         s->last_step_graph = 0;   // set again by launch_graph_step when a replay really runs
@@ -818,16 +819,10 @@ static int ensure_graph(emmax_session* s, int B, hipStream_t st) {
         return graph_fail(s, r != 0 ? ("launch during capture: " + g_err) : (std::string("hipStreamEndCapture: ") + hipGetErrorString(e)));
     }
     hipGraphExec_t ge = nullptr;
-    {   // lab: EMMAX_GRAPH_FLAGS = hipGraphInstantiateWithFlags flags, EMMAX_GRAPH_UPLOAD=1 = hipGraphUpload before the first replay
-        const char* gf = getenv("EMMAX_GRAPH_FLAGS");
-        e = gf ? hipGraphInstantiateWithFlags(&ge, g, (unsigned long long)atoll(gf)) : hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-    }
+    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
     if (e != hipSuccess) {
         (void)hipGraphDestroy(g);
         return graph_fail(s, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-    }
-    if (const char* gu = getenv("EMMAX_GRAPH_UPLOAD")) {
-        if (atoi(gu) != 0) (void)hipGraphUpload(ge, st);
     }
     s->graph = g; s->graph_exec = ge; s->graph_B = B; s->graph_stream_cap = st;
     return 0;
