@@ -1264,6 +1264,23 @@ int emmax_slot_prefill(emmax_session* s, int slot, const int32_t* ids, int len, 
     return slot_leave(s, user, st);
 }
 
+int emmax_slots_prefill(emmax_session* s, int slot0, int n, const int32_t* ids, int P_max, const int32_t* lens_host, const void* patches,
+                        const int32_t* max_new_host, emmax_stream stream) {
+    if (!s || !ids || !lens_host || !max_new_host) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (!s->slots_open) return fail(EMMAX_ERR_STATE, "emmax_slots_prefill before emmax_slots_open");
+    if (n < 1 || slot0 < 0 || slot0 + n > s->cur_B) return fail(EMMAX_ERR_INVALID, "slots %d..%d outside 0..%d", slot0, slot0 + n - 1, s->cur_B - 1);
+    for (int i = 0; i < n; ++i)
+        if (max_new_host[i] < 1 || max_new_host[i] > s->max_out)
+            return fail(EMMAX_ERR_INVALID, "slot %d: max_new_tokens %d outside 1..%d", slot0 + i, max_new_host[i], s->max_out);
+    hipStream_t user = (hipStream_t)stream, st;
+    int r = slot_enter(s, user, &st);
+    if (r) return r;
+    r = run_prefill(s, ids, lens_host, n, P_max, patches, st, slot0);   // one packed pass over the n requests (ragged lengths)
+    if (r) return r;
+    for (int i = 0; i < n; ++i) KCHK(launch_set_ints(s->max_new_d + slot0 + i, 1, max_new_host[i], st));
+    return slot_leave(s, user, st);
+}
+
 int emmax_slots_step(emmax_session* s, int n_steps, emmax_stream stream) {
     if (!s) return fail(EMMAX_ERR_INVALID, "null argument");
     if (!s->slots_open) return fail(EMMAX_ERR_STATE, "emmax_slots_step before emmax_slots_open");

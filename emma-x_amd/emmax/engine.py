@@ -236,6 +236,30 @@ class EmmaxEngine:
                                                int(max_new_tokens), _lib.current_stream()), "emmax_slot_prefill")
         torch.cuda.current_stream().synchronize()   # `ids_d` must outlive the embedding gather
 
+    def slots_prefill(self, slot0: int, prompts: Sequence[Sequence[int]], patch_embeds: Optional[Sequence[torch.Tensor]],
+                      max_new_tokens: Sequence[int]) -> None:
+        """Prefill len(prompts) requests into the consecutive slots slot0.. in ONE packed pass (ragged prompt lengths)."""
+        n = len(prompts)
+        if n < 1 or len(max_new_tokens) != n:
+            raise ValueError("slots_prefill: one token budget per prompt, at least one prompt")
+        lens = [len(p) for p in prompts]
+        P = max(lens)
+        ids = torch.zeros(n, P, dtype=torch.int32)
+        for i, p in enumerate(prompts):
+            ids[i, : lens[i]] = torch.as_tensor(list(p), dtype=torch.int32)
+        ids_d = ids.to(self.device)
+        pe = None
+        if patch_embeds is not None:
+            if len(patch_embeds) != n:
+                raise ValueError("slots_prefill: one patch-embedding tensor per prompt")
+            pe = torch.stack([t.reshape(self.cfg.n_patches, self.cfg.llm.hidden_size) for t in patch_embeds]).contiguous()
+            assert pe.dtype == torch.bfloat16
+        lens_c = (C.c_int32 * n)(*lens)
+        budget_c = (C.c_int32 * n)(*[int(v) for v in max_new_tokens])
+        _lib.check(self.lib.emmax_slots_prefill(self._session, int(slot0), n, ids_d.data_ptr(), P, lens_c, _lib.ptr(pe), budget_c,
+                                                _lib.current_stream()), "emmax_slots_prefill")
+        torch.cuda.current_stream().synchronize()   # `ids_d` / `pe` must outlive the pass
+
     def slots_step(self, n_steps: int) -> None:
         _lib.check(self.lib.emmax_slots_step(self._session, int(n_steps), _lib.current_stream()), "emmax_slots_step")
 

@@ -2,7 +2,7 @@
 
 The reference answers one request at a time (`generate_actions`, prismatic.py:634-696: bs = 1, always decoded to EOS or
 512 new tokens).  Here the decode batch is a set of independent request SLOTS: every slot owns its KV pages, context length,
-token budget and stop state on the device; a finished slot is refilled (vision encode + single-row prefill) while the other
+token budget and stop state on the device; finished slots are refilled (vision encode + prefill, consecutive free slots in one packed pass) while the other
 slots keep decoding, so a long reasoning chain never holds short ones back.  With a stop rule (`stop_trigger`,
 `stop_after`) a request ends as soon as its action line is complete instead of at EOS -- the emitted ids are exactly the
 prefix of the full greedy generation, so the parsed action is unchanged.
@@ -106,9 +106,24 @@ class SlotScheduler:
             for r, pe in zip(todo + ahead, got):
                 self._embeds[id(r)] = pe
         embeds = [self._embeds.pop(id(r)) for r, _ in batch]
-        for slot, (req, t_sub), pe in zip(free, batch, embeds):
-            self.engine.slot_prefill(slot, list(req.prompt_ids), pe, req.max_new_tokens)
-            self.active[slot] = _Active(req, t_sub, self.clock())
+        # runs of CONSECUTIVE free slots are prefilled in one packed pass (eight one-row prefills cost ~1.6x one eight-row pass);
+        # engines without `slots_prefill` (test doubles) get the requests one by one
+        slots = free[:take]
+        i = 0
+        while i < take:
+            j = i + 1
+            while j < take and slots[j] == slots[j - 1] + 1:
+                j += 1
+            if j - i > 1 and hasattr(self.engine, "slots_prefill"):
+                self.engine.slots_prefill(slots[i], [list(batch[k][0].prompt_ids) for k in range(i, j)], embeds[i:j] if embeds[i] is not None else None,
+                                          [batch[k][0].max_new_tokens for k in range(i, j)])
+            else:
+                for k in range(i, j):
+                    self.engine.slot_prefill(slots[k], list(batch[k][0].prompt_ids), embeds[k], batch[k][0].max_new_tokens)
+            t_adm = self.clock()
+            for k in range(i, j):
+                self.active[slots[k]] = _Active(batch[k][0], batch[k][1], t_adm)
+            i = j
         return take
 
     def _retire(self) -> int:

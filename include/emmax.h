@@ -161,6 +161,12 @@ int emmax_slots_open(emmax_session* s, int n_slots, emmax_stream stream);
  * token is in place afterwards. */
 int emmax_slot_prefill(emmax_session* s, int slot, const int32_t* ids_dev, int len, const void* patch_embeds_dev, int max_new,
                        emmax_stream stream);
+/* Prefill n requests into the CONSECUTIVE slots slot0 .. slot0 + n - 1 in one packed pass (what a scheduler does when several
+ * slots are free at once: eight one-row prefills cost ~1.6x one eight-row prefill): ids_dev int32 [n][P_max] (row i: lens_host[i]
+ * ids, the rest ignored), patch_embeds_dev [n][n_patches, hidden] bf16 (NULL = language-only), max_new_host[i] the token budgets.
+ * The other slots are not disturbed; every row's first generated token is in place afterwards. */
+int emmax_slots_prefill(emmax_session* s, int slot0, int n, const int32_t* ids_dev, int P_max, const int32_t* lens_host,
+                        const void* patch_embeds_dev, const int32_t* max_new_host, emmax_stream stream);
 /* n_steps greedy decode steps over all slots (hipGraph replay, no host synchronisation); idle / finished slots stay put. */
 int emmax_slots_step(emmax_session* s, int n_steps, emmax_stream stream);
 /* Copy the per-slot done flags and generated-token counts to device buffers int32[n_slots] (asynchronous on `stream`). */

@@ -162,3 +162,37 @@ def test_static_baseline_helper():
 
     assert serve_static(gen, reqs, 2) == [[0], [1], [2], [3], [4]]
     assert seen == [2, 2, 1]
+
+
+class BatchingFakeEngine(FakeEngine):
+    """The fake engine with the packed multi-slot prefill of the C ABI (emmax_slots_prefill)."""
+
+    def __init__(self, plans):
+        super().__init__(plans)
+        self.packed = []
+
+    def slots_prefill(self, slot0, prompts, embeds, budgets):
+        assert len(prompts) == len(embeds) == len(budgets) >= 2
+        self.packed.append((slot0, len(prompts)))
+        for i, (ids, pe, mx) in enumerate(zip(prompts, embeds, budgets)):
+            self.slot_prefill(slot0 + i, ids, pe, mx)
+
+
+def test_consecutive_free_slots_are_prefilled_in_one_packed_pass():
+    lengths = [30, 4, 4, 30, 12, 12, 9, 9, 9]
+    plans = _plans(lengths)
+    eng = BatchingFakeEngine(plans)
+    sch = SlotScheduler(eng, _encode_factory([]), n_slots=4, poll_every=4)
+    for i in range(len(lengths)):
+        sch.submit(Request(rid=i, frame=i, prompt_ids=[1, 7, i + 3], max_new_tokens=512))
+    res = sch.run()
+    assert sorted(r.rid for r in res) == list(range(len(lengths)))
+    for r in res:
+        assert r.ids == plans[r.rid]
+    assert eng.packed[0] == (0, 4)                    # the initial fill: all four slots in one pass
+    assert (1, 2) in eng.packed                       # requests 1 and 2 finish together: slots 1, 2 refilled as one run
+    # slots 0 and 3 (the long requests) free up together later but are NOT neighbours: two single-row prefills
+    singles = [slot for slot, rid, _ in eng.prefills if rid in (6, 7, 8)]
+    assert all((s0, n) != (0, 2) for s0, n in eng.packed) and len(singles) == 3
+    # every request went through exactly one prefill
+    assert sorted(rid for _, rid, _ in eng.prefills) == list(range(len(lengths)))

@@ -126,6 +126,38 @@ def test_slot_serving_equals_bs1_generate(device, served, n_slots, poll):
     assert [ids[b, : int(lens[b])].cpu().tolist() for b in range(2)] == want[:2]
 
 
+def test_packed_multi_slot_prefill_equals_single_slot_prefills(device, served):
+    """emmax_slots_prefill: three requests with ragged prompts into slots 1..3 in ONE packed pass while slot 0 is in the middle of
+    its own decode -- every request's ids equal its bs = 1 generate (and therefore what three emmax_slot_prefill calls give), and
+    slot 0 is not disturbed."""
+    from emmax._lib import EmmaxError
+
+    cfg, model = served
+    eng = model.engine
+    ks = [21, 3, 9, 15]
+    frames, rows = _requests(cfg, ks, seed=23)
+    fr = torch.from_numpy(frames).to(device)
+    want = []
+    for i in range(len(ks)):
+        ids, lens = model.generate_ids(rows[i:i + 1], frames_u8=fr[i:i + 1], max_new_tokens=48)
+        want.append(ids[0, : int(lens[0])].cpu().tolist())
+    pe = eng.vision_encode(fr)
+    eng.slots_open(4)
+    eng.slot_prefill(0, rows[0], pe[0], 48)
+    eng.slots_step(5)                                     # slot 0 is 5 tokens in when the others arrive
+    eng.slots_prefill(1, rows[1:4], [pe[1], pe[2], pe[3]], [48, 48, 6])
+    eng.slots_step(48)
+    done, n_out = eng.slots_state()
+    assert done == [1, 1, 1, 1]
+    got = [eng.slot_output(sl, n_out[sl]) for sl in range(4)]
+    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+    assert got[3] == want[3][:6]                          # its own budget
+    with pytest.raises(EmmaxError):
+        eng.slots_prefill(3, rows[1:3], [pe[1], pe[2]], [8, 8])      # runs past the open slots
+    for sl in range(4):
+        eng.slot_release(sl)
+
+
 def test_slot_api_state_errors(device, served):
     from emmax._lib import EmmaxError
 
