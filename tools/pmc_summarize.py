@@ -17,6 +17,9 @@ STAGE_OF = [  # (substring of the kernel name, stage)
     ("emmax_decode_gemv_kernel<1, 0,", "qkv_gemv"), ("emmax_decode_attn_kernel", "paged_attn"),
     ("emmax_decode_gemv_kernel<1, 1, false, true,", "oproj_gemv"), ("emmax_decode_gemv_kernel<1, 2,", "gateup_gemv"),
     ("emmax_decode_gemv_kernel<1, 1, false, false,", "down_gemv"), ("emmax_decode_gemv_kernel<1, 3,", "lmhead_argmax"),
+    # batch >= 3 (PROBE_BATCH=8), round 3: the K-split MFMA kernels of decode_km.hip <MODE, NORM, XATTN, FP8, F8N> / the two-phase down kernel
+    ("emmax_decode_km_kernel<0,", "qkv_gemv"), ("emmax_decode_km_kernel<1,", "oproj_gemv"), ("emmax_decode_km_kernel<2,", "gateup_gemv"),
+    ("emmax_decode_km_kernel<3,", "lmhead_argmax"), ("emmax_decode_kmd_kernel<", "down_gemv"),
     # batch >= 3 (PROBE_BATCH=8): the MFMA small-batch kernel <MODE, NORM, XATTN, FP8>
     ("emmax_decode_mfma_kernel<0,", "qkv_gemv"), ("emmax_decode_mfma_kernel<1, false, true,", "oproj_gemv"),
     ("emmax_decode_mfma_kernel<2,", "gateup_gemv"), ("emmax_decode_mfma_kernel<1, false, false,", "down_gemv"),
