@@ -141,24 +141,47 @@ def cpu_baseline(cfg, prompt_tokens, new_tokens, seed=0, decode_steps=16, distin
             "seconds_per_action": round(t_action, 3), "parts_s": {k: round(v, 5) for k, v in t.items()}}
 
 
-def _profiled_single_gpu(args, B):
-    """The committed 1-GPU rate of the SAME per-GPU workload (profiles/r03_bench_variants.jsonl), so that an N > 1 line (8
-    frames per GPU) can be read against the right N = 1 number -- the N = 1 default of this script is configs[1] (1 frame)."""
-    if args.tiny or args.prompt_tokens != 512 or args.new_tokens != 512:
+def _alone_baseline(args, model, frames, prompts, T, rank, world, B):
+    """N > 1: the one-GPU rate of the SAME per-GPU workload, measured live in this very job -- rank 0 runs `--alone-steps` steps of
+    its own shard while every other rank is parked at the barrier below (nothing else touches rank 0's GPU; there is no
+    collective inside a step anyway).  `--scale-baseline V` replaces the measurement.  Runs before the warm-up, outside the
+    timed region."""
+    from emmax import dist as edist
+
+    if world == 1:
         return None
-    try:
-        lines = list(open(os.path.join(ROOT, "profiles", "r03_bench_variants.jsonl"))) + list(open(os.path.join(ROOT, "profiles", "r03_bench_n1.json")))
-        for line in lines:
-            if not line.strip().startswith("{"):
-                continue
-            d = json.loads(line)
-            c = d.get("config", {})
-            if (d.get("n_gpus") == 1 and c.get("batch_per_gpu") == B and bool(c.get("hipgraph")) == bool(args.graph)
-                    and ("fp8" in d.get("dtype", "")) == bool(args.fp8)):
-                return {"value": d["value"], "unit": d["unit"], "source": "profiles/r03_bench_variants.jsonl / r03_bench_n1.json"}
-    except OSError:
-        pass
-    return None
+    if args.scale_baseline is not None:
+        return {"value": float(args.scale_baseline), "unit": "actions/s", "source": "--scale-baseline (given on the command line)"}
+    val = None
+    if rank == 0:
+        model.generate_actions_batch(frames, prompts, max_new_tokens=T, stop_on_eos=False)   # warm-up (allocations, first launches)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(max(1, args.alone_steps)):
+            model.generate_actions_batch(frames, prompts, max_new_tokens=T, stop_on_eos=False)
+        torch.cuda.synchronize()
+        val = B * max(1, args.alone_steps) / (time.perf_counter() - t0)
+    edist.barrier()
+    if val is None:
+        return None
+    return {"value": round(val, 4), "unit": "actions/s",
+            "source": "live: rank 0 alone on its GPU, %d step(s) of the same %d-frame shard, other ranks parked at a barrier" % (max(1, args.alone_steps), B)}
+
+
+def _self_launch(n):
+    """Re-exec this script under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1` with the
+    same arguments (an external torchrun sets WORLD_SIZE and never gets here)."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL needs it)
+    argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, argv)
 
 
 def _workload(args, world, B, P, T):
@@ -172,8 +195,10 @@ def _workload(args, world, B, P, T):
         head = "BASELINE configs[2] shard (8 frames/GPU; 64 frames over 8 GPUs at N=8), data-parallel over %d GPU(s), one RCCL all_gather of the results per batch" % world
     else:
         head = "BASELINE configs[1] extended to %d frame(s)/GPU" % B
-    return head + (": Emma-X-7B bf16, %d frame(s)/GPU 224x224, %d-token prompt, greedy, %d new tokens (EOS disabled), random-init weights"
-                   % (B, P, T))
+    return head + (": Emma-X-7B bf16, %d frame(s)/GPU 224x224, %d-token prompt, greedy, %d new tokens (EOS disabled), random-init weights; "
+                   "uint8 frames and prompt ids are resident in HBM when the timed region starts; the 7-vector is de-tokenised from the "
+                   "generated ids by the ids-level stand-in `actions_from_ids` (no LLaMA tokenizer offline: decode -> Solver text parse is "
+                   "host work of microseconds, covered by tests, not in the timed step)" % (B, P, T))
 
 
 def main():
@@ -189,9 +214,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the decode step as a hipGraph (EMMAX_GRAPH=1) instead of eager launch-ahead")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5: fp8-e4m3 decode weights (NOT the bf16 headline)")
+    ap.add_argument("--scale-baseline", type=float, default=None,
+                    help="N > 1 only: actions/s of ONE GPU on the same per-GPU workload, measured elsewhere; default: rank 0 measures it "
+                         "live (alone on its GPU, the other ranks parked at a barrier) before the group run")
+    ap.add_argument("--alone-steps", type=int, default=2, help="N > 1 only: steps of the live one-GPU baseline run on rank 0")
     args = ap.parse_args()
     if args.graph:
         os.environ["EMMAX_GRAPH"] = "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the driver's own launch line (one process per GPU, RCCL)
+        _self_launch(args.gpus)
 
     from emmax import dist as edist
     from emmax.config import EmmaXConfig
@@ -220,6 +252,7 @@ def main():
     frames = torch.from_numpy(rng.integers(0, 256, size=(B, 224, 224, 3), dtype=np.uint8)).to(dev)
     prompts = [[1] + [int(x) for x in rng.integers(3, 31744, size=P - 1)] for _ in range(B)]
 
+    alone = _alone_baseline(args, model, frames, prompts, T, rank, world, B)
     gather_s = []
 
     def step():
@@ -276,7 +309,10 @@ def main():
         # HBM traffic of the same kernel from PMC counters (separate rocprofv3 --pmc passes over tools/pmc_probe.py, B=1;
         # FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); not collected during this run
         traffic = None
-        pmc_name = {(1, False): "r03_pmc_traffic.json", (8, False): "r02_pmc_traffic_b8.json", (1, True): "r02_pmc_traffic_fp8.json"}.get((B, bool(args.fp8)))
+        # (measured on the kernels the line names: r03 = the K-split kernels of decode_ks.hip / decode_km.hip, unchanged since; an
+        # N > 1 line carries no number that was not measured in its own run, so it reports null)
+        pmc_name = {(1, False): "r03_pmc_traffic.json", (8, False): "r03_pmc_traffic_b8_bf16.json",
+                    (8, True): "r03_pmc_traffic_b8_fp8.json"}.get((B, bool(args.fp8))) if world == 1 else None
         pmc_file = os.path.join(ROOT, "profiles", pmc_name or "none")
         if not args.tiny and pmc_name and os.path.isfile(pmc_file):
             with open(pmc_file) as f:
@@ -295,10 +331,13 @@ def main():
             "metric": "actions/sec", "value": round(actions_per_s, 4), "unit": "actions/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not args.fp8 else "bf16 activations / fp8-e4m3 decode weights", "data": "synthetic",
+            "cmd": "python bench.py --gpus %d --steps %d --warmup %d --batch-per-gpu %d --prompt-tokens %d --new-tokens %d%s%s%s"
+                   % (world, args.steps, args.warmup, B, P, T, " --fp8" if args.fp8 else "", " --graph" if args.graph else "", " --tiny" if args.tiny else ""),
             "config": {"workload": _workload(args, world, B, P, T),
                        "batch_per_gpu": B, "global_batch": B * world, "prompt_tokens": P, "new_tokens": T, "context": ctx + T,
                        "parallelism": f"dp{world}", "hipgraph": eng.graph_active(), "persistent_layer_chain": eng.pchain_active()},
-            "value_per_gpu": round(actions_per_s / world, 4), "single_gpu_same_workload": _profiled_single_gpu(args, B),
+            "value_per_gpu": round(actions_per_s / world, 4), "single_gpu_same_workload": alone,
+            "scaling_efficiency": round(actions_per_s / (world * alone["value"]), 4) if alone else None,
             "rccl_ranks": rccl_ranks, "dist_backend": edist.backend_name(),
             "gather_ms": round(gather_ms, 4), "gather_share": round(gather_ms / ms_per_step, 6),
             "p50_latency_ms": round(float(np.median(lat)) * 1e3, 2),

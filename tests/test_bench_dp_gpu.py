@@ -41,6 +41,38 @@ def test_bench_two_ranks_tiny_gloo(device):
     assert d["gather_ms"] > 0 and 0 < d["gather_share"] < 0.5
     assert "cpu_baseline" not in d                 # rank 0 at N = 1 only
     assert d["roofline"]["bound"] == "hbm"
+    _check_live_scaling_fields(d)
+
+
+def _check_live_scaling_fields(d):
+    """An N > 1 line carries its own one-GPU baseline, measured in the same job, and nothing read from a committed file."""
+    one = d["single_gpu_same_workload"]
+    assert one["source"].startswith("live") and one["value"] > 0
+    assert abs(d["scaling_efficiency"] - d["value"] / (d["n_gpus"] * one["value"])) < 1e-3
+    assert d["roofline"]["traffic"] is None and d["roofline"]["traffic_source"] is None
+    assert "--batch-per-gpu %d" % d["config"]["batch_per_gpu"] in d["cmd"] and "--gpus %d" % d["n_gpus"] in d["cmd"]
+
+
+def test_bench_self_launch_two_ranks_tiny_gloo(device):
+    """`python bench.py --gpus 2` with no launcher around it re-executes itself under torch.distributed.run (the N = 1 driver line
+    is a plain `python bench.py --gpus 1`; the same spelling at N > 1 must not die on WORLD_SIZE)."""
+    env = dict(os.environ, EMMAX_FORCE_DEVICE="0", EMMAX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--tiny",
+           "--prompt-tokens", "24", "--new-tokens", "12", "--batch-per-gpu", "3"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["config"]["batch_per_gpu"] == 3 and d["config"]["global_batch"] == 6
+    _check_live_scaling_fields(d)
+    # --scale-baseline replaces the live measurement
+    out = subprocess.run(cmd + ["--scale-baseline", "123.5"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["single_gpu_same_workload"]["value"] == 123.5 and "command line" in d["single_gpu_same_workload"]["source"]
 
 
 def test_bench_one_rank_rccl_singleton(device):

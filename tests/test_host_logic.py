@@ -252,6 +252,23 @@ def test_bench_contract_flags_and_committed_bench_line():
     assert d["rccl_ranks"] == 1 and d["gather_ms"] >= 0 and d["config"]["workload"].startswith("BASELINE configs[1]")
 
 
+def test_bench_gpus_n_without_a_launcher_re_executes_under_torchrun():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must become the driver's own multi-process launch line instead
+    of dying on the WORLD_SIZE check.  Without a GPU every rank then stops at the device check -- once per rank."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--tiny", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode != 0
+    assert "WORLD_SIZE=" not in out.stderr
+    assert out.stderr.count("bench.py needs a HIP device") == 2
+
+
 def test_stop_rule_is_tokenised_in_context_sentencepiece_style():
     """a SentencePiece / LLaMA tokenizer prepends a dummy `▁` to a bare string, giving `▁POLICIES` -- a piece that
     never follows `\\n` in generated text.  The stop rule must be what the model emits after a newline."""
