@@ -220,7 +220,7 @@ def main():
     ap.add_argument("--alone-steps", type=int, default=2, help="N > 1 only: steps of the live one-GPU baseline run on rank 0")
     args = ap.parse_args()
     if args.graph:
-        os.environ["EMMAX_GRAPH"] = "1"
+        os.environ["EMMAX_GRAPH"] = "1"   # read once by the library at start-up (include/emmax.h: tuning switches); inherited by self-launched ranks
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: become the driver's own launch line (one process per GPU, RCCL)
         _self_launch(args.gpus)
@@ -335,7 +335,7 @@ def main():
                    % (world, args.steps, args.warmup, B, P, T, " --fp8" if args.fp8 else "", " --graph" if args.graph else "", " --tiny" if args.tiny else ""),
             "config": {"workload": _workload(args, world, B, P, T),
                        "batch_per_gpu": B, "global_batch": B * world, "prompt_tokens": P, "new_tokens": T, "context": ctx + T,
-                       "parallelism": f"dp{world}", "hipgraph": eng.graph_active(), "persistent_layer_chain": eng.pchain_active()},
+                       "parallelism": f"dp{world}", "hipgraph": eng.graph_active()},
             "value_per_gpu": round(actions_per_s / world, 4), "single_gpu_same_workload": alone,
             "scaling_efficiency": round(actions_per_s / (world * alone["value"]), 4) if alone else None,
             "rccl_ranks": rccl_ranks, "dist_backend": edist.backend_name(),

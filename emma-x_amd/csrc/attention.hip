@@ -730,11 +730,11 @@ int launch_attention(const AttnParams& p, int head_dim, hipStream_t stream) {
     if (p.B <= 0 || p.max_seqlen <= 0) return 0;
     if (p.Hq % p.Hkv != 0) return -1;
     if ((p.ld_qkv % 8) || (p.q_off % 8) || (p.k_off % 8) || (p.v_off % 8) || (p.ld_out % 4)) return -1;
-    static const bool no_resident = getenv("EMMAX_ATTN_RESIDENT") && atoi(getenv("EMMAX_ATTN_RESIDENT")) == 0;   // tuning hook
+    const int force = emmax_tune().attn_resident;   // -1 default; 0 never; 2 = whenever it fits (tests)
+    const bool no_resident = force == 0;
     // short non-causal sequences with enough (sequence, head) items to keep persistent blocks busy: the resident form (see
     // above).  Thresholds from tools/attn_lab.hip and the in-situ kernel trace: head_dim 64 wins from 32 frames on (190 vs 229 us
     // at 256 frames), head_dim 72 -- no room for the pipelined step -- only at the largest batches (174 vs 182 us in situ)
-    static const int force = getenv("EMMAX_ATTN_RESIDENT") ? atoi(getenv("EMMAX_ATTN_RESIDENT")) : -1;   // tests: 2 = whenever it fits
     const int items = p.B * p.Hq;
     if (!p.causal && !no_resident) {
         const bool big64 = force == 2 ? items >= 8 : items >= 512, big72 = force == 2 ? items >= 8 : items >= 2048;

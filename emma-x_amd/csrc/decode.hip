@@ -710,15 +710,13 @@ __global__ __launch_bounds__(256) void emmax_decode_embed_kernel(const int32_t* 
 //   part[((b*Hq + h)*nsplit + s) * PSTRIDE] = { o[0..HD) un-normalised, m, l, pad }
 // The cross-split merge is fused into the staging prologue of the o-proj GEMV (XATTN).
 // ---------------------------------------------------------------------------------------------------------------------
-// MERGE (batch 1-2 bf16 path, round 3): the cross-split merge happens HERE instead of in every block of the o-proj launch (135 KB
-// of partial reads per o-proj block; inside the persistent layer chain, where every WAVE would re-merge its heads, 10-25 us).
-// Every block writes its partial through (16-byte sc1 stores), drains, and bumps the (row, kv head)'s arrival counter; the block
-// that arrives LAST re-reads the nsplit partials past its XCD's L2 (sc1 loads), merges with attn_merge_chunk_loop -- the
-// arithmetic of the o-proj prologues, bit for bit -- writes bf16 o[G x 128] and re-arms the counter (MI355X_MICROARCH.md:
-// drained sc1 payload, then an agent-scope atomic as the flag; no spin anywhere, so nothing can hang).
-template <int HD, int G, bool MERGE = false, int NW = 4>   // NW: waves per block (4, or 8: twice the K/V requests in flight per block)
-__global__ __launch_bounds__(NW * 64) void emmax_decode_attn_kernel(DecodeAttnParams p) {
-    constexpr int NT = NW * 64;
+// DIRECT (one KV split per (row, head): batch >= 5 at 32 heads): nothing to merge -- the block holds the head's whole result,
+// normalises it and writes the bf16 row the o-proj reads (the arithmetic of a one-split merge), no partials, no o-proj prologue.
+// (Round 3 also measured a cross-split merge INSIDE this launch for 2-8 splits -- sc1 partials, arrival counter, last arriver
+// merges: 12.6 against 5.7 us per launch at B = 1; removed from the product source in round 4)
+template <int HD, int G, bool DIRECT = false>
+__global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams p) {
+    constexpr int NW = 4, NT = NW * 64;   // waves per block (8-wave blocks were measured no faster)
     static_assert(HD == 128, "decode attention maps 16 lanes x 8 elements onto one 128-wide K/V row");
     constexpr int KU = G <= 2 ? 4 : 2;    // keys per lane group per chunk (block chunk = 16 * KU keys), two chunks in flight
     constexpr int SP = 512;  // page ids kept in LDS = the longest page table the launcher accepts (32 K tokens at 64 per page)
@@ -756,39 +754,10 @@ __global__ __launch_bounds__(NW * 64) void emmax_decode_attn_kernel(DecodeAttnPa
     const int Hq = p.Hkv * G;
     float* part = p.part + ((size_t)(b * Hq + hk * G) * nsplit + split) * PSTRIDE;
 
-    // MERGE: arrival of this block at the (row, kv head)'s counter; the last arriver merges the splits of its G heads
-    __shared__ int s_last;
-    auto arrive_and_merge = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
-        __syncthreads();
-        unsigned int* ctr = p.merge_ctr + (size_t)b * p.Hkv + hk;
-        if (tid == 0) {
-            const unsigned int prev = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = prev == (unsigned)nsplit - 1u;
-            if (s_last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everyone has arrived: re-arm
-        }
-        __syncthreads();
-        if (!s_last) return;
-        if (tid < G * 16) {
-            const int gq = tid >> 4, c = tid & 15;
-            const float* pp = p.part + (size_t)(b * Hq + hk * G + gq) * nsplit * PSTRIDE;
-            const u32x4_t v = attn_merge_chunk_loop(pp, c * 8, nsplit, true);
-            *((u32x4_t*)((bf16_t*)p.o_out + (size_t)b * p.ldq + (hk * G + gq) * HD) + c) = v;
-        }
-    };
     if (k0 >= L || row_done) {   // empty split, or a row that no longer decodes: no K/V traffic
-        if constexpr (MERGE) {
-            if (nsplit == 1) {   // a row that no longer decodes: zeros (what the merge of an empty partial gives)
-                for (int i = tid; i < G * (HD / 8); i += NT)
-                    *((u32x4_t*)((bf16_t*)p.o_out + (size_t)b * p.ldq + hk * G * HD) + i) = (u32x4_t){0u, 0u, 0u, 0u};
-                return;
-            }
-            for (int i = tid; i < G * (PSTRIDE / 4); i += NT) {
-                const int gq = i / (PSTRIDE / 4), j4 = i - gq * (PSTRIDE / 4);
-                const f32x4_t v = {j4 * 4 == HD ? -INFINITY : 0.f, 0.f, 0.f, 0.f};
-                st_sc1_f32x4(part + (size_t)gq * nsplit * PSTRIDE + j4 * 4, v);
-            }
-            arrive_and_merge();
+        if constexpr (DIRECT) {   // a row that no longer decodes: zeros (what the merge of an empty partial gives)
+            for (int i = tid; i < G * (HD / 8); i += NT)
+                *((u32x4_t*)((bf16_t*)p.o_out + (size_t)b * p.ldq + hk * G * HD) + i) = (u32x4_t){0u, 0u, 0u, 0u};
             return;
         }
         for (int i = tid; i < G * PSTRIDE; i += NT) {
@@ -920,25 +889,16 @@ __global__ __launch_bounds__(NW * 64) void emmax_decode_attn_kernel(DecodeAttnPa
         }
         return v;
     };
-    if constexpr (MERGE) {
-        if (nsplit == 1) {   // nothing to merge: this block holds the head's whole result -- normalise and write the bf16 row directly
-            for (int i = tid; i < G * (HD / 8); i += NT) {
-                const int gq = i / (HD / 8), c = i - gq * (HD / 8);
-                const float den = part_value(gq, HD + 1);
-                const float inv = den > 0.f ? 1.0f / den : 0.f;   // the arithmetic of attn_merge_chunk<1> (weight exp(m - M) = 1)
-                u32x4_t v;
+    if constexpr (DIRECT) {   // this block holds the head's whole result -- normalise and write the bf16 row directly
+        for (int i = tid; i < G * (HD / 8); i += NT) {
+            const int gq = i / (HD / 8), c = i - gq * (HD / 8);
+            const float den = part_value(gq, HD + 1);
+            const float inv = den > 0.f ? 1.0f / den : 0.f;   // the arithmetic of attn_merge_chunk<1> (weight exp(m - M) = 1)
+            u32x4_t v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = pack_bf16x2(part_value(gq, c * 8 + 2 * j) * inv, part_value(gq, c * 8 + 2 * j + 1) * inv);
-                *((u32x4_t*)((bf16_t*)p.o_out + (size_t)b * p.ldq + (hk * G + gq) * HD) + c) = v;
-            }
-            return;
+            for (int j = 0; j < 4; ++j) v[j] = pack_bf16x2(part_value(gq, c * 8 + 2 * j) * inv, part_value(gq, c * 8 + 2 * j + 1) * inv);
+            *((u32x4_t*)((bf16_t*)p.o_out + (size_t)b * p.ldq + (hk * G + gq) * HD) + c) = v;
         }
-        for (int i = tid; i < G * (PSTRIDE / 4); i += NT) {   // 33 write-through stores of 16 bytes per head
-            const int gq = i / (PSTRIDE / 4), j4 = i - gq * (PSTRIDE / 4);
-            const f32x4_t v = {part_value(gq, j4 * 4), part_value(gq, j4 * 4 + 1), part_value(gq, j4 * 4 + 2), part_value(gq, j4 * 4 + 3)};
-            st_sc1_f32x4(part + (size_t)gq * nsplit * PSTRIDE + j4 * 4, v);
-        }
-        arrive_and_merge();
         return;
     }
     for (int i = tid; i < G * PSTRIDE; i += NT) {
@@ -1064,22 +1024,6 @@ template <int B, int MODE, bool NORM, bool XATTN = false, int F8 = 0>
 static int launch_gemv_t(const GemvParams& p, hipStream_t stream, int* grid_out) {
     const size_t smem = (size_t)B * (p.kc * 2 + 16);
     int grid = gemv_grid(B, smem, p.n_groups, (F8 == 1 || F8 == 2) ? 256 : p.max_grid);
-    {   // tuning hook: EMMAX_GEMV_GRID="qkv,resid,gateup,lmhead,plain" (0 = default) overrides the persistent grid per mode
-        static int forced[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        static bool parsed = false;
-        if (!parsed) {
-            parsed = true;
-            if (const char* e = getenv("EMMAX_GEMV_GRID")) {
-                int i = 0;
-                while (*e && i < 8) {
-                    forced[i++] = atoi(e);
-                    while (*e && *e != ',') ++e;
-                    if (*e == ',') ++e;
-                }
-            }
-        }
-        if (forced[MODE] > 0 && p.max_grid == 0) grid = min(forced[MODE], cdiv(p.n_groups, GW));
-    }
     if (MODE == MODE_LMHEAD) grid = min(grid, p.max_parts);
     if (grid_out) *grid_out = grid;
     auto kern = emmax_decode_gemv_kernel<B, MODE, NORM, XATTN, F8>;
@@ -1177,7 +1121,7 @@ int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, i
 
 // splits of the KV range per (row, kv head): ~512 blocks in flight, at most 8 partials to merge
 int decode_attn_nsplit(int B, int Hkv) {
-    static const int forced = getenv("EMMAX_ATTN_NSPLIT") ? atoi(getenv("EMMAX_ATTN_NSPLIT")) : 0;   // tuning hook
+    const int forced = emmax_tune().attn_nsplit;
     if (forced > 0) {   // rounded down to a power of two (the kernel divides by shifting)
         int f = forced > 16 ? 16 : forced;
         while (f & (f - 1)) f &= f - 1;
@@ -1200,17 +1144,13 @@ int launch_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_dim
     if (nsplit < 1 || (nsplit & (nsplit - 1))) return -1;   // the kernel divides the keys among the splits by shifting
     p.page_shift = 0;
     while ((1 << p.page_shift) < p.page) ++p.page_shift;
-    if (p.o_out && nsplit > 1 && !p.merge_ctr) return -1;   // the in-kernel merge needs its arrival counters (one split: nothing to merge)
+    if (p.o_out && nsplit != 1) return -1;   // the direct form exists for one split only (nothing to merge)
     const int G = Hq / p.Hkv;
     dim3 grid(nsplit, p.Hkv, B), block(256);
-    // lab: EMMAX_ATTN_WAVES=8 -- 8-wave blocks (twice the K/V requests in flight per block)
-    static const bool nw8 = getenv("EMMAX_ATTN_WAVES") && atoi(getenv("EMMAX_ATTN_WAVES")) == 8;
     switch (G) {
 #define ATTN_CASE(GG)                                                                                                   \
     case GG:                                                                                                           \
-        if (p.o_out && nw8) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true, 8>), grid, dim3(512), 0, stream, p); \
-        else if (p.o_out) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true>), grid, block, 0, stream, p);     \
-        else if (nw8) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, false, 8>), grid, dim3(512), 0, stream, p);  \
+        if (p.o_out) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true>), grid, block, 0, stream, p);          \
         else hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG>), grid, block, 0, stream, p);                         \
         break
         ATTN_CASE(1); ATTN_CASE(2); ATTN_CASE(4); ATTN_CASE(8);

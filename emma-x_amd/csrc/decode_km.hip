@@ -80,12 +80,10 @@ __device__ __forceinline__ void km_merge_rows(const float* __restrict__ attn_par
 // FP8: the tiles are e4m3 (16 rows x 64 k per KiB, decode_mfma.hip's emmax_quant_fm8_kernel layout) + one fp32 scale per row,
 // de-quantised in registers (exact), two MFMAs per load.
 // ---------------------------------------------------------------------------------------------------------------------
-// F8N (lab, EMMAX_KM_FP8_NATIVE=1; perf A/B only): the e4m3 tiles go straight into v_mfma_f32_16x16x32_fp8_fp8, the wave's activation
-// slice quantised to e4m3 once per launch with one scale per (wave slice, batch column) -- no de-quantisation VALU work, different
-// numerics (3-bit activation mantissas: NOT what the oracle computes, never on the product path).
-template <int MODE, bool NORM, bool XATTN, bool FP8, bool F8N = false>
+// (v_mfma_f32_16x16x32_fp8_fp8 on e4m3-quantised activations was measured in round 3: no faster -- the kernel is memory-bound by 14x --
+// and 1.0e-1 of max|logit| from the oracle; removed from the product source)
+template <int MODE, bool NORM, bool XATTN, bool FP8>
 __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p) {
-    static_assert(!F8N || FP8, "native fp8 MFMA needs the e4m3 tiles");
     extern __shared__ __attribute__((aligned(16))) unsigned char km_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g4 = lane >> 4, c16 = lane & 15;
@@ -216,40 +214,13 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
         }
     }
     issue(wb, 1);   // the second tile once the prologue's temporaries are dead (all of them next to two tiles would not fit 256 VGPRs)
-    long xq[KM_STEPS];      // F8N: the fragments as e4m3, and the column's scale
-    float xscale = 1.f;
-    if constexpr (F8N) {
-        float am = 0.f;
-#pragma unroll
-        for (int s = 0; s < KM_STEPS; ++s) {
-            const u32x4_t v = __builtin_bit_cast(u32x4_t, xf[s]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) am = fmaxf(am, fmaxf(fabsf(bf_lo(v[e])), fabsf(bf_hi(v[e]))));
-        }
-        am = rows_max(am);   // over the four k-groups of the batch column
-        xscale = am > 0.f ? am / 448.0f : 1.0f;
-        const float inv = 1.0f / xscale;
-#pragma unroll
-        for (int s = 0; s < KM_STEPS; ++s) {
-            const u32x4_t v = __builtin_bit_cast(u32x4_t, xf[s]);
-            int lo = 0, hi = 0;
-            lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[0]) * inv, bf_hi(v[0]) * inv, lo, false);
-            lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[1]) * inv, bf_hi(v[1]) * inv, lo, true);
-            hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[2]) * inv, bf_hi(v[2]) * inv, hi, false);
-            hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[3]) * inv, bf_hi(v[3]) * inv, hi, true);
-            xq[s] = (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-        }
-    }
 
     // ---- main loop: two tiles per trip (register sets a / b); a set is consumed MFMA by MFMA and refilled with the tile two ahead ----
     auto run_tile = [&](u32x4_t (&w)[NSTEP], int tl) {
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
-            if constexpr (F8N) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)(((unsigned long long)w[s][1] << 32) | w[s][0]), xq[2 * s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)(((unsigned long long)w[s][3] << 32) | w[s][2]), xq[2 * s + 1], acc, 0, 0, 0);
-            } else if constexpr (FP8) {
+            if constexpr (FP8) {
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(km_fp8x8(w[s][0], w[s][1]), xf[2 * s], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(km_fp8x8(w[s][2], w[s][3]), xf[2 * s + 1], acc, 0, 0, 0);
             } else {
@@ -259,7 +230,6 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
         __builtin_amdgcn_sched_barrier(0);
         issue(w, tl + 2);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (F8N) acc = acc * xscale;   // a lane's four results belong to its own batch column
         if (tl < ntb) *(f32x4_t*)(part + ((size_t)(wave * tiles_cap + tl) * 64 + lane) * 4) = acc;
     };
     for (int tl = 0; tl < ntb; tl += 2) {
@@ -528,16 +498,6 @@ int km_launch_t(GemvParams p, int B, hipStream_t stream, int* grid_out) {
                         (XATTN ? (size_t)B * p.K * 2 : (size_t)KM_WAVES * EMMAX_MAX_DECODE_BATCH * (KM_STEPS * 64 + 16));
     if (smem > 150 * 1024) return -2;
     if (grid_out) *grid_out = grid;
-    if constexpr (FP8) {
-        static const bool native = getenv("EMMAX_KM_FP8_NATIVE") && atoi(getenv("EMMAX_KM_FP8_NATIVE")) != 0;   // lab, perf A/B only
-        if (native) {
-            auto kn = emmax_decode_km_kernel<MODE, NORM, XATTN, true, true>;
-            static bool raised = false;
-            if (!raised) { (void)hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); raised = true; }
-            hipLaunchKernelGGL(kn, dim3(grid), dim3(KM_NT), smem, stream, p);
-            return hipGetLastError() == hipSuccess ? 0 : -4;
-        }
-    }
     auto kern = emmax_decode_km_kernel<MODE, NORM, XATTN, FP8>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(KM_NT), smem, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -585,11 +545,8 @@ int decode_km_init() {
     return done;
 }
 
-// tuning hook: EMMAX_KM=0 keeps every batch >= 3 projection on decode_mfma.hip (the A/B partner)
-bool decode_km_enabled() {
-    const char* e = getenv("EMMAX_KM");
-    return !(e && atoi(e) == 0);
-}
+// tuning switch `km` = 0 keeps every batch >= 3 projection on decode_mfma.hip (the A/B partner)
+bool decode_km_enabled() { return emmax_tune().km != 0; }
 
 // perm: 0 natural row order, 1 qkv (head_dim given), 2 gate/up (source in decode.hip's 16-row interleaved order)
 int launch_repack_km(const void* src, int ld, void* dst, int N, int K, int perm, int head_dim, hipStream_t stream) {
@@ -606,8 +563,7 @@ int launch_decode_km(int mode, const GemvParams& p, int B, hipStream_t stream, i
     if (B < 1 || B > EMMAX_MAX_DECODE_BATCH) return -2;
     if (decode_km_init() != 0) return -4;
     if (mode == GEMV_RESID && !p.attn_part && p.K > KM_WAVES * KM_STEPS * 32) {   // the down projection: two K phases (natural row order copy)
-        static const bool off = getenv("EMMAX_KM_DOWN") && atoi(getenv("EMMAX_KM_DOWN")) == 0;   // A/B partner: decode_mfma.hip
-        if (off) return -2;
+        if (!emmax_tune().km_down) return -2;   // A/B partner: decode_mfma.hip
         return p.wscale ? kmd_launch<true>(p, B, stream) : kmd_launch<false>(p, B, stream);
     }
     return p.wscale ? km_launch_mode<true>(mode, p, B, stream, grid_out) : km_launch_mode<false>(mode, p, B, stream, grid_out);

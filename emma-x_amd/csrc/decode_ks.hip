@@ -99,39 +99,19 @@ __device__ __forceinline__ bool ks_lane_stores(int lane) {
 // rows in flight per wave: 16 loads of 16 B per lane at batch 1 (64 VGPRs), 8 at batch 2 (two accumulators per row)
 template <int B, int CPL> struct KsShape { static constexpr int RB = (B == 1 ? 16 : 8) / (CPL == 1 ? 1 : CPL == 2 ? 2 : 4); };
 
-// rows in flight per wave: 16 loads of 16 B per lane at batch 1 (64 VGPRs), 8 at batch 2 (two accumulators per row)
-// (KsShape above); the weight registers are one flat array shared by every op of a chain
+// weight registers of a wave: one flat array
 template <int B> struct KsRegs { static constexpr int N = B == 1 ? 16 : 8; };
 
-// ---------------------------------------------------------------------------------------------------------------------
-// In-launch hand-off of an activation vector (persistent chain, below): a MAILBOX of 8-byte granules {2 x bf16, tag}, written
-// with ONE agent-scope (write-through, sc1) store each and polled in place with sc1 loads -- the data is the flag, no
-// fence, no counter (MI355X_MICROARCH.md, "R2 granules"; 16-byte sc1 loads of two granules are observed untorn).  The tag is
-// the launch's epoch + the edge's index: every granule of a mailbox is rewritten by every launch, so a stale tag never matches.
-// ---------------------------------------------------------------------------------------------------------------------
-struct KsLink {
-    const unsigned long long* in;    // mailbox the op's activations arrive in, [B][K / 2] granules (null: global memory / partials)
-    unsigned long long* out;         // mailbox its outputs go to, [B][N / 2] granules (null: none)
-    unsigned in_tag, out_tag;
-    unsigned* err;                   // set when a poll gave up (bounded spin); every later poll falls through
-};
-enum { XS_GLOBAL = 0, XS_ATTN = 1, XS_MBOX = 2 };
+enum { XS_GLOBAL = 0, XS_ATTN = 1 };
 #ifdef DECODE_LAB_TRACE
-// lab builds only (tools/chain_trace.py): s_memrealtime stamps (100 MHz) of waves 0 and 7 of every block, per op of the chain:
-// [block][wave 0 | 7][op][0 op entered, 1 activations in registers, 2 polls that came back stale, 3 stream done, 4 barrier passed,
-// 5 epilogue done]
+// lab builds only (tools/ks_trace.py): s_memrealtime stamps (100 MHz) of waves 0 and 7 of every block:
+// [block][wave 0 | 7][op = 0][0 entered, 1 activations in registers, 2 unused, 3 stream done, 4 barrier passed, 5 epilogue done]
 __device__ unsigned long long g_ks_trace[512 * 2 * 4 * 6];
 #define KS_STAMP(op, k, v) do { if ((threadIdx.x == 0 || threadIdx.x == 448) && blockIdx.x < 512 && (op) >= 0) \
     g_ks_trace[((blockIdx.x * 2 + (threadIdx.x ? 1 : 0)) * 4 + (op)) * 6 + (k)] = (v); } while (0)
 #else
 #define KS_STAMP(op, k, v) do { } while (0)
 #endif
-constexpr unsigned KS_SPIN_LIMIT = 1u << 18;   // x ~0.2 us: a legitimate wait lasts a few us; ~50 ms means a producer is not resident
-
-__device__ __forceinline__ void ks_put(unsigned long long* g, unsigned tag, uint32_t v) {
-    __hip_atomic_store(g, ((unsigned long long)tag << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 template <int MODE>
 __device__ __forceinline__ void ks_pair_rows(const GemvParams& p, int g, int& r0, int& r1) {
     if (MODE == GEMV_QKV) {
@@ -147,14 +127,12 @@ __device__ __forceinline__ void ks_pair_rows(const GemvParams& p, int g, int& r0
         r1 = min(2 * g + 1, p.n_rows - 1);
     }
 }
-// block b's contiguous share of the row PAIRS, in units of p.ks_unit pairs (2 inside a chain where a granule holds the outputs
-// of two neighbouring pairs: gate/up)
+// block b's contiguous share of the row PAIRS
 __device__ __forceinline__ void ks_share(const GemvParams& p, int& g_lo, int& npairs) {
-    const int G = gridDim.x, bid = blockIdx.x, u = p.ks_unit;
-    const int units = (p.n_groups + u - 1) / u;
-    const int q = units / G, r = units % G;
-    g_lo = (bid * q + min(bid, r)) * u;
-    npairs = min((q + (bid < r ? 1 : 0)) * u, max(p.n_groups - g_lo, 0));
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int q = p.n_groups / G, r = p.n_groups % G;
+    g_lo = bid * q + min(bid, r);
+    npairs = min(q + (bid < r ? 1 : 0), max(p.n_groups - g_lo, 0));
 }
 
 // the matrix as a buffer: ONE descriptor, the row's byte offset in an SGPR (soffset), the lane's chunk in a 32-bit VGPR -- with
@@ -194,20 +172,17 @@ __device__ __forceinline__ void ks_chunks(int K, int wave, int lane, int (&coff)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// One projection.  The first batch of its weights is ALREADY in flight (requested from inside the previous op of a chain -- the
-// weight stream never stops at an op boundary) unless OWN_HEAD (first op of a launch: requested here, right behind the
-// activation loads / the split merge, whose ~60 registers the head would otherwise have to share); `next_head` is called in
-// the refill slot of the last batch.  part / sumsq: this op's LDS scratch (double-buffered by the chain).
-//   XS: where the activations come from (global row, attention split partials, mailbox)
-//   KEEP_IN / KEEP_OUT (RESID): the residual operand comes from / the result stays in `keep` (o-proj -> down of one chain: same
-//   rows, same block, same lane) instead of global memory;  GOUT: also store the result to p.y
+// One projection.  The first batch of its weights is requested right behind the activation loads / the split merge (whose ~60
+// registers the head would otherwise have to share).  part / sumsq: the launch's LDS scratch.
+//   XS: where the activations come from (global row, attention split partials)
+// (Round 3 chained four of these in one persistent launch with in-kernel mailbox hand-offs: bit-identical and 18 % slower --
+// DESIGN.md section 6; that variant lives in the history, commit 61d5036, not in the product source.)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int B, int MODE, bool NORM, int XS, int CPL, bool KEEP_IN, bool KEEP_OUT, bool GOUT, bool OWN_HEAD, class NextHead>
-__device__ __forceinline__ void ks_run_op(const GemvParams& p, const KsLink lk, u32x4_t (&wr)[KsRegs<B>::N], float* part, float* sumsq,
-                                          int rows_cap, float (&keep)[2], NextHead&& next_head, int trace_op = -1) {
+template <int B, int MODE, bool NORM, int XS, int CPL>
+__device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsRegs<B>::N], float* part, float* sumsq, int rows_cap,
+                                          int trace_op = -1) {
     constexpr int RB = KsShape<B, CPL>::RB;
     KS_STAMP(trace_op, 0, wall_clock64());
-    if ((p.ks_flags & 1) && blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = p.K, bid = blockIdx.x;
     int g_lo, npairs;
@@ -223,7 +198,7 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, const KsLink lk, 
     float pre_a = 0.f, pre_b = 0.f;
     int pre_pos = 0, pre_pg = 0;
     if (epi) {
-        if (MODE == GEMV_RESID && !KEEP_IN) {
+        if (MODE == GEMV_RESID) {
             const bf16_t* hp = (const bf16_t*)p.y + (size_t)eb * p.ldy;
             pre_a = bf2f(hp[er0]);
             pre_b = bf2f(hp[er1]);
@@ -259,42 +234,15 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, const KsLink lk, 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xr[b][j][e] = cok[j] ? v[e] : 0u;
             }
-        if constexpr (OWN_HEAD) {
-            __builtin_amdgcn_sched_barrier(0);
-            ks_issue<B, MODE, CPL>(p, g_lo, nrows, 0, voff, wr);
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        ks_issue<B, MODE, CPL>(p, g_lo, nrows, 0, voff, wr);
     } else {
         u32x4_t nw[CPL];
         if constexpr (NORM) {
 #pragma unroll
             for (int j = 0; j < CPL; ++j) nw[j] = *((const u32x4_t*)p.norm_w + coff[j]);
         }
-        if constexpr (XS == XS_MBOX) {
-            // the slice's granules, polled in place: chunk c = granules 4c .. 4c + 3 = 32 bytes.  The polls sit BEHIND the head of
-            // the weight stream in this wave's load queue, so the first answer arrives when the head has landed -- by when the
-            // producers are normally done: the hand-off hides under the stream it could not start without.
-            const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)lk.in, 0, B * K * 4, 0x00020000);
-            for (unsigned spins = 0;; ++spins) {
-                KS_STAMP(trace_op, 2, (unsigned long long)spins);
-                bool ok = true;
-#pragma unroll
-                for (int b = 0; b < B; ++b)
-#pragma unroll
-                    for (int j = 0; j < CPL; ++j) {
-                        const unsigned at = (unsigned)(b * K * 4) + (unsigned)coff[j] * 32u;
-                        const u32x4_t lo = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, at, 0, 16));        // aux 16 = sc1
-                        const u32x4_t hi = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, at + 16u, 0, 16));
-                        xr[b][j] = (u32x4_t){lo[0], lo[2], hi[0], hi[2]};
-                        ok &= !cok[j] || (lo[1] == lk.in_tag && lo[3] == lk.in_tag && hi[1] == lk.in_tag && hi[3] == lk.in_tag);
-                    }
-                if (__all(ok)) break;
-                if (spins >= KS_SPIN_LIMIT || __hip_atomic_load(lk.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    if (lane == 0) __hip_atomic_store(lk.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-        } else {
+        {
 #pragma unroll
             for (int b = 0; b < B; ++b) {
                 // layer 0: the row is the embedding of the current token (the embed launch folded in); block 0 leaves a copy in the
@@ -309,10 +257,7 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, const KsLink lk, 
             }
         }
         // right behind the activations: they are waited for by count while the head of the stream is in flight
-        if constexpr (OWN_HEAD) {
-            if (p.ks_flags & 2) __builtin_amdgcn_s_barrier();
-            ks_issue<B, MODE, CPL>(p, g_lo, nrows, 0, voff, wr);
-        }
+        ks_issue<B, MODE, CPL>(p, g_lo, nrows, 0, voff, wr);
         float ss[B];
 #pragma unroll
         for (int b = 0; b < B; ++b) {
@@ -370,7 +315,6 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, const KsLink lk, 
             if (ks_lane_stores<RB>(lane)) part[(wave * B + b) * rows_cap + bb * RB + ks_row_of_lane<RB>(lane)] = t;
         }
     }
-    next_head();   // the head of the NEXT op's stream (chain): in flight across the barrier, the epilogue and the hand-off
     KS_STAMP(trace_op, 3, wall_clock64());
     __syncthreads();
     KS_STAMP(trace_op, 4, wall_clock64());
@@ -401,22 +345,14 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, const KsLink lk, 
         }
     } else if (MODE == GEMV_RESID) {
         if (epi) {
-            const uint32_t hv = pack_bf16x2((KEEP_IN ? keep[0] : pre_a) + red0, (KEEP_IN ? keep[1] : pre_b) + red1);
-            if (KEEP_OUT) { keep[0] = bf_lo(hv); keep[1] = bf_hi(hv); }
-            if (GOUT) {
-                bf16_t* hp = (bf16_t*)p.y + (size_t)eb * p.ldy;
-                hp[er0] = (bf16_t)(hv & 0xffffu);
-                if (has1) hp[er1] = (bf16_t)(hv >> 16);
-            }
-            if (lk.out) ks_put(lk.out + (size_t)eb * (p.n_rows >> 1) + epair, lk.out_tag, hv);   // rows 2g, 2g + 1 = one granule
+            const uint32_t hv = pack_bf16x2(pre_a + red0, pre_b + red1);
+            bf16_t* hp = (bf16_t*)p.y + (size_t)eb * p.ldy;
+            hp[er0] = (bf16_t)(hv & 0xffffu);
+            if (has1) hp[er1] = (bf16_t)(hv >> 16);
         }
     } else if (MODE == GEMV_GATEUP) {
         const float a = silu(red0) * red1;
-        if (GOUT && epi) ((bf16_t*)p.y)[(size_t)eb * p.ldy + epair] = f2bf(a);
-        if (lk.out && wave < B) {   // a granule = the outputs of two neighbouring pairs (the share is even-aligned: ks_unit 2)
-            const float nb = __shfl_down(a, 1);
-            if (epi && !(lane & 1)) ks_put(lk.out + (size_t)eb * (p.n_pairs >> 1) + (epair >> 1), lk.out_tag, pack_bf16x2(a, nb));
-        }
+        if (epi) ((bf16_t*)p.y)[(size_t)eb * p.ldy + epair] = f2bf(a);
     } else if (MODE == GEMV_QKV) {
         if (epi) {
             const int hd = p.head_dim, half = hd >> 1;
@@ -478,70 +414,7 @@ __global__ __launch_bounds__(KS_NT, 4) void emmax_decode_ks_kernel(GemvParams p)
     float* part = (float*)ks_smem;          // [KS_WAVES][B][rows_cap]
     float* sumsq = part + KS_WAVES * B * rows_cap;   // [KS_WAVES][B]
     u32x4_t wr[KsRegs<B>::N];
-    float keep[2] = {0.f, 0.f};
-    KsLink lk;
-    lk.in = nullptr; lk.out = nullptr; lk.in_tag = lk.out_tag = 0u; lk.err = nullptr;
-    ks_run_op<B, MODE, NORM, XATTN ? XS_ATTN : XS_GLOBAL, CPL, false, false, true, true>(p, lk, wr, part, sumsq, rows_cap, keep, [] {}, 0);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Persistent chain: o-proj -> gate/up -> down -> (next layer's qkv | lm-head) of one decoder layer in ONE launch.  Every wave
-// walks the four matrices as one weight stream: the head of op i + 1 is requested in the refill slot of op i's last batch, so
-// HBM keeps delivering while the activation vector of the edge travels through its mailbox (KsLink).  What a kernel boundary
-// costs a weight-streaming launch -- drain, dispatch, ramp, and a prologue that waits for activations behind the first burst --
-// happens once per layer (in front of the attention kernel, which stays its own launch) instead of four times.
-// All 2 x CUs blocks must be resident (they are: 512 threads, <= 128 VGPRs, a few KB of LDS; the launcher checks the occupancy
-// query once); every poll is bounded and reports through p.err.
-// ---------------------------------------------------------------------------------------------------------------------
-struct KsChainParams {
-    GemvParams op[4];                 // o-proj (x = merged attention row), gate/up, down, tail (qkv of the next layer or the lm-head)
-    unsigned long long* mbox[3];      // h' [B][H/2], act [B][inter/2], h'' [B][H/2] granules
-    unsigned int* epoch;              // device word: tag base of this launch; block 0 advances it by 4 when it is done
-    unsigned int* err;
-    int rows_cap;
-};
-template <int B, int CPLD, int TAIL>   // CPLD: chunks per lane of the down projection (K = inter); TAIL: GEMV_QKV | GEMV_LMHEAD | -1 (none)
-__global__ __launch_bounds__(KS_NT, 4) void emmax_decode_chain_kernel(KsChainParams c) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rows_cap = c.rows_cap;
-    float* part0 = (float*)ks_smem;                               // two LDS sets: op i + 1 reduces while op i's epilogue still reads
-    float* part1 = part0 + KS_WAVES * B * rows_cap;
-    float* sq0 = part1 + KS_WAVES * B * rows_cap;
-    float* sq1 = sq0 + KS_WAVES * B;
-    // every block reads the epoch before it can contribute to the last edge, and block 0 bumps it only after that edge
-    const unsigned tag0 = __hip_atomic_load(c.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-    u32x4_t wr[KsRegs<B>::N];
-    float keep[2] = {0.f, 0.f};
-    constexpr int NOPS = TAIL >= 0 ? 4 : 3;
-    int g_lo[4], npairs[4];
-#pragma unroll
-    for (int i = 0; i < NOPS; ++i) ks_share(c.op[i], g_lo[i], npairs[i]);
-    int coffH[1], coffD[CPLD];
-    bool cokH[1], cokD[CPLD];
-    unsigned voffH[1], voffD[CPLD];
-    ks_chunks<1>(c.op[0].K, wave, lane, coffH, cokH, voffH);       // K = hidden for o-proj (q_dim == hidden checked by the launcher), gate/up, tail
-    ks_chunks<CPLD>(c.op[2].K, wave, lane, coffD, cokD, voffD);
-
-    KsLink l0, l1, l2, l3;
-    l0.in = nullptr;   l0.in_tag = 0u;       l0.out = c.mbox[0]; l0.out_tag = tag0 + 1u; l0.err = c.err;
-    l1.in = c.mbox[0]; l1.in_tag = tag0 + 1u; l1.out = c.mbox[1]; l1.out_tag = tag0 + 2u; l1.err = c.err;
-    l2.in = c.mbox[1]; l2.in_tag = tag0 + 2u; l2.out = TAIL >= 0 ? c.mbox[2] : nullptr; l2.out_tag = tag0 + 3u; l2.err = c.err;
-    l3.in = c.mbox[2]; l3.in_tag = tag0 + 3u; l3.out = nullptr;  l3.out_tag = 0u;        l3.err = c.err;
-
-    ks_run_op<B, GEMV_RESID, false, XS_GLOBAL, 1, false, true, false, true>(c.op[0], l0, wr, part0, sq0, rows_cap, keep,
-        [&] { ks_issue<B, GEMV_GATEUP, 1>(c.op[1], g_lo[1], 2 * npairs[1], 0, voffH, wr); }, 0);
-    ks_run_op<B, GEMV_GATEUP, true, XS_MBOX, 1, false, false, false, false>(c.op[1], l1, wr, part1, sq1, rows_cap, keep,
-        [&] { ks_issue<B, GEMV_RESID, CPLD>(c.op[2], g_lo[2], 2 * npairs[2], 0, voffD, wr); }, 1);
-    if constexpr (TAIL >= 0) {
-        ks_run_op<B, GEMV_RESID, false, XS_MBOX, CPLD, true, false, true, false>(c.op[2], l2, wr, part0, sq0, rows_cap, keep,
-            [&] { ks_issue<B, TAIL, 1>(c.op[3], g_lo[3], 2 * npairs[3], 0, voffH, wr); }, 2);
-        ks_run_op<B, TAIL, true, XS_MBOX, 1, false, false, true, false>(c.op[3], l3, wr, part1, sq1, rows_cap, keep, [] {}, 3);
-    } else {
-        ks_run_op<B, GEMV_RESID, false, XS_MBOX, CPLD, true, false, true, false>(c.op[2], l2, wr, part0, sq0, rows_cap, keep, [] {}, 2);
-    }
-    if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(c.epoch, tag0 + 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ks_run_op<B, MODE, NORM, XATTN ? XS_ATTN : XS_GLOBAL, CPL>(p, wr, part, sumsq, rows_cap, 0);
 }
 
 template <int B, int MODE, bool NORM, bool XATTN, int CPL>
@@ -554,21 +427,18 @@ int ks_launch_t(GemvParams p, hipStream_t stream, int* grid_out) {
     const int pairs_max = cdiv(p.n_groups, grid);
     if (pairs_max > 64) return -2;   // the epilogue maps one lane to a pair
     p.kc = cdiv(2 * pairs_max, RB) * RB;
-    p.ks_unit = 1;
-    p.ks_flags = getenv("EMMAX_KS_FLAGS") ? atoi(getenv("EMMAX_KS_FLAGS")) : 0;
     const size_t smem = (size_t)(KS_WAVES * B * p.kc + KS_WAVES * B) * sizeof(float);
     if (grid_out) *grid_out = grid;
     hipLaunchKernelGGL((emmax_decode_ks_kernel<B, MODE, NORM, XATTN, CPL>), dim3(grid), dim3(KS_NT), smem, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-// pairs / shift of a mode (shared by the stand-alone launcher and the chain)
+// pairs / shift of a mode
 template <int MODE>
 int ks_prepare(GemvParams& p) {
     if (MODE == GEMV_QKV || MODE == GEMV_GATEUP) p.n_groups = p.n_rows / 2;
     else p.n_groups = (p.n_rows + 1) / 2;
     p.n_pairs = p.n_groups;
-    p.ks_unit = 1;
     if (MODE == GEMV_QKV) {
         p.ks_shift = 0;
         while ((2 << p.ks_shift) < p.head_dim) ++p.ks_shift;
@@ -587,34 +457,10 @@ int ks_launch_mode(GemvParams p, int B, hipStream_t stream, int* grid_out) {
     return -2;
 }
 
-template <int B, int CPLD, int TAIL>
-int chain_launch_t(KsChainParams& c, int grid, size_t smem, hipStream_t stream) {
-    auto kern = emmax_decode_chain_kernel<B, CPLD, TAIL>;
-    static int resident = -1;   // blocks per CU the runtime admits for this instantiation at this LDS size (queried when it changes)
-    static size_t resident_smem = 0;
-    if (resident < 0 || resident_smem != smem) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, KS_NT, smem) != hipSuccess) n = 0;
-        resident = n;
-        resident_smem = smem;
-    }
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -4;
-    }
-    if (grid > resident * cus) return -2;   // a block that is not resident would be waited for by the others
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(KS_NT), smem, stream, c);
-    return hipGetLastError() == hipSuccess ? 0 : -4;
-}
-
 }  // namespace
 
-// tuning hook: EMMAX_KS=0 keeps the batch 1-2 bf16 projections on decode.hip's LDS-staged GEMV (the A/B partner)
-bool decode_ks_enabled() {   // read per call (a getenv per launch is noise next to a >= 5 us kernel): tests switch it inside one process
-    const char* e = getenv("EMMAX_KS");
-    return !(e && atoi(e) == 0);
-}
+// tuning switch `ks` = 0 keeps the batch 1-2 bf16 projections on decode.hip's LDS-staged GEMV (the A/B partner)
+bool decode_ks_enabled() { return emmax_tune().ks != 0; }
 
 // -2: shape outside this kernel (the caller falls back to launch_decode_gemv's LDS-staged kernel); bf16 weights, batch 1-2,
 // plain stream ordering, K a multiple of 64 and at most 12288 (three 16-byte chunks per lane)
@@ -628,13 +474,11 @@ int launch_decode_ks(int mode, const GemvParams& p, int B, hipStream_t stream, i
             // The o-proj with the split merge in its prologue: every WAVE merges the chunks of its own four heads (24 loads in
             // flight per lane, no LDS stage, no barrier).  With 512 blocks that is twice the L2 reads of decode.hip's 256-block
             // LDS-staged merge and slower (12.2 against 10.1 us at B = 1, 7B); with ONE block per CU it is the faster one
-            // (9.3 us: step 2.624 -> 2.594 ms/token).  EMMAX_KS_OPROJ=0: decode.hip's kernel; EMMAX_KS_OPROJ_GRID: lab.
+            // (9.3 us: step 2.624 -> 2.594 ms/token).  Tuning switches ks_oproj = 0: decode.hip's kernel; ks_oproj_grid.
             if (p.attn_part) {
-                const char* e = getenv("EMMAX_KS_OPROJ");
-                if (e && atoi(e) == 0) return -2;
-                const char* g = getenv("EMMAX_KS_OPROJ_GRID");
+                if (!emmax_tune().ks_oproj) return -2;
                 GemvParams q = p;
-                q.max_grid = g ? atoi(g) : 256;
+                q.max_grid = emmax_tune().ks_oproj_grid;
                 return ks_launch_mode<GEMV_RESID, false, true>(q, B, stream, grid_out);
             }
             return ks_launch_mode<GEMV_RESID, false, false>(p, B, stream, grid_out);
@@ -650,48 +494,3 @@ extern "C" int emmax_debug_ks_trace(unsigned long long* host_out, int n_words) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ks_trace), (size_t)n_words * 8) == hipSuccess ? 0 : -1;
 }
 #endif
-
-// ---- persistent chain ----
-size_t decode_chain_mbox_bytes(int B, int hidden, int inter) { return (size_t)B * (2 * (size_t)hidden + (size_t)inter) * 4; }
-
-// oproj (x = the merged attention output, y = h in place), gateup, down, tail (qkv of the next layer, or the lm-head; tail_mode -1:
-// no tail, `tail` is ignored) as the stand-alone launches would get them; mbox: decode_chain_mbox_bytes() of device memory, zeroed once; epoch / err: device words.
-// -2: outside the chain's shapes (the caller launches the four stages one by one)
-int launch_decode_chain(const GemvParams& oproj, const GemvParams& gateup, const GemvParams& down, const GemvParams& tail, int tail_mode,
-                        int B, void* mbox, unsigned int* epoch, unsigned int* err, hipStream_t stream, int* tail_grid_out) {
-    if (B < 1 || B > 2 || !mbox || !epoch || !err) return -2;
-    if (tail_mode != GEMV_QKV && tail_mode != GEMV_LMHEAD && tail_mode != -1) return -2;
-    const int H = gateup.K, I = down.K, nops = tail_mode >= 0 ? 4 : 3;
-    if (oproj.K != H || (nops == 4 && tail.K != H) || oproj.n_rows != H || down.n_rows != H || gateup.n_rows != 2 * I) return -2;
-    if (H % 64 || H > 4096 || I % 64 || I > 64 * 64 * 3 || H % 2 || (I / 2) % 2) return -2;   // H: one chunk per lane; even shares of gate/up
-    if (oproj.attn_part) return -2;   // the attention launch merges its splits (DecodeAttnParams::o_out): the o-proj reads a bf16 row
-    for (const GemvParams* q : {&oproj, &gateup, &down, &tail})
-        if ((q != &tail || nops == 4) && (q->wscale || q->ldw % 8)) return -2;
-    KsChainParams c;
-    c.op[0] = oproj; c.op[1] = gateup; c.op[2] = down; c.op[3] = tail;
-    if (ks_prepare<GEMV_RESID>(c.op[0]) || ks_prepare<GEMV_GATEUP>(c.op[1]) || ks_prepare<GEMV_RESID>(c.op[2])) return -2;
-    if (nops == 4 && (tail_mode == GEMV_QKV ? ks_prepare<GEMV_QKV>(c.op[3]) : ks_prepare<GEMV_LMHEAD>(c.op[3]))) return -2;
-    c.op[1].ks_unit = 2;
-    int grid = 512;
-    for (int i = 0; i < nops; ++i) grid = min(grid, cdiv(c.op[i].n_groups, c.op[i].ks_unit));
-    if (tail_mode == GEMV_LMHEAD) grid = min(grid, tail.max_parts);
-    if (grid < 1) return -2;
-    int pairs_max = 0;
-    for (int i = 0; i < nops; ++i) pairs_max = max(pairs_max, cdiv(cdiv(c.op[i].n_groups, c.op[i].ks_unit), grid) * c.op[i].ks_unit);
-    if (pairs_max > 64) return -2;
-    c.rows_cap = cdiv(2 * pairs_max, 16) * 16;
-    unsigned long long* mb = (unsigned long long*)mbox;
-    c.mbox[0] = mb; c.mbox[1] = mb + (size_t)B * (H / 2); c.mbox[2] = mb + (size_t)B * (H / 2 + I / 2);
-    c.epoch = epoch; c.err = err;
-    const size_t smem = (size_t)2 * (KS_WAVES * B * c.rows_cap + KS_WAVES * B) * sizeof(float);
-    if (tail_grid_out) *tail_grid_out = grid;
-    const int cpld = cdiv(I >> 6, 64);
-#define CH_CASE(BB, CC)                                                                                  \
-    if (B == BB && cpld == CC)                                                                           \
-        return tail_mode == GEMV_QKV      ? chain_launch_t<BB, CC, GEMV_QKV>(c, grid, smem, stream)       \
-               : tail_mode == GEMV_LMHEAD ? chain_launch_t<BB, CC, GEMV_LMHEAD>(c, grid, smem, stream)    \
-                                          : chain_launch_t<BB, CC, -1>(c, grid, smem, stream)
-    CH_CASE(1, 1); CH_CASE(1, 2); CH_CASE(1, 3); CH_CASE(2, 1); CH_CASE(2, 2); CH_CASE(2, 3);
-#undef CH_CASE
-    return -2;
-}

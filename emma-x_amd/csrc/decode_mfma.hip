@@ -685,10 +685,7 @@ static int launch_mfma_t(GemvParams p, int B, hipStream_t stream, int* grid_out)
         if (!(MODE == MODE_LMHEAD && p.n_rows % 16 == 0)) return -1;
     }
     p.batch = B;
-    {   // tuning hook EMMAX_MFMA_XBAR (default on for the prologues that load activations ahead of the head)
-        static const int xbar = [] { const char* e = getenv("EMMAX_MFMA_XBAR"); return e ? atoi(e) : 1; }();
-        p.x_bar = XATTN ? 0 : xbar;
-    }
+    p.x_bar = XATTN ? 0 : emmax_tune().mfma_xbar;   // default on for the prologues that load activations ahead of the head
     p.kc = mfma_kc(B, p.K, TILES, FP8 ? 64 : 32);
     if (NORM && p.kc != p.K) return -1;
     p.n_groups = p.n_rows / (16 * TILES);

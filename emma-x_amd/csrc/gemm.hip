@@ -557,9 +557,9 @@ static int splitk_plan(const GemmParams& p) {
 
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0) return 0;
-    static const int force = getenv("EMMAX_GEMM_BIG") ? atoi(getenv("EMMAX_GEMM_BIG")) : -1;   // 0 / 1: one geometry, no split
+    const int force = emmax_tune().gemm_big;   // 0 / 1: one geometry, no split
     if (force >= 0) return launch_gemm_geom(p, force != 0, stream);
-    static const bool no_splitk = getenv("EMMAX_GEMM_SPLITK") && atoi(getenv("EMMAX_GEMM_SPLITK")) == 0;   // tuning hook
+    const bool no_splitk = emmax_tune().gemm_splitk == 0;
     if (const int ks = no_splitk ? 0 : splitk_plan(p)) return launch_gemm_splitk(p, ks, stream);
     long m1 = 0;
     const double whole = plan_rows(p.M, p.N, &m1);

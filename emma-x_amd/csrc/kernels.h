@@ -78,6 +78,31 @@ int launch_resize_bicubic_u8(const uint8_t* src, int B, int H, int W, uint8_t* d
                              const int32_t* kk_h, int ksize_h, const int32_t* bounds_v, const int32_t* kk_v, int ksize_v, hipStream_t stream);
 int launch_gather_last_rows(const void* in, void* out, const int32_t* cu, int B, int D, hipStream_t stream);
 
+// ---- tuning switches (model.hip) ----
+// ONE table of named integers, read from the environment (EMMAX_<NAME>) ONCE, when the library first needs a value; after that only
+// emmax_tuning_set() (include/emmax.h) changes them.  No launcher calls getenv.  Defaults are the product path; the other values
+// are the A/B partners DESIGN.md's measurements quote.
+struct EmmaxTune {
+    int graph;           // 0: eager launch-ahead decode steps (default); 1: replay a captured hipGraph of the step
+    int ks;              // 1: batch 1-2 bf16 projections on decode_ks.hip; 0: decode.hip's LDS-staged GEMV
+    int ks_oproj;        // 1: ... including the o-proj with the split merge (one block per CU); 0: decode.hip's kernel
+    int ks_oproj_grid;   // grid cap of that o-proj launch (256)
+    int km;              // 1: batch >= 3 (and fp8) projections on decode_km.hip; 0: decode_mfma.hip
+    int km_down;         // 1: ... including the two-phase down projection
+    int streamk;         // 1: stream-K work split in decode_mfma.hip; 0: whole tasks per block
+    int fp8_gemv;        // -1: default routing of the batch 1-2 fp8 projections; >= 0: bit mask (1 qkv, 2 o-proj, 4 gate/up, 8 down, 16 lm-head) on the row GEMV
+    int attn_nsplit;     // 0: KV splits of the decode attention chosen from (B, kv heads); > 0: forced (rounded down to 2^k, <= 16)
+    int attn_direct;     // 1: with one KV split the attention launch writes the normalised bf16 row itself
+    int fold_embed;      // 1: layer 0's qkv launch gathers the embedding row itself (batch 1-2, bf16)
+    int mfma_xbar;       // 1: decode_mfma.hip orders the activation requests ahead of the weight head with a block barrier
+    int gemm_big;        // -1: planned tile geometry; 0 / 1: all small / all big tiles, no split-K
+    int gemm_splitk;     // 1: split-K for under-filled long-K GEMMs
+    int gemm_lnfuse;     // 1: LayerNorm / RMSNorm applied by the GEMM that consumes the normalised rows (no separate norm pass)
+    int attn_resident;   // -1: resident ViT attention kernel where measured faster; 0: never; 2: whenever it fits (tests)
+    int epoch;           // bumped by every emmax_tuning_set: sessions drop captured graphs when it moves
+};
+const EmmaxTune& emmax_tune();
+
 // ---- decode.hip ----
 enum { GEMV_QKV = 0, GEMV_RESID = 1, GEMV_GATEUP = 2, GEMV_LMHEAD = 3, GEMV_PLAIN = 4 };
 struct GemvParams {
@@ -116,25 +141,15 @@ struct GemvParams {
     int x_bar;                   // MFMA path, set by the launcher: block barrier between the activation requests and the weight head
     int max_grid;           // 0: default persistent grid; > 0: cap (the K-split o-proj with the split merge runs one block per CU)
     int ks_shift;           // K-split kernel, QKV, set by its launcher: log2(head_dim / 2)
-    int ks_unit;            // K-split kernel, set by its launcher: pairs per unit of the block shares (2: gate/up inside a chain)
     const int32_t* x_tok;   // K-split kernel, non-null: x row b = x[x_tok[b]] (p.x = embedding table, ids clamped to x_vocab): the embed launch
     void* x_copy;           //   folded into layer 0's qkv; block 0 also copies the rows to x_copy [B, ldx] (the residual stream)
     int x_vocab;
-    int ks_flags;           // K-split kernel, lab (EMMAX_KS_FLAGS): 1 = raise the wave priority of the blocks dispatched second,
-                            // 2 = block barrier between the activation requests and the weight head
 };
 int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
 // decode_ks.hip: the batch 1-2 bf16 projections with K split across the waves of a block (activation slice in registers, no
-// block-wide stage); returns -2 for a shape it does not take.  launch_decode_gemv tries it first (EMMAX_KS=0: never).
+// block-wide stage); returns -2 for a shape it does not take.  launch_decode_gemv tries it first (tuning switch `ks` = 0: never).
 int launch_decode_ks(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
 bool decode_ks_enabled();
-// persistent layer chain (decode_ks.hip): o-proj -> gate/up -> down -> tail (qkv of the next layer | lm-head) in one launch, the
-// activation vectors of the three edges handed over through mailboxes of data-tagged granules.  The four GemvParams are what the
-// stand-alone launches would get.  mbox: decode_chain_mbox_bytes() bytes, zeroed once; epoch / err: device words, zeroed once.
-// -2: outside the chain's shapes (the caller launches the stages one by one).
-size_t decode_chain_mbox_bytes(int B, int hidden, int inter);
-int launch_decode_chain(const GemvParams& oproj, const GemvParams& gateup, const GemvParams& down, const GemvParams& tail, int tail_mode,
-                        int B, void* mbox, unsigned int* epoch, unsigned int* err, hipStream_t stream, int* tail_grid_out);
 int decode_gemv_init();   // raise the dynamic-LDS limit of every GEMV instantiation (call once, outside graph capture)
 int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, hipStream_t stream);
 
@@ -146,8 +161,7 @@ struct DecodeAttnParams {
     const int32_t* ctx_len;
     const int32_t* done;    // int32 [B] or null: finished / idle rows read no K/V (their partials are written empty)
     float* part;            // f32 [B][Hq][nsplit][132] = { o[128] un-normalised, m, l, pad }
-    void* o_out;            // non-null: ALSO merge the splits in this launch (last-arriving block per (row, kv head)): bf16 [B, ldq]
-    unsigned int* merge_ctr;   // ... arrival counters [B][Hkv], zero between launches (the last arriver re-arms its counter)
+    void* o_out;            // non-null (one split only): the block normalises its result and writes the bf16 row [B, ldq] itself
     int ldq, Hkv, page, max_pages;
     int page_shift;         // log2(page), set by the launcher
     float scale;

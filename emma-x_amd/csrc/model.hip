@@ -7,7 +7,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cctype>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -39,6 +41,38 @@ static int fail(int code, const char* fmt, ...) {
         int r_ = (x);                                                                                               \
         if (r_ != 0) return fail(r_ == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "%s failed (%d) (%s:%d)", #x, r_, __FILE__, __LINE__); \
     } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// tuning switches: one table, read from the environment once (kernels.h: EmmaxTune)
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct TuneEntry { const char* name; int EmmaxTune::*field; int def; };
+const TuneEntry kTune[] = {
+    {"graph", &EmmaxTune::graph, 0},           {"ks", &EmmaxTune::ks, 1},
+    {"ks_oproj", &EmmaxTune::ks_oproj, 1},     {"ks_oproj_grid", &EmmaxTune::ks_oproj_grid, 256},
+    {"km", &EmmaxTune::km, 1},                 {"km_down", &EmmaxTune::km_down, 1},
+    {"streamk", &EmmaxTune::streamk, 1},       {"fp8_gemv", &EmmaxTune::fp8_gemv, -1},
+    {"attn_nsplit", &EmmaxTune::attn_nsplit, 0}, {"attn_direct", &EmmaxTune::attn_direct, 1},
+    {"fold_embed", &EmmaxTune::fold_embed, 1}, {"mfma_xbar", &EmmaxTune::mfma_xbar, 1},
+    {"gemm_big", &EmmaxTune::gemm_big, -1},    {"gemm_splitk", &EmmaxTune::gemm_splitk, 1},
+    {"gemm_lnfuse", &EmmaxTune::gemm_lnfuse, 1}, {"attn_resident", &EmmaxTune::attn_resident, -1},
+};
+EmmaxTune g_tune;
+std::once_flag g_tune_once;
+void tune_init() {
+    g_tune.epoch = 0;
+    for (const TuneEntry& e : kTune) {
+        g_tune.*(e.field) = e.def;
+        std::string env = "EMMAX_";
+        for (const char* c = e.name; *c; ++c) env += (char)toupper((unsigned char)*c);
+        if (const char* v = getenv(env.c_str())) g_tune.*(e.field) = atoi(v);   // the ONLY getenv of the library
+    }
+}
+}  // namespace
+const EmmaxTune& emmax_tune() {
+    std::call_once(g_tune_once, tune_init);
+    return g_tune;
+}
 
 static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 static const int PAGE = 64;   // KV page: 64 tokens x head_dim bf16 per kv head
@@ -276,11 +310,7 @@ struct emmax_session {
     int graph_failed = 0;
     int last_step_graph = 0;   // the most recent decode step was a graph replay (what emmax_session_graph_active reports)
     hipEvent_t ev = nullptr;
-    unsigned int* merge_ctr = nullptr;       // device: arrival counters of the in-attention split merge, [max_batch][kv heads], zero between launches
-    unsigned long long* pc_mbox = nullptr;   // device: mailboxes of the persistent layer chain (decode_ks.hip), batch <= 2
-    int pc_lm_grid = 0;                      // argmax partials the last chain launch wrote (= its grid)
-    unsigned int* pc_words = nullptr;        // device: [0] epoch of the chain launches, [32] error word (a bounded poll gave up)
-    int pchain = 0;                          // persistent layer chain (batch 1-2, bf16), measured slower than the stage launches: EMMAX_PCHAIN=1 enables
+    int graph_epoch = -1;      // emmax_tune().epoch the graph was captured under (a changed switch re-captures)
     hipStream_t own_stream = nullptr;   // used by emmax_generate when the caller's stream is the (uncapturable) legacy stream
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     std::string graph_err;
@@ -347,9 +377,6 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->stop_cfg = (int32_t*)b.take(2 * 4);
     s->stop_m = (int32_t*)b.take(Bd * 4);
     s->stop_after = (int32_t*)b.take(Bd * 4);
-    s->pc_mbox = (unsigned long long*)b.take((int64_t)decode_chain_mbox_bytes(2, m->H, m->inter_p));
-    s->pc_words = (unsigned int*)b.take(64 * 4);
-    s->merge_ctr = (unsigned int*)b.take((int64_t)Bd * m->cfg.n_kv_heads * 4);
     s->page_table = (int32_t*)b.take((int64_t)Bd * s->max_pages * 4);
     s->sk_ws = (unsigned long long*)b.take((int64_t)256 * 2 * 256 * 8);
     s->splitk_bytes = (int64_t)64 << 20;   // e.g. 4 slices of a 768 x 4096 prefill GEMM = 50 MB; smaller budgets just split less
@@ -437,13 +464,10 @@ static int run_vision(emmax_session* s, bool from_u8, const void* src, int B, vo
     return 0;
 }
 
-// tuning hook: EMMAX_STREAMK=0 gives every MFMA decode block whole tasks (the split before stream-K)
-static bool streamk_on() {
-    const char* e = getenv("EMMAX_STREAMK");
-    return !(e && atoi(e) == 0);
-}
+// tuning switch streamk = 0 gives every MFMA decode block whole tasks (the split before stream-K)
+static bool streamk_on() { return emmax_tune().streamk != 0; }
 
-// tuning hook: EMMAX_FP8_GEMV = bit mask of the batch 1-2 fp8 projections that run as dot-product GEMV over the e4m3 row copy
+// tuning switch fp8_gemv = bit mask of the batch 1-2 fp8 projections that run as dot-product GEMV over the e4m3 row copy
 // (1 qkv, 2 o-proj, 4 gate/up, 8 down, 16 lm-head); the others go through the MFMA kernels like every larger batch.
 // Default (round 3, once the K-split MFMA kernels of decode_km.hip existed): the o-proj, and at batch 1 the lm-head.  Per launch
 // at B = 1 / B = 2, row GEMV against decode_km.hip (one box, tools/ab_bench.sh): qkv 14.1 / 17.3 against 12.5 / 12.7 us, gate/up
@@ -451,12 +475,8 @@ static bool streamk_on() {
 // 25.7 / 24.4: step 1.939 -> 1.886 ms/token at B = 1 with everything on the MFMA kernels, 2.287 -> 2.028 at B = 2.
 enum { F8_QKV = 1, F8_OPROJ = 2, F8_GATEUP = 4, F8_DOWN = 8, F8_LMHEAD = 16 };
 static int fp8_gemv_mask(int B) {
-    static int mask = -2;
-    if (mask == -2) {
-        const char* e = getenv("EMMAX_FP8_GEMV");
-        mask = e ? atoi(e) & 31 : -1;
-    }
-    if (mask >= 0) return mask;
+    const int mask = emmax_tune().fp8_gemv;
+    if (mask >= 0) return mask & 31;
     return B == 1 ? (F8_OPROJ | F8_LMHEAD) : F8_OPROJ;
 }
 
@@ -597,19 +617,12 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
     return 0;
 }
 
-enum { STAGE_QKV = 0, STAGE_ATTN = 1, STAGE_OPROJ = 2, STAGE_GATEUP = 3, STAGE_DOWN = 4, STAGE_LMHEAD = 5, STAGE_CHAIN = 6 };
+enum { STAGE_QKV = 0, STAGE_ATTN = 1, STAGE_OPROJ = 2, STAGE_GATEUP = 3, STAGE_DOWN = 4, STAGE_LMHEAD = 5 };
 
-// batch 1-2 on bf16 weights: the attention launch merges its own splits (last-arriving block per head) and the o-proj reads a
-// plain bf16 row; every other path (MFMA batch >= 3, fp8, the two-stream chained launch) merges in the o-proj prologue
-// Measured (7B, B = 1): the merging attention launch takes 12.6 us against 5.7 (write-through stores, drain, atomic, re-read: four
-// dependent trips through the fabric) and the plain o-proj 8.9 against 10.1 -- a loss of 5.7 us per layer, so it is ON only where
-// it is needed (inside the persistent layer chain, whose o-proj cannot afford the per-wave merge) or asked for (EMMAX_ATTN_MERGE=1).
-static bool attn_merge_on(const emmax_session* s, int B) {
-    // one KV split per (row, head) (batch >= 5 at 32 heads): nothing to merge, the attention launch writes the bf16 row itself
-    if (decode_attn_nsplit(B, s->m->cfg.n_kv_heads) == 1 && !(getenv("EMMAX_ATTN_DIRECT") && atoi(getenv("EMMAX_ATTN_DIRECT")) == 0)) return true;
-    if (!(B < EMMAX_MFMA_MIN_BATCH && !s->m->fp8 && decode_ks_enabled())) return false;
-    const char* e = getenv("EMMAX_ATTN_MERGE");
-    return s->pchain || (e && atoi(e) != 0);
+// one KV split per (row, head) (batch >= 5 at 32 heads): nothing to merge -- the attention launch normalises and writes the bf16 row
+// itself and the o-proj is a plain projection; otherwise the o-proj prologue merges the split partials.
+static bool attn_direct_on(const emmax_session* s, int B) {
+    return decode_attn_nsplit(B, s->m->cfg.n_kv_heads) == 1 && emmax_tune().attn_direct != 0;
 }
 
 // GemvParams of a projection stage of decoder layer `li` (qkv / o-proj / gate-up / down), as every launcher takes them
@@ -629,7 +642,7 @@ static void stage_params(emmax_session* s, int B, int li, int stage, GemvParams&
             break;
         case STAGE_OPROJ:
             p.x = s->datt; p.ldx = m->q_dim; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
-            if (!attn_merge_on(s, B)) {   // split merge fused into the staging
+            if (!attn_direct_on(s, B)) {   // split merge fused into the staging
                 p.attn_part = s->part; p.nsplit = decode_attn_nsplit(B, c.n_kv_heads); p.Hq = c.n_heads;
             }
             break;
@@ -668,8 +681,7 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             a.q = s->dq; a.ldq = m->q_dim; a.kcache = kcache_of(s, li); a.vcache = vcache_of(s, li);
             a.page_table = s->page_table; a.ctx_len = s->ctx_len; a.done = s->done; a.part = s->part; a.Hkv = c.n_kv_heads; a.page = PAGE;
             a.max_pages = s->max_pages; a.scale = 1.0f / sqrtf((float)c.head_dim);
-            a.o_out = nullptr; a.merge_ctr = nullptr;
-            if (attn_merge_on(s, B)) { a.o_out = s->datt; a.merge_ctr = s->merge_ctr; }
+            a.o_out = attn_direct_on(s, B) ? s->datt : nullptr;
             const int ns = decode_attn_nsplit(B, c.n_kv_heads);
             KCHK(launch_decode_attn(a, B, c.n_heads, c.head_dim, ns, st));
             return 0;
@@ -692,63 +704,6 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
     }
 }
 
-// Persistent layer chain (decode_ks.hip): batch 1-2, bf16 weights, plain stream ordering.  The step is then
-//   embed, qkv(0), { attention(l), chain(l) = o-proj + gate/up + down + [qkv(l + 1) | lm-head] } x layers, finish
-// = 2 + 2 x layers + 1 launches instead of 3 + 5 x layers; -2 from the launcher (shape outside the chain) falls back for good.
-extern "C" int emmax_session_pchain_fault(emmax_session* s, emmax_stream stream);
-static bool pchain_on(const emmax_session* s, int B) {
-    return s->pchain && B < EMMAX_MFMA_MIN_BATCH && !s->m->fp8 && decode_ks_enabled();
-}
-// tail_out: 1 = the launch included the tail (next layer's qkv / the lm-head: s->pc_lm_grid partials), 0 = the caller launches it
-static int run_layer_chain(emmax_session* s, int B, int li, hipStream_t st, int* tail_out) {
-    emmax_model* m = s->m;
-    const LayerW& L = m->layers[li];
-    GemvParams po, pg, pd, pt;
-    stage_params(s, B, li, STAGE_OPROJ, po); po.W = L.wo;
-    stage_params(s, B, li, STAGE_GATEUP, pg); pg.W = L.wgu;
-    stage_params(s, B, li, STAGE_DOWN, pd); pd.W = L.wdown;
-    const bool last = li + 1 == m->cfg.n_layers;
-    if (last) { lmhead_params(s, 0, nullptr, pt); pt.W = m->lm_head; }
-    else { stage_params(s, B, li + 1, STAGE_QKV, pt); pt.W = m->layers[li + 1].wqkv; }
-    int tail_grid = 0;
-    int r = launch_decode_chain(po, pg, pd, pt, last ? GEMV_LMHEAD : GEMV_QKV, B, s->pc_mbox, s->pc_words, s->pc_words + 32, st, &tail_grid);
-    *tail_out = 1;
-    if (r == -2) {   // e.g. a small grid leaves more lm-head rows per block than the epilogue maps: the three layer stages alone
-        r = launch_decode_chain(po, pg, pd, pt, -1, B, s->pc_mbox, s->pc_words, s->pc_words + 32, st, nullptr);
-        *tail_out = 0;
-    }
-    if (r == 0 && last && *tail_out) s->pc_lm_grid = tail_grid;
-    return r;
-}
-static int run_decode_step_pchain(emmax_session* s, int B, hipStream_t st) {
-    emmax_model* m = s->m;
-    const int nl = m->cfg.n_layers;
-    KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st));
-    int r = run_decode_stage(s, B, 0, STAGE_QKV, st);
-    if (r) return r;
-    for (int li = 0; li < nl; ++li) {
-        if ((r = run_decode_stage(s, B, li, STAGE_ATTN, st))) return r;
-        int with_tail = 0;
-        r = run_layer_chain(s, B, li, st, &with_tail);
-        if (r == -2) {   // a shape the chain does not take at all (first layer: nothing of the step has been skipped yet)
-            if (li != 0) return fail(EMMAX_ERR_STATE, "persistent chain refused layer %d after accepting layer 0", li);
-            s->pchain = 0;
-            for (int stage = STAGE_OPROJ; stage <= STAGE_DOWN; ++stage)
-                if ((r = run_decode_stage(s, B, 0, stage, st))) return r;
-            for (int l2 = 1; l2 < nl; ++l2)
-                for (int stage = STAGE_QKV; stage <= STAGE_DOWN; ++stage)
-                    if ((r = run_decode_stage(s, B, l2, stage, st))) return r;
-            return run_lm_head_step(s, B, false, nullptr, true, st);
-        }
-        if (r) return fail(EMMAX_ERR_HIP, "persistent chain launch failed (layer %d, code %d)", li, r);
-        if (!with_tail) {
-            if (li + 1 == nl) return run_lm_head_step(s, B, false, nullptr, true, st);
-            if ((r = run_decode_stage(s, B, li + 1, STAGE_QKV, st))) return r;
-        }
-    }
-    return launch_finish_step(s, B, false, s->pc_lm_grid, 0, st);
-}
-
 // layer 0's qkv with the embedding gather folded in (K-split kernel; anything else: embed launch + the plain stage)
 static int run_qkv0_with_embed(emmax_session* s, int B, hipStream_t st) {
     emmax_model* m = s->m;
@@ -766,10 +721,9 @@ static int run_qkv0_with_embed(emmax_session* s, int B, hipStream_t st) {
 
 static int run_decode_step(emmax_session* s, int B, hipStream_t st) {
     emmax_model* m = s->m;
-    if (pchain_on(s, B)) return run_decode_step_pchain(s, B, st);
     // batch 1-2 on bf16 weights: the embedding row is read by layer 0's qkv launch itself (K-split kernel) -- one launch fewer
     const bool fold_embed = B < EMMAX_MFMA_MIN_BATCH && !m->fp8 && decode_ks_enabled() && m->H % 64 == 0 && m->H <= 12288 &&
-                            !(getenv("EMMAX_FOLD_EMBED") && atoi(getenv("EMMAX_FOLD_EMBED")) == 0);
+                            emmax_tune().fold_embed != 0;
     if (!fold_embed) KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st));
     for (int li = 0; li < m->cfg.n_layers; ++li)
         for (int stage = STAGE_QKV; stage <= STAGE_DOWN; ++stage) {
@@ -800,13 +754,11 @@ static int ensure_graph(emmax_session* s, int B, hipStream_t st) {
     // ahead of the device, and measured on MI355X / ROCm 7.2 the replayed graph is the SLOWER option: 3.05 vs 2.95 ms/token
     // at B = 1 (~0.6 us more per kernel node than a same-stream launch; round 3: 2.73 vs 2.62, and neither hipGraphUpload, the
     // instantiate flags, DEBUG_HIP_GRAPH_BATCH_SIZE / DEBUG_HIP_FORCE_GRAPH_QUEUES nor the kernarg placement move it).
-    // EMMAX_GRAPH=1 selects graph replay (a host whose launch thread cannot be kept free); read per call so a process can switch.
-    {
-        const char* e = getenv("EMMAX_GRAPH");
-        s->last_step_graph = 0;   // set again by launch_graph_step when a replay really runs
-        if (!e || atoi(e) == 0) return 1;   // eager step: a captured graph stays valid for the next caller that wants replay
-    }
-    if (s->graph_exec && s->graph_B == B && s->graph_stream_cap == st) return 0;
+    // Tuning switch graph = 1 (EMMAX_GRAPH=1 at start-up, or emmax_tuning_set) selects graph replay (a host whose launch thread
+    // cannot be kept free).
+    s->last_step_graph = 0;   // set again by launch_graph_step when a replay really runs
+    if (!emmax_tune().graph) return 1;   // eager step: a captured graph stays valid for the next caller that wants replay
+    if (s->graph_exec && s->graph_B == B && s->graph_stream_cap == st && s->graph_epoch == emmax_tune().epoch) return 0;
     drop_graph(s);
     if (s->graph_failed) return 1;
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
@@ -824,7 +776,7 @@ static int ensure_graph(emmax_session* s, int B, hipStream_t st) {
         (void)hipGraphDestroy(g);
         return graph_fail(s, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
     }
-    s->graph = g; s->graph_exec = ge; s->graph_B = B; s->graph_stream_cap = st;
+    s->graph = g; s->graph_exec = ge; s->graph_B = B; s->graph_stream_cap = st; s->graph_epoch = emmax_tune().epoch;
     return 0;
 }
 
@@ -842,6 +794,29 @@ extern "C" {
 const char* emmax_version(void) { return "emmax-hip 0.1.0 (gfx950)"; }
 const char* emmax_last_error(void) { return g_err.c_str(); }
 int emmax_abi_version(void) { return EMMAX_ABI_VERSION; }
+int emmax_config_size(void) { return (int)sizeof(emmax_config); }
+
+int emmax_tuning_set(const char* name, int value) {
+    if (!name) return fail(EMMAX_ERR_INVALID, "null argument");
+    (void)emmax_tune();
+    for (const TuneEntry& e : kTune)
+        if (!strcmp(e.name, name)) {
+            g_tune.*(e.field) = value;
+            g_tune.epoch += 1;
+            return 0;
+        }
+    return fail(EMMAX_ERR_INVALID, "unknown tuning switch `%s`", name);
+}
+int emmax_tuning_get(const char* name, int* value_out) {
+    if (!name || !value_out) return fail(EMMAX_ERR_INVALID, "null argument");
+    const EmmaxTune& t = emmax_tune();
+    for (const TuneEntry& e : kTune)
+        if (!strcmp(e.name, name)) {
+            *value_out = t.*(e.field);
+            return 0;
+        }
+    return fail(EMMAX_ERR_INVALID, "unknown tuning switch `%s`", name);
+}
 
 int emmax_model_create(const emmax_config* cfg, emmax_model** out) {
     if (!cfg || !out) return fail(EMMAX_ERR_INVALID, "null argument");
@@ -1021,7 +996,6 @@ int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_
     HIPCHK(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
-    s->pchain = getenv("EMMAX_PCHAIN") && atoi(getenv("EMMAX_PCHAIN")) != 0;
     // static page assignment: row b owns pages [b*max_pages, (b+1)*max_pages)
     {
         std::vector<int32_t> pt((size_t)max_batch * s->max_pages);
@@ -1117,8 +1091,7 @@ int emmax_decode_step(emmax_session* s, emmax_stream stream) {
     if (!s) return fail(EMMAX_ERR_INVALID, "null argument");
     if (!s->prefilled) return fail(EMMAX_ERR_STATE, "decode before prefill");
     s->dec_steps += 1;
-    const char* e = getenv("EMMAX_GRAPH");
-    if (e && atoi(e) != 0) {   // EMMAX_GRAPH=1: the step is a replay of the captured hipGraph (as in emmax_generate / emmax_slots_step)
+    if (emmax_tune().graph) {   // the step is a replay of the captured hipGraph (as in emmax_generate / emmax_slots_step)
         hipStream_t user = (hipStream_t)stream, st;
         int r = slot_enter(s, user, &st);
         if (r) return r;
@@ -1186,10 +1159,6 @@ int emmax_generate(emmax_session* s, int max_new, int stop_on_eos, int32_t* out_
     HIPCHK(hipMemcpy2DAsync(out_ids, (size_t)max_new * 4, s->out_ids, (size_t)s->max_out * 4, (size_t)max_new * 4, B,
                             hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(out_lens, s->n_out, B * 4, hipMemcpyDeviceToDevice, st));
-    if (pchain_on(s, B)) {   // a hand-off poll of the persistent chain that gave up is an error, never a silent wrong answer
-        int r = emmax_session_pchain_fault(s, (emmax_stream)st);
-        if (r) return r;
-    }
     if (special) {
         HIPCHK(hipEventRecord(s->ev_out, st));
         HIPCHK(hipStreamWaitEvent(user, s->ev_out, 0));
@@ -1331,20 +1300,6 @@ int emmax_slot_release(emmax_session* s, int slot, emmax_stream stream) {
     return slot_leave(s, user, st);
 }
 
-int emmax_session_pchain_active(emmax_session* s) { return s && s->prefilled && pchain_on(s, s->cur_B) ? 1 : 0; }
-
-int emmax_session_pchain_fault(emmax_session* s, emmax_stream stream) {
-    if (!s) return fail(EMMAX_ERR_INVALID, "null argument");
-    hipStream_t st = (hipStream_t)stream;
-    HIPCHK(hipMemcpyAsync(s->pinned + 1025, s->pc_words + 32, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (s->pinned[1025] == 0) return 0;
-    s->pchain = 0;
-    HIPCHK(hipMemsetAsync(s->pc_words + 32, 0, 4, st));
-    return fail(EMMAX_ERR_HIP, "persistent layer chain: a hand-off wait timed out -- is the GPU shared? (results since the last check are "
-                               "invalid; the chain is now off for this session; EMMAX_PCHAIN=0 disables it up front)");
-}
-
 int emmax_session_graph_active(emmax_session* s) {
     if (s && !s->graph_exec && !s->graph_err.empty()) g_err = s->graph_err;   // why the capture was refused
     return s && s->graph_exec && s->last_step_graph ? 1 : 0;
@@ -1369,14 +1324,6 @@ int emmax_profile_decode_stage(emmax_session* s, int stage, int reps, float* avg
             if (stage == STAGE_LMHEAD) {
                 r = run_lm_head_step(s, B, false, nullptr, false, st);
                 launches += pass;
-            } else if (stage == STAGE_CHAIN) {   // the persistent layer chain: o-proj + gate/up + down + next qkv (last layer: lm-head)
-                if (!pchain_on(s, B)) return fail(EMMAX_ERR_STATE, "stage 6 (persistent layer chain) is not active for this session / batch");
-                for (int li = 0; li < nl && r == 0; ++li) {
-                    int with_tail = 0;
-                    r = run_layer_chain(s, B, li, st, &with_tail);
-                    if (r) return fail(EMMAX_ERR_INVALID, "persistent chain refused layer %d (code %d)", li, r);
-                    launches += pass;
-                }
             } else {
                 for (int li = 0; li < nl && r == 0; ++li) {
                     r = run_decode_stage(s, B, li, stage, st);
@@ -1451,22 +1398,17 @@ int emmax_op_decode_attention(const void* q, const void* kcache, const void* vca
     if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_decode_attention: unsupported (GQA group in {1,2,4,8}, page = 2^k, max_pages <= 512, nsplit = 2^k)");
     return 0;
 }
-int emmax_op_decode_attention_merged(const void* q, const void* kcache, const void* vcache, const int32_t* page_table, const int32_t* ctx_len,
-                                     const int32_t* done, float* part_ws, void* o_out, uint32_t* arrival_ctr, int B, int Hq, int Hkv, int page,
-                                     int max_pages, int nsplit, float scale, int* nsplit_out, emmax_stream st) {
-    if (!q || !kcache || !vcache || !page_table || !ctx_len || !part_ws || !o_out || !arrival_ctr)
-        return fail(EMMAX_ERR_INVALID, "emmax_op_decode_attention_merged: null argument");
-    if (B < 1 || B > EMMAX_MAX_DECODE_BATCH || Hkv < 1 || Hq % Hkv) return fail(EMMAX_ERR_INVALID, "emmax_op_decode_attention_merged: bad B / heads");
+int emmax_op_decode_attention_direct(const void* q, const void* kcache, const void* vcache, const int32_t* page_table, const int32_t* ctx_len,
+                                     const int32_t* done, void* o_out, int B, int Hq, int Hkv, int page, int max_pages, float scale,
+                                     emmax_stream st) {
+    if (!q || !kcache || !vcache || !page_table || !ctx_len || !o_out) return fail(EMMAX_ERR_INVALID, "emmax_op_decode_attention_direct: null argument");
+    if (B < 1 || B > EMMAX_MAX_DECODE_BATCH || Hkv < 1 || Hq % Hkv) return fail(EMMAX_ERR_INVALID, "emmax_op_decode_attention_direct: bad B / heads");
     DecodeAttnParams a;
     memset(&a, 0, sizeof(a));
     a.q = q; a.ldq = Hq * 128; a.kcache = kcache; a.vcache = vcache; a.page_table = page_table; a.ctx_len = ctx_len; a.done = done;
-    a.part = part_ws; a.Hkv = Hkv; a.page = page; a.max_pages = max_pages; a.scale = scale;
-    a.o_out = o_out; a.merge_ctr = arrival_ctr;
-    const int ns = nsplit > 0 ? nsplit : decode_attn_nsplit(B, Hkv);
-    if (nsplit_out) *nsplit_out = ns;
-    if (ns > 16) return fail(EMMAX_ERR_INVALID, "emmax_op_decode_attention_merged: nsplit %d > 16", ns);
-    int r = launch_decode_attn(a, B, Hq, 128, ns, (hipStream_t)st);
-    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_decode_attention_merged: unsupported (GQA group in {1,2,4,8}, page = 2^k, max_pages <= 512, nsplit = 2^k)");
+    a.part = nullptr; a.Hkv = Hkv; a.page = page; a.max_pages = max_pages; a.scale = scale; a.o_out = o_out;
+    int r = launch_decode_attn(a, B, Hq, 128, 1, (hipStream_t)st);
+    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_decode_attention_direct: unsupported (GQA group in {1,2,4,8}, page = 2^k, max_pages <= 512)");
     return 0;
 }
 int emmax_op_gemv(const void* x, const void* W, void* y, int B, int N, int K, emmax_stream st) {

@@ -43,11 +43,16 @@ class ConfigC(C.Structure):
     ]
 
 
+ABI_VERSION = 3   # EMMAX_ABI_VERSION of include/emmax.h this binding was written against
+
 # name -> (restype, argtypes): exactly the entry points of include/emmax.h
 SIGNATURES = {
     "emmax_version": (C.c_char_p, []),
     "emmax_last_error": (C.c_char_p, []),
     "emmax_abi_version": (C.c_int, []),
+    "emmax_config_size": (C.c_int, []),
+    "emmax_tuning_set": (C.c_int, [C.c_char_p, C.c_int]),
+    "emmax_tuning_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "emmax_model_create": (C.c_int, [C.POINTER(ConfigC), C.POINTER(_vp)]),
     "emmax_model_destroy": (None, [_vp]),
     "emmax_model_bind_weight": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int, _c_i64p, C.c_int]),
@@ -67,8 +72,6 @@ SIGNATURES = {
     "emmax_set_current_tokens": (C.c_int, [_vp, _vp, _vp]),
     "emmax_generate": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "emmax_session_graph_active": (C.c_int, [_vp]),
-    "emmax_session_pchain_active": (C.c_int, [_vp]),
-    "emmax_session_pchain_fault": (C.c_int, [_vp, _vp]),
     "emmax_profile_decode_stage": (C.c_int, [_vp, C.c_int, C.c_int, _c_f32p, _vp]),
     "emmax_session_set_stop": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "emmax_slots_open": (C.c_int, [_vp, C.c_int, _vp]),
@@ -88,8 +91,7 @@ SIGNATURES = {
                                      C.c_int, C.c_int, C.c_float, C.c_int, _vp]),
     "emmax_op_decode_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_float, C.POINTER(C.c_int), _vp]),
-    "emmax_op_decode_attention_merged": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
-                                                   C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), _vp]),
+    "emmax_op_decode_attention_direct": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
     "emmax_op_gemv": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "emmax_op_resize_bicubic_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "emmax_op_quant_fm8": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp]),
@@ -119,10 +121,42 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.emmax_abi_version() != 1:
-        raise EmmaxError(f"ABI mismatch: library reports {lib.emmax_abi_version()}, host expects 1")
+    if lib.emmax_abi_version() != ABI_VERSION:
+        raise EmmaxError(f"ABI mismatch: library reports {lib.emmax_abi_version()}, host expects {ABI_VERSION}")
+    if lib.emmax_config_size() != C.sizeof(ConfigC):
+        raise EmmaxError(f"emmax_config is {lib.emmax_config_size()} bytes in the library, {C.sizeof(ConfigC)} in this binding")
     _lib = lib
     return lib
+
+
+def tuning_set(name: str, value: int) -> None:
+    """Set one of the library's tuning switches (include/emmax.h: emmax_tuning_set); the environment is only read once, at start-up."""
+    check(load().emmax_tuning_set(name.encode(), int(value)), f"emmax_tuning_set({name})")
+
+
+def tuning_get(name: str) -> int:
+    v = C.c_int(0)
+    check(load().emmax_tuning_get(name.encode(), C.byref(v)), f"emmax_tuning_get({name})")
+    return int(v.value)
+
+
+class tuning:
+    """`with tuning(graph=1, ks=0): ...` -- switch for the duration of a block (tests / A-B measurements), restoring the old values."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+        self.old = {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = tuning_get(k)
+            tuning_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            tuning_set(k, v)
+        return False
 
 
 def check(status: int, what: str = "") -> None:

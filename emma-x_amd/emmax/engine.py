@@ -283,14 +283,6 @@ class EmmaxEngine:
     def graph_active(self) -> bool:
         return bool(self.lib.emmax_session_graph_active(self._session))
 
-    def pchain_active(self) -> bool:
-        """True when the decode steps of the active batch run the persistent layer chain (batch 1-2, bf16)."""
-        return bool(self.lib.emmax_session_pchain_active(self._session))
-
-    def pchain_check(self) -> None:
-        """Raises if an in-kernel hand-off of the persistent chain timed out since the last check (see include/emmax.h)."""
-        _lib.check(self.lib.emmax_session_pchain_fault(self._session, _lib.current_stream()), "emmax_session_pchain_fault")
-
     def profile_decode_stage(self, stage: int, reps: int = 3) -> float:
         """Mean duration (microseconds) of one launch of decode stage `stage` (see include/emmax.h), HIP-event timed."""
         us = C.c_float()

@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Tuple
 
+import ast
+
 import numpy as np
 
 from .actions import ActionTokenizer
@@ -91,9 +93,38 @@ class Solver:
         return require_unorm, np.array(movement)
 
     def extract_2d_coordinates(self, text: str):
+        """The first non-empty line after "NEXT GRIPPER:" as a Python value -- the reference `eval`s it (solver.py:33-40), so lists,
+        tuples, floats and arithmetic all pass and come back as whatever they evaluate to; anything else (and every failure) is
+        [0, 0].  Generated text is untrusted: the line is evaluated over its literal / arithmetic syntax tree only -- names and
+        calls, which the reference would execute, give [0, 0] here (an undefined name gives [0, 0] in the reference too)."""
         try:
             block = text[text.index(self.coordinates_key) + len(self.coordinates_key):]
-            x, y = _first_content_line(block).strip("[] ").split(",")
-            return [int(x), int(y)]
+            return _safe_eval(_first_content_line(block))
         except Exception:
             return [0, 0]
+
+
+_BIN = {ast.Add: lambda a, b: a + b, ast.Sub: lambda a, b: a - b, ast.Mult: lambda a, b: a * b, ast.Div: lambda a, b: a / b,
+        ast.FloorDiv: lambda a, b: a // b, ast.Mod: lambda a, b: a % b}
+
+
+def _safe_eval(src: str):
+    """`eval` restricted to literals, tuples / lists and + - * / // % on numbers."""
+    def ev(n):
+        if isinstance(n, ast.Constant) and (n.value is None or isinstance(n.value, (int, float, complex, str, bool))):
+            return n.value
+        if isinstance(n, ast.List):
+            return [ev(e) for e in n.elts]
+        if isinstance(n, ast.Tuple):
+            return tuple(ev(e) for e in n.elts)
+        if isinstance(n, ast.UnaryOp) and isinstance(n.op, (ast.UAdd, ast.USub)):
+            v = ev(n.operand)
+            return +v if isinstance(n.op, ast.UAdd) else -v
+        if isinstance(n, ast.BinOp) and type(n.op) in _BIN:
+            a, b = ev(n.left), ev(n.right)
+            if not all(isinstance(v, (int, float, complex)) and not isinstance(v, bool) for v in (a, b)):
+                raise ValueError("arithmetic on non-numbers")
+            return _BIN[type(n.op)](a, b)
+        raise ValueError("outside the literal / arithmetic subset")
+
+    return ev(ast.parse(src.strip(), mode="eval").body)

@@ -32,7 +32,10 @@
 extern "C" {
 #endif
 
-#define EMMAX_ABI_VERSION 1
+/* Bumped whenever emmax_config / emmax_tower_config change layout or an entry point changes signature.
+ *   1: rounds 1-2;  2: emmax_config grew `decode_fp8` (round 2, not bumped then);  3: round 4 -- emmax_config_size / emmax_tuning_*
+ *   added, the lab-only entry points (persistent layer chain, in-attention split merge) removed. */
+#define EMMAX_ABI_VERSION 3
 
 typedef enum emmax_status {
     EMMAX_OK = 0,
@@ -71,6 +74,18 @@ typedef struct emmax_config {
 const char* emmax_version(void);
 const char* emmax_last_error(void);
 int emmax_abi_version(void);
+/* sizeof(emmax_config) as the LIBRARY was compiled: a binding whose mirror struct has another size must refuse to call
+ * emmax_model_create (it would be read out of bounds).  emma-x_amd/emmax/_lib.py checks it at load time. */
+int emmax_config_size(void);
+
+/* Tuning switches: a fixed table of named integers (emma-x_amd/csrc/kernels.h, struct EmmaxTune).  The library reads the
+ * environment variable EMMAX_<NAME> for each of them ONCE, the first time any value is needed; afterwards only emmax_tuning_set
+ * changes them (no launcher reads the environment).  Every default is the product path; the other values are the A/B partners
+ * DESIGN.md quotes.  Names: graph (1 = hipGraph replay of the decode step, BASELINE configs[4]), ks, ks_oproj, ks_oproj_grid, km,
+ * km_down, streamk, fp8_gemv, attn_nsplit, attn_direct, fold_embed, mfma_xbar, gemm_big, gemm_splitk, gemm_lnfuse, attn_resident.
+ * Not thread-safe against concurrent launches; a session re-captures its decode graph after a change. */
+int emmax_tuning_set(const char* name, int value);
+int emmax_tuning_get(const char* name, int* value_out);
 
 /* ---- model: weights ------------------------------------------------------------------------------------------------
  * bind every tensor of the HF state dict (key names: vla-scripts/extern/convert_openvla_weights_to_hf.py:74-116) as a
@@ -123,25 +138,17 @@ int emmax_decode_step(emmax_session* s, emmax_stream stream);
  * own greedy prediction was: done flags, stop-rule state and token budgets are cleared.  EMMAX_ERR_NOMEM when a row's context
  * is full (the next append would leave the KV pages), EMMAX_ERR_STATE while request slots are open. */
 int emmax_set_current_tokens(emmax_session* s, const int32_t* tokens_dev, emmax_stream stream);
-/* Run up to max_new_tokens steps (including the token produced by prefill) as replays of a captured hipGraph of
- * emmax_decode_step; stop early once all rows are done if stop_on_eos != 0.
+/* Run up to max_new_tokens steps (including the token produced by prefill) -- eager launch-ahead by default, replays of a
+ * captured hipGraph of emmax_decode_step with the tuning switch graph = 1; no host synchronisation per token; stops early once
+ * all rows are done if stop_on_eos != 0.
  * out_ids_dev int32 [B,max_new_tokens] (pad_id after a row's EOS), out_lens_dev int32 [B] (tokens incl. EOS). */
 int emmax_generate(emmax_session* s, int max_new_tokens, int stop_on_eos, int32_t* out_ids_dev, int32_t* out_lens_dev,
                    emmax_stream stream);
 
 /* 1 when emmax_generate is replaying a captured hipGraph of the step (0: eager launches). */
 int emmax_session_graph_active(emmax_session* s);
-/* 1 when the decode steps of the active batch run the PERSISTENT LAYER CHAIN (batch 1-2, bf16 weights; default on, EMMAX_PCHAIN=0
- * at session creation disables): o-proj + gate/up + down + the next layer's qkv (last layer: lm-head) are ONE launch whose
- * blocks hand the activation vectors over in-kernel; replaces the same HF `LlamaDecoderLayer` math as the per-stage launches
- * (prismatic/extern/hf/modeling_prismatic.py:325-341), bit for bit. */
-int emmax_session_pchain_active(emmax_session* s);
-/* Synchronises `stream` and reports whether an in-kernel hand-off of the persistent chain gave up waiting since the last check
- * (EMMAX_ERR_HIP: the results since then are invalid and the chain is switched off for the session; 0: fine).  emmax_generate
- * checks by itself; callers that drive emmax_decode_step / the slot API call this where they would trust the ids. */
-int emmax_session_pchain_fault(emmax_session* s, emmax_stream stream);
 /* Measurement hook (bench.py `roofline`): launch decode stage `stage` (0 qkv GEMV, 1 paged attention, 2 o-proj GEMV,
- * 3 gate/up GEMV, 4 down GEMV: once per layer; 5 lm-head GEMV+argmax; 6 the persistent layer chain, once per layer) `reps` sweeps on `stream`, bracketed by HIP
+ * 3 gate/up GEMV, 4 down GEMV: once per layer; 5 lm-head GEMV+argmax) `reps` sweeps on `stream`, bracketed by HIP
  * events on that stream; returns the mean duration of one launch in microseconds.  Needs a prefilled session; the
  * residual stream it leaves behind is garbage (run a new prefill afterwards). */
 int emmax_profile_decode_stage(emmax_session* s, int stage, int reps, float* avg_us_out, emmax_stream stream);
@@ -167,7 +174,7 @@ int emmax_slot_prefill(emmax_session* s, int slot, const int32_t* ids_dev, int l
  * The other slots are not disturbed; every row's first generated token is in place afterwards. */
 int emmax_slots_prefill(emmax_session* s, int slot0, int n, const int32_t* ids_dev, int P_max, const int32_t* lens_host,
                         const void* patch_embeds_dev, const int32_t* max_new_host, emmax_stream stream);
-/* n_steps greedy decode steps over all slots (hipGraph replay, no host synchronisation); idle / finished slots stay put. */
+/* n_steps greedy decode steps over all slots (no host synchronisation); idle / finished slots stay put. */
 int emmax_slots_step(emmax_session* s, int n_steps, emmax_stream stream);
 /* Copy the per-slot done flags and generated-token counts to device buffers int32[n_slots] (asynchronous on `stream`). */
 int emmax_slots_state(emmax_session* s, int32_t* done_dev, int32_t* n_out_dev, emmax_stream stream);
@@ -203,20 +210,19 @@ int emmax_op_attention(const void* qkv_dev, int ld_qkv, int q_off, int k_off, in
  * kernel sits at position ctx_len[b]).  q: bf16 [B, Hq*128] rotated queries; k/vcache: bf16 [n_pages][Hkv][page][128];
  * page_table: int32 [B][max_pages] (token t of row b lives in page page_table[b][t / page]); done_dev: int32 [B] or NULL
  * (rows flagged done read no K/V).  Writes the un-merged partials f32 [B][Hq][nsplit][132] = {o[128] un-normalised, m, l,
- * pad}; the decode step merges them in the o-proj prologue.  nsplit: power of two <= 16, or 0 = what the session picks
+ * pad}; the decode step merges them in the o-proj prologue (with ONE split the session's launch normalises and writes the
+ * bf16 row itself).  nsplit: power of two <= 16, or 0 = what the session picks
  * for this (B, Hkv) (returned through nsplit_out when non-NULL).  head_dim 128, page = 2^k, max_pages <= 512. */
 int emmax_op_decode_attention(const void* q_dev, const void* kcache_dev, const void* vcache_dev, const int32_t* page_table_dev,
                               const int32_t* ctx_len_dev, const int32_t* done_dev, float* part_out_dev, int B, int Hq, int Hkv,
                               int page, int max_pages, int nsplit, float scale, int* nsplit_out, emmax_stream stream);
+/* The ONE-split form of the same kernel, as the decode step launches it when a (row, kv head) has a single KV split (batch >= 5 at
+ * 32 heads): the block holds the head's whole result, normalises it and writes o_out_dev bf16 [B, Hq*128] -- the row the o-proj
+ * reads -- instead of partials (rows flagged done: zeros). */
+int emmax_op_decode_attention_direct(const void* q_dev, const void* kcache_dev, const void* vcache_dev, const int32_t* page_table_dev,
+                                     const int32_t* ctx_len_dev, const int32_t* done_dev, void* o_out_dev, int B, int Hq, int Hkv,
+                                     int page, int max_pages, float scale, emmax_stream stream);
 /* Decode-path weight-streaming GEMV: y[b,n] = sum_k x[b,k] W[n,k]  (bf16 in, fp32 accumulate, bf16 out), B <= 8. */
-/* The same launch with the cross-split merge INSIDE it (what emmax_decode_step runs at batch 1-2 on bf16 weights): the block that
- * arrives last at a (row, kv head)'s counter merges the splits and writes o_out_dev bf16 [B, Hq*128] -- the row the o-proj reads.
- * part_ws_dev: f32 [B][Hq][nsplit][132] scratch; arrival_ctr_dev: uint32 [B][Hkv], ZERO before the first launch (every launch
- * leaves it zero again). */
-int emmax_op_decode_attention_merged(const void* q_dev, const void* kcache_dev, const void* vcache_dev, const int32_t* page_table_dev,
-                                     const int32_t* ctx_len_dev, const int32_t* done_dev, float* part_ws_dev, void* o_out_dev,
-                                     uint32_t* arrival_ctr_dev, int B, int Hq, int Hkv, int page, int max_pages, int nsplit, float scale,
-                                     int* nsplit_out, emmax_stream stream);
 int emmax_op_gemv(const void* x_dev, const void* W_dev, void* y_dev, int B, int N, int K, emmax_stream stream);
 
 /* Pillow-exact antialiased bicubic resize of uint8 RGB frames [B,H,W,3] -> [B,OH,OW,3] on the device (the `resize-naive`

@@ -303,7 +303,16 @@ class Solver:
 
     def __init__(self, tokenizer, vocab_size: int = 32000, n_bins: int = 256):
         self.tok, self.vocab_size, self.n_bins = tokenizer, vocab_size, n_bins
-        self.movement_key, self.policy_key = "MOVEMENT:", "POLICIES:"
+        self.movement_key, self.policy_key, self.coordinates_key = "MOVEMENT:", "POLICIES:", "NEXT GRIPPER:"
+
+    def extract_2d_coordinates(self, text: str):
+        """prismatic/vla/solver.py:33-40: first non-empty line after the key, `eval`ed as the reference does (test inputs only)."""
+        try:
+            at = text.index(self.coordinates_key) + len(self.coordinates_key)
+            lines = [o for o in text[at:].split("\n") if len(o.strip()) != 0]
+            return eval(lines[0].strip())
+        except Exception:
+            return [0, 0]
 
     def _decode(self, ids):
         return decode_token_ids_to_actions(np.array(ids), self.vocab_size, self.n_bins)

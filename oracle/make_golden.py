@@ -269,12 +269,25 @@ def g7_solver():
         "no actions here",
         "MOVEMENT:\nmove forward 3; move left 2; rotate clockwise 10; close gripper\nPOLICIES:\n" + act_text(a1),
         "MOVEMENT:\nmove sideways 3; close gripper\n",     # unknown direction -> [-100]*7
+        # extract_2d_coordinates (solver.py:33-40 evals the line): tuple, floats, arithmetic, nesting, garbage, missing line
+        "NEXT GRIPPER: (105, 74)\n",
+        "NEXT GRIPPER:\n\n  [105.5, 74]  \nMOVEMENT:\n",
+        "NEXT GRIPPER: 105, 74\n",
+        "NEXT GRIPPER: [100 + 5, 148 // 2]\n",
+        "NEXT GRIPPER: [[1, 2], [3, 4]]\n",
+        "NEXT GRIPPER: -3.5\n",
+        "NEXT GRIPPER: one hundred, five\n",
+        "NEXT GRIPPER: [105, 74\n",
+        "NEXT GRIPPER: [105, x]\n",                        # undefined name -> NameError -> [0, 0]
+        "NEXT GRIPPER:\n",
     ]
     out = []
     for c in cases:
         pol, remain = solver.extract_action_policies(c)
         req, mv = solver.extract_movement_plan(c)
-        out.append({"text": c, "policies": pol, "remain": remain, "require_unorm": req, "movement": np.asarray(mv).tolist()})
+        coord = solver.extract_2d_coordinates(c)
+        out.append({"text": c, "policies": pol, "remain": remain, "require_unorm": req, "movement": np.asarray(mv).tolist(),
+                    "coordinates": json.loads(json.dumps(coord)), "coordinates_type": type(coord).__name__})
     with open(os.path.join(OUT, "solver.json"), "w") as f:
         json.dump(out, f, indent=1, ensure_ascii=False)
     print("G7 ok", [len(o["policies"]) for o in out])

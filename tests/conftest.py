@@ -22,3 +22,21 @@ def device():
     if not torch.cuda.is_available():
         pytest.fail("`-m gpu` tests need a HIP device; none is visible")
     return "cuda:0"
+
+
+@pytest.fixture
+def tune():
+    """`tune(graph=1, ks=0)`: set tuning switches of libemmax_hip.so through its setter (the library reads the environment only once,
+    at start-up); the previous values come back after the test."""
+    from emmax import _lib
+
+    undo = []
+
+    def set_(**kw):
+        for k, v in kw.items():
+            undo.append((k, _lib.tuning_get(k)))
+            _lib.tuning_set(k, v)
+
+    yield set_
+    for k, v in reversed(undo):
+        _lib.tuning_set(k, v)

@@ -29,7 +29,75 @@ def test_every_declared_symbol_is_exported(lib):
     for name in sorted(declared):
         assert hasattr(so, name), f"{name} declared in include/emmax.h but not exported"
     assert declared == set(L.SIGNATURES), "ctypes signature table and header drifted apart"
-    assert so.emmax_abi_version() == 1 and b"gfx950" in so.emmax_version()
+    assert so.emmax_abi_version() == L.ABI_VERSION and b"gfx950" in so.emmax_version()
+    m = re.search(r"#define EMMAX_ABI_VERSION (\d+)", header)
+    assert m and int(m.group(1)) == L.ABI_VERSION
+
+
+def _c_struct_fields(header, name):
+    """(type, field) pairs of `typedef struct name { ... } name;` in the header, comments stripped, arrays as `field[n]`."""
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), header, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ty, rest = decl.split(None, 1)
+        out += [(ty, f.strip()) for f in rest.split(",")]
+    return out
+
+
+def test_config_struct_layout_header_binding_and_integration_stub_agree(lib):
+    """INTEGRATION.md's reference-side stub had drifted from emmax_config (no `decode_fp8`: a struct 4 bytes short).
+    The header's struct, the ctypes mirror in emmax/_lib.py, the stub printed in INTEGRATION.md and the library's own
+    sizeof(emmax_config) must all agree, field for field."""
+    L, so = lib
+    header = open(os.path.join(ROOT, "include", "emmax.h")).read()
+    ctype = {"int32_t": C.c_int32, "float": C.c_float}
+
+    def flat(fields):
+        return [(n, t) for n, t in fields]
+
+    want_tower = [(f.split("[")[0], ctype[t] * int(f.split("[")[1][:-1]) if "[" in f else ctype[t]) for t, f in _c_struct_fields(header, "emmax_tower_config")]
+    assert flat(L.TowerConfigC._fields_) == want_tower
+    cfg_fields = _c_struct_fields(header, "emmax_config")
+    assert cfg_fields[0] == ("emmax_tower_config", "tower[2]")
+    want_cfg = [("tower", L.TowerConfigC * 2)] + [(f, ctype[t]) for t, f in cfg_fields[1:]]
+    assert [(n, t) for n, t in L.ConfigC._fields_][1:] == want_cfg[1:] and L.ConfigC._fields_[0][0] == "tower"
+    assert so.emmax_config_size() == C.sizeof(L.ConfigC) == 2 * C.sizeof(L.TowerConfigC) + 4 * len(cfg_fields[1:])
+    # the stub a maintainer would paste (INTEGRATION.md section 2): execute its two struct definitions and compare
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = md[md.index("class EmmaxTower(C.Structure):"):md.index("def load(state_dict")]
+    ns = {"C": C, "lib": so}   # the stub's own size / ABI assertion runs too
+    exec(code, ns)
+    assert [n for n, _ in ns["EmmaxTower"]._fields_] == [n for n, _ in L.TowerConfigC._fields_]
+    assert [n for n, _ in ns["EmmaxConfig"]._fields_] == [n for n, _ in L.ConfigC._fields_]
+    assert C.sizeof(ns["EmmaxConfig"]) == so.emmax_config_size()
+
+
+def test_tuning_switches_are_a_table_with_a_setter(lib):
+    """The library reads EMMAX_<NAME> once; afterwards only emmax_tuning_set moves a switch (no launcher calls getenv)."""
+    L, so = lib
+    names = ["graph", "ks", "ks_oproj", "ks_oproj_grid", "km", "km_down", "streamk", "fp8_gemv", "attn_nsplit", "attn_direct", "fold_embed",
+             "mfma_xbar", "gemm_big", "gemm_splitk", "gemm_lnfuse", "attn_resident"]
+    header = open(os.path.join(ROOT, "include", "emmax.h")).read()
+    for n in names:
+        assert re.search(r"\b%s\b" % n, header), n
+        L.tuning_get(n)
+    assert L.tuning_get("graph") == int(os.environ.get("EMMAX_GRAPH", "0")) and L.tuning_get("ks") == int(os.environ.get("EMMAX_KS", "1"))
+    with L.tuning(graph=1, attn_nsplit=4):
+        assert L.tuning_get("graph") == 1 and L.tuning_get("attn_nsplit") == 4
+        os.environ["EMMAX_GRAPH"] = "0"          # the environment is not consulted again
+        assert L.tuning_get("graph") == 1
+        del os.environ["EMMAX_GRAPH"]
+    assert L.tuning_get("graph") == 0 and L.tuning_get("attn_nsplit") == 0
+    assert so.emmax_tuning_set(b"no_such_switch", 1) == -1 and b"no_such_switch" in so.emmax_last_error()
+    # exactly one getenv in the library sources
+    import glob
+
+    hits = [(f, ln) for f in glob.glob(os.path.join(ROOT, "emma-x_amd", "csrc", "*.h*")) for ln in open(f) if "getenv(" in ln and not ln.lstrip().startswith("//")]
+    assert len(hits) == 1 and hits[0][0].endswith("model.hip"), hits
 
 
 def _model(L, so, cfg):

@@ -70,8 +70,8 @@ def test_fullsize_ragged_batch_equals_bs1_and_is_deterministic(device, big):
         assert ids_b[b, : lens_b[b]].tolist() == ids_1[0, : lens_b[b]].cpu().tolist()
 
 
-def test_fullsize_graph_equals_eager(device, big, monkeypatch):
-    monkeypatch.setenv("EMMAX_GRAPH", "1")
+def test_fullsize_graph_equals_eager(device, big, tune):
+    tune(graph=1)
     cfg, model = big
     frames, rows = _rows(cfg, [200, 64], [25, 40], seed=5)
     fr = frames.to(device)
@@ -85,17 +85,17 @@ def test_fullsize_graph_equals_eager(device, big, monkeypatch):
     assert torch.equal(ids_g, ids_e) and torch.equal(lens_g, lens_e)
 
 
-def test_fullsize_graph_replay_on_the_mfma_streamk_path(device, big, monkeypatch):
+def test_fullsize_graph_replay_on_the_mfma_streamk_path(device, big, tune):
     """B = 4 at 7B shapes: the small-batch MFMA projections split their work stream-K (tasks straddle two blocks and meet
     through tagged granules that the finishing block clears).  A captured step replays the same launches 40 times: if a
     granule survived a launch, or a replay read one too early, the ids would leave the eager run's."""
     cfg, model = big
     frames, rows = _rows(cfg, [300, 64, 128, 33], [20, 33, 9, 28], seed=17)
     fr = frames.to(device)
-    monkeypatch.setenv("EMMAX_GRAPH", "1")
+    tune(graph=1)
     _, ids_g, lens_g = model.generate_actions_batch(fr, rows, max_new_tokens=40)
     assert model.engine.graph_active()
-    monkeypatch.setenv("EMMAX_GRAPH", "0")
+    tune(graph=0)
     _, ids_e, lens_e = model.generate_actions_batch(fr, rows, max_new_tokens=40)
     assert not model.engine.graph_active()
     assert torch.equal(ids_g, ids_e) and torch.equal(lens_g, lens_e)
@@ -115,7 +115,7 @@ def test_fullsize_graph_replay_on_the_mfma_streamk_path(device, big, monkeypatch
         return out
 
     with_sk = forced_logits()
-    monkeypatch.setenv("EMMAX_STREAMK", "0")
+    tune(streamk=0)
     model.engine.new_session(model.engine.max_batch, model.engine.max_prompt, model.engine.max_ctx)
     without = forced_logits()
     for a, w in zip(with_sk, without):
@@ -124,7 +124,7 @@ def test_fullsize_graph_replay_on_the_mfma_streamk_path(device, big, monkeypatch
         top2 = torch.topk(a, 2, dim=1).values
         clear = (top2[:, 0] - top2[:, 1]) > 2 * diff
         assert torch.equal(a.argmax(dim=1)[clear], w.argmax(dim=1)[clear])
-    monkeypatch.delenv("EMMAX_STREAMK")
+    tune(streamk=1)
     model.engine.new_session(model.engine.max_batch, model.engine.max_prompt, model.engine.max_ctx)
 
 

@@ -136,10 +136,10 @@ def _teacher_forced(model, frames, rows, gens, traces, sel, T, device):
 
 @pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipgraph"])
 @pytest.mark.parametrize("sel", [[0], list(range(8))], ids=["B1", "B8"])
-def test_bf16_decode_at_context_768_matches_oracle(device, setup, oracle_bf16, model_bf16, monkeypatch, sel, graph):
+def test_bf16_decode_at_context_768_matches_oracle(device, setup, oracle_bf16, model_bf16, tune, sel, graph):
     cfg, _, _, frames, rows = setup
     gens, traces = oracle_bf16
-    monkeypatch.setenv("EMMAX_GRAPH", "1" if graph else "0")
+    tune(graph=1 if graph else 0)
     worst, checked, agree = _teacher_forced(model_bf16, frames, rows, gens, traces, sel, T8, device)
     assert model_bf16.engine.graph_active() == graph
     assert worst < TOL, worst
@@ -148,11 +148,11 @@ def test_bf16_decode_at_context_768_matches_oracle(device, setup, oracle_bf16, m
 
 @pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipgraph"])
 @pytest.mark.parametrize("sel", [[0], list(range(8))], ids=["B1", "B8"])
-def test_fp8_decode_at_context_768_matches_dequantised_oracle(device, setup, oracle_fp8, model_fp8, monkeypatch, sel, graph):
+def test_fp8_decode_at_context_768_matches_dequantised_oracle(device, setup, oracle_fp8, model_fp8, tune, sel, graph):
     """BASELINE configs[4] at its stated shape: fp8-e4m3 decode weights, B = 8, the step replayed from a hipGraph."""
     cfg, _, _, frames, rows = setup
     gens, traces = oracle_fp8
-    monkeypatch.setenv("EMMAX_GRAPH", "1" if graph else "0")
+    tune(graph=1 if graph else 0)
     worst, checked, agree = _teacher_forced(model_fp8, frames, rows, gens, traces, sel, 40, device)
     assert model_fp8.engine.graph_active() == graph
     assert worst < TOL, worst

@@ -129,6 +129,12 @@ def test_solver_matches_reference_class():
             req, mv = s.extract_movement_plan(c["text"])
             assert pol == c["policies"] and remain == c["remain"] and req == c["require_unorm"]
             assert np.allclose(np.asarray(mv, dtype=float), c["movement"])
+            xy = s.extract_2d_coordinates(c["text"])          # solver.py:33-40: the reference evals the line
+            assert type(xy).__name__ == c["coordinates_type"] and json.loads(json.dumps(xy)) == c["coordinates"], (c["text"], xy)
+    assert sum(c["coordinates"] != [0, 0] for c in cases) >= 6
+    # names and calls -- which the reference would execute -- are refused (generated text is untrusted)
+    assert mine.extract_2d_coordinates("NEXT GRIPPER: __import__('os').getcwd()") == [0, 0]
+    assert mine.extract_2d_coordinates("NEXT GRIPPER: [abs(-3), 4]") == [0, 0]
     # never raises, zeros on garbage (reference contract)
     assert mine.extract_action_policies("POLICIES:")[0] == [[0] * 7]
     assert mine.extract_movement_plan("")[1].tolist() == [-100] * 7

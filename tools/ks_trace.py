@@ -1,5 +1,5 @@
 """Phase stamps of the stand-alone K-split projections IN SITU (lab; needs the -DDECODE_LAB_TRACE library, see
-tools/chain_trace.sh): for every GEMV stage the last launch of emmax_profile_decode_stage (layer 31) is dissected -- us from the
+tools/lab_trace.sh): for every GEMV stage the last launch of emmax_profile_decode_stage (layer 31) is dissected -- us from the
 first block's entry: min / median / max over the blocks, waves 0 (epilogue wave) and 7."""
 import ctypes as C
 import os
