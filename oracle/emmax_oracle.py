@@ -149,7 +149,7 @@ def rms_norm(x: Tensor, w: Tensor, eps: float) -> Tensor:
 
 def rope_cos_sin(positions: Tensor, head_dim: int, theta: float, dtype) -> Tuple[Tensor, Tensor]:
     """HF LlamaRotaryEmbedding: inv_freq = theta^(-2i/d) (fp32), emb = cat(freqs, freqs), cos/sin fp32 -> act dtype."""
-    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).to(torch.float32) / head_dim))
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64, device=positions.device).to(torch.float32) / head_dim))
     freqs = positions.to(torch.float32)[:, None] * inv_freq[None, :]
     emb = torch.cat([freqs, freqs], dim=-1)
     return emb.cos().to(dtype), emb.sin().to(dtype)
@@ -187,7 +187,7 @@ def llama_layer(h: Tensor, sd, li: int, lc, positions: Tensor, kv: Optional[Tupl
     vv = v.repeat_interleave(rep, dim=1) if rep > 1 else v
     att = torch.matmul(q, kk.transpose(2, 3)) * (hd ** -0.5)
     # causal mask: query at absolute position positions[t] may see keys 0..positions[t]
-    key_pos = torch.arange(L)
+    key_pos = torch.arange(L, device=positions.device)
     mask = key_pos[None, :] > positions[:, None]
     att = att.masked_fill(mask[None, None], float("-inf"))
     att = F.softmax(att, dim=-1, dtype=torch.float32).to(dtype)
@@ -205,7 +205,7 @@ def llama_forward(embeds: Tensor, sd, lc, kv_cache: Optional[List], dtype=torch.
     h = embeds.to(dtype)
     T = h.shape[1]
     past = 0 if kv_cache is None else kv_cache[0][0].shape[2]
-    positions = torch.arange(past, past + T)
+    positions = torch.arange(past, past + T, device=h.device)   # tensors follow the inputs' device (tests may execute the fp32 restatement on the GPU)
     new_cache = []
     nl = lc.num_layers if n_layers is None else n_layers
     for li in range(nl):

@@ -140,3 +140,193 @@ def test_full_depth_random_weights_batch8_mfma_path(device, full, oracle_trace):
     assert all(np.isfinite(per_step))
     assert worst < TOL, (worst, per_step)
     assert agree == checked
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4 (VERDICT r03 "next" #4): fp8 and RAGGED batch 8 at full depth, and how often an id COULD flip over a whole generation.
+#
+# The checker for these is the SAME fp32 restatement (oracle/emmax_oracle.py), executed by torch on the GPU instead of the host
+# cores: 8 ragged rows x (32-layer prefill + decode steps) and a 512-step generation are ~15 minutes of host fp32 against seconds
+# on the device.  `test_device_executed_oracle_equals_the_cpu_oracle` ties that execution to the CPU oracle first: same frame,
+# same prompt, every one of the 12 steps of `oracle_trace` -- logits to 1e-4 of max|logit| (fp32 summation order is the only
+# difference), ids equal.  Nothing here is product code: the product path stays libemmax_hip.so through ctypes.
+# ---------------------------------------------------------------------------------------------------------------------
+LENS8 = [572, 64, 570, 32, 128, 575, 16, 300]   # prompt tokens per row: S = 828 / 830 / 831 cross the KV page boundary at 832 in steps 4 / 2 / 1
+T_R8 = 8
+PROJ = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
+
+
+def _dequant_e4m3_rows(w):
+    w = w.float()
+    scale = (w.abs().amax(dim=1, keepdim=True) / 448.0).clamp_min(1e-30)
+    return (w / scale).to(torch.float8_e4m3fn).float() * scale
+
+
+@pytest.fixture(scope="module")
+def dev_oracle(device, full):
+    """fp32 weights of the oracle on the device: `ref` = the bf16-rounded values (what the bf16 model holds), `q` = the decode
+    projections + lm-head as e4m3 x per-row scale de-quantised (what the fp8 model streams), `prefill_q` = bf16 weights with the
+    fp8 lm-head (the fp8 model's prefill)."""
+    _, _, sd_ref, _ = full
+    ref = {k: v.to(device) for k, v in sd_ref.items()}
+    q = {k: (_dequant_e4m3_rows(v) if (any(p in k for p in PROJ) or k.endswith("lm_head.weight")) else v) for k, v in ref.items()}
+    prefill_q = dict(ref)
+    prefill_q["language_model.lm_head.weight"] = q["language_model.lm_head.weight"]
+    return ref, q, prefill_q
+
+
+def _dev_trace(cfg, sd_prefill, sd_decode, frames, row, T, device):
+    """Greedy ids + last-position logits (cpu f32) of T steps of ONE request, fp32 restatement executed on `device`."""
+    from oracle import emmax_oracle as orc
+
+    with torch.inference_mode():
+        pix = orc.preprocess_frames(frames, cfg).to(device)
+        proj = orc.projector(orc.vision_backbone(pix, sd_prefill, cfg), sd_prefill)
+        emb = orc.splice(torch.tensor([row], device=device), proj, sd_prefill)
+        logits, cache = orc.llama_forward(emb, sd_prefill, cfg.llm, None, last_only=True)
+        gen, trace = [], []
+        for _ in range(T):
+            last = logits[0, -1].float()
+            trace.append(last.cpu())
+            gen.append(int(last.argmax()))
+            logits, cache = orc.llama_forward(orc.embed_tokens(torch.tensor([[gen[-1]]], device=device), sd_decode), sd_decode, cfg.llm, cache)
+    return gen, trace
+
+
+def test_device_executed_oracle_equals_the_cpu_oracle(device, full, oracle_trace, dev_oracle):
+    cfg = full[0]
+    frames, row, gen, trace = oracle_trace
+    ref = dev_oracle[0]
+    gen_d, trace_d = _dev_trace(cfg, ref, ref, frames, row, T_B1, device)
+    worst = max(((a - b).abs().max() / b.abs().max()).item() for a, b in zip(trace_d, trace))
+    print(f"\nfp32 restatement on the device against on the host cores: worst |diff| / max|logit| over {T_B1} steps = {worst:.2e}")
+    assert worst < 1e-4
+    assert gen_d == gen
+
+
+@pytest.fixture(scope="module")
+def ragged8(full):
+    rng = np.random.default_rng(404)
+    frames = rng.integers(0, 256, size=(8, 224, 224, 3), dtype=np.uint8)
+    rows = [[1] + [int(x) for x in rng.integers(3, 31744, size=n - 1)] for n in LENS8]
+    return frames, rows
+
+
+def _teacher_forced_rows(model, frames, rows, gens, traces, sel, T, device):
+    eng = model.engine
+    model._prefill([rows[i] for i in sel], None, torch.from_numpy(frames[sel]).to(device), max_new=T + 1)
+    per_step, checked, agree = [], 0, 0
+    for t in range(T):
+        got = eng.last_logits().float().cpu()
+        w = 0.0
+        for j, i in enumerate(sel):
+            ref = traces[i][t]
+            err = (got[j] - ref).abs().max().item()
+            w = max(w, err / ref.abs().max().item())
+            top2 = torch.topk(ref, 2).values
+            if (top2[0] - top2[1]).item() > 2 * err:
+                checked += 1
+                agree += int(int(got[j].argmax()) == gens[i][t])
+        per_step.append(w)
+        eng.set_current_tokens([gens[i][t] for i in sel])
+        eng.decode_step()
+    return per_step, checked, agree
+
+
+def test_full_depth_ragged_batch8_bf16(device, full, dev_oracle, ragged8):
+    """configs[2]'s per-GPU shard as it really looks: eight DIFFERENT requests of different lengths at full depth (the round-3 test
+    replicated one request 8x), three of them crossing the KV page boundary at 832 inside the window."""
+    cfg, model, _, _ = full
+    frames, rows = ragged8
+    ref = dev_oracle[0]
+    model.engine.new_session(8, 576, 256 + 576 + 32)
+    gens, traces = zip(*[_dev_trace(cfg, ref, ref, frames[b:b + 1], rows[b], T_R8, device) for b in range(8)])
+    per_step, checked, agree = _teacher_forced_rows(model, frames, rows, gens, traces, list(range(8)), T_R8, device)
+    print("\nfull depth, ragged B=8, bf16: worst |err|/max|ref| per step:", " ".join(f"{v:.2e}" for v in per_step),
+          f"| argmax checked {checked}/{8 * T_R8} agreed {agree}")
+    assert all(np.isfinite(per_step)) and max(per_step) < TOL, per_step
+    assert agree == checked and checked >= 8
+
+
+def test_full_depth_fp8_batch1_and_ragged_batch8(device, full, dev_oracle, ragged8):
+    """BASELINE configs[4] at full depth (round 3 checked fp8 at 2 layers only): e4m3 decode weights with per-row scales, all 32
+    layers, against the fp32 restatement run on the DE-QUANTISED weights -- B = 1 (fp8 row GEMV / K-split MFMA routing) and the
+    ragged B = 8 (K-split MFMA kernels), eager launches and hipGraph replay of the step."""
+    import copy
+
+    from emmax import _lib
+    from emmax.modeling import EmmaXForActionPrediction
+
+    cfg, _, _, sd_bf = full
+    frames, rows = ragged8
+    _, q, prefill_q = dev_oracle
+    c8 = copy.deepcopy(cfg)
+    c8.decode_weight_dtype = "fp8"
+    model8 = EmmaXForActionPrediction(c8, dict(sd_bf)).to(device, max_batch=8, max_prompt=576, max_ctx=256 + 576 + 32)
+    gens, traces = zip(*[_dev_trace(cfg, prefill_q, q, frames[b:b + 1], rows[b], T_R8, device) for b in range(8)])
+    for graph in (0, 1):
+        with _lib.tuning(graph=graph):
+            for sel in ([0], list(range(8))):
+                per_step, checked, agree = _teacher_forced_rows(model8, frames, rows, gens, traces, sel, T_R8, device)
+                assert model8.engine.graph_active() == bool(graph)
+                print(f"\nfull depth fp8, B={len(sel)}{' ragged' if len(sel) > 1 else ''}, {'hipGraph' if graph else 'eager'}: worst |err|/max|ref| per step:",
+                      " ".join(f"{v:.2e}" for v in per_step), f"| argmax checked {checked}/{len(sel) * T_R8} agreed {agree}")
+                assert all(np.isfinite(per_step)) and max(per_step) < TOL, per_step
+                assert agree == checked and checked >= 1
+    del model8
+    torch.cuda.empty_cache()
+
+
+def test_how_often_an_id_could_flip_over_a_512_token_generation(device, full, dev_oracle, oracle_trace):
+    """The statistic the parity claim rests on: over a FULL 512-step teacher-forced generation at full depth (bf16, B = 1, the
+    bench's own step sequence: contexts 768 .. 1279), per step the HIP path's logit error and the fp32 top-2 margin.  An id is
+    reproducible where margin > 2 x error; the fraction of steps below that is how often a greedy id COULD differ from the fp32
+    reference on weights with THESE margins (random weights: the thinnest margins there are -- a trained checkpoint's action
+    tokens sit far above).  Asserted: the argmax is right on every step above the line; the numbers go to
+    gpurun_out/r04_margin_statistic.json and are printed."""
+    import json
+    import os
+
+    from conftest import ROOT
+
+    cfg, model, _, _ = full
+    frames, row, _, _ = oracle_trace
+    ref = dev_oracle[0]
+    T = 512
+    model.engine.new_session(1, 512, 256 + 512 + T + 1)
+    gen, trace = _dev_trace(cfg, ref, ref, frames, row, T, device)
+    eng = model.engine
+    model._prefill([list(row)], None, torch.from_numpy(frames).to(device), max_new=T + 1)
+    errs, margins, could_flip, flipped, wrong_above = [], [], 0, 0, 0
+    for t in range(T):
+        got = eng.last_logits().float().cpu()[0]
+        r = trace[t]
+        scale = r.abs().max().item()
+        err = (got - r).abs().max().item()
+        top2 = torch.topk(r, 2).values
+        margin = (top2[0] - top2[1]).item()
+        errs.append(err / scale)
+        margins.append(margin / scale)
+        same = int(got.argmax()) == gen[t]
+        if margin > 2 * err:
+            wrong_above += int(not same)
+        else:
+            could_flip += 1
+            flipped += int(not same)
+        eng.set_current_tokens([gen[t]])
+        eng.decode_step()
+    e, m = np.array(errs), np.array(margins)
+    out = {"steps": T, "contexts": [768, 768 + T - 1], "rel_err_median": float(np.median(e)), "rel_err_p95": float(np.percentile(e, 95)),
+           "rel_err_max": float(e.max()), "margin_median": float(np.median(m)), "margin_p05": float(np.percentile(m, 5)),
+           "steps_margin_below_2x_err": could_flip, "fraction_could_flip": could_flip / T, "steps_actually_flipped": flipped,
+           "wrong_above_the_line": wrong_above,
+           "what": "Emma-X-7B shape, 32 layers, RANDOM weights (seed 33), bf16 HIP path B=1 teacher-forced against the fp32 restatement; "
+                   "errors and margins relative to max|logit| of the step"}
+    print("\n512-step margin statistic:", json.dumps(out))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r04_margin_statistic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    assert wrong_above == 0
+    assert e.max() < TOL
+    assert flipped <= could_flip
+    model.engine.new_session(8, 512, 256 + 512 + 32)
