@@ -343,6 +343,8 @@ def main():
             "p50_latency_ms": round(float(np.median(lat)) * 1e3, 2),
             "decode_ms_per_token": round(step_ms, 4), "decode_tokens_per_s": round(B * 1e3 / step_ms, 1),
             "decode_step_hbm_gbs": round(step_gbs, 1), "decode_step_hbm_frac": round(step_gbs / HBM_PEAK_GBS, 4),
+            "weights": {"arena_gb": round(eng.arena.numel() / 1e9, 2), "aux_gb_batch_ge_3": round((eng.weight_bytes() - eng.arena.numel()) / 1e9, 2),
+                        "finalize_s": round(eng.finalize_s, 3), "aux_build_s": round(eng.aux_build_s, 3)},
             "stage_us": {k: round(v, 2) for k, v in stage_us.items()},
             "stage_gbs": {k: round(stage_bytes[k] / (stage_us[k] * 1e-6) / 1e9, 1) for k in stage_names},
             "roofline": {"kernel": ("emmax_decode_ks_kernel<B=%d,GATEUP,NORM,CPL=1>" % B if B <= 2 and not args.fp8 else "emmax_decode_km_kernel<GATEUP,NORM%s> (B=%d)" % (",FP8" if args.fp8 else "", B)) + " (gate/up projection + SiLU*mul)", "bound": "hbm",

@@ -121,6 +121,8 @@ struct emmax_model {
     bf16 *embed, *final_norm, *lm_head, *lm_head_fm, *lm_head_r8 = nullptr;
     float* lm_head_sc = nullptr;
     bool fp8 = false;
+    bool aux_built = false;      // the batch >= 3 copies exist (fp8 models: always, they are part of the main arena)
+    bool aux_ab = false;         // ... including decode_mfma.hip's qkv / gate-up pair
     std::vector<LayerW> layers;
 };
 
@@ -178,6 +180,8 @@ static void derive(emmax_model* m) {
         T.blk.resize(T.n_blocks);
     }
     m->layers.resize(c.n_layers);
+    for (auto& L : m->layers) memset(&L, 0, sizeof(L));
+    m->lm_head_fm = nullptr;
     m->fp8 = c.decode_fp8 != 0;
 }
 
@@ -223,13 +227,14 @@ static void plan_arena(emmax_model* m, Bump& b) {
         L.ln2 = b.take(m->H);
         L.wgu = b.take((int64_t)2 * m->inter_p * m->H);
         L.wdown = b.take((int64_t)m->H * m->inter_p);
-        const int d = m->fp8 ? 2 : 1;   // fp8 tiles take half the bytes
-        L.wqkv_fm = b.take((int64_t)m->qkv_dim * m->H / d);
-        L.wo_fm = b.take((int64_t)m->H * m->q_dim / d);
-        L.wgu_fm = b.take((int64_t)2 * m->inter_p * m->H / d);
-        L.wdown_fm = b.take((int64_t)m->H * m->inter_p / d);
-        L.wqkv_km = b.take((int64_t)m->qkv_dim * m->H / d);
-        L.wgu_km = b.take((int64_t)2 * m->inter_p * m->H / d);
+        if (m->fp8) {   // fp8 tiles take half the bytes; every batch regime reads some of them, so they live in the main arena
+            L.wqkv_fm = b.take((int64_t)m->qkv_dim * m->H / 2);
+            L.wo_fm = b.take((int64_t)m->H * m->q_dim / 2);
+            L.wgu_fm = b.take((int64_t)2 * m->inter_p * m->H / 2);
+            L.wdown_fm = b.take((int64_t)m->H * m->inter_p / 2);
+            L.wqkv_km = b.take((int64_t)m->qkv_dim * m->H / 2);
+            L.wgu_km = b.take((int64_t)2 * m->inter_p * m->H / 2);
+        }
         L.wqkv_km_sc = L.wgu_km_sc = nullptr;
         L.wqkv_sc = L.wo_sc = L.wgu_sc = L.wdown_sc = nullptr;
         L.wqkv_r8 = L.wo_r8 = L.wgu_r8 = L.wdown_r8 = nullptr;
@@ -248,11 +253,27 @@ static void plan_arena(emmax_model* m, Bump& b) {
     }
     m->final_norm = b.take(m->H);
     m->lm_head = b.take((int64_t)m->vocab_p * m->H);
-    m->lm_head_fm = b.take((int64_t)m->vocab_p * m->H / (m->fp8 ? 2 : 1));
     if (m->fp8) {
+        m->lm_head_fm = b.take((int64_t)m->vocab_p * m->H / 2);
         m->lm_head_sc = (float*)b.take(2 * (int64_t)m->vocab_p);
         m->lm_head_r8 = b.take((int64_t)m->vocab_p * m->H / 2);
     }
+}
+
+// bf16 models: the copies only the batch >= 3 decode kernels read -- row-permuted fragment-major qkv / gate-up (decode_km.hip),
+// fragment-major o-proj / down / lm-head (decode_km.hip's natural-order form and decode_mfma.hip) -- live in a SECOND arena that
+// a model serving batches 1-2 never needs (13.2 GB at 7B).  The fragment-major qkv / gate-up pair of decode_mfma.hip is the A/B
+// partner of decode_km.hip and is built only when the tuning switch km is 0 at build time (+9 GB).
+static void plan_aux(emmax_model* m, Bump& b, bool with_ab_partner) {
+    for (auto& L : m->layers) {
+        L.wqkv_km = b.take((int64_t)m->qkv_dim * m->H);
+        L.wgu_km = b.take((int64_t)2 * m->inter_p * m->H);
+        L.wo_fm = b.take((int64_t)m->H * m->q_dim);
+        L.wdown_fm = b.take((int64_t)m->H * m->inter_p);
+        L.wqkv_fm = with_ab_partner ? b.take((int64_t)m->qkv_dim * m->H) : nullptr;
+        L.wgu_fm = with_ab_partner ? b.take((int64_t)2 * m->inter_p * m->H) : nullptr;
+    }
+    m->lm_head_fm = b.take((int64_t)m->vocab_p * m->H);
 }
 
 // copy a bound [rows, cols] bf16 matrix into dst (row pitch dst_ld elements) starting at dst row `row0`
@@ -501,6 +522,7 @@ static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_
             const int r = launch_decode_km(mode, q, B, st, grid_out);
             if (r != -2) return r;
         }
+        if (!w_fm) return fail(EMMAX_ERR_STATE, "decode_mfma.hip's copy of this matrix was not built (tuning switch km was 1 at emmax_model_build_aux)");
         p.W = w_fm;
         p.wscale = w_scale;
         return launch_decode_mfma(mode, p, B, st, grid_out);
@@ -555,6 +577,8 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
     if (!m->finalized) return fail(EMMAX_ERR_STATE, "model not finalized");
     if (B <= 0 || B > s->max_batch || B > EMMAX_MAX_DECODE_BATCH)
         return fail(EMMAX_ERR_INVALID, "prefill batch %d outside 1..min(max_batch=%d, %d)", B, s->max_batch, EMMAX_MAX_DECODE_BATCH);
+    if (B >= EMMAX_MFMA_MIN_BATCH && !m->aux_built)
+        return fail(EMMAX_ERR_STATE, "batch %d decodes on the fragment-major weight copies: call emmax_model_build_aux first", B);
     const int np = patches ? m->tw[0].n_patches : 0;
     const bool slot_mode = slot0 >= 0;
     const int r0 = slot_mode ? slot0 : 0;
@@ -918,13 +942,6 @@ int emmax_model_finalize(emmax_model* m, void* arena, int64_t arena_bytes, emmax
             KCHK(launch_quant_rm8(L.wdown, m->inter_p, L.wdown_r8, L.wdown_sc, m->H, m->inter_p, st));
             KCHK(launch_quant_fm8(L.wqkv, m->H, L.wqkv_km, L.wqkv_km_sc, m->qkv_dim, m->H, st, 1, m->cfg.head_dim));
             KCHK(launch_quant_fm8(L.wgu, m->H, L.wgu_km, L.wgu_km_sc, 2 * m->inter_p, m->H, st, 2, 0));
-        } else {
-            KCHK(launch_repack_km(L.wqkv, m->H, L.wqkv_km, m->qkv_dim, m->H, 1, m->cfg.head_dim, st));
-            KCHK(launch_repack_km(L.wgu, m->H, L.wgu_km, 2 * m->inter_p, m->H, 2, 0, st));
-            KCHK(launch_repack_fm(L.wqkv, m->H, L.wqkv_fm, m->qkv_dim, m->H, st));
-            KCHK(launch_repack_fm(L.wo, m->q_dim, L.wo_fm, m->H, m->q_dim, st));
-            KCHK(launch_repack_fm(L.wgu, m->H, L.wgu_fm, 2 * m->inter_p, m->H, st));
-            KCHK(launch_repack_fm(L.wdown, m->inter_p, L.wdown_fm, m->H, m->inter_p, st));
         }
     }
     PUT1("language_model.model.norm.weight", m->H, m->final_norm);
@@ -932,12 +949,52 @@ int emmax_model_finalize(emmax_model* m, void* arena, int64_t arena_bytes, emmax
     if (m->fp8) {
         KCHK(launch_quant_fm8(m->lm_head, m->H, m->lm_head_fm, m->lm_head_sc, m->vocab_p, m->H, st));
         KCHK(launch_quant_rm8(m->lm_head, m->H, m->lm_head_r8, m->lm_head_sc, m->vocab_p, m->H, st));
-    } else KCHK(launch_repack_fm(m->lm_head, m->H, m->lm_head_fm, m->vocab_p, m->H, st));
+    }
 #undef PUT2
 #undef PUT1
     HIPCHK(hipStreamSynchronize(st));
     m->finalized = true;
+    m->aux_built = m->fp8;
     m->bound.clear();
+    return 0;
+}
+
+int64_t emmax_model_aux_bytes(const emmax_model* m) {
+    if (!m) return -1;
+    if (m->fp8) return 0;
+    // sized on a copy of the layer table: a const query must not move the pointers of a built arena
+    emmax_model tmp = *m;
+    Bump b{nullptr};
+    plan_aux(&tmp, b, emmax_tune().km == 0);
+    return b.off + 256;
+}
+
+int emmax_model_build_aux(emmax_model* m, void* aux, int64_t aux_bytes, emmax_stream stream) {
+    if (!m) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (!m->finalized) return fail(EMMAX_ERR_STATE, "emmax_model_build_aux before emmax_model_finalize");
+    if (m->fp8) return 0;   // nothing to build: the e4m3 copies of every regime are in the main arena
+    if (!aux) return fail(EMMAX_ERR_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const bool ab = emmax_tune().km == 0;
+    const int64_t need = emmax_model_aux_bytes(m);
+    if (aux_bytes < need) return fail(EMMAX_ERR_NOMEM, "aux arena too small: %lld < %lld", (long long)aux_bytes, (long long)need);
+    if ((uintptr_t)aux % 256) return fail(EMMAX_ERR_INVALID, "aux arena must be 256-byte aligned");
+    Bump b{(char*)aux};
+    plan_aux(m, b, ab);
+    for (auto& L : m->layers) {
+        KCHK(launch_repack_km(L.wqkv, m->H, L.wqkv_km, m->qkv_dim, m->H, 1, m->cfg.head_dim, st));
+        KCHK(launch_repack_km(L.wgu, m->H, L.wgu_km, 2 * m->inter_p, m->H, 2, 0, st));
+        KCHK(launch_repack_fm(L.wo, m->q_dim, L.wo_fm, m->H, m->q_dim, st));
+        KCHK(launch_repack_fm(L.wdown, m->inter_p, L.wdown_fm, m->H, m->inter_p, st));
+        if (ab) {
+            KCHK(launch_repack_fm(L.wqkv, m->H, L.wqkv_fm, m->qkv_dim, m->H, st));
+            KCHK(launch_repack_fm(L.wgu, m->H, L.wgu_fm, 2 * m->inter_p, m->H, st));
+        }
+    }
+    KCHK(launch_repack_fm(m->lm_head, m->H, m->lm_head_fm, m->vocab_p, m->H, st));
+    HIPCHK(hipStreamSynchronize(st));
+    m->aux_built = true;
+    m->aux_ab = ab;
     return 0;
 }
 
@@ -1208,6 +1265,8 @@ int emmax_slots_open(emmax_session* s, int n_slots, emmax_stream stream) {
     if (!s) return fail(EMMAX_ERR_INVALID, "null argument");
     if (n_slots < 1 || n_slots > s->max_batch || n_slots > EMMAX_MAX_DECODE_BATCH)
         return fail(EMMAX_ERR_INVALID, "%d slots outside 1..min(max_batch=%d, %d)", n_slots, s->max_batch, EMMAX_MAX_DECODE_BATCH);
+    if (n_slots >= EMMAX_MFMA_MIN_BATCH && !s->m->aux_built)
+        return fail(EMMAX_ERR_STATE, "%d slots decode on the fragment-major weight copies: call emmax_model_build_aux first", n_slots);
     hipStream_t user = (hipStream_t)stream, st;
     int r = slot_enter(s, user, &st);
     if (r) return r;

@@ -58,6 +58,8 @@ SIGNATURES = {
     "emmax_model_bind_weight": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int, _c_i64p, C.c_int]),
     "emmax_model_arena_bytes": (C.c_int64, [_vp]),
     "emmax_model_finalize": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
+    "emmax_model_aux_bytes": (C.c_int64, [_vp]),
+    "emmax_model_build_aux": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "emmax_session_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _c_i64p, _c_i64p]),
     "emmax_session_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp, C.c_int64, C.POINTER(_vp)]),
     "emmax_session_destroy": (None, [_vp]),

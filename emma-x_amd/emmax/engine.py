@@ -68,8 +68,14 @@ class EmmaxEngine:
         nbytes = self.lib.emmax_model_arena_bytes(self._model)
         self.arena = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         stream = _lib.current_stream()
+        import time
+
+        t0 = time.perf_counter()
         _lib.check(self.lib.emmax_model_finalize(self._model, self.arena.data_ptr(), nbytes, stream), "emmax_model_finalize")
+        self.finalize_s = time.perf_counter() - t0     # re-layout of the bound tensors into the arena (synchronous)
+        self.aux_build_s = 0.0
         del keep
+        self.aux_arena: Optional[torch.Tensor] = None    # the batch >= 3 weight copies, built when a batch >= 3 first decodes
         self.max_batch = self.max_prompt = self.max_ctx = 0
         self.new_session(max_batch, max_prompt, max_ctx)
 
@@ -90,6 +96,22 @@ class EmmaxEngine:
                                                  ws.value, self.kv.data_ptr(), kv.value, C.byref(self._session)),
                    "emmax_session_create")
         self.max_batch, self.max_prompt, self.max_ctx = max_batch, max_prompt, max_ctx
+
+    def ensure_decode_batch(self, batch: int) -> None:
+        """Decode batches >= 3 read MFMA-fragment-major weight copies that live in a second arena (include/emmax.h:
+        emmax_model_build_aux); a model that only ever serves batches 1-2 never pays for them (13 GB at 7B)."""
+        if batch < 3 or self.aux_arena is not None:
+            return
+        n = int(self.lib.emmax_model_aux_bytes(self._model))
+        import time
+
+        t0 = time.perf_counter()
+        self.aux_arena = torch.empty(max(n, 256), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.emmax_model_build_aux(self._model, self.aux_arena.data_ptr(), n, _lib.current_stream()), "emmax_model_build_aux")
+        self.aux_build_s = time.perf_counter() - t0
+
+    def weight_bytes(self) -> int:
+        return int(self.arena.numel()) + (int(self.aux_arena.numel()) if self.aux_arena is not None else 0)
 
     def ensure_capacity(self, batch: int, prompt: int, max_new: int) -> None:
         need_ctx = self.cfg.n_patches + prompt + max_new + 1
@@ -162,6 +184,7 @@ class EmmaxEngine:
     def prefill(self, input_ids: Sequence[Sequence[int]], patch_embeds: torch.Tensor) -> List[int]:
         """Ragged prompts (row b = list of ids starting with BOS). Returns per-row packed lengths S_b = 256 + P_b."""
         B = len(input_ids)
+        self.ensure_decode_batch(B)
         lens = [len(r) for r in input_ids]
         P_max = max(lens)
         ids = torch.full((B, P_max), self.cfg.pad_token_id, dtype=torch.int32)
@@ -221,6 +244,7 @@ class EmmaxEngine:
                    "emmax_session_set_stop")
 
     def slots_open(self, n_slots: int) -> None:
+        self.ensure_decode_batch(int(n_slots))
         _lib.check(self.lib.emmax_slots_open(self._session, int(n_slots), _lib.current_stream()), "emmax_slots_open")
         self._n_slots = int(n_slots)
         self._slot_state = torch.empty(2, n_slots, dtype=torch.int32, device=self.device)

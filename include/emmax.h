@@ -90,15 +90,21 @@ int emmax_tuning_get(const char* name, int* value_out);
 /* ---- model: weights ------------------------------------------------------------------------------------------------
  * bind every tensor of the HF state dict (key names: vla-scripts/extern/convert_openvla_weights_to_hf.py:74-116) as a
  * bf16 device pointer, then finalize(): all weights are re-laid-out into `arena` (kernel-native: fused QKV rows,
- * 16-row interleaved gate/up, K/N padded to tile multiples, im2col-ordered patch-embed; plus an MFMA-fragment-major
- * copy of the LLM projections for the batch >= 3 decode path).  After finalize the bound
- * pointers are no longer referenced and may be freed. */
+ * 16-row interleaved gate/up, K/N padded to tile multiples, im2col-ordered patch-embed; fp8 models: plus the e4m3 copies).
+ * After finalize the bound pointers are no longer referenced and may be freed. */
 int emmax_model_create(const emmax_config* cfg, emmax_model** out);
 void emmax_model_destroy(emmax_model* m);
 int emmax_model_bind_weight(emmax_model* m, const char* hf_key, const void* ptr_dev, int dtype,
                             const int64_t* shape, int ndim);
 int64_t emmax_model_arena_bytes(const emmax_model* m);
 int emmax_model_finalize(emmax_model* m, void* arena_dev, int64_t arena_bytes, emmax_stream stream);
+/* bf16 models: decode batches >= 3 stream the LLM projections from MFMA-fragment-major copies that a model serving batches 1-2
+ * never reads.  They live in a SECOND caller-owned arena, built on demand from the finalized main arena (no bound tensors
+ * needed): 13.2 GB at 7B (main arena 15.1 GB; with the tuning switch km = 0 at build time decode_mfma.hip's qkv / gate-up pair is
+ * added, +9 GB).  Until it is built, emmax_prefill / emmax_slots_open with B >= 3 return EMMAX_ERR_STATE.  fp8 models keep every
+ * e4m3 copy in the main arena: aux_bytes is 0 and build_aux a no-op. */
+int64_t emmax_model_aux_bytes(const emmax_model* m);
+int emmax_model_build_aux(emmax_model* m, void* aux_arena_dev, int64_t aux_bytes, emmax_stream stream);
 
 /* ---- session: activations workspace + paged KV cache for up to max_batch sequences of <= max_ctx tokens ------------ */
 int emmax_session_bytes(const emmax_model* m, int max_batch, int max_prompt, int max_ctx,

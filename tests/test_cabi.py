@@ -115,10 +115,20 @@ def test_config_validation_and_sizing(lib):
     rc, h = _model(L, so, EmmaXConfig.emma_x_7b())
     assert rc == 0
     arena = so.emmax_model_arena_bytes(h)
-    # all weights the path reads, bf16 (7.53 B params minus the unused last block of each tower, plus tile padding)
-    # + the MFMA-fragment-major copy of the LLM projections used by the batch >= 3 decode path (6.74 B params)
-    # + the row-permuted fragment-major copy of qkv and gate/up for the K-split MFMA kernel (decode_km.hip: 4.5 B params)
-    assert 36.8e9 < arena < 37.8e9
+    # main arena: all weights the path reads, bf16, once (7.53 B params minus the unused last block of each tower, plus tile
+    # padding) -- what a model serving decode batches 1-2 holds (it was 37 GB whatever the batch regime)
+    assert 15.0e9 < arena < 15.6e9
+    # aux arena, built on demand for decode batches >= 3: qkv + gate/up in decode_km.hip's row order, o-proj / down / lm-head
+    # fragment-major = one more copy of the LLM projections (6.61 B params) -> B = 8 bf16 model = 28.5 GB
+    aux = so.emmax_model_aux_bytes(h)
+    assert 13.0e9 < aux < 13.6e9 and arena + aux < 30e9
+    # fp8 decode weights: every e4m3 copy lives in the main arena, nothing to build later
+    import copy
+    c8 = copy.deepcopy(EmmaXConfig.emma_x_7b())
+    c8.decode_weight_dtype = "fp8"
+    rc8, h8 = _model(L, so, c8)
+    assert rc8 == 0 and so.emmax_model_aux_bytes(h8) == 0 and 15.0e9 < so.emmax_model_arena_bytes(h8) < 37e9
+    so.emmax_model_destroy(h8)
     ws, kv = C.c_int64(), C.c_int64()
     assert so.emmax_session_bytes(h, 8, 512, 1281, C.byref(ws), C.byref(kv)) == 0
     # paged KV: 32 layers x 2 x 8 rows x 21 pages x 32 heads x 64 x 128 bf16
