@@ -85,7 +85,7 @@ __device__ __forceinline__ void glds16_group4(unsigned int lds_base, unsigned in
 // bf16 epilogue through LDS: a wave parks 64 rows of its result (64 columns; SwiGLU: 32) in its private 8 KiB window
 // (16-byte chunks XOR-swizzled with the row, so both the 8-byte writes in accumulator layout and the 16-byte reads in row
 // layout are conflict-free) and stores them back as whole rows.
-template <class G, int ACT>
+template <class G, int ACT, bool LN = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const f32x4_t (&acc)[G::MT][G::NT], int m0, int n0, int wm, int wn,
                                                      int g, int li, int lane, unsigned char* wl) {
     constexpr int WC = (ACT == 2) ? 32 : 64;   // output columns of this wave
@@ -97,14 +97,19 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
     const int n_ok = (ACT == 2) ? p.N / 2 : min(p.N, p.N_store);
     const int ocol0 = (ACT == 2) ? ((n0 + wn * 64) >> 1) : (n0 + wn * 64);
     const bool vec_r = (p.ldr & 3) == 0;
-    float bv[NG][4], sv[NG][4];
+    float bv[NG][4], sv[NG][4], cs[LN ? NG : 1][4];   // LN: bv = ln_c (fp32), cs = ln_s
 #pragma unroll
     for (int jo = 0; jo < NG; ++jo)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int col = ocol0 + jo * 16 + g * 4 + r;
-            bv[jo][r] = (ACT != 2 && bias && col < n_ok) ? bf2f(bias[col]) : 0.f;
-            sv[jo][r] = (ACT != 2 && scale && col < n_ok) ? bf2f(scale[col]) : 1.f;
+            if constexpr (LN) {
+                bv[jo][r] = col < n_ok ? p.ln_c[col] : 0.f;
+                cs[jo][r] = col < n_ok ? p.ln_s[col] : 0.f;
+            } else {
+                bv[jo][r] = (ACT != 2 && bias && col < n_ok) ? bf2f(bias[col]) : 0.f;
+            }
+            sv[jo][r] = (!LN && ACT != 2 && scale && col < n_ok) ? bf2f(scale[col]) : 1.f;   // (LN form: no LayerScale, checked by the launcher)
         }
 #pragma unroll
     for (int h = 0; h < G::MT / 4; ++h) {
@@ -112,6 +117,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
         for (int ii = 0; ii < 4; ++ii) {
             const int i = 4 * h + ii, rl = ii * 16 + li;          // row inside the 64-row window
             const int row = m0 + wm * (G::MT * 16) + i * 16 + li;
+            f32x2_t st = {0.f, 1.f};                               // LN: (mean, rstd) of this output row
+            if constexpr (LN) st = *(const f32x2_t*)(p.ln_stats + (size_t)min(row, p.M - 1) * 2);
 #pragma unroll
             for (int jo = 0; jo < NG; ++jo) {
                 float v[4];
@@ -120,9 +127,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
                     if (ACT == 2) {
                         v[r] = silu(acc[i][2 * jo][r]) * acc[i][2 * jo + 1][r];
                     } else {
-                        v[r] = acc[i][jo][r] + bv[jo][r];
+                        if constexpr (LN) v[r] = (acc[i][jo][r] - st[0] * cs[jo][r]) * st[1] + bv[jo][r];
+                        else v[r] = acc[i][jo][r] + bv[jo][r];
                         if (ACT == 1) v[r] = gelu_erf(v[r]);
-                        v[r] *= sv[jo][r];
+                        if constexpr (!LN) v[r] *= sv[jo][r];
                     }
                 }
                 if (ACT != 2 && res && row < p.M) {
@@ -203,10 +211,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4_t
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = n0 + wn * 64 + j * 16 + g * 4;
-        float bv[4], sv[4];
+        float bv[4], sv[4], cs[4];
+        const bool ln = p.ln_stats != nullptr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            bv[r] = (bias && col + r < n_ok) ? bf2f(bias[col + r]) : 0.f;
+            bv[r] = (col + r < n_ok) ? (ln ? p.ln_c[col + r] : bias ? bf2f(bias[col + r]) : 0.f) : 0.f;
+            cs[r] = (ln && col + r < n_ok) ? p.ln_s[col + r] : 0.f;
             sv[r] = (scale && col + r < n_ok) ? bf2f(scale[col + r]) : 1.f;
         }
         const bool full = col + 3 < n_ok;
@@ -214,10 +224,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4_t
         for (int i = 0; i < G::MT; ++i) {
             const int row = m0 + wm * (G::MT * 16) + i * 16 + li;
             if (row >= p.M || col >= n_ok) continue;
+            f32x2_t st = {0.f, 1.f};
+            if (ln) st = *(const f32x2_t*)(p.ln_stats + (size_t)row * 2);
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v[r] = acc[i][j][r] + bv[r];
+                v[r] = (acc[i][j][r] - st[0] * cs[r]) * st[1] + bv[r];
                 if (ACT == 1) v[r] = gelu_erf(v[r]);
                 v[r] *= sv[r];
             }
@@ -255,7 +267,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4_t
     }
 }
 
-template <class G, int ACT, bool OUT_F32>
+template <class G, int ACT, bool OUT_F32, bool LN = false>
 __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams p) {
     constexpr int BM = G::BM, BN = G::BN, MT = G::MT, NT = G::NT, STAGE_BYTES = G::STAGE, OP_BYTES = G::OPA;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -387,7 +399,7 @@ __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams 
         if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[ntrace++] = wall_clock64();
         if (!(p.dbg & 2)) {
             // stage 1 is free between the last K step of this tile and the second DMA of the next one
-            if (!OUT_F32 && staged_ok) gemm_epilogue_staged<G, ACT>(p, acc, cm0, cn0, wm, wn, g, li, lane, smem + STAGE_BYTES + wave * G::WIN);
+            if (!OUT_F32 && staged_ok) gemm_epilogue_staged<G, ACT, LN>(p, acc, cm0, cn0, wm, wn, g, li, lane, smem + STAGE_BYTES + wave * G::WIN);
             else gemm_epilogue<G, ACT, OUT_F32>(p, acc, cm0, cn0, wm, wn, g, li, c_off);
         }
         if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[ntrace++] = wall_clock64();
@@ -429,9 +441,9 @@ __global__ __launch_bounds__(256) void emmax_splitk_reduce_kernel(GemmParams p) 
     }
 }
 
-template <class G, int ACT, bool OUT_F32>
+template <class G, int ACT, bool OUT_F32, bool LN = false>
 int launch_t(const GemmParams& p, hipStream_t stream) {
-    auto kern = emmax_gemm_bf16_kernel<G, ACT, OUT_F32>;
+    auto kern = emmax_gemm_bf16_kernel<G, ACT, OUT_F32, LN>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM) != hipSuccess) return -4;
@@ -451,6 +463,8 @@ int launch_geom(const GemmParams& p, hipStream_t stream) {
         if (p.out_f32) return -1;
         return launch_t<G, 2, false>(p, stream);
     }
+    if (p.ln_stats && !p.out_f32)   // LayerNorm folded in: the staged epilogue's LN form (an unaligned C falls to the direct epilogue, which reads p.ln_*)
+        return p.act == 1 ? launch_t<G, 1, false, true>(p, stream) : launch_t<G, 0, false, true>(p, stream);
     if (p.act == 1) return p.out_f32 ? launch_t<G, 1, true>(p, stream) : launch_t<G, 1, false>(p, stream);
     return p.out_f32 ? launch_t<G, 0, true>(p, stream) : launch_t<G, 0, false>(p, stream);
 }
@@ -464,6 +478,7 @@ int launch_gemm_geom(const GemmParams& p, int big, hipStream_t stream) {
     if (p.M <= 0) return 0;
     if (p.K % BK != 0 || p.N % 128 != 0 || p.K <= 0 || p.N <= 0) return -1;
     if ((p.lda % 8) || (p.ldw % 8)) return -1;
+    if (p.ln_stats && (!p.ln_s || !p.ln_c || p.bias || p.scale || p.act == 2 || p.ksplit > 1)) return -1;
     return big ? launch_geom<GeomBig>(p, stream) : launch_geom<GeomSmall>(p, stream);
 }
 
@@ -491,6 +506,7 @@ static int launch_rows(const GemmParams& p, size_t r0, int rows, int big, hipStr
     q.A = (const bf16_t*)p.A + r0 * p.lda;
     q.C = p.out_f32 ? (void*)((float*)p.C + r0 * p.ldc) : (void*)((bf16_t*)p.C + r0 * p.ldc);
     if (p.residual) q.residual = (const bf16_t*)p.residual + r0 * p.ldr;
+    if (p.ln_stats) q.ln_stats = p.ln_stats + r0 * 2;
     return launch_gemm_geom(q, big, stream);
 }
 
@@ -524,7 +540,7 @@ static int launch_planned_rows(const GemmParams& p, long m1, hipStream_t stream)
 // grinding through K alone (M = 768 prefill o / down: 192 tiles, 64-172 K steps at ~0.75 us; batch-1 ViT fc2: 24 tiles).
 // ks slices per tile fill the chip (<= 512 resident blocks), each >= 8 K steps; the partial tiles meet in a second pass.
 int launch_gemm_splitk(const GemmParams& p, int ks, hipStream_t stream) {
-    if (ks < 2 || p.act == 2 || !p.ws || p.K % BK || p.N % 128) return -1;
+    if (ks < 2 || p.act == 2 || !p.ws || p.K % BK || p.N % 128 || p.ln_stats) return -1;
     if ((long long)ks * p.M * p.N * 4 > p.ws_bytes) return -1;
     if (p.K / BK < ks) return -1;
     GemmParams a = p;
@@ -544,7 +560,7 @@ int launch_gemm_splitk(const GemmParams& p, int ks, hipStream_t stream) {
 
 // slices for launch_gemm_splitk, or 0 when splitting does not pay
 static int splitk_plan(const GemmParams& p) {
-    if (!p.ws || p.act == 2) return 0;
+    if (!p.ws || p.act == 2 || p.ln_stats) return 0;
     const int nk = p.K / BK;
     const long ts = (long)cdiv(p.M, GeomSmall::BM) * cdiv(p.N, GeomSmall::BN);
     if (nk < 32 || ts > 224) return 0;              // K >= 2048, at most ~1 block per CU without the split
@@ -581,6 +597,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
             if (p.bias) b.bias = (const bf16_t*)p.bias + n1;
             if (p.scale) b.scale = (const bf16_t*)p.scale + n1;
             if (p.residual) b.residual = (const bf16_t*)p.residual + n1;
+            if (p.ln_stats) { b.ln_s = p.ln_s + n1; b.ln_c = p.ln_c + n1; }
             const int r = launch_planned_rows(a, m1a, stream);
             if (r) return r;
             return b.N_store > 0 ? launch_gemm_geom(b, 0, stream) : 0;

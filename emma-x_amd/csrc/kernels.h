@@ -25,6 +25,14 @@ struct GemmParams {
     float* ws;
     long long ws_bytes;
     int ksplit;
+    // LayerNorm folded into this GEMM (the ViT qkv / fc1 projections): A holds the RAW rows x, W holds
+    // W' = bf16(W .* gamma) (launch_ln_fold at finalize), and the epilogue finishes the algebra per output element
+    //     y[m, n] = rstd[m] * (acc[m, n] - mean[m] * ln_s[n]) + ln_c[n],   ln_s[n] = sum_k W'[n, k],  ln_c[n] = sum_k W[n, k] beta[k] + bias[n]
+    // = LN(x) W^T + bias without ever writing LN(x).  ln_stats: f32 [M][2] = (mean, rstd) per row (launch_row_stats);
+    // ln_s / ln_c: f32 [N].  All three null: plain GEMM.  bias must be null when they are set (it lives in ln_c).
+    const float* ln_stats;
+    const float* ln_s;
+    const float* ln_c;
     int dbg;               // tools only: 1 = skip the operand DMA after K step 1 (LDS + MFMA time alone), 2 = skip the stores
     long long* trace;      // tools only (tools/gemm_trace.hip): block 0 writes wall_clock64() stamps per tile phase; null in the product
 };
@@ -37,6 +45,12 @@ int launch_gemm_splitk(const GemmParams& p, int ksplit, hipStream_t stream);  //
 int launch_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, int ldx, int ldy, float eps,
                      hipStream_t stream);
 int launch_rmsnorm(const void* x, void* y, const void* w, int rows, int D, int ldx, int ldy, float eps, hipStream_t stream);
+// LayerNorm statistics alone: stats f32 [rows][2] = (mean, rstd) of every bf16 row (two-pass variance from registers, as launch_layernorm)
+int launch_row_stats(const void* x, float* stats, int rows, int D, int ldx, float eps, hipStream_t stream);
+// fold a LayerNorm into the [N, ldw] bf16 weight of the projection that consumes it (in place): W[n, k] <- bf16(W[n, k] * gamma[k]),
+// ln_s[n] = sum_k W'[n, k] (of the rounded values), ln_c[n] = sum_k W[n, k] * beta[k] + bias[n] (fp32; bias may be null)
+int launch_ln_fold(void* W, int ldw, int N, int K, const void* gamma, const void* beta, const void* bias, float* ln_s, float* ln_c,
+                   hipStream_t stream);
 
 // ---- attention.hip ----
 struct AttnParams {

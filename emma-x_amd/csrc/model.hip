@@ -95,6 +95,7 @@ struct Bound {
 
 struct BlockW {
     bf16 *n1w, *n1b, *qkv_w, *qkv_b, *proj_w, *proj_b, *ls1, *n2w, *n2b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ls2;
+    float *ln1_s, *ln1_c, *ln2_s, *ln2_c;   // LayerNorm folded into qkv / fc1 (kernels.h: GemmParams::ln_*): column sums of W' and the constant term
 };
 struct TowerW {
     int D, Dp, D3p, M, Mp, N, n_prefix, n_patches, hd, Kpe, n_blocks;
@@ -121,6 +122,7 @@ struct emmax_model {
     bf16 *embed, *final_norm, *lm_head, *lm_head_fm, *lm_head_r8 = nullptr;
     float* lm_head_sc = nullptr;
     bool fp8 = false;
+    bool ln_folded = false;      // the ViT LayerNorms are folded into the qkv / fc1 weights (tuning switch gemm_lnfuse at finalize)
     bool aux_built = false;      // the batch >= 3 copies exist (fp8 models: always, they are part of the main arena)
     bool aux_ab = false;         // ... including decode_mfma.hip's qkv / gate-up pair
     std::vector<LayerW> layers;
@@ -214,6 +216,8 @@ static void plan_arena(emmax_model* m, Bump& b) {
             k.fc1_w = b.take((int64_t)T.Mp * T.Dp); k.fc1_b = b.take(T.Mp);
             k.fc2_w = b.take((int64_t)T.Dp * T.Mp); k.fc2_b = b.take(T.Dp);
             k.ls2 = b.take(T.Dp);
+            k.ln1_s = (float*)b.take(2 * (int64_t)T.D3p); k.ln1_c = (float*)b.take(2 * (int64_t)T.D3p);
+            k.ln2_s = (float*)b.take(2 * (int64_t)T.Mp); k.ln2_c = (float*)b.take(2 * (int64_t)T.Mp);
         }
     }
     m->pj1_w = b.take((int64_t)m->P1p * m->Vp); m->pj1_b = b.take(m->P1p);
@@ -299,6 +303,7 @@ struct emmax_session {
     int max_batch, max_prompt, max_ctx, max_pages, max_rows /* packed prefill rows */, max_out;
     // vision scratch
     bf16 *vA, *vpe, *vtok, *vln, *vqkv, *vatt, *vmlp, *feats, *pj1, *pj2, *patch_embeds;
+    float* vstats;              // LayerNorm (mean, rstd) of every token row, f32 [rows][2]
     int32_t* cu_vit[2];
     // prefill scratch
     bf16 *ph, *pxn, *pqkv, *patt, *pact;
@@ -363,6 +368,7 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->vpe = (bf16*)b.take((int64_t)Bv * np * maxDp * 2);
     s->vtok = (bf16*)b.take(vr * maxDp * 2);
     s->vln = (bf16*)b.take(vr * maxDp * 2);
+    s->vstats = (float*)b.take(vr * 2 * 4);
     s->vqkv = (bf16*)b.take(vr * maxD3p * 2);
     s->vatt = (bf16*)b.take(vr * maxDp * 2);
     s->vmlp = (bf16*)b.take(vr * maxMp * 2);
@@ -445,9 +451,17 @@ static int run_vision(emmax_session* s, bool from_u8, const void* src, int B, vo
         const int rows = B * T.N;
         for (int i = 0; i < T.n_blocks; ++i) {
             const BlockW& k = T.blk[i];
-            KCHK(launch_layernorm(s->vtok, s->vln, k.n1w, k.n1b, rows, T.D, T.Dp, T.Dp, tc.ln_eps, st));
-            g = gps(s, s->vln, T.Dp, k.qkv_w, T.Dp, s->vqkv, T.D3p, rows, T.D3p, T.Dp);
-            g.bias = k.qkv_b;
+            // LayerNorm folded into the projection: only the row statistics are computed here, the GEMM reads the raw rows and
+            // its epilogue finishes the algebra (kernels.h) -- no normalised copy of the tokens is ever written or re-read
+            if (m->ln_folded) {
+                KCHK(launch_row_stats(s->vtok, s->vstats, rows, T.D, T.Dp, tc.ln_eps, st));
+                g = gps(s, s->vtok, T.Dp, k.qkv_w, T.Dp, s->vqkv, T.D3p, rows, T.D3p, T.Dp);
+                g.ln_stats = s->vstats; g.ln_s = k.ln1_s; g.ln_c = k.ln1_c;
+            } else {
+                KCHK(launch_layernorm(s->vtok, s->vln, k.n1w, k.n1b, rows, T.D, T.Dp, T.Dp, tc.ln_eps, st));
+                g = gps(s, s->vln, T.Dp, k.qkv_w, T.Dp, s->vqkv, T.D3p, rows, T.D3p, T.Dp);
+                g.bias = k.qkv_b;
+            }
             KCHK(launch_gemm(g, st));
             AttnParams a;
             a.qkv = s->vqkv; a.out = s->vatt; a.cu_seqlens = s->cu_vit[t];
@@ -458,9 +472,16 @@ static int run_vision(emmax_session* s, bool from_u8, const void* src, int B, vo
             g = gps(s, s->vatt, T.Dp, k.proj_w, T.Dp, s->vtok, T.Dp, rows, T.Dp, T.Dp);
             g.bias = k.proj_b; g.scale = tc.layerscale ? k.ls1 : nullptr; g.residual = s->vtok; g.ldr = T.Dp;
             KCHK(launch_gemm(g, st));
-            KCHK(launch_layernorm(s->vtok, s->vln, k.n2w, k.n2b, rows, T.D, T.Dp, T.Dp, tc.ln_eps, st));
-            g = gps(s, s->vln, T.Dp, k.fc1_w, T.Dp, s->vmlp, T.Mp, rows, T.Mp, T.Dp);
-            g.bias = k.fc1_b; g.act = 1;
+            if (m->ln_folded) {
+                KCHK(launch_row_stats(s->vtok, s->vstats, rows, T.D, T.Dp, tc.ln_eps, st));
+                g = gps(s, s->vtok, T.Dp, k.fc1_w, T.Dp, s->vmlp, T.Mp, rows, T.Mp, T.Dp);
+                g.ln_stats = s->vstats; g.ln_s = k.ln2_s; g.ln_c = k.ln2_c;
+            } else {
+                KCHK(launch_layernorm(s->vtok, s->vln, k.n2w, k.n2b, rows, T.D, T.Dp, T.Dp, tc.ln_eps, st));
+                g = gps(s, s->vln, T.Dp, k.fc1_w, T.Dp, s->vmlp, T.Mp, rows, T.Mp, T.Dp);
+                g.bias = k.fc1_b;
+            }
+            g.act = 1;
             KCHK(launch_gemm(g, st));
             g = gps(s, s->vmlp, T.Mp, k.fc2_w, T.Mp, s->vtok, T.Dp, rows, T.Dp, T.Mp);
             g.bias = k.fc2_b; g.scale = tc.layerscale ? k.ls2 : nullptr; g.residual = s->vtok; g.ldr = T.Dp;
@@ -882,6 +903,7 @@ int emmax_model_finalize(emmax_model* m, void* arena, int64_t arena_bytes, emmax
     plan_arena(m, b);
     HIPCHK(hipMemsetAsync(arena, 0, need, st));   // all padding is zero
     const char* pre[2] = {"vision_backbone.featurizer.", "vision_backbone.fused_featurizer."};
+    const bool fold_ln = emmax_tune().gemm_lnfuse != 0;
     int r;
 #define PUT2(key, rows, cols, dst, ld, row0) if ((r = put2d(m, key, rows, cols, dst, ld, row0, st))) return r
 #define PUT1(key, n, dst) if ((r = put1d(m, key, n, dst, st))) return r
@@ -904,6 +926,10 @@ int emmax_model_finalize(emmax_model* m, void* arena, int64_t arena_bytes, emmax
             PUT2(Bp + "mlp.fc1.weight", T.M, T.D, k.fc1_w, T.Dp, 0); PUT1(Bp + "mlp.fc1.bias", T.M, k.fc1_b);
             PUT2(Bp + "mlp.fc2.weight", T.D, T.M, k.fc2_w, T.Mp, 0); PUT1(Bp + "mlp.fc2.bias", T.D, k.fc2_b);
             if (tc.layerscale) { PUT1(Bp + "ls1.scale_factor", T.D, k.ls1); PUT1(Bp + "ls2.scale_factor", T.D, k.ls2); }
+            if (fold_ln) {   // W <- bf16(W .* gamma) in place; the norm weights stay in the arena for the un-fused A/B path of OTHER models only
+                KCHK(launch_ln_fold(k.qkv_w, T.Dp, 3 * T.D, T.D, k.n1w, k.n1b, k.qkv_b, k.ln1_s, k.ln1_c, st));
+                KCHK(launch_ln_fold(k.fc1_w, T.Dp, T.M, T.D, k.n2w, k.n2b, k.fc1_b, k.ln2_s, k.ln2_c, st));
+            }
         }
     }
     PUT2("projector.fc1.weight", m->P1, m->V, m->pj1_w, m->Vp, 0); PUT1("projector.fc1.bias", m->P1, m->pj1_b);
@@ -954,6 +980,7 @@ int emmax_model_finalize(emmax_model* m, void* arena, int64_t arena_bytes, emmax
 #undef PUT1
     HIPCHK(hipStreamSynchronize(st));
     m->finalized = true;
+    m->ln_folded = fold_ln;
     m->aux_built = m->fp8;
     m->bound.clear();
     return 0;
@@ -1420,6 +1447,18 @@ int emmax_op_gemm_splitk(const void* A, int lda, const void* W, int ldw, void* C
     int r = launch_gemm_splitk(p, ksplit, (hipStream_t)st);
     if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID,
                        "emmax_op_gemm_splitk: unsupported (2 <= ksplit <= K/64, act in {0,1}, ws >= ksplit*M*N*4 bytes, K%%64, N%%128)");
+    return 0;
+}
+int emmax_op_gemm_ln(const void* X, int ldx, void* W, int ldw, void* C, int ldc, int M, int N, int K, const void* gamma, const void* beta,
+                     const void* bias, float eps, int act, float* stats_ws, float* ln_s_ws, float* ln_c_ws, emmax_stream stream) {
+    if (!X || !W || !C || !gamma || !stats_ws || !ln_s_ws || !ln_c_ws) return fail(EMMAX_ERR_INVALID, "emmax_op_gemm_ln: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    KCHK(launch_ln_fold(W, ldw, N, K, gamma, beta, bias, ln_s_ws, ln_c_ws, st));
+    KCHK(launch_row_stats(X, stats_ws, M, K, ldx, eps, st));
+    GemmParams p = gp(X, ldx, W, ldw, C, ldc, M, N, K);
+    p.act = act; p.ln_stats = stats_ws; p.ln_s = ln_s_ws; p.ln_c = ln_c_ws;
+    int r = launch_gemm(p, st);
+    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_gemm_ln: unsupported shape (K%%64, N%%128, ld%%8, act in {0,1})");
     return 0;
 }
 int emmax_op_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, float eps, emmax_stream st) {

@@ -82,7 +82,92 @@ __global__ __launch_bounds__(256) void emmax_rownorm_kernel(const bf16_t* __rest
     }
 }
 
+// LayerNorm statistics of every row, nothing else: one wave per row, the row read once
+template <int MAXV>
+__global__ __launch_bounds__(256) void emmax_row_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats, int rows, int D, int ldx, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = D >> 3;
+    const bf16_t* xr = x + (size_t)row * ldx;
+    u32x4_t v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = (u32x4_t){0u, 0u, 0u, 0u};
+        if (c < nchunk) {
+            v[i] = *(const u32x4_t*)(xr + c * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += bf_lo(v[i][j]) + bf_hi(v[i][j]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float vs = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = bf_lo(v[i][j]) - mean, bb = bf_hi(v[i][j]) - mean;
+                vs += a * a + bb * bb;
+            }
+        }
+    }
+    vs = wave_sum(vs);
+    if (lane == 0) *(f32x2_t*)(stats + (size_t)row * 2) = (f32x2_t){mean, rsqrtf(vs / (float)D + eps)};
+}
+
+// one block per weight row n: W'[n, :] = bf16(W[n, :] .* gamma), ln_s[n] = sum W'[n, :], ln_c[n] = sum W[n, :] .* beta + bias[n]
+__global__ __launch_bounds__(256) void emmax_ln_fold_kernel(bf16_t* __restrict__ W, int ldw, int K, const bf16_t* __restrict__ gamma,
+                                                           const bf16_t* __restrict__ beta, const bf16_t* __restrict__ bias,
+                                                           float* __restrict__ ln_s, float* __restrict__ ln_c) {
+    const int n = blockIdx.x;
+    bf16_t* w = W + (size_t)n * ldw;
+    float s = 0.f, c = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float wv = bf2f(w[k]);
+        const bf16_t wf = f2bf(wv * bf2f(gamma[k]));
+        c += wv * (beta ? bf2f(beta[k]) : 0.f);
+        s += bf2f(wf);
+        w[k] = wf;
+    }
+    __shared__ float rs[4], rc[4];
+    s = wave_sum(s);
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rc[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ln_s[n] = rs[0] + rs[1] + rs[2] + rs[3];
+        ln_c[n] = rc[0] + rc[1] + rc[2] + rc[3] + (bias ? bf2f(bias[n]) : 0.f);
+    }
+}
+
 }  // namespace
+
+int launch_row_stats(const void* x, float* stats, int rows, int D, int ldx, float eps, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    if (D % 8 != 0 || D > 8 * 64 * 16 || ldx % 8) return -1;
+    dim3 grid(cdiv(rows, 4)), block(256);
+    const int nv = cdiv(D / 8, 64);
+#define LAUNCH(MAXV) hipLaunchKernelGGL((emmax_row_stats_kernel<MAXV>), grid, block, 0, stream, (const bf16_t*)x, stats, rows, D, ldx, eps)
+    if (nv <= 1) LAUNCH(1);
+    else if (nv <= 2) LAUNCH(2);
+    else if (nv <= 4) LAUNCH(4);
+    else if (nv <= 8) LAUNCH(8);
+    else LAUNCH(16);
+#undef LAUNCH
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_ln_fold(void* W, int ldw, int N, int K, const void* gamma, const void* beta, const void* bias, float* ln_s, float* ln_c,
+                   hipStream_t stream) {
+    if (N <= 0 || K <= 0 || !gamma || !ln_s || !ln_c) return -1;
+    hipLaunchKernelGGL(emmax_ln_fold_kernel, dim3(N), dim3(256), 0, stream, (bf16_t*)W, ldw, K, (const bf16_t*)gamma, (const bf16_t*)beta,
+                       (const bf16_t*)bias, ln_s, ln_c);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
 
 static int launch_rownorm(bool rms, const void* x, void* y, const void* w, const void* b, int rows, int D, int ldx, int ldy,
                           float eps, hipStream_t stream) {

@@ -87,6 +87,7 @@ SIGNATURES = {
                                 C.c_int, C.c_int, _vp]),
     "emmax_op_gemm_splitk": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp,
                                        C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp]),
+    "emmax_op_gemm_ln": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_float, C.c_int, _vp, _vp, _vp, _vp]),
     "emmax_op_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp]),
     "emmax_op_rmsnorm": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp]),
     "emmax_op_attention": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,

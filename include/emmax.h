@@ -202,6 +202,13 @@ int emmax_op_gemm(const void* A_dev, int lda, const void* W_dev, int ldw, void* 
 int emmax_op_gemm_splitk(const void* A_dev, int lda, const void* W_dev, int ldw, void* C_dev, int ldc, int M, int N, int K,
                          const void* bias_dev, int act, const void* scale_dev, const void* residual_dev, int ldr, int out_f32,
                          int ksplit, void* ws_dev, int64_t ws_bytes, emmax_stream stream);
+/* LayerNorm folded into the projection that consumes it, as the ViT qkv / fc1 stages run (timm Block: norm1 -> attn.qkv, norm2 ->
+ * mlp.fc1): C[M,N] = act(LN(X; gamma, beta, eps) @ W^T + bias) without materialising LN(X).  W_dev bf16 [N, ldw] is REWRITTEN in
+ * place to bf16(W .* gamma) (what emmax_model_finalize does once per model); stats_ws f32 [M][2], ln_s_ws / ln_c_ws f32 [N] are
+ * caller scratch.  act in {0, 1}; K % 64 == 0, N % 128 == 0, K = the LayerNorm width. */
+int emmax_op_gemm_ln(const void* X_dev, int ldx, void* W_dev, int ldw, void* C_dev, int ldc, int M, int N, int K, const void* gamma_dev,
+                     const void* beta_dev, const void* bias_dev, float eps, int act, float* stats_ws_dev, float* ln_s_ws_dev,
+                     float* ln_c_ws_dev, emmax_stream stream);
 int emmax_op_layernorm(const void* x_dev, void* y_dev, const void* w_dev, const void* b_dev, int rows, int D, float eps,
                        emmax_stream stream);
 int emmax_op_rmsnorm(const void* x_dev, void* y_dev, const void* w_dev, int rows, int D, float eps, emmax_stream stream);

