@@ -51,7 +51,8 @@ struct Geom {
     static constexpr int BM = WMW * MT * 16, BN = WNW * NT * 16;
     static constexpr int OPA = BM * BK * 2, OPB = BN * BK * 2;   // operand tile bytes
     static constexpr int STAGE = OPA + OPB;
-    static constexpr int SMEM = 2 * STAGE;
+    static constexpr int SMEM = 2 * STAGE;                        // two stages of A and W
+    static constexpr int SMEM_A3 = 2 * STAGE + OPA;              // three A stages + two W stages (big: all 160 KiB of the CU)
     static constexpr int SA = BM / 8 / NW, SB = BN / 8 / NW;      // 1 KiB DMA slabs (8 rows) per wave and operand
     static constexpr int WIN = 8192;                              // epilogue window per wave: 64 rows x 128 B
     static_assert(NT == 4 && MT % 4 == 0 && NT <= MT, "epilogue / fragment pipeline assume 64-column wave tiles");
@@ -88,6 +89,10 @@ __device__ __forceinline__ void glds16_group4(unsigned int lds_base, unsigned in
 template <class G, int ACT, bool LN = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const f32x4_t (&acc)[G::MT][G::NT], int m0, int n0, int wm, int wn,
                                                      int g, int li, int lane, unsigned char* wl) {
+    // the window addresses below depend on the lane only: left alone, hipcc computes them once per kernel, cannot keep them through the
+    // 256-register main loop and spills them to scratch (with a vmcnt(0) per reload inside this epilogue).  Opaque copies of the
+    // lane indices make them a handful of VALU instructions per tile instead.
+    asm volatile("" : "+v"(lane), "+v"(li), "+v"(g));
     constexpr int WC = (ACT == 2) ? 32 : 64;   // output columns of this wave
     constexpr int CH = WC / 8;                  // 16-byte chunks per staged row
     constexpr int NG = WC / 16;                 // 16-column output groups
@@ -159,13 +164,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
             const int row = m0 + wm * (G::MT * 16) + h * 64 + rr, col = ocol0 + cl * 8;
             if (row < p.M) {
                 bf16_t* dst = (bf16_t*)p.C + (size_t)row * p.ldc + col;
-                if (col + 7 < n_ok) {
-                    *(u32x4_t*)dst = val;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (col + e < n_ok) dst[e] = (bf16_t)((val[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-                }
+                if (col + 7 < n_ok) *(u32x4_t*)dst = val;   // (the launcher routes a column count that is not a multiple of 8 to the direct epilogue)
             }
         }
     }
@@ -267,10 +266,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4_t
     }
 }
 
-template <class G, int ACT, bool OUT_F32, bool LN = false>
+// DEEP = 1 / 2: THREE stages of the A / of the W operand, two of the other (LDS image [A0 | W0 | A1 | A2 | W1] / [A0 | W0 | A1 | W1 | W2]:
+// all 160 KiB of the CU for the 256 x 256 tile).  One operand of these GEMMs streams from HBM / MALL once per band of tiles -- the
+// activations of a ViT batch (137 MB against 2-9 MB of weights), the weights of a LLaMA prefill (100-180 MB against 6-50 MB of rows)
+// -- while the panels of the other are re-read by every tile of the band and sit in the XCD's L2.  The streaming operand's request
+// of K step t + 2 goes out during step t and is waited for by COUNT (vmcnt(4): its four slab requests stay in flight across the
+// step barrier, a bare s_barrier); the resident operand keeps one step of lead.  Measured (round 4, interleaved A/B on one box):
+// ViT shapes +3 .. 8 % with DEEP = 1 and -3 % with it on the LLaMA shapes, where the weights are the stream.
+template <class G, int ACT, bool OUT_F32, bool LN = false, int DEEP = 0>
 __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams p) {
     constexpr int BM = G::BM, BN = G::BN, MT = G::MT, NT = G::NT, STAGE_BYTES = G::STAGE, OP_BYTES = G::OPA;
+    static_assert(G::OPA == G::OPB, "the stage slots of A and W are interchangeable");
+    constexpr int NSA = DEEP == 1 ? 3 : 2, NSW = DEEP == 2 ? 3 : 2;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    // byte offsets of the stages: A slot 0 and W slot 0 form "stage 0", everything behind them (64 KiB at least) is free while a
+    // tile's epilogue runs (the next tile's K step 0 is already in flight into stage 0)
+    auto a_slot = [](int i) { return i == 0 ? 0 : STAGE_BYTES + (i - 1) * OP_BYTES; };
+    auto w_slot = [](int j) { return j == 0 ? OP_BYTES : STAGE_BYTES + (NSA - 1 + j - 1) * OP_BYTES; };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -325,54 +337,90 @@ __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams 
             offB_l[j] = (unsigned int)gn * (unsigned int)(p.ldw * 2) + ((lane & 7) ^ ((row >> 1) & 7)) * 16 + (DMA_BIAS - j * 1024);
         }
     };
-    auto issue = [&](int kt) {
-        const unsigned int st = lds0 + (kt & 1) * STAGE_BYTES;
-        const unsigned long long koff = (unsigned long long)(kbeg + kt) * (BK * 2);
-        static_assert(G::SA == 4 && G::SB == 4, "a wave's slabs of one operand share one M0 (immediates 0 .. 3072)");
-        const unsigned long long sa = baseA + koff, sb = baseB + koff;
-        glds16_group4(st + wave * G::SA * 1024, offA_l[0], offA_l[1], offA_l[2], offA_l[3], sa);
-        glds16_group4(st + OP_BYTES + wave * G::SB * 1024, offB_l[0], offB_l[1], offB_l[2], offB_l[3], sb);
+    static_assert(G::SA == 4 && G::SB == 4, "a wave's slabs of one operand share one M0 (immediates 0 .. 3072)");
+    auto issueA = [&](int kt, int slot) {   // K step kt of the current tile into A slot `slot`
+        glds16_group4(lds0 + a_slot(slot) + wave * G::SA * 1024, offA_l[0], offA_l[1], offA_l[2], offA_l[3],
+                      baseA + (unsigned long long)(kbeg + kt) * (BK * 2));
+    };
+    auto issueW = [&](int kt, int slot) {
+        glds16_group4(lds0 + w_slot(slot) + wave * G::SB * 1024, offB_l[0], offB_l[1], offB_l[2], offB_l[3],
+                      baseB + (unsigned long long)(kbeg + kt) * (BK * 2));
     };
 
     // ---- fragment read offsets: row base + swizzled chunk; (row >> 1) & 7 == (li >> 1) & 7 for every 16-row tile ----
     const int swz = (li >> 1) & 7;
     const int c0 = (g ^ swz) << 4;            // k half 0: logical chunk g;  half 1: logical chunk 4 + g == c0 ^ 64
-    const int offA = (wm * (MT * 16) + li) * 128, offB = OP_BYTES + (wn * (NT * 16) + li) * 128;
+    const int offA = (wm * (MT * 16) + li) * 128, offB = (wn * (NT * 16) + li) * 128;
     // position s = kk * MT + i of the K step: k half kk, row tile i
     auto ldA = [&](const unsigned char* st, int s_) { return *(const bf16x8_t*)(st + offA + (s_ % MT) * 2048 + ((s_ / MT) ? (c0 ^ 64) : c0)); };
     auto ldB = [&](const unsigned char* st, int kk, int j) { return *(const bf16x8_t*)(st + offB + j * 2048 + (kk ? (c0 ^ 64) : c0)); };
 
-    const bool staged_ok = (p.ldc & 7) == 0 && (((size_t)p.C) & 15) == 0 && !(p.dbg & 8);   // 16-byte row-layout stores possible
+    const bool staged_ok = (p.ldc & 7) == 0 && (((size_t)p.C) & 15) == 0 && !(p.dbg & 8) &&
+                           (ACT == 2 ? (p.N & 15) == 0 : (min(p.N, p.N_store) & 7) == 0);   // 16-byte row-layout stores possible
     int it = blockIdx.x >> 3;
     if (it >= run_n) return;
+#ifdef GEMM_LAB_TRACE
     int ntrace = 0;
+#define GEMM_STAMP() do { if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[ntrace++] = wall_clock64(); } while (0)
+#else
+#define GEMM_STAMP() do { } while (0)
+#endif
     int m0, n0;
     tile_origin(it, m0, n0);
     set_sources(m0, n0);
-    issue(0);
+    issueA(0, 0);
+    issueW(0, 0);
     while (true) {
         f32x4_t acc[MT][NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K step 0 has landed (and the previous tile's stores retired)
+        // K step 0 has landed and the previous tile's stores have retired.  As a BUILTIN (vmcnt(0), expcnt / lgkmcnt untouched): hipcc does
+        // not read the counters an asm statement waits for, believed the epilogue's stores still pending and drained the queue -- the
+        // freshly issued requests of the next steps with it -- in the middle of every tile's first K step
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
-        if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[ntrace++] = wall_clock64();
+        if (nk > 1) {                                        // (slot 1 was part of the epilogue window until this barrier)
+            if (DEEP == 1) issueA(1, 1);
+            if (DEEP == 2) issueW(1, 1);
+        }
+        GEMM_STAMP();
+        int sd = 0;                                          // slot of the three-stage operand for the current K step (the other: kt & 1)
         for (int kt = 0; kt < nk; ++kt) {
-            const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
-            if (kt + 1 < nk && !((p.dbg & 1) && kt > 0)) issue(kt + 1);   // lands during the MFMAs below
+            const int sd1 = sd + 1 == 3 ? 0 : sd + 1, sd2 = sd1 + 1 == 3 ? 0 : sd1 + 1;
+            // (the slot offsets stay scalar, opaque values: hipcc otherwise keeps a per-lane fragment address for every slot in
+            // registers across the loop -- ten VGPRs the 256-register main loop does not have)
+            int offsA = a_slot(DEEP == 1 ? sd : (kt & 1)), offsW = w_slot(DEEP == 2 ? sd : (kt & 1));
+            asm volatile("" : "+s"(offsA), "+s"(offsW));
+            const unsigned char* stA = smem + offsA;
+            const unsigned char* stW = smem + offsW;
+            const bool dma_on = !((p.dbg & 1) && kt > 0);
+            auto issue_step = [&]() {   // the resident operand of step kt + 1 first, then the streaming one of step kt + 2 (stays in flight)
+                if (!dma_on) return;
+                if (DEEP == 1) {
+                    if (kt + 1 < nk) issueW(kt + 1, (kt + 1) & 1);
+                    if (kt + 2 < nk) issueA(kt + 2, sd2);
+                } else if (DEEP == 2) {
+                    if (kt + 1 < nk) issueA(kt + 1, (kt + 1) & 1);
+                    if (kt + 2 < nk) issueW(kt + 2, sd2);
+                } else if (kt + 1 < nk) {
+                    issueA(kt + 1, (kt + 1) & 1);
+                    issueW(kt + 1, (kt + 1) & 1);
+                }
+            };
+            issue_step();
             bf16x8_t fb[2][NT], fa[4];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[0][j] = ldB(st, 0, j);
-            fa[0] = ldA(st, 0);
-            fa[1] = ldA(st, 1);
+            for (int j = 0; j < NT; ++j) fb[0][j] = ldB(stW, 0, j);
+            fa[0] = ldA(stA, 0);
+            fa[1] = ldA(stA, 1);
             __builtin_amdgcn_sched_group_barrier(0x100, NT + 2, 0);
 #pragma unroll
             for (int s_ = 0; s_ < 2 * MT; ++s_) {
                 const int kk = s_ / MT, i = s_ % MT;
-                if (s_ + 2 < 2 * MT) fa[(s_ + 2) & 3] = ldA(st, s_ + 2);
-                if (s_ < NT) fb[1][s_] = ldB(st, 1, s_);
+                if (s_ + 2 < 2 * MT) fa[(s_ + 2) & 3] = ldA(stA, s_ + 2);
+                if (s_ < NT) fb[1][s_] = ldB(stW, 1, s_);
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[s_ & 3], acc[i][j], 0, 0, 0);
@@ -381,12 +429,20 @@ __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams 
                 else if (s_ < NT || s_ + 2 < 2 * MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage has landed ...
-            __syncthreads();                                    // ... and everybody is done reading this one
+            if (DEEP) {
+                // everything but the streaming operand's request of step kt + 2 (this wave's last four) has landed; the barrier carries no memory wait
+                if (kt + 2 < nk && dma_on) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage has landed ...
+                __syncthreads();                                    // ... and everybody is done reading this one
+            }
+            sd = sd1;
         }
         // the next tile's first K step is requested BEFORE this tile's epilogue: its HBM/L2 latency (and the block
         // re-launch a one-tile-per-block grid would pay) hides under the stores
-        if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[ntrace++] = wall_clock64();
+        GEMM_STAMP();
         const int cm0 = m0, cn0 = n0;
         const size_t c_off = ks > 1 ? (size_t)kidx * p.M * p.ldc : 0;
         it += per_xcd;
@@ -394,15 +450,16 @@ __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams 
         if (more) {
             tile_origin(it, m0, n0);
             set_sources(m0, n0);
-            issue(0);
+            issueA(0, 0);
+            issueW(0, 0);
         }
-        if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[ntrace++] = wall_clock64();
+        GEMM_STAMP();
         if (!(p.dbg & 2)) {
-            // stage 1 is free between the last K step of this tile and the second DMA of the next one
+            // everything behind stage 0 is free between the last K step of this tile and the second DMA of the next one
             if (!OUT_F32 && staged_ok) gemm_epilogue_staged<G, ACT, LN>(p, acc, cm0, cn0, wm, wn, g, li, lane, smem + STAGE_BYTES + wave * G::WIN);
             else gemm_epilogue<G, ACT, OUT_F32>(p, acc, cm0, cn0, wm, wn, g, li, c_off);
         }
-        if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[ntrace++] = wall_clock64();
+        GEMM_STAMP();
         if (!more) break;
     }
 }
@@ -441,19 +498,33 @@ __global__ __launch_bounds__(256) void emmax_splitk_reduce_kernel(GemmParams p) 
     }
 }
 
-template <class G, int ACT, bool OUT_F32, bool LN = false>
+template <class G, int ACT, bool OUT_F32, bool LN = false, int DEEP = 0>
 int launch_t(const GemmParams& p, hipStream_t stream) {
-    auto kern = emmax_gemm_bf16_kernel<G, ACT, OUT_F32, LN>;
+    if constexpr (DEEP == 0 && !OUT_F32) {
+        // Third stage by shape (tuning switch gemm_deep = -1; 0 = two stages of both as in rounds 1-3, 1 / 2 = force A / W).  Measured in
+        // the pipeline (tools/stage_bench.py, interleaved runs on one box, profiles/r04_gemm_deep_ab.txt): the ViT stages, whose
+        // activations (137 MB) stream past 2-9 MB of weights, gain 2-4 % end to end with the deep A ring (single shapes +3 .. 14 %); the
+        // 128 x 128 geometry (split-K slices of the one-frame prefill, row remainders) gains 25-30 % per launch; the big-tile LLaMA
+        // prefill GEMMs, where both operands stream, lose 1-4 % with either ring and keep two stages.
+        int deep = emmax_tune().gemm_deep;
+        if (deep < 0) deep = (std::is_same<G, GeomSmall>::value || (long long)p.M >= 4ll * p.N) ? 1 : 0;
+        if (deep == 1) return launch_t<G, ACT, OUT_F32, LN, 1>(p, stream);
+        if (deep == 2 && !LN) return launch_t<G, ACT, OUT_F32, LN, 2>(p, stream);
+    }
+    auto kern = emmax_gemm_bf16_kernel<G, ACT, OUT_F32, LN, DEEP>;
+    constexpr int SMEM = DEEP ? G::SMEM_A3 : G::SMEM;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM) != hipSuccess) return -4;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return -4;
         attr_done = true;
     }
     // persistent: as many blocks as fit the chip at once (one big / two small per CU), a multiple of the 8 XCDs
     const int tiles = cdiv(p.M, G::BM) * cdiv(p.N, G::BN) * (p.ksplit > 1 ? p.ksplit : 1);
-    const int resident = 256 * (160 * 1024 / G::SMEM);
+    const int resident = 256 * (160 * 1024 / SMEM);
     const int grid = tiles < resident ? (tiles + 7) / 8 * 8 : resident;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NW * 64), G::SMEM, stream, p);
+    GemmParams q = p;
+    q.dbg |= emmax_tune().gemm_dbg;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NW * 64), SMEM, stream, q);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -27,8 +27,17 @@ SHAPES = [
 
 def main():
     global SHAPES
-    if len(sys.argv) > 1:   # custom shapes: "M,N,K,act;M,N,K,act;..."
-        SHAPES = [(f"custom{i}",) + tuple(int(v) for v in t.split(",")) for i, t in enumerate(sys.argv[1].split(";"))]
+    # --ab name=v0,v1[,v2]: every shape under each value of the tuning switch `name` (emmax_tuning_set), repetitions interleaved
+    # in ONE process on ONE box (boxes differ by up to 20 %: numbers from different gpurun calls do not compare)
+    ab = None
+    argv = list(sys.argv[1:])
+    if "--ab" in argv:
+        i = argv.index("--ab")
+        name, vals = argv[i + 1].split("=")
+        ab = (name, [int(v) for v in vals.split(",")])
+        del argv[i:i + 2]
+    if argv:   # custom shapes: "M,N,K,act;M,N,K,act;..."
+        SHAPES = [(f"custom{i}",) + tuple(int(v) for v in t.split(",")) for i, t in enumerate(argv[0].split(";"))]
     lib = L.load()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
@@ -44,6 +53,26 @@ def main():
         run()
         torch.cuda.synchronize()
         reps = 5
+        if ab:
+            tot = {v: 0.0 for v in ab[1]}
+            for v in ab[1]:          # first launch of each variant (attribute set-up) outside the timing
+                L.tuning_set(ab[0], v)
+                run()
+            for _ in range(4):       # 4 interleaved rounds of `reps` launches per variant
+                for v in ab[1]:
+                    L.tuning_set(ab[0], v)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        run()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    tot[v] += e0.elapsed_time(e1) / reps / 4
+            tfs = {v: 2.0 * M * N * K / tot[v] / 1e9 for v in ab[1]}
+            out[name] = {f"{ab[0]}={v}": round(tfs[v], 1) for v in ab[1]}
+            print(f"{name:18s} M={M:6d} N={N:6d} K={K:6d} act={act}  " + "  ".join(f"{ab[0]}={v}: {tot[v]:8.4f} ms {tfs[v]:7.1f} TF/s" for v in ab[1]), flush=True)
+            del A, W, C
+            continue
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):

@@ -1,5 +1,5 @@
 // gemm_trace.hip -- tuning aid (not part of the product): phase timestamps of block 0 of the GEMM (argv[5]: 1 = 256x256 geometry (default), 0 = 128x128).
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iemma-x_amd/csrc tools/gemm_trace.hip emma-x_amd/csrc/gemm.hip -o tools/bin/gemm_trace
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DGEMM_LAB_TRACE -Iemma-x_amd/csrc tools/gemm_trace.hip emma-x_amd/csrc/gemm.hip -o tools/bin/gemm_trace
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
