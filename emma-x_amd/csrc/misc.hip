@@ -200,7 +200,30 @@ __global__ void emmax_slots_idle_kernel(int n, int32_t* cur_tok, int32_t* ctx_le
     }
 }
 
+// one block per committed request
+__global__ __launch_bounds__(256) void emmax_slots_commit_kernel(CommitParams c) {
+    const int i = blockIdx.x, src = c.stg0 + i, dst = c.slot[i], tid = threadIdx.x;
+    for (int k = tid; k < c.max_out; k += 256) c.out_ids[(size_t)dst * c.max_out + k] = c.out_ids[(size_t)src * c.max_out + k];
+    for (int k = tid; k < c.max_pages; k += 256) {
+        const int32_t a = c.page_table[(size_t)src * c.max_pages + k], b = c.page_table[(size_t)dst * c.max_pages + k];
+        c.page_table[(size_t)dst * c.max_pages + k] = a;
+        c.page_table[(size_t)src * c.max_pages + k] = b;
+    }
+    if (tid == 0) {
+        c.cur_tok[dst] = c.cur_tok[src]; c.ctx_len[dst] = c.ctx_len[src]; c.n_out[dst] = c.n_out[src]; c.max_new[dst] = c.max_new[src];
+        c.stop_m[dst] = c.stop_m[src]; c.stop_after[dst] = c.stop_after[src];
+        c.done[dst] = c.done[src];
+        c.done[src] = 1; c.ctx_len[src] = 0;
+    }
+}
+
 }  // namespace
+
+int launch_slots_commit(const CommitParams& c, hipStream_t stream) {
+    if (c.n < 1 || c.n > EMMAX_MAX_DECODE_BATCH) return -1;
+    hipLaunchKernelGGL(emmax_slots_commit_kernel, dim3(c.n), dim3(256), 0, stream, c);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
 
 int launch_prefill_state(const PrefillState& st, int32_t* cu, int32_t* ctx_len, int32_t* done, int32_t* n_out, int32_t* max_new,
                          int32_t* stop_m, int32_t* stop_after, hipStream_t stream) {

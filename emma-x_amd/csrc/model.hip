@@ -302,6 +302,11 @@ static int put1d(emmax_model* m, const std::string& key, int n, bf16* dst, hipSt
 struct emmax_session {
     emmax_model* m;
     int max_batch, max_prompt, max_ctx, max_pages, max_rows /* packed prefill rows */, max_out;
+    // STAGING rows (overlapped admission, emmax_slots_prefill_staged): every per-row array and the paged KV region hold
+    // rows_total = max_batch + n_stg rows; rows stg0 .. are never part of a decode batch -- a request is prefilled into them on a
+    // second stream while the live rows keep decoding, and emmax_slots_commit moves it into its slot between two decode steps
+    // (state copied, page-table rows swapped: no K/V moves)
+    int rows_total, stg0, n_stg;
     // vision scratch
     bf16 *vA, *vpe, *vtok, *vln, *vqkv, *vatt, *vmlp, *feats, *pj1, *pj2, *patch_embeds;
     float* vstats;              // LayerNorm (mean, rstd) of every token row, f32 [rows][2]
@@ -311,7 +316,8 @@ struct emmax_session {
     int32_t* cu;
     // decode
     bf16 *dh, *dq, *datt, *dact;
-    float *part, *part_val, *logits;
+    float *part, *part_val, *logits, *part_val2 /* lm-head argmax partials of a staged prefill */;
+    int32_t *part_idx2;
     int32_t *part_idx, *cur_tok, *ctx_len, *done, *n_out, *out_ids, *max_new_d /* [max_batch] */, *page_table;
     float* splitk_ws;           // fp32 partial tiles of split-K GEMMs (gemm.hip)
     int64_t splitk_bytes;
@@ -385,8 +391,8 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->patt = (bf16*)b.take(R * m->q_dim * 2);
     s->pact = (bf16*)b.take(R * m->inter_p * 2);
     s->cu = (int32_t*)b.take((s->max_batch + 1) * 4);
-    const int Bd = s->max_batch;
-    s->dh = (bf16*)b.take((int64_t)Bd * m->H * 2);
+    const int Bd = s->max_batch, Br = s->rows_total;   // decode batch rows / all rows incl. the staging rows
+    s->dh = (bf16*)b.take((int64_t)Br * m->H * 2);
     s->dq = (bf16*)b.take((int64_t)Bd * m->q_dim * 2);
     s->datt = (bf16*)b.take((int64_t)Bd * m->q_dim * 2);
     s->dact = (bf16*)b.take((int64_t)Bd * m->inter_p * 2);
@@ -394,18 +400,20 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->n_lm_blocks = 512;   // persistent lm-head grid: one argmax partial per block
     s->part_val = (float*)b.take((int64_t)s->n_lm_blocks * Bd * 4);
     s->part_idx = (int32_t*)b.take((int64_t)s->n_lm_blocks * Bd * 4);
+    s->part_val2 = (float*)b.take((int64_t)s->n_lm_blocks * Bd * 4);
+    s->part_idx2 = (int32_t*)b.take((int64_t)s->n_lm_blocks * Bd * 4);
     s->logits = (float*)b.take((int64_t)Bd * m->vocab * 4);
-    s->cur_tok = (int32_t*)b.take(Bd * 4);
-    s->ctx_len = (int32_t*)b.take(Bd * 4);
-    s->done = (int32_t*)b.take(Bd * 4);
-    s->n_out = (int32_t*)b.take(Bd * 4);
-    s->out_ids = (int32_t*)b.take((int64_t)Bd * s->max_out * 4);
-    s->max_new_d = (int32_t*)b.take(Bd * 4);
+    s->cur_tok = (int32_t*)b.take(Br * 4);
+    s->ctx_len = (int32_t*)b.take(Br * 4);
+    s->done = (int32_t*)b.take(Br * 4);
+    s->n_out = (int32_t*)b.take(Br * 4);
+    s->out_ids = (int32_t*)b.take((int64_t)Br * s->max_out * 4);
+    s->max_new_d = (int32_t*)b.take(Br * 4);
     s->stop_ids = (int32_t*)b.take(EMMAX_MAX_STOP_IDS * 4);
     s->stop_cfg = (int32_t*)b.take(2 * 4);
-    s->stop_m = (int32_t*)b.take(Bd * 4);
-    s->stop_after = (int32_t*)b.take(Bd * 4);
-    s->page_table = (int32_t*)b.take((int64_t)Bd * s->max_pages * 4);
+    s->stop_m = (int32_t*)b.take(Br * 4);
+    s->stop_after = (int32_t*)b.take(Br * 4);
+    s->page_table = (int32_t*)b.take((int64_t)Br * s->max_pages * 4);
     s->sk_ws = (unsigned long long*)b.take((int64_t)256 * 2 * 256 * 8);
     s->splitk_bytes = (int64_t)64 << 20;   // e.g. 4 slices of a 768 x 4096 prefill GEMM = 50 MB; smaller budgets just split less
     s->splitk_ws = (float*)b.take(s->splitk_bytes);
@@ -567,7 +575,8 @@ static int launch_finish_step(emmax_session* s, int B, bool is_prefill, int n_pa
     // the partial count is the grid the launch really used (every launcher reports it): a count modelled separately went
     // stale when a launcher capped its grid (fp8 row GEMV shapes 1/2, EMMAX_GEMV_GRID) and stale partials could win the argmax
     if (n_part <= 0 || n_part > s->n_lm_blocks) return fail(EMMAX_ERR_STATE, "lm-head launch reported no partial count");
-    f.part_val = s->part_val; f.part_idx = s->part_idx; f.n_part = n_part;
+    const bool stg = slot0 >= s->stg0;   // a staged prefill runs beside the live batch's decode steps: its own partial buffers
+    f.part_val = stg ? s->part_val2 : s->part_val; f.part_idx = stg ? s->part_idx2 : s->part_idx; f.n_part = n_part;
     f.B = B;
     f.cur_tok = s->cur_tok + slot0; f.ctx_len = s->ctx_len + slot0; f.done = s->done + slot0; f.n_out = s->n_out + slot0;
     f.out_ids = s->out_ids + (size_t)slot0 * s->max_out;
@@ -606,10 +615,12 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
     const int r0 = slot_mode ? slot0 : 0;
     if (slot_mode) {
         if (!s->slots_open) return fail(EMMAX_ERR_STATE, "slot prefill before emmax_slots_open");
-        if (r0 + B > s->cur_B) return fail(EMMAX_ERR_INVALID, "slot %d outside the %d open slots", r0, s->cur_B);
-        if ((int)s->S.size() < s->cur_B) s->S.resize(s->cur_B, 0);
+        if (r0 >= s->stg0) {   // staging rows
+            if (r0 + B > s->rows_total) return fail(EMMAX_ERR_INVALID, "%d requests exceed the %d staging rows", B, s->n_stg);
+        } else if (r0 + B > s->cur_B) return fail(EMMAX_ERR_INVALID, "slot %d outside the %d open slots", r0, s->cur_B);
+        if ((int)s->S.size() < s->rows_total) s->S.resize(s->rows_total, 0);
     } else {
-        s->S.assign(B, 0);
+        s->S.assign(s->rows_total, 0);
         s->slots_open = false;
     }
     int total = 0, maxS = 0;
@@ -707,7 +718,9 @@ static void lmhead_params(emmax_session* s, int slot0, float* logits_out, GemvPa
     memset(&p, 0, sizeof(p));
     p.sk_ws = streamk_on() ? s->sk_ws : nullptr;
     p.x = s->dh + (size_t)slot0 * m->H; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = m->final_norm; p.eps = m->cfg.rms_eps;
-    p.n_rows = m->vocab; p.max_parts = s->n_lm_blocks; p.part_val = s->part_val; p.part_idx = s->part_idx; p.logits_out = logits_out;
+    const bool stg = slot0 >= s->stg0;
+    p.n_rows = m->vocab; p.max_parts = s->n_lm_blocks; p.part_val = stg ? s->part_val2 : s->part_val; p.part_idx = stg ? s->part_idx2 : s->part_idx;
+    p.logits_out = logits_out;
 }
 
 // one stage of decoder layer `li` (the unit the profiler times); the step is stages 0..4 of every layer + lm head
@@ -1044,10 +1057,11 @@ int emmax_session_bytes(const emmax_model* m, int max_batch, int max_prompt, int
     tmp.m = const_cast<emmax_model*>(m);
     tmp.max_batch = max_batch; tmp.max_prompt = max_prompt; tmp.max_ctx = max_ctx; tmp.max_pages = mp; tmp.max_rows = mr;
     tmp.max_out = max_ctx;
+    tmp.n_stg = std::min(max_batch, EMMAX_MAX_DECODE_BATCH); tmp.stg0 = max_batch; tmp.rows_total = max_batch + tmp.n_stg;
     SBump b{nullptr};
     plan_session(&tmp, b);
     if (ws) *ws = b.off + 256;
-    if (kv) *kv = kv_bytes_for(m, max_batch, mp);
+    if (kv) *kv = kv_bytes_for(m, tmp.rows_total, mp);
     return 0;
 }
 
@@ -1068,10 +1082,11 @@ int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_
     s->max_batch = max_batch; s->max_prompt = max_prompt; s->max_ctx = max_ctx;
     session_dims(m, max_batch, max_prompt, max_ctx, &s->max_pages, &s->max_rows);
     s->max_out = max_ctx;
+    s->n_stg = std::min(max_batch, EMMAX_MAX_DECODE_BATCH); s->stg0 = max_batch; s->rows_total = max_batch + s->n_stg;
     SBump b{(char*)ws};
     plan_session(s, b);
     s->kv = (bf16*)kv;
-    s->kv_layer_stride = (int64_t)2 * max_batch * s->max_pages * m->cfg.n_kv_heads * PAGE * m->cfg.head_dim;
+    s->kv_layer_stride = (int64_t)2 * s->rows_total * s->max_pages * m->cfg.n_kv_heads * PAGE * m->cfg.head_dim;
     HIPCHK(hipMemset(ws, 0, need_ws));   // padding columns of every activation buffer stay zero forever
     HIPCHK(hipMemset(kv, 0, need_kv));
     HIPCHK(hipDeviceSynchronize());
@@ -1083,7 +1098,7 @@ int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_
     HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
     // static page assignment: row b owns pages [b*max_pages, (b+1)*max_pages)
     {
-        std::vector<int32_t> pt((size_t)max_batch * s->max_pages);
+        std::vector<int32_t> pt((size_t)s->rows_total * s->max_pages);
         for (size_t i = 0; i < pt.size(); ++i) pt[i] = (int32_t)i;
         HIPCHK(hipMemcpy(s->page_table, pt.data(), pt.size() * 4, hipMemcpyHostToDevice));
         for (int t = 0; t < 2; ++t) {
@@ -1300,7 +1315,7 @@ int emmax_slots_open(emmax_session* s, int n_slots, emmax_stream stream) {
     if (r) return r;
     KCHK(launch_slots_idle(n_slots, s->cur_tok, s->ctx_len, s->done, s->n_out, s->m->cfg.pad_id, st));
     s->cur_B = n_slots;
-    s->S.assign(n_slots, 0);
+    s->S.assign(s->rows_total, 0);
     s->slots_open = true;
     s->prefilled = true;   // decode steps are legal: idle slots are rows that are already done
     return slot_leave(s, user, st);
@@ -1334,6 +1349,45 @@ int emmax_slots_prefill(emmax_session* s, int slot0, int n, const int32_t* ids, 
     r = run_prefill(s, ids, lens_host, n, P_max, patches, st, slot0);   // one packed pass over the n requests (ragged lengths)
     if (r) return r;
     for (int i = 0; i < n; ++i) KCHK(launch_set_ints(s->max_new_d + slot0 + i, 1, max_new_host[i], st));
+    return slot_leave(s, user, st);
+}
+
+int emmax_slots_prefill_staged(emmax_session* s, int n, const int32_t* ids, int P_max, const int32_t* lens_host, const void* patches,
+                               const int32_t* max_new_host, emmax_stream stream) {
+    if (!s || !ids || !lens_host || !max_new_host) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (!s->slots_open) return fail(EMMAX_ERR_STATE, "emmax_slots_prefill_staged before emmax_slots_open");
+    if (n < 1 || n > s->n_stg) return fail(EMMAX_ERR_INVALID, "%d staged requests outside 1..%d", n, s->n_stg);
+    if ((uintptr_t)stream <= 2) return fail(EMMAX_ERR_INVALID, "a staged prefill needs its own (non-default) stream: it runs beside the decode steps");
+    for (int i = 0; i < n; ++i)
+        if (max_new_host[i] < 1 || max_new_host[i] > s->max_out)
+            return fail(EMMAX_ERR_INVALID, "staged request %d: max_new_tokens %d outside 1..%d", i, max_new_host[i], s->max_out);
+    hipStream_t st = (hipStream_t)stream;
+    int r = run_prefill(s, ids, lens_host, n, P_max, patches, st, s->stg0);
+    if (r) return r;
+    for (int i = 0; i < n; ++i) KCHK(launch_set_ints(s->max_new_d + s->stg0 + i, 1, max_new_host[i], st));
+    return 0;
+}
+
+int emmax_slots_commit(emmax_session* s, const int32_t* slots_host, int n, emmax_stream stream) {
+    if (!s || !slots_host) return fail(EMMAX_ERR_INVALID, "null argument");
+    if (!s->slots_open) return fail(EMMAX_ERR_STATE, "emmax_slots_commit before emmax_slots_open");
+    if (n < 1 || n > s->n_stg) return fail(EMMAX_ERR_INVALID, "%d commits outside 1..%d", n, s->n_stg);
+    CommitParams c;
+    memset(&c, 0, sizeof(c));
+    for (int i = 0; i < n; ++i) {
+        if (slots_host[i] < 0 || slots_host[i] >= s->cur_B) return fail(EMMAX_ERR_INVALID, "slot %d outside 0..%d", slots_host[i], s->cur_B - 1);
+        for (int j = 0; j < i; ++j)
+            if (slots_host[j] == slots_host[i]) return fail(EMMAX_ERR_INVALID, "slot %d committed twice", slots_host[i]);
+        c.slot[i] = slots_host[i];
+    }
+    c.n = n; c.stg0 = s->stg0; c.max_pages = s->max_pages; c.max_out = s->max_out;
+    c.cur_tok = s->cur_tok; c.ctx_len = s->ctx_len; c.done = s->done; c.n_out = s->n_out; c.max_new = s->max_new_d;
+    c.stop_m = s->stop_m; c.stop_after = s->stop_after; c.out_ids = s->out_ids; c.page_table = s->page_table;
+    hipStream_t user = (hipStream_t)stream, st;
+    int r = slot_enter(s, user, &st);
+    if (r) return r;
+    KCHK(launch_slots_commit(c, st));
+    for (int i = 0; i < n; ++i) s->S[slots_host[i]] = s->S[s->stg0 + i];
     return slot_leave(s, user, st);
 }
 

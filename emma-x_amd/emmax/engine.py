@@ -37,6 +37,19 @@ def _config_c(cfg: EmmaXConfig) -> _lib.ConfigC:
     return c
 
 
+class _Staged:
+    """A staged prefill in flight on the admission stream."""
+
+    def __init__(self, n, event, keep):
+        self.n, self.event, self.keep = n, event, keep
+
+    def ready(self) -> bool:
+        return self.event.query()
+
+    def wait(self) -> None:
+        self.event.synchronize()
+
+
 class EmmaxEngine:
     """Model weights (re-laid-out into one device arena) + one session (workspace + paged KV cache)."""
 
@@ -283,6 +296,55 @@ class EmmaxEngine:
         _lib.check(self.lib.emmax_slots_prefill(self._session, int(slot0), n, ids_d.data_ptr(), P, lens_c, _lib.ptr(pe), budget_c,
                                                 _lib.current_stream()), "emmax_slots_prefill")
         torch.cuda.current_stream().synchronize()   # `ids_d` / `pe` must outlive the pass
+
+    # ---- overlapped admission: staged prefill on a second stream + commit between two decode steps (include/emmax.h) ----
+    def admission(self):
+        """Context manager: everything issued inside (frame encode, staged prefill, their uploads) runs on the engine's admission
+        stream, beside the decode steps of the current stream; ordered after the previous commit."""
+        if getattr(self, "_adm_stream", None) is None:
+            self._adm_stream = torch.cuda.Stream(device=self.device)
+            self._commit_event = None
+        if self._commit_event is not None:
+            self._adm_stream.wait_event(self._commit_event)
+        return torch.cuda.stream(self._adm_stream)
+
+    def slots_prefill_staged(self, prompts: Sequence[Sequence[int]], patch_embeds: Optional[Sequence[torch.Tensor]],
+                             max_new_tokens: Sequence[int]):
+        """Prefill len(prompts) requests into the session's STAGING rows; call inside `with engine.admission():`.  Returns a handle
+        (`.ready()` -> bool, non-blocking) for `slots_commit`."""
+        n = len(prompts)
+        if n < 1 or len(max_new_tokens) != n:
+            raise ValueError("slots_prefill_staged: one token budget per prompt, at least one prompt")
+        lens = [len(p) for p in prompts]
+        P = max(lens)
+        ids = torch.zeros(n, P, dtype=torch.int32)
+        for i, p in enumerate(prompts):
+            ids[i, : lens[i]] = torch.as_tensor(list(p), dtype=torch.int32)
+        ids_d = ids.to(self.device)
+        pe = None
+        if patch_embeds is not None:
+            if len(patch_embeds) != n:
+                raise ValueError("slots_prefill_staged: one patch-embedding tensor per prompt")
+            pe = torch.stack([t.reshape(self.cfg.n_patches, self.cfg.llm.hidden_size) for t in patch_embeds]).contiguous()
+            assert pe.dtype == torch.bfloat16
+        lens_c = (C.c_int32 * n)(*lens)
+        budget_c = (C.c_int32 * n)(*[int(v) for v in max_new_tokens])
+        _lib.check(self.lib.emmax_slots_prefill_staged(self._session, n, ids_d.data_ptr(), P, lens_c, _lib.ptr(pe), budget_c,
+                                                       _lib.current_stream()), "emmax_slots_prefill_staged")
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return _Staged(n, ev, (ids_d, pe))
+
+    def slots_commit(self, staged: "_Staged", slots: Sequence[int]) -> None:
+        """Move the staged requests into `slots` (idle) on the CURRENT (decode) stream, after the staged prefill has finished."""
+        if len(slots) != staged.n:
+            raise ValueError("slots_commit: one slot per staged request")
+        torch.cuda.current_stream().wait_event(staged.event)
+        arr = (C.c_int32 * staged.n)(*[int(v) for v in slots])
+        _lib.check(self.lib.emmax_slots_commit(self._session, arr, staged.n, _lib.current_stream()), "emmax_slots_commit")
+        self._commit_event = torch.cuda.Event()
+        self._commit_event.record(torch.cuda.current_stream())
+        staged.keep = None
 
     def slots_step(self, n_steps: int) -> None:
         _lib.check(self.lib.emmax_slots_step(self._session, int(n_steps), _lib.current_stream()), "emmax_slots_step")

@@ -66,7 +66,7 @@ class SlotScheduler:
 
     def __init__(self, engine, encode: Callable[[List[Any]], List[Any]], n_slots: int = 8, poll_every: int = 16,
                  stop_trigger: Sequence[int] = (), stop_after: int = 0, clock: Callable[[], float] = time.perf_counter,
-                 encode_ahead: int = 0) -> None:
+                 encode_ahead: int = 0, overlap: Optional[bool] = None) -> None:
         if not 1 <= n_slots <= 8:
             raise ValueError(f"n_slots {n_slots} outside 1..8")
         if poll_every < 1:
@@ -83,6 +83,15 @@ class SlotScheduler:
         self.polls = 0
         self.encode_ahead = max(int(encode_ahead), 0)
         self._embeds: Dict[int, Any] = {}          # id(request) -> patch embeddings encoded ahead of admission
+        # overlap: admissions (frame encode + prefill) run on the engine's admission stream into staging rows while the occupied
+        # slots keep decoding, and join their slots between two decode steps (engine.admission / slots_prefill_staged /
+        # slots_commit).  Default: on whenever the engine has the staged API.
+        has = all(hasattr(engine, a) for a in ("admission", "slots_prefill_staged", "slots_commit"))
+        if overlap and not has:
+            raise ValueError("overlap=True needs an engine with admission / slots_prefill_staged / slots_commit")
+        self.overlap = has if overlap is None else bool(overlap)
+        self._pending = None                         # (staged handle, [(request, t_submit), ...]) of the admission in flight
+        self.overlapped_admissions = 0
         engine.set_stop(list(stop_trigger), stop_after)
         engine.slots_open(n_slots)
 
@@ -97,15 +106,7 @@ class SlotScheduler:
         if take == 0:
             return 0
         batch = [self.queue.popleft() for _ in range(take)]
-        todo = [r for r, _ in batch if id(r) not in self._embeds]
-        if todo:   # one ViT pass for the admitted frames that are not encoded yet + the head of the queue
-            ahead = [r for r, _ in list(self.queue)[: max(self.encode_ahead - len(todo), 0)] if id(r) not in self._embeds]
-            got = self.encode([r.frame for r in todo + ahead])
-            if len(got) != len(todo) + len(ahead):
-                raise RuntimeError(f"encode returned {len(got)} embeddings for {len(todo) + len(ahead)} frames")
-            for r, pe in zip(todo + ahead, got):
-                self._embeds[id(r)] = pe
-        embeds = [self._embeds.pop(id(r)) for r, _ in batch]
+        embeds = self._encode_for(batch)
         # runs of CONSECUTIVE free slots are prefilled in one packed pass (eight one-row prefills cost ~1.6x one eight-row pass);
         # engines without `slots_prefill` (test doubles) get the requests one by one
         slots = free[:take]
@@ -126,6 +127,51 @@ class SlotScheduler:
             i = j
         return take
 
+    def _encode_for(self, batch) -> List[Any]:
+        """Patch embeddings of the requests in `batch` (one ViT pass for those not encoded yet + the head of the queue)."""
+        todo = [r for r, _ in batch if id(r) not in self._embeds]
+        if todo:
+            ahead = [r for r, _ in list(self.queue)[: max(self.encode_ahead - len(todo), 0)] if id(r) not in self._embeds]
+            got = self.encode([r.frame for r in todo + ahead])
+            if len(got) != len(todo) + len(ahead):
+                raise RuntimeError(f"encode returned {len(got)} embeddings for {len(todo) + len(ahead)} frames")
+            for r, pe in zip(todo + ahead, got):
+                self._embeds[id(r)] = pe
+        return [self._embeds.pop(id(r)) for r, _ in batch]
+
+    def _start_admission(self) -> bool:
+        """Overlap mode: issue frame encode + staged prefill of as many queued requests as there are free slots on the admission
+        stream; returns at once (nothing is awaited)."""
+        free = [s for s in range(self.n_slots) if s not in self.active]
+        take = min(len(free), len(self.queue))
+        if take == 0 or self._pending is not None:
+            return False
+        batch = [self.queue.popleft() for _ in range(take)]
+        with self.engine.admission():
+            embeds = self._encode_for(batch)
+            staged = self.engine.slots_prefill_staged([list(r.prompt_ids) for r, _ in batch], embeds if embeds[0] is not None else None,
+                                                      [r.max_new_tokens for r, _ in batch])
+        self._pending = (staged, batch)
+        return True
+
+    def _join_admission(self, wait: bool) -> int:
+        """Commit the admission in flight once its prefill has finished (wait=True: block for it -- nothing else to do)."""
+        if self._pending is None:
+            return 0
+        staged, batch = self._pending
+        if not staged.ready():
+            if not wait:
+                return 0
+            staged.wait()
+        slots = [s for s in range(self.n_slots) if s not in self.active][: len(batch)]
+        self.engine.slots_commit(staged, slots)
+        t_adm = self.clock()
+        for slot, (req, t_sub) in zip(slots, batch):
+            self.active[slot] = _Active(req, t_sub, t_adm)
+        self._pending = None
+        self.overlapped_admissions += 1
+        return len(batch)
+
     def _retire(self) -> int:
         done, n_out = self.engine.slots_state()
         self.polls += 1
@@ -141,6 +187,16 @@ class SlotScheduler:
 
     def run(self) -> List[Result]:
         """Serve until the queue is empty and every slot is idle.  Returns the results in completion order."""
+        if self.overlap:
+            while self.queue or self.active or self._pending is not None:
+                self._start_admission()
+                self._join_admission(wait=not self.active)     # idle decode batch: the admission is all there is to wait for
+                if not self.active:
+                    continue
+                self.engine.slots_step(self.poll_every)
+                self.steps += self.poll_every
+                self._retire()
+            return self.results
         while self.queue or self.active:
             self._admit()
             if not self.active:

@@ -180,6 +180,19 @@ int emmax_slot_prefill(emmax_session* s, int slot, const int32_t* ids_dev, int l
  * The other slots are not disturbed; every row's first generated token is in place afterwards. */
 int emmax_slots_prefill(emmax_session* s, int slot0, int n, const int32_t* ids_dev, int P_max, const int32_t* lens_host,
                         const void* patch_embeds_dev, const int32_t* max_new_host, emmax_stream stream);
+/* Overlapped admission.  emmax_slot_prefill and emmax_slots_prefill run on the stream the slots decode on: while a request is prefilled (16 ms for one
+ * 7B row, 70 ms for eight) the other slots stand still.  The staged pair removes that stall: every session holds min(max_batch, 8)
+ * STAGING rows beside its decode rows (per-row state, output row, KV pages: emmax_session_bytes accounts for them).
+ *   emmax_slots_prefill_staged  prefills n requests into the staging rows on `stream`, which must be a stream of its own (not the
+ *                               default stream, not the one the decode steps run on): the call touches nothing a decode step reads,
+ *                               so decode steps may run beside it.  Arguments as emmax_slots_prefill without slot0.
+ *   emmax_slots_commit          moves staged request i into slot slots_host[i] (idle, released) on the DECODE stream, between two
+ *                               steps: per-row state and the output row are copied and the page-table rows swapped -- no K/V moves.
+ *                               The caller orders it after the staged prefill (event), and orders the NEXT staged prefill after it.
+ * One staged batch at a time.  Host scheduler: emmax/serving.py (SlotScheduler, overlap=True). */
+int emmax_slots_prefill_staged(emmax_session* s, int n, const int32_t* ids_dev, int P_max, const int32_t* lens_host,
+                               const void* patch_embeds_dev, const int32_t* max_new_host, emmax_stream stream);
+int emmax_slots_commit(emmax_session* s, const int32_t* slots_host, int n, emmax_stream stream);
 /* n_steps greedy decode steps over all slots (no host synchronisation); idle / finished slots stay put. */
 int emmax_slots_step(emmax_session* s, int n_steps, emmax_stream stream);
 /* Copy the per-slot done flags and generated-token counts to device buffers int32[n_slots] (asynchronous on `stream`). */

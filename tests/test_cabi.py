@@ -131,8 +131,8 @@ def test_config_validation_and_sizing(lib):
     so.emmax_model_destroy(h8)
     ws, kv = C.c_int64(), C.c_int64()
     assert so.emmax_session_bytes(h, 8, 512, 1281, C.byref(ws), C.byref(kv)) == 0
-    # paged KV: 32 layers x 2 x 8 rows x 21 pages x 32 heads x 64 x 128 bf16
-    assert kv.value == 32 * 2 * 8 * 21 * 32 * 64 * 128 * 2
+    # paged KV: 32 layers x 2 x (8 decode rows + 8 staging rows of the overlapped admission) x 21 pages x 32 heads x 64 x 128 bf16
+    assert kv.value == 32 * 2 * 16 * 21 * 32 * 64 * 128 * 2
     assert so.emmax_session_bytes(h, 8, 512, 700, C.byref(ws), C.byref(kv)) != 0
     assert b"max_ctx" in so.emmax_last_error()
     so.emmax_model_destroy(h)

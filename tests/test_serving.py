@@ -196,3 +196,77 @@ def test_consecutive_free_slots_are_prefilled_in_one_packed_pass():
     assert all((s0, n) != (0, 2) for s0, n in eng.packed) and len(singles) == 3
     # every request went through exactly one prefill
     assert sorted(rid for _, rid, _ in eng.prefills) == list(range(len(lengths)))
+
+
+class FakeStagedEngine(FakeEngine):
+    """FakeEngine + the overlapped-admission contract (engine.admission / slots_prefill_staged / slots_commit): a staged prefill
+    becomes ready only after `lag` further decode steps, and touches no slot until it is committed."""
+
+    def __init__(self, plans, lag=3):
+        super().__init__(plans)
+        self.lag, self.in_admission, self.staged, self.commits = lag, False, None, []
+
+    def admission(self):
+        eng = self
+
+        class Ctx:
+            def __enter__(self):
+                eng.in_admission = True
+
+            def __exit__(self, *a):
+                eng.in_admission = False
+
+        return Ctx()
+
+    def slots_prefill_staged(self, prompts, embeds, max_new):
+        assert self.in_admission and self.staged is None, "one staged batch at a time, issued on the admission stream"
+        eng, due = self, self.steps + self.lag
+
+        class H:
+            n = len(prompts)
+
+            def ready(self):
+                return eng.steps >= due
+
+            def wait(self):
+                eng.steps = max(eng.steps, due)      # nothing else was running: the host blocks
+
+        self.staged = (H(), [{"plan": self.plans[pe["rid"]], "budget": b, "out": [self.plans[pe["rid"]][0]], "rid": pe["rid"]}
+                              for pe, b in zip(embeds, max_new)], [tuple(p) for p in prompts])
+        assert all(pe["encoded"] for pe in embeds)
+        return self.staged[0]
+
+    def slots_commit(self, handle, slots):
+        h, sts, prompts = self.staged
+        assert h is handle and h.ready() and len(slots) == len(sts) and not self.in_admission
+        for slot, st, pr in zip(slots, sts, prompts):
+            assert self.slots[slot] is None, "commit into a busy slot"
+            self.slots[slot] = st
+            self.prefills.append((slot, st["rid"], pr))
+        self.commits.append(list(slots))
+        self.staged = None
+
+
+def test_overlapped_admission_keeps_decoding_while_a_request_is_prefilled():
+    lengths = [30, 4, 4, 9, 25, 3, 14, 6, 40, 5]
+    plans = _plans(lengths)
+    eng, calls = FakeStagedEngine(plans, lag=3), []
+    sch = SlotScheduler(eng, _encode_factory(calls), n_slots=3, poll_every=2, encode_ahead=2)
+    assert sch.overlap
+    for i in range(len(lengths)):
+        sch.submit(Request(rid=i, frame=i, prompt_ids=[1, 9, i + 3]))
+    res = sch.run()
+    assert sorted(r.rid for r in res) == list(range(len(lengths)))
+    for r in res:
+        assert r.ids == plans[r.rid] and r.t_submit <= r.t_admit <= r.t_done
+    assert sch.overlapped_admissions == len(eng.commits) >= 4 and eng.staged is None
+    assert sum(len(c) for c in eng.commits) == len(lengths)
+    # the same requests through the blocking admission give the same outputs
+    eng2 = FakeEngine(plans)
+    sch2 = SlotScheduler(eng2, _encode_factory([]), n_slots=3, poll_every=2)
+    assert not sch2.overlap
+    for i in range(len(lengths)):
+        sch2.submit(Request(rid=i, frame=i, prompt_ids=[1, 9, i + 3]))
+    assert {r.rid: r.ids for r in sch2.run()} == {r.rid: r.ids for r in res}
+    with pytest.raises(ValueError):
+        SlotScheduler(FakeEngine(plans), _encode_factory([]), n_slots=2, overlap=True)

@@ -85,8 +85,10 @@ def test_multi_id_trigger_and_restart(device, served):
     assert ids[0, : int(lens[0])].cpu().tolist() == chain[:7]
 
 
-@pytest.mark.parametrize("n_slots,poll", [(3, 4), (1, 3), (4, 16)])
-def test_slot_serving_equals_bs1_generate(device, served, n_slots, poll):
+@pytest.mark.parametrize("n_slots,poll,overlap", [(3, 4, True), (1, 3, True), (4, 16, True), (3, 4, False), (4, 16, False)])
+def test_slot_serving_equals_bs1_generate(device, served, n_slots, poll, overlap):
+    """overlap=True: admissions are prefilled into the staging rows on a second stream while the occupied slots decode and join
+    between two steps (emmax_slots_prefill_staged / emmax_slots_commit); False: the round-3 admission on the decode stream."""
     from emmax.serving import Request, SlotScheduler
     from emmax.weights import planted_chain
 
@@ -105,10 +107,11 @@ def test_slot_serving_equals_bs1_generate(device, served, n_slots, poll):
         pe = eng.vision_encode(torch.stack(fs))
         return [pe[i] for i in range(len(fs))]
 
-    sch = SlotScheduler(eng, encode, n_slots=n_slots, poll_every=poll, encode_ahead=4 if n_slots == 3 else 0)
+    sch = SlotScheduler(eng, encode, n_slots=n_slots, poll_every=poll, encode_ahead=4 if n_slots == 3 else 0, overlap=overlap)
     for i in range(len(ks)):
         sch.submit(Request(i, fr[i], rows[i], max_new_tokens=48))
     res = sch.run()
+    assert sch.overlap == overlap and (sch.overlapped_admissions >= 3) == overlap
     assert sorted(r.rid for r in res) == list(range(len(ks)))
     for r in res:
         assert r.ids == want[r.rid], f"request {r.rid} (slot {r.slot})"
@@ -116,7 +119,7 @@ def test_slot_serving_equals_bs1_generate(device, served, n_slots, poll):
     if n_slots > 1:
         assert [r.rid for r in res] != list(range(len(ks)))
     # budget: a request capped below its natural length stops at the cap, the rest is untouched
-    sch = SlotScheduler(eng, encode, n_slots=n_slots, poll_every=poll)
+    sch = SlotScheduler(eng, encode, n_slots=n_slots, poll_every=poll, overlap=overlap)
     sch.submit(Request("cap", fr[0], rows[0], max_new_tokens=5))
     sch.submit(Request("free", fr[1], rows[1], max_new_tokens=48))
     res = {r.rid: r.ids for r in sch.run()}
@@ -227,10 +230,11 @@ def test_eight_slots_random_weights_against_the_oracle(device):
         pe = eng.vision_encode(torch.stack(fs))
         return [pe[i] for i in range(len(fs))]
 
-    sch = SlotScheduler(eng, encode, n_slots=8, poll_every=4, encode_ahead=4)
+    sch = SlotScheduler(eng, encode, n_slots=8, poll_every=4, encode_ahead=4, overlap=True)   # admissions overlap the decode steps
     for i in range(n_req):
         sch.submit(Request(i, fr[i], rows[i], max_new_tokens=budgets[i]))
     res = {r.rid: r for r in sch.run()}
+    assert sch.overlapped_admissions >= 2
     assert sorted(res) == list(range(n_req)) and {r.slot for r in res.values()} == set(range(8))
     checked = 0
     for i in range(n_req):

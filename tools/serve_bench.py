@@ -71,9 +71,9 @@ def main():
         pe = eng.vision_encode(torch.stack(fs))
         return [pe[i] for i in range(len(fs))]
 
-    def serve(trigger, after):
+    def serve(trigger, after, overlap=True):
         sch = SlotScheduler(eng, encode, n_slots=args.slots, poll_every=args.poll, stop_trigger=trigger, stop_after=after,
-                            encode_ahead=args.slots)
+                            encode_ahead=args.slots, overlap=overlap)
         sync(); t0 = time.perf_counter()
         for i in range(N):
             sch.submit(Request(i, frames[i], rows[i], MAXN))
@@ -83,6 +83,8 @@ def main():
         eng.set_stop([], 0)
         return dt, {r.rid: r for r in res}, sch
 
+    serve([], 0)                                        # warm-up of both admission paths (allocator, first launches)
+    t_block, res_block, sch_b = serve([], 0, overlap=False)   # round-3 behaviour: admissions on the decode stream
     t_cont, res_cont, sch_c = serve([], 0)
     t_early, res_early, sch_e = serve([29871], 8)
     # Agreement between the serving modes is REPORTED, not asserted, at this size: the launch plan picks tile geometry and
@@ -103,6 +105,7 @@ def main():
     def pct(v, q):
         return float(np.percentile(np.asarray(v), q))
 
+    lb = [res_block[i].latency_s for i in range(N)]
     lc = [res_cont[i].latency_s for i in range(N)]
     le = [res_early[i].latency_s for i in range(N)]
     out = {
@@ -111,12 +114,15 @@ def main():
         "requests_following_the_planted_chain": n_chain,
         "static": {"seconds": round(t_static, 3), "actions_per_s": round(N / t_static, 3), "latency_p50_s": round(pct(lat_static, 50), 3),
                    "latency_p95_s": round(pct(lat_static, 95), 3)},
-        "continuous": {"seconds": round(t_cont, 3), "actions_per_s": round(N / t_cont, 3), "latency_p50_s": round(pct(lc, 50), 3),
+        "continuous_blocking_admission": {"seconds": round(t_block, 3), "actions_per_s": round(N / t_block, 3), "latency_p50_s": round(pct(lb, 50), 3),
+                                          "latency_p95_s": round(pct(lb, 95), 3), "decode_steps": sch_b.steps},
+        "continuous": {"admission": "overlapped (staging rows, second stream)", "overlapped_admissions": sch_c.overlapped_admissions, "seconds": round(t_cont, 3), "actions_per_s": round(N / t_cont, 3), "latency_p50_s": round(pct(lc, 50), 3),
                        "latency_p95_s": round(pct(lc, 95), 3), "decode_steps": sch_c.steps, "polls": sch_c.polls},
         "continuous_early_exit": {"seconds": round(t_early, 3), "actions_per_s": round(N / t_early, 3), "latency_p50_s": round(pct(le, 50), 3),
                                   "latency_p95_s": round(pct(le, 95), 3), "decode_steps": sch_e.steps},
         "requests_with_identical_ids": {"static_vs_bs1": same_bs1_static, "continuous_vs_bs1": same_bs1_cont,
-                                        "continuous_vs_static": same_static_cont, "early_exit_is_prefix_of_continuous": early_prefix, "of": N},
+                                        "continuous_vs_static": same_static_cont,
+                                        "overlapped_vs_blocking_admission": sum(int(res_cont[i].ids == res_block[i].ids) for i in range(N)), "early_exit_is_prefix_of_continuous": early_prefix, "of": N},
     }
     print(json.dumps(out))
 
