@@ -80,11 +80,11 @@ struct PrefillState {
 // per-row decode state of B fresh sequences (pointers already offset to the first row / slot)
 int launch_prefill_state(const PrefillState& st, int32_t* cu, int32_t* ctx_len, int32_t* done, int32_t* n_out, int32_t* max_new,
                          int32_t* stop_m, int32_t* stop_after, hipStream_t stream);
-// emmax_slots_commit: staging rows stg0 .. stg0 + n - 1 become slots slot[0 .. n): per-row state and the output row copied, page-table
-// rows swapped (the slot's old pages become the staging row's)
+// emmax_slots_commit: staging rows src[i] become slots slot[i]: per-row state and the output row copied, page-table rows swapped (the
+// slot's old pages become the staging row's)
 struct CommitParams {
-    int n, stg0, max_pages, max_out;
-    int slot[EMMAX_MAX_DECODE_BATCH];
+    int n, max_pages, max_out;
+    int slot[EMMAX_MAX_DECODE_BATCH], src[EMMAX_MAX_DECODE_BATCH];
     int32_t *cur_tok, *ctx_len, *done, *n_out, *max_new, *stop_m, *stop_after, *out_ids, *page_table;
 };
 int launch_slots_commit(const CommitParams& c, hipStream_t stream);

@@ -202,7 +202,7 @@ __global__ void emmax_slots_idle_kernel(int n, int32_t* cur_tok, int32_t* ctx_le
 
 // one block per committed request
 __global__ __launch_bounds__(256) void emmax_slots_commit_kernel(CommitParams c) {
-    const int i = blockIdx.x, src = c.stg0 + i, dst = c.slot[i], tid = threadIdx.x;
+    const int i = blockIdx.x, src = c.src[i], dst = c.slot[i], tid = threadIdx.x;
     for (int k = tid; k < c.max_out; k += 256) c.out_ids[(size_t)dst * c.max_out + k] = c.out_ids[(size_t)src * c.max_out + k];
     for (int k = tid; k < c.max_pages; k += 256) {
         const int32_t a = c.page_table[(size_t)src * c.max_pages + k], b = c.page_table[(size_t)dst * c.max_pages + k];

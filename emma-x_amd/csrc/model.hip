@@ -1368,26 +1368,28 @@ int emmax_slots_prefill_staged(emmax_session* s, int n, const int32_t* ids, int 
     return 0;
 }
 
-int emmax_slots_commit(emmax_session* s, const int32_t* slots_host, int n, emmax_stream stream) {
-    if (!s || !slots_host) return fail(EMMAX_ERR_INVALID, "null argument");
+int emmax_slots_commit(emmax_session* s, const int32_t* staged_idx_host, const int32_t* slots_host, int n, emmax_stream stream) {
+    if (!s || !slots_host || !staged_idx_host) return fail(EMMAX_ERR_INVALID, "null argument");
     if (!s->slots_open) return fail(EMMAX_ERR_STATE, "emmax_slots_commit before emmax_slots_open");
     if (n < 1 || n > s->n_stg) return fail(EMMAX_ERR_INVALID, "%d commits outside 1..%d", n, s->n_stg);
     CommitParams c;
     memset(&c, 0, sizeof(c));
     for (int i = 0; i < n; ++i) {
         if (slots_host[i] < 0 || slots_host[i] >= s->cur_B) return fail(EMMAX_ERR_INVALID, "slot %d outside 0..%d", slots_host[i], s->cur_B - 1);
+        if (staged_idx_host[i] < 0 || staged_idx_host[i] >= s->n_stg) return fail(EMMAX_ERR_INVALID, "staged request %d outside 0..%d", staged_idx_host[i], s->n_stg - 1);
         for (int j = 0; j < i; ++j)
-            if (slots_host[j] == slots_host[i]) return fail(EMMAX_ERR_INVALID, "slot %d committed twice", slots_host[i]);
+            if (slots_host[j] == slots_host[i] || staged_idx_host[j] == staged_idx_host[i]) return fail(EMMAX_ERR_INVALID, "slot / staged request named twice");
         c.slot[i] = slots_host[i];
+        c.src[i] = s->stg0 + staged_idx_host[i];
     }
-    c.n = n; c.stg0 = s->stg0; c.max_pages = s->max_pages; c.max_out = s->max_out;
+    c.n = n; c.max_pages = s->max_pages; c.max_out = s->max_out;
     c.cur_tok = s->cur_tok; c.ctx_len = s->ctx_len; c.done = s->done; c.n_out = s->n_out; c.max_new = s->max_new_d;
     c.stop_m = s->stop_m; c.stop_after = s->stop_after; c.out_ids = s->out_ids; c.page_table = s->page_table;
     hipStream_t user = (hipStream_t)stream, st;
     int r = slot_enter(s, user, &st);
     if (r) return r;
     KCHK(launch_slots_commit(c, st));
-    for (int i = 0; i < n; ++i) s->S[slots_host[i]] = s->S[s->stg0 + i];
+    for (int i = 0; i < n; ++i) s->S[slots_host[i]] = s->S[s->stg0 + staged_idx_host[i]];
     return slot_leave(s, user, st);
 }
 

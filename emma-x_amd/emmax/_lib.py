@@ -80,7 +80,7 @@ SIGNATURES = {
     "emmax_slot_prefill": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp]),
     "emmax_slots_prefill": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "emmax_slots_prefill_staged": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
-    "emmax_slots_commit": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "emmax_slots_commit": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "emmax_slots_step": (C.c_int, [_vp, C.c_int, _vp]),
     "emmax_slots_state": (C.c_int, [_vp, _vp, _vp, _vp]),
     "emmax_slot_output": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp]),

@@ -41,7 +41,7 @@ class _Staged:
     """A staged prefill in flight on the admission stream."""
 
     def __init__(self, n, event, keep):
-        self.n, self.event, self.keep = n, event, keep
+        self.n, self.event, self.keep, self.committed = n, event, keep, 0
 
     def ready(self) -> bool:
         return self.event.query()
@@ -335,16 +335,23 @@ class EmmaxEngine:
         ev.record(torch.cuda.current_stream())
         return _Staged(n, ev, (ids_d, pe))
 
-    def slots_commit(self, staged: "_Staged", slots: Sequence[int]) -> None:
-        """Move the staged requests into `slots` (idle) on the CURRENT (decode) stream, after the staged prefill has finished."""
-        if len(slots) != staged.n:
-            raise ValueError("slots_commit: one slot per staged request")
+    def slots_commit(self, staged: "_Staged", slots: Sequence[int], staged_idx: Optional[Sequence[int]] = None) -> None:
+        """Move staged requests `staged_idx` (default: the first len(slots) not yet committed) into `slots` (idle) on the CURRENT
+        (decode) stream, after the staged prefill has finished.  A batch may be committed piecemeal as slots free up."""
+        k = len(slots)
+        if staged_idx is None:
+            staged_idx = list(range(staged.committed, staged.committed + k))
+        if k < 1 or len(staged_idx) != k or max(staged_idx) >= staged.n:
+            raise ValueError("slots_commit: one staged request per slot")
         torch.cuda.current_stream().wait_event(staged.event)
-        arr = (C.c_int32 * staged.n)(*[int(v) for v in slots])
-        _lib.check(self.lib.emmax_slots_commit(self._session, arr, staged.n, _lib.current_stream()), "emmax_slots_commit")
+        sl = (C.c_int32 * k)(*[int(v) for v in slots])
+        si = (C.c_int32 * k)(*[int(v) for v in staged_idx])
+        _lib.check(self.lib.emmax_slots_commit(self._session, si, sl, k, _lib.current_stream()), "emmax_slots_commit")
+        staged.committed += k
         self._commit_event = torch.cuda.Event()
         self._commit_event.record(torch.cuda.current_stream())
-        staged.keep = None
+        if staged.committed >= staged.n:
+            staged.keep = None
 
     def slots_step(self, n_steps: int) -> None:
         _lib.check(self.lib.emmax_slots_step(self._session, int(n_steps), _lib.current_stream()), "emmax_slots_step")

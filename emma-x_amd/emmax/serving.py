@@ -66,7 +66,7 @@ class SlotScheduler:
 
     def __init__(self, engine, encode: Callable[[List[Any]], List[Any]], n_slots: int = 8, poll_every: int = 16,
                  stop_trigger: Sequence[int] = (), stop_after: int = 0, clock: Callable[[], float] = time.perf_counter,
-                 encode_ahead: int = 0, overlap: Optional[bool] = None) -> None:
+                 encode_ahead: int = 0, overlap: Optional[bool] = None, stage_batch: Optional[int] = None) -> None:
         if not 1 <= n_slots <= 8:
             raise ValueError(f"n_slots {n_slots} outside 1..8")
         if poll_every < 1:
@@ -90,7 +90,10 @@ class SlotScheduler:
         if overlap and not has:
             raise ValueError("overlap=True needs an engine with admission / slots_prefill_staged / slots_commit")
         self.overlap = has if overlap is None else bool(overlap)
-        self._pending = None                         # (staged handle, [(request, t_submit), ...]) of the admission in flight
+        # requests are staged AHEAD of need, `stage_batch` at a time (default: half the slots), whether or not a slot is free: a slot
+        # that retires finds its successor prefilled and is refilled at the same poll
+        self.stage_batch = max(1, min(int(stage_batch) if stage_batch else max(1, n_slots // 2), n_slots))
+        self._pending = None                         # [staged handle, [(request, t_submit), ...], committed so far] of the staged batch
         self.overlapped_admissions = 0
         engine.set_stop(list(stop_trigger), stop_after)
         engine.slots_open(n_slots)
@@ -140,37 +143,42 @@ class SlotScheduler:
         return [self._embeds.pop(id(r)) for r, _ in batch]
 
     def _start_admission(self) -> bool:
-        """Overlap mode: issue frame encode + staged prefill of as many queued requests as there are free slots on the admission
-        stream; returns at once (nothing is awaited)."""
-        free = [s for s in range(self.n_slots) if s not in self.active]
-        take = min(len(free), len(self.queue))
-        if take == 0 or self._pending is not None:
+        """Overlap mode: issue frame encode + staged prefill of the next `stage_batch` queued requests on the admission stream --
+        ahead of need, whether or not a slot is free; returns at once (nothing is awaited)."""
+        if self._pending is not None or not self.queue:
             return False
+        free = sum(1 for s in range(self.n_slots) if s not in self.active)
+        take = min(len(self.queue), max(self.stage_batch, free))
         batch = [self.queue.popleft() for _ in range(take)]
         with self.engine.admission():
             embeds = self._encode_for(batch)
             staged = self.engine.slots_prefill_staged([list(r.prompt_ids) for r, _ in batch], embeds if embeds[0] is not None else None,
                                                       [r.max_new_tokens for r, _ in batch])
-        self._pending = (staged, batch)
+        self._pending = [staged, batch, 0]
         return True
 
     def _join_admission(self, wait: bool) -> int:
-        """Commit the admission in flight once its prefill has finished (wait=True: block for it -- nothing else to do)."""
+        """Move staged requests into the slots that are free right now, if the staged prefill has finished (wait=True: block for it
+        -- the decode batch is idle, there is nothing else to do)."""
         if self._pending is None:
             return 0
-        staged, batch = self._pending
+        staged, batch, k0 = self._pending
+        slots = [s for s in range(self.n_slots) if s not in self.active][: len(batch) - k0]
+        if not slots:
+            return 0
         if not staged.ready():
             if not wait:
                 return 0
             staged.wait()
-        slots = [s for s in range(self.n_slots) if s not in self.active][: len(batch)]
-        self.engine.slots_commit(staged, slots)
+        self.engine.slots_commit(staged, slots, list(range(k0, k0 + len(slots))))
         t_adm = self.clock()
-        for slot, (req, t_sub) in zip(slots, batch):
+        for slot, (req, t_sub) in zip(slots, batch[k0:k0 + len(slots)]):
             self.active[slot] = _Active(req, t_sub, t_adm)
-        self._pending = None
+        self._pending[2] = k0 + len(slots)
+        if self._pending[2] >= len(batch):
+            self._pending = None
         self.overlapped_admissions += 1
-        return len(batch)
+        return len(slots)
 
     def _retire(self) -> int:
         done, n_out = self.engine.slots_state()
@@ -190,7 +198,8 @@ class SlotScheduler:
         if self.overlap:
             while self.queue or self.active or self._pending is not None:
                 self._start_admission()
-                self._join_admission(wait=not self.active)     # idle decode batch: the admission is all there is to wait for
+                if self._join_admission(wait=not self.active):   # (idle decode batch: the admission is all there is to wait for)
+                    self._start_admission()                       # staging rows free again: the next batch goes out at once
                 if not self.active:
                     continue
                 self.engine.slots_step(self.poll_every)

@@ -186,13 +186,15 @@ int emmax_slots_prefill(emmax_session* s, int slot0, int n, const int32_t* ids_d
  *   emmax_slots_prefill_staged  prefills n requests into the staging rows on `stream`, which must be a stream of its own (not the
  *                               default stream, not the one the decode steps run on): the call touches nothing a decode step reads,
  *                               so decode steps may run beside it.  Arguments as emmax_slots_prefill without slot0.
- *   emmax_slots_commit          moves staged request i into slot slots_host[i] (idle, released) on the DECODE stream, between two
- *                               steps: per-row state and the output row are copied and the page-table rows swapped -- no K/V moves.
- *                               The caller orders it after the staged prefill (event), and orders the NEXT staged prefill after it.
+ *   emmax_slots_commit          moves staged request staged_idx_host[i] (0 .. n_staged-1 of the last staged batch) into slot
+ *                               slots_host[i] (idle, released) on the DECODE stream, between two steps: per-row state and the output
+ *                               row are copied and the page-table rows swapped -- no K/V moves.  A staged batch may be committed
+ *                               piecemeal, as slots free up.  The caller orders it after the staged prefill (event), and orders the
+ *                               NEXT staged prefill after the last commit of the batch.
  * One staged batch at a time.  Host scheduler: emmax/serving.py (SlotScheduler, overlap=True). */
 int emmax_slots_prefill_staged(emmax_session* s, int n, const int32_t* ids_dev, int P_max, const int32_t* lens_host,
                                const void* patch_embeds_dev, const int32_t* max_new_host, emmax_stream stream);
-int emmax_slots_commit(emmax_session* s, const int32_t* slots_host, int n, emmax_stream stream);
+int emmax_slots_commit(emmax_session* s, const int32_t* staged_idx_host, const int32_t* slots_host, int n, emmax_stream stream);
 /* n_steps greedy decode steps over all slots (no host synchronisation); idle / finished slots stay put. */
 int emmax_slots_step(emmax_session* s, int n_steps, emmax_stream stream);
 /* Copy the per-slot done flags and generated-token counts to device buffers int32[n_slots] (asynchronous on `stream`). */

@@ -236,15 +236,18 @@ class FakeStagedEngine(FakeEngine):
         assert all(pe["encoded"] for pe in embeds)
         return self.staged[0]
 
-    def slots_commit(self, handle, slots):
+    def slots_commit(self, handle, slots, staged_idx=None):
         h, sts, prompts = self.staged
-        assert h is handle and h.ready() and len(slots) == len(sts) and not self.in_admission
-        for slot, st, pr in zip(slots, sts, prompts):
+        assert h is handle and h.ready() and not self.in_admission and len(slots) == len(staged_idx) >= 1
+        for slot, i in zip(slots, staged_idx):
             assert self.slots[slot] is None, "commit into a busy slot"
-            self.slots[slot] = st
-            self.prefills.append((slot, st["rid"], pr))
+            assert sts[i] is not None, "staged request committed twice"
+            self.slots[slot] = sts[i]
+            self.prefills.append((slot, sts[i]["rid"], prompts[i]))
+            sts[i] = None
         self.commits.append(list(slots))
-        self.staged = None
+        if all(st is None for st in sts):
+            self.staged = None
 
 
 def test_overlapped_admission_keeps_decoding_while_a_request_is_prefilled():
@@ -259,7 +262,7 @@ def test_overlapped_admission_keeps_decoding_while_a_request_is_prefilled():
     assert sorted(r.rid for r in res) == list(range(len(lengths)))
     for r in res:
         assert r.ids == plans[r.rid] and r.t_submit <= r.t_admit <= r.t_done
-    assert sch.overlapped_admissions == len(eng.commits) >= 4 and eng.staged is None
+    assert sch.overlapped_admissions == len(eng.commits) >= 4 and eng.staged is None and sch.stage_batch == 1
     assert sum(len(c) for c in eng.commits) == len(lengths)
     # the same requests through the blocking admission give the same outputs
     eng2 = FakeEngine(plans)
