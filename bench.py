@@ -311,7 +311,7 @@ def main():
         traffic = None
         # (measured on the kernels the line names: r03 = the K-split kernels of decode_ks.hip / decode_km.hip, unchanged since; an
         # N > 1 line carries no number that was not measured in its own run, so it reports null)
-        pmc_name = {(1, False): "r03_pmc_traffic.json", (8, False): "r03_pmc_traffic_b8_bf16.json",
+        pmc_name = {(1, False): "r04_pmc_traffic.json", (8, False): "r03_pmc_traffic_b8_bf16.json",
                     (8, True): "r03_pmc_traffic_b8_fp8.json"}.get((B, bool(args.fp8))) if world == 1 else None
         pmc_file = os.path.join(ROOT, "profiles", pmc_name or "none")
         if not args.tiny and pmc_name and os.path.isfile(pmc_file):

@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void emmax_splitk_reduce_kernel(GemmParams p) 
 
 template <class G, int ACT, bool OUT_F32, bool LN = false, int DEEP = 0>
 int launch_t(const GemmParams& p, hipStream_t stream) {
-    if constexpr (DEEP == 0 && !OUT_F32) {
+    if constexpr (DEEP == 0) {   // (fp32 output included: the split-K slices of the one-frame prefill are 128 x 128 launches)
         // Third stage by shape (tuning switch gemm_deep = -1; 0 = two stages of both as in rounds 1-3, 1 / 2 = force A / W).  Measured in
         // the pipeline (tools/stage_bench.py, interleaved runs on one box, profiles/r04_gemm_deep_ab.txt): the ViT stages, whose
         // activations (137 MB) stream past 2-9 MB of weights, gain 2-4 % end to end with the deep A ring (single shapes +3 .. 14 %); the
