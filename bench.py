@@ -335,7 +335,7 @@ def main():
                    % (world, args.steps, args.warmup, B, P, T, " --fp8" if args.fp8 else "", " --graph" if args.graph else "", " --tiny" if args.tiny else ""),
             "config": {"workload": _workload(args, world, B, P, T),
                        "batch_per_gpu": B, "global_batch": B * world, "prompt_tokens": P, "new_tokens": T, "context": ctx + T,
-                       "parallelism": f"dp{world}", "hipgraph": eng.graph_active(), "attention_in_qkv_launch": eng.attn_fused()},
+                       "parallelism": f"dp{world}", "hipgraph": eng.graph_active()},
             "value_per_gpu": round(actions_per_s / world, 4), "single_gpu_same_workload": alone,
             "scaling_efficiency": round(actions_per_s / (world * alone["value"]), 4) if alone else None,
             "rccl_ranks": rccl_ranks, "dist_backend": edist.backend_name(),

@@ -20,7 +20,6 @@
 #include <cstdlib>
 
 #include "common.h"
-#include "decode_attn_tail.h"
 #include "kernels.h"
 
 namespace {
@@ -113,21 +112,8 @@ __device__ unsigned long long g_ks_trace[512 * 2 * 4 * 6];
 #else
 #define KS_STAMP(op, k, v) do { } while (0)
 #endif
-// FUSE (qkv launch with the attention tail, MHA): the launch's pairs are handed out in CLUSTER order -- the 16 consecutive blocks
-// 16 h .. 16 h + 15 own the q, k and v rows of head h (3 x head_dim / 2 pairs = 12 per block at head_dim 128) -- instead of q of all
-// heads, then k, then v.  gv: position in that order;  returns the pair index of the stand-alone order (head block hb = g >> shift)
-template <bool FUSE>
-__device__ __forceinline__ int ks_real_pair(const GemvParams& p, int gv) {
-    if (!FUSE) return gv;
-    const int ph = 1 << p.ks_shift;                 // pairs per head
-    const int c = gv / (3 * ph), idx = gv - c * (3 * ph);
-    const int part = idx >> p.ks_shift, d = idx & (ph - 1);
-    return ((part * p.Hq + c) << p.ks_shift) + d;
-}
-
-template <int MODE, bool FUSE = false>
+template <int MODE>
 __device__ __forceinline__ void ks_pair_rows(const GemvParams& p, int g, int& r0, int& r1) {
-    g = ks_real_pair<FUSE>(p, g);
     if (MODE == GEMV_QKV) {
         const int half = p.head_dim >> 1;
         const int hb = g >> p.ks_shift, d = g - hb * half;   // head_dim is a power of two (launcher)
@@ -153,7 +139,7 @@ __device__ __forceinline__ void ks_share(const GemvParams& p, int& g_lo, int& np
 // flat pointers hipcc kept a 64-bit VGPR address per row in flight (32 registers, and spills at 16 rows).  Rows past the
 // block's share get row index n_rows = the first byte past the matrix: the load returns zeros without touching memory, so a
 // batch is always RB unconditional loads (counted waits, no branches).
-template <int B, int MODE, int CPL, bool FUSE = false>
+template <int B, int MODE, int CPL>
 __device__ __forceinline__ void ks_issue(const GemvParams& p, int g_lo, int nrows, int bb, const unsigned (&voff)[CPL], u32x4_t (&wr)[KsRegs<B>::N]) {
     constexpr int RB = KsShape<B, CPL>::RB;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)((unsigned)p.n_rows * (unsigned)p.ldw * 2u), 0x00020000);
@@ -161,7 +147,7 @@ __device__ __forceinline__ void ks_issue(const GemvParams& p, int g_lo, int nrow
     for (int jj = 0; jj < RB; ++jj) {
         const int i = bb * RB + jj;
         int r0, r1;
-        ks_pair_rows<MODE, FUSE>(p, g_lo + (i >> 1), r0, r1);
+        ks_pair_rows<MODE>(p, g_lo + (i >> 1), r0, r1);
         // mask arithmetic, not a select: hipcc turned the select into a branch around the multiply, sixteen basic blocks per batch
         const int m = (i - nrows) >> 31;   // all ones: valid
         const int r = (((i & 1) ? r1 : r0) & m) | (p.n_rows & ~m);
@@ -192,7 +178,7 @@ __device__ __forceinline__ void ks_chunks(int K, int wave, int lane, int (&coff)
 // (Round 3 chained four of these in one persistent launch with in-kernel mailbox hand-offs: bit-identical and 18 % slower --
 // DESIGN.md section 6; that variant lives in the history, commit 61d5036, not in the product source.)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int B, int MODE, bool NORM, int XS, int CPL, bool FUSE = false>
+template <int B, int MODE, bool NORM, int XS, int CPL>
 __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsRegs<B>::N], float* part, float* sumsq, int rows_cap,
                                           int trace_op = -1) {
     constexpr int RB = KsShape<B, CPL>::RB;
@@ -208,8 +194,7 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
     const bool epi = wave < B && lane < npairs;
     const int eb = wave < B ? wave : 0, epair = g_lo + min(lane, max(npairs - 1, 0));
     int er0, er1;
-    ks_pair_rows<MODE, FUSE>(p, epair, er0, er1);
-    const int rpair = ks_real_pair<FUSE>(p, epair);   // the pair in the stand-alone order: head block and element from it
+    ks_pair_rows<MODE>(p, epair, er0, er1);
     float pre_a = 0.f, pre_b = 0.f;
     int pre_pos = 0, pre_pg = 0;
     if (epi) {
@@ -221,7 +206,7 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
             pre_pos = p.ctx_len[eb];
             pre_pg = p.page_table[(size_t)eb * p.max_pages + pre_pos / p.page];
             const int half = p.head_dim >> 1;
-            const int hb = rpair >> p.ks_shift, d = rpair - hb * half;
+            const int hb = epair >> p.ks_shift, d = epair - hb * half;
             if (hb < p.Hq + p.Hkv) {
                 pre_a = p.cos_t[(size_t)pre_pos * half + d];
                 pre_b = p.sin_t[(size_t)pre_pos * half + d];
@@ -250,7 +235,7 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
                 for (int e = 0; e < 4; ++e) xr[b][j][e] = cok[j] ? v[e] : 0u;
             }
         __builtin_amdgcn_sched_barrier(0);
-        ks_issue<B, MODE, CPL, FUSE>(p, g_lo, nrows, 0, voff, wr);
+        ks_issue<B, MODE, CPL>(p, g_lo, nrows, 0, voff, wr);
     } else {
         u32x4_t nw[CPL];
         if constexpr (NORM) {
@@ -272,7 +257,7 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
             }
         }
         // right behind the activations: they are waited for by count while the head of the stream is in flight
-        ks_issue<B, MODE, CPL, FUSE>(p, g_lo, nrows, 0, voff, wr);
+        ks_issue<B, MODE, CPL>(p, g_lo, nrows, 0, voff, wr);
         float ss[B];
 #pragma unroll
         for (int b = 0; b < B; ++b) {
@@ -322,7 +307,7 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
         __builtin_amdgcn_sched_barrier(0);
         // (past the last batch every row is out of range: RB free loads of zeros -- a branch here cost hipcc its register
         // assignment: the refill landed in fresh registers and the kernel spilled)
-        ks_issue<B, MODE, CPL, FUSE>(p, g_lo, nrows, bb + 1, voff, wr);
+        ks_issue<B, MODE, CPL>(p, g_lo, nrows, bb + 1, voff, wr);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < B; ++b) {
@@ -371,25 +356,24 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
     } else if (MODE == GEMV_QKV) {
         if (epi) {
             const int hd = p.head_dim, half = hd >> 1;
-            const int hb = rpair >> p.ks_shift, d = rpair - hb * half;
+            const int hb = epair >> p.ks_shift, d = epair - hb * half;
             // linear outputs are bf16 activations in the reference; RoPE acts on those
             const float x0 = bf2f(f2bf(red0)), x1 = bf2f(f2bf(red1));
             if (hb < p.Hq + p.Hkv) {
-                // FUSE: the attention tail of sibling blocks (possibly on another XCD) reads these rows inside this launch: write-through
                 const bf16_t y0 = f2bf(x0 * pre_a - x1 * pre_b), y1 = f2bf(x1 * pre_a + x0 * pre_b);
                 if (hb < p.Hq) {
                     bf16_t* q = (bf16_t*)p.y + (size_t)eb * p.ldy + hb * hd;
-                    st_act_bf16(q + d, y0, FUSE);
-                    st_act_bf16(q + d + half, y1, FUSE);
+                    q[d] = y0;
+                    q[d + half] = y1;
                 } else {
                     bf16_t* kc = (bf16_t*)p.kcache + (((size_t)pre_pg * p.Hkv + (hb - p.Hq)) * p.page + pre_pos % p.page) * hd;
-                    st_act_bf16(kc + d, y0, FUSE);
-                    st_act_bf16(kc + d + half, y1, FUSE);
+                    kc[d] = y0;
+                    kc[d + half] = y1;
                 }
             } else {
                 bf16_t* vc = (bf16_t*)p.vcache + (((size_t)pre_pg * p.Hkv + (hb - p.Hq - p.Hkv)) * p.page + pre_pos % p.page) * hd;
-                st_act_bf16(vc + d, f2bf(x0), FUSE);
-                st_act_bf16(vc + d + half, f2bf(x1), FUSE);
+                vc[d] = f2bf(x0);
+                vc[d + half] = f2bf(x1);
             }
         }
     } else if (MODE == GEMV_LMHEAD) {
@@ -422,7 +406,7 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
 // work on pairs: (d, d + hd/2) of a head for QKV, (gate_i, up_i) for GATEUP, two consecutive rows otherwise).
 // Dynamic LDS: float part[8 waves][B][rows_cap] + float sumsq[8][B].
 // ---------------------------------------------------------------------------------------------------------------------
-template <int B, int MODE, bool NORM, bool XATTN, int CPL, bool FUSE = false>
+template <int B, int MODE, bool NORM, bool XATTN, int CPL>
 __global__ __launch_bounds__(KS_NT, 4) void emmax_decode_ks_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -430,38 +414,10 @@ __global__ __launch_bounds__(KS_NT, 4) void emmax_decode_ks_kernel(GemvParams p)
     float* part = (float*)ks_smem;          // [KS_WAVES][B][rows_cap]
     float* sumsq = part + KS_WAVES * B * rows_cap;   // [KS_WAVES][B]
     u32x4_t wr[KsRegs<B>::N];
-    ks_run_op<B, MODE, NORM, XATTN ? XS_ATTN : XS_GLOBAL, CPL, FUSE>(p, wr, part, sumsq, rows_cap, 0);
-    if constexpr (FUSE) {
-        // ---- the attention of this step as the tail of the qkv launch (decode_attn_tail.h).  Cluster h = blocks 16 h .. 16 h + 15 = the
-        // q / k / v rows of head h.  Arrival: every storing wave drains its write-through stores, one agent-scope add on the cluster's
-        // counter; the counter only grows (16 per launch): a block's target is the next multiple of 16 above its ticket.  All blocks
-        // of the launch are resident (the launcher checks the occupancy: 2 per CU), a spinning block never holds up a sibling.
-        static_assert(MODE == GEMV_QKV, "the attention tail belongs to the qkv launch");
-        __shared__ attn_tail::Shared sh;
-        const int cluster = blockIdx.x >> 4, j = blockIdx.x & 15;
-        unsigned int* ctr = p.attn_ctr + cluster;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned t = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sh.target = (t & ~15u) + 16u;
-        }
-        if (j >= 8 * B) return;             // batch 1: blocks 8 .. 15 of a cluster have no split to compute
-        attn_tail::run(p, j >> 3, cluster, j & 7, 8, sh, [&] {
-            if (tid == 0) {
-                const unsigned target = sh.target;
-                unsigned spins = 0;
-                while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 22)) break;   // ~1 s: a sibling block is not resident (never on a launch the launcher admitted)
-                }
-            }
-            __syncthreads();
-        });
-    }
+    ks_run_op<B, MODE, NORM, XATTN ? XS_ATTN : XS_GLOBAL, CPL>(p, wr, part, sumsq, rows_cap, 0);
 }
 
-template <int B, int MODE, bool NORM, bool XATTN, int CPL, bool FUSE = false>
+template <int B, int MODE, bool NORM, bool XATTN, int CPL>
 int ks_launch_t(GemvParams p, hipStream_t stream, int* grid_out) {
     constexpr int RB = KsShape<B, CPL>::RB;
     int grid = min(512, p.n_groups);
@@ -473,21 +429,7 @@ int ks_launch_t(GemvParams p, hipStream_t stream, int* grid_out) {
     p.kc = cdiv(2 * pairs_max, RB) * RB;
     const size_t smem = (size_t)(KS_WAVES * B * p.kc + KS_WAVES * B) * sizeof(float);
     if (grid_out) *grid_out = grid;
-    auto kern = emmax_decode_ks_kernel<B, MODE, NORM, XATTN, CPL, FUSE>;
-    if constexpr (FUSE) {
-        // clusters of 16 blocks wait for each other inside the launch: every block must be resident (512 blocks = 2 per CU)
-        static int resident = -1;
-        static size_t resident_smem = 0;
-        if (resident < 0 || resident_smem != smem) {
-            int n = 0, dev = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, KS_NT, smem) != hipSuccess) n = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-            resident = n * cus;
-            resident_smem = smem;
-        }
-        if (grid != 512 || p.n_groups != 512 * 12 || grid > resident) return -2;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(KS_NT), smem, stream, p);
+    hipLaunchKernelGGL((emmax_decode_ks_kernel<B, MODE, NORM, XATTN, CPL>), dim3(grid), dim3(KS_NT), smem, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
@@ -526,15 +468,7 @@ int launch_decode_ks(int mode, const GemvParams& p, int B, hipStream_t stream, i
     if (B < 1 || B > 2 || p.wscale) return -2;
     if (p.K % 64 || p.K > 64 * 64 * 3 || p.ldw % 8 || p.ldx % 8 || p.K < 64) return -2;
     switch (mode) {
-        case GEMV_QKV:
-            if (p.attn_part_out) {   // with this step's attention as its tail: MHA at head_dim 128, K = one chunk per lane, 12 pairs per block
-                if (p.Hq != p.Hkv || p.head_dim != 128 || p.K > 4096 || !p.attn_ctr || p.page < 1 || (p.page & (p.page - 1)) || p.max_pages > attn_tail::SP) return -2;
-                GemvParams q = p;
-                if (ks_prepare<GEMV_QKV>(q)) return -2;
-                if (B == 1) return ks_launch_t<1, GEMV_QKV, true, false, 1, true>(q, stream, grid_out);
-                return ks_launch_t<2, GEMV_QKV, true, false, 1, true>(q, stream, grid_out);
-            }
-            return ks_launch_mode<GEMV_QKV, true, false>(p, B, stream, grid_out);
+        case GEMV_QKV: return ks_launch_mode<GEMV_QKV, true, false>(p, B, stream, grid_out);
         case GEMV_RESID:
             if (p.attn_part && (p.K != p.Hq * 128)) return -2;   // the merge maps 16 chunks to a 128-wide head
             // The o-proj with the split merge in its prologue: every WAVE merges the chunks of its own four heads (24 loads in

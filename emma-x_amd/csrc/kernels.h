@@ -116,7 +116,6 @@ struct EmmaxTune {
     int attn_nsplit;     // 0: KV splits of the decode attention chosen from (B, kv heads); > 0: forced (rounded down to 2^k, <= 16)
     int attn_direct;     // 1: with one KV split the attention launch writes the normalised bf16 row itself
     int fold_embed;      // 1: layer 0's qkv launch gathers the embedding row itself (batch 1-2, bf16)
-    int attn_fuse;       // 1: batch 1-2 bf16 MHA: the decode attention runs as the tail of the qkv launch (no attention launch)
     int mfma_xbar;       // 1: decode_mfma.hip orders the activation requests ahead of the weight head with a block barrier
     int gemm_big;        // -1: planned tile geometry; 0 / 1: all small / all big tiles, no split-K
     int gemm_splitk;     // 1: split-K for under-filled long-K GEMMs
@@ -169,13 +168,6 @@ struct GemvParams {
     const int32_t* x_tok;   // K-split kernel, non-null: x row b = x[x_tok[b]] (p.x = embedding table, ids clamped to x_vocab): the embed launch
     void* x_copy;           //   folded into layer 0's qkv; block 0 also copies the rows to x_copy [B, ldx] (the residual stream)
     int x_vocab;
-    // K-split kernel, QKV, non-null: this step's split-KV attention runs as the TAIL of the launch (decode_attn_tail.h): the partials
-    // f32 [B][Hq][8][132] the o-proj merges, the per-head cluster counters (uint32 [Hkv], only ever incremented), the rows' done
-    // flags (or null) and the softmax scale.  launch_decode_ks returns -2 when the shape is outside the fused form.
-    float* attn_part_out;
-    unsigned int* attn_ctr;
-    const int32_t* attn_done;
-    float attn_scale;
 };
 int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
 // decode_ks.hip: the batch 1-2 bf16 projections with K split across the waves of a block (activation slice in registers, no

@@ -54,7 +54,6 @@ const TuneEntry kTune[] = {
     {"streamk", &EmmaxTune::streamk, 1},       {"fp8_gemv", &EmmaxTune::fp8_gemv, -1},
     {"attn_nsplit", &EmmaxTune::attn_nsplit, 0}, {"attn_direct", &EmmaxTune::attn_direct, 1},
     {"fold_embed", &EmmaxTune::fold_embed, 1}, {"mfma_xbar", &EmmaxTune::mfma_xbar, 1},
-    {"attn_fuse", &EmmaxTune::attn_fuse, 1},
     {"gemm_big", &EmmaxTune::gemm_big, -1},    {"gemm_splitk", &EmmaxTune::gemm_splitk, 1},
     {"gemm_deep", &EmmaxTune::gemm_deep, -1},       {"gemm_dbg", &EmmaxTune::gemm_dbg, 0},
     {"gemm_lnfuse", &EmmaxTune::gemm_lnfuse, 1}, {"attn_resident", &EmmaxTune::attn_resident, -1},
@@ -344,10 +343,7 @@ struct emmax_session {
     int graph_failed = 0;
     int last_step_graph = 0;   // the most recent decode step was a graph replay (what emmax_session_graph_active reports)
     hipEvent_t ev = nullptr;
-    unsigned int* attn_ctr = nullptr;   // device: cluster counters of the fused qkv + attention launch, [layers][kv heads], only ever incremented
-    int graph_epoch = -1;
-    bool profiling = false;     // emmax_profile_decode_stage: the attention stage is launched stand-alone even when the step fuses it
-    bool fuse_ok = true;        // cleared when the fused qkv + attention launcher refused the shape (the stages run unfused from then on)      // emmax_tune().epoch the graph was captured under (a changed switch re-captures)
+    int graph_epoch = -1;      // emmax_tune().epoch the graph was captured under (a changed switch re-captures)
     hipStream_t own_stream = nullptr;   // used by emmax_generate when the caller's stream is the (uncapturable) legacy stream
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     std::string graph_err;
@@ -418,7 +414,6 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->stop_m = (int32_t*)b.take(Br * 4);
     s->stop_after = (int32_t*)b.take(Br * 4);
     s->page_table = (int32_t*)b.take((int64_t)Br * s->max_pages * 4);
-    s->attn_ctr = (unsigned int*)b.take((int64_t)m->cfg.n_layers * m->cfg.n_kv_heads * 4);
     s->sk_ws = (unsigned long long*)b.take((int64_t)256 * 2 * 256 * 8);
     s->splitk_bytes = (int64_t)64 << 20;   // e.g. 4 slices of a 768 x 4096 prefill GEMM = 50 MB; smaller budgets just split less
     s->splitk_ws = (float*)b.take(s->splitk_bytes);
@@ -687,15 +682,6 @@ static bool attn_direct_on(const emmax_session* s, int B) {
     return decode_attn_nsplit(B, s->m->cfg.n_kv_heads) == 1 && emmax_tune().attn_direct != 0;
 }
 
-// batch 1-2 on bf16 weights, MHA, head_dim 128, 8 KV splits: the qkv launch computes the attention partials itself (decode_ks.hip /
-// decode_attn_tail.h) and the step has no attention launch.  The launcher may still refuse (-2: shape / residency) -> plain stages.
-static bool attn_fused(const emmax_session* s, int B) {
-    const auto& c = s->m->cfg;
-    return emmax_tune().attn_fuse != 0 && s->fuse_ok && B < EMMAX_MFMA_MIN_BATCH && !s->m->fp8 && decode_ks_enabled() && c.n_heads == c.n_kv_heads &&
-           c.head_dim == 128 && s->m->H <= 4096 && s->m->H % 64 == 0 && s->m->qkv_dim == 512 * 24 && decode_attn_nsplit(B, c.n_kv_heads) == 8 &&
-           s->max_pages <= 512;
-}
-
 // GemvParams of a projection stage of decoder layer `li` (qkv / o-proj / gate-up / down), as every launcher takes them
 static void stage_params(emmax_session* s, int B, int li, int stage, GemvParams& p) {
     emmax_model* m = s->m;
@@ -710,10 +696,6 @@ static void stage_params(emmax_session* s, int B, int li, int stage, GemvParams&
             p.head_dim = c.head_dim; p.Hq = c.n_heads; p.Hkv = c.n_kv_heads; p.page = PAGE; p.max_pages = s->max_pages;
             p.ctx_len = s->ctx_len; p.page_table = s->page_table; p.cos_t = s->cos_t; p.sin_t = s->sin_t;
             p.kcache = kcache_of(s, li); p.vcache = vcache_of(s, li);
-            if (attn_fused(s, B)) {   // this step's attention as the tail of the qkv launch
-                p.attn_part_out = s->part; p.attn_ctr = s->attn_ctr + (size_t)li * c.n_kv_heads; p.attn_done = s->done;
-                p.attn_scale = 1.0f / sqrtf((float)c.head_dim);
-            }
             break;
         case STAGE_OPROJ:
             p.x = s->datt; p.ldx = m->q_dim; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
@@ -751,18 +733,9 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
     switch (stage) {
         case STAGE_QKV:
             stage_params(s, B, li, stage, p);
-            if (p.attn_part_out) {
-                p.W = L.wqkv;
-                const int r = launch_decode_ks(GEMV_QKV, p, B, st, &grid);
-                if (r == 0) return 0;
-                if (r != -2) return fail(EMMAX_ERR_HIP, "fused qkv + attention launch failed (layer %d, code %d)", li, r);
-                s->fuse_ok = false;          // outside the fused form (shape / residency): plain stages from here on, this layer included
-                stage_params(s, B, li, stage, p);
-            }
             KCHK(launch_proj(GEMV_QKV, p, L.wqkv, L.wqkv_fm, B, st, &grid, L.wqkv_sc, L.wqkv_r8, F8_QKV, L.wqkv_km, L.wqkv_km_sc));
             return 0;
         case STAGE_ATTN: {
-            if (attn_fused(s, B) && !s->profiling) return 0;   // computed by the qkv launch of this layer
             DecodeAttnParams a;
             a.q = s->dq; a.ldq = m->q_dim; a.kcache = kcache_of(s, li); a.vcache = vcache_of(s, li);
             a.page_table = s->page_table; a.ctx_len = s->ctx_len; a.done = s->done; a.part = s->part; a.Hkv = c.n_kv_heads; a.page = PAGE;
@@ -798,11 +771,6 @@ static int run_qkv0_with_embed(emmax_session* s, int B, hipStream_t st) {
     p.W = m->layers[0].wqkv;
     p.x = m->embed; p.x_tok = s->cur_tok; p.x_copy = s->dh; p.x_vocab = m->vocab;
     int r = launch_decode_ks(GEMV_QKV, p, B, st, nullptr);
-    if (r == -2 && p.attn_part_out) {   // the fused form refused: the same launch without the attention tail
-        s->fuse_ok = false;
-        p.attn_part_out = nullptr;
-        r = launch_decode_ks(GEMV_QKV, p, B, st, nullptr);
-    }
     if (r == -2) {
         KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st));
         return run_decode_stage(s, B, 0, STAGE_QKV, st);
@@ -1475,8 +1443,6 @@ int emmax_slot_release(emmax_session* s, int slot, emmax_stream stream) {
     return slot_leave(s, user, st);
 }
 
-int emmax_session_attn_fused(emmax_session* s) { return s && s->prefilled && attn_fused(s, s->cur_B) ? 1 : 0; }
-
 int emmax_session_graph_active(emmax_session* s) {
     if (s && !s->graph_exec && !s->graph_err.empty()) g_err = s->graph_err;   // why the capture was refused
     return s && s->graph_exec && s->last_step_graph ? 1 : 0;
@@ -1492,7 +1458,6 @@ int emmax_profile_decode_stage(emmax_session* s, int stage, int reps, float* avg
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     int launches = 0, r = 0;
-    s->profiling = true;   // (the attention stage is launched stand-alone even when the step computes it inside the qkv launch)
     // one untimed sweep (instruction cache, clocks), then `reps` timed sweeps over all layers: every launch streams a
     // different layer's weights, so nothing is served from the 256 MiB Infinity Cache that a real step would not get
     for (int pass = 0; pass < 2 && r == 0; ++pass) {
@@ -1510,7 +1475,6 @@ int emmax_profile_decode_stage(emmax_session* s, int stage, int reps, float* avg
             }
         }
     }
-    s->profiling = false;
     if (r) return r;
     HIPCHK(hipEventRecord(e1, st));
     HIPCHK(hipEventSynchronize(e1));

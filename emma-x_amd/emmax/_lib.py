@@ -74,7 +74,6 @@ SIGNATURES = {
     "emmax_set_current_tokens": (C.c_int, [_vp, _vp, _vp]),
     "emmax_generate": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "emmax_session_graph_active": (C.c_int, [_vp]),
-    "emmax_session_attn_fused": (C.c_int, [_vp]),
     "emmax_profile_decode_stage": (C.c_int, [_vp, C.c_int, C.c_int, _c_f32p, _vp]),
     "emmax_session_set_stop": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
     "emmax_slots_open": (C.c_int, [_vp, C.c_int, _vp]),

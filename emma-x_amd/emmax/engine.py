@@ -376,10 +376,6 @@ class EmmaxEngine:
     def graph_active(self) -> bool:
         return bool(self.lib.emmax_session_graph_active(self._session))
 
-    def attn_fused(self) -> bool:
-        """True when the decode steps of the active batch run the attention as the tail of the qkv launch (include/emmax.h)."""
-        return bool(self.lib.emmax_session_attn_fused(self._session))
-
     def profile_decode_stage(self, stage: int, reps: int = 3) -> float:
         """Mean duration (microseconds) of one launch of decode stage `stage` (see include/emmax.h), HIP-event timed."""
         us = C.c_float()

@@ -82,7 +82,7 @@ int emmax_config_size(void);
  * environment variable EMMAX_<NAME> for each of them ONCE, the first time any value is needed; afterwards only emmax_tuning_set
  * changes them (no launcher reads the environment).  Every default is the product path; the other values are the A/B partners
  * DESIGN.md quotes.  Names: graph (1 = hipGraph replay of the decode step, BASELINE configs[4]), ks, ks_oproj, ks_oproj_grid, km,
- * km_down, streamk, fp8_gemv, attn_nsplit, attn_direct, attn_fuse, fold_embed, mfma_xbar, gemm_big, gemm_splitk, gemm_deep, gemm_lnfuse, attn_resident.
+ * km_down, streamk, fp8_gemv, attn_nsplit, attn_direct, fold_embed, mfma_xbar, gemm_big, gemm_splitk, gemm_deep, gemm_lnfuse, attn_resident.
  * Not thread-safe against concurrent launches; a session re-captures its decode graph after a change. */
 int emmax_tuning_set(const char* name, int value);
 int emmax_tuning_get(const char* name, int* value_out);
@@ -153,11 +153,6 @@ int emmax_generate(emmax_session* s, int max_new_tokens, int stop_on_eos, int32_
 
 /* 1 when emmax_generate is replaying a captured hipGraph of the step (0: eager launches). */
 int emmax_session_graph_active(emmax_session* s);
-/* 1 when the decode steps of the active batch compute the attention inside the qkv launch (batch 1-2, bf16 weights, MHA at head_dim
- * 128: the 16 blocks that own a head's q / k / v rows hand over through a cluster counter and run the head's 8 KV splits as the tail
- * of the launch -- no attention launch; emma-x_amd/csrc/decode_attn_tail.h; tuning switch attn_fuse).  Same HF cached-attention math
- * as the stage launches (modeling_prismatic.py:325-341), bit for bit. */
-int emmax_session_attn_fused(emmax_session* s);
 /* Measurement hook (bench.py `roofline`): launch decode stage `stage` (0 qkv GEMV, 1 paged attention, 2 o-proj GEMV,
  * 3 gate/up GEMV, 4 down GEMV: once per layer; 5 lm-head GEMV+argmax) `reps` sweeps on `stream`, bracketed by HIP
  * events on that stream; returns the mean duration of one launch in microseconds.  Needs a prefilled session; the

@@ -159,35 +159,6 @@ def test_fp8_decode_at_context_768_matches_dequantised_oracle(device, setup, ora
     assert checked >= len(sel) * 40 // 8 and agree == checked, (agree, checked)
 
 
-@pytest.mark.parametrize("graph", [0, 1], ids=["eager", "hipgraph"])
-def test_attention_as_the_tail_of_the_qkv_launch_is_bit_identical(device, setup, model_bf16, tune, graph):
-    """Round 4 (VERDICT r03 "next" #2): at batch 1-2 the decode attention runs as the TAIL of the qkv launch -- the 16 blocks that own a
-    head's q / k / v rows hand over through a cluster counter and compute the head's 8 KV splits themselves (decode_attn_tail.h); the step has
-    no attention launch.  Same arithmetic in the same order: the logits of 70 steps (contexts 768 -> 838: the page boundary at 832 is
-    crossed, the newest key moves through every split position) must equal the stage launches' (tuning switch attn_fuse = 0) BIT FOR
-    BIT, at B = 1 and at a ragged B = 2, eager and replayed from a hipGraph."""
-    from emmax import _lib
-
-    cfg, _, _, frames, rows = setup
-    eng = model_bf16.engine
-    tune(graph=graph)
-    for sel in ([0], [2, 4]):            # prompts of 512 / (480, 300) tokens
-        fr = torch.from_numpy(frames[sel]).to(device)
-        outs = {}
-        for fuse in (1, 0):
-            tune(attn_fuse=fuse)
-            model_bf16._prefill([rows[i] for i in sel], None, fr, max_new=T8 + 2)
-            logits, ids = [], []
-            for _ in range(T8):
-                logits.append(eng.last_logits().clone())
-                eng.decode_step()
-            outs[fuse] = torch.stack(logits)
-            assert eng.graph_active() == bool(graph) and eng.attn_fused() == bool(fuse)
-        assert torch.isfinite(outs[1]).all()
-        assert torch.equal(outs[1], outs[0]), (sel, float((outs[1] - outs[0]).abs().max()))
-    assert _lib.tuning_get("attn_fuse") == 0
-
-
 def test_bf16_prefill_512_every_logit_row(device, setup, model_bf16):
     """All 768 prefill positions of one 512-token row (the M = 768 GEMM plans incl. split-K, causal attention at S = 768)."""
     from oracle import emmax_oracle as orc
