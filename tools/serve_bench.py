@@ -28,7 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--requests", type=int, default=32)
     ap.add_argument("--slots", type=int, default=8)
-    ap.add_argument("--poll", type=int, default=16, help="decode steps between two device polls")
+    ap.add_argument("--poll", type=int, default=4, help="decode steps between two device polls")
     ap.add_argument("--tiny", action="store_true")
     args = ap.parse_args()
     cfg = EmmaXConfig.tiny() if args.tiny else EmmaXConfig.emma_x_7b()
