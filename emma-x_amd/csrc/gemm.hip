@@ -277,7 +277,8 @@ template <class G, int ACT, bool OUT_F32, bool LN = false, int DEEP = 0>
 __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams p) {
     constexpr int BM = G::BM, BN = G::BN, MT = G::MT, NT = G::NT, STAGE_BYTES = G::STAGE, OP_BYTES = G::OPA;
     static_assert(G::OPA == G::OPB, "the stage slots of A and W are interchangeable");
-    constexpr int NSA = DEEP == 1 ? 3 : 2, NSW = DEEP == 2 ? 3 : 2;
+    constexpr int NSA = DEEP == 1 ? 3 : 2, NSW = DEEP >= 2 ? 3 : 2;
+    constexpr bool PP = DEEP == 3;   // staggered wave groups (below)
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     // byte offsets of the stages: A slot 0 and W slot 0 form "stage 0", everything behind them (64 KiB at least) is free while a
     // tile's epilogue runs (the next tile's K step 0 is already in flight into stage 0)
@@ -381,6 +382,66 @@ __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams 
         // freshly issued requests of the next steps with it -- in the middle of every tile's first K step
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
+        if constexpr (PP) {
+            // ---- DEEP = 3, lab: the two wave groups of the block -- waves 0 .. NW/2-1 (tile rows 0 .. BM/2) and their SIMD partners
+            // NW/2 .. NW-1 -- run HALF A K STEP APART, with a bare s_barrier per half step, so that one group's DMA issue and first
+            // fragment reads fall under the other's MFMAs.  A halves are private to a group (two stages, requested by the group at
+            // the start of its own step, one step ahead); W is shared by both groups for three half steps, hence THREE W slots: the
+            // request of step kt + 2 goes out as soon as step kt - 1's last reader has passed its end barrier.  Counted waits:
+            //   group 0, end of step kt:  all but W(kt + 2) landed;   group 1, middle of step kt: its W(kt + 1) rows landed (group 0
+            //   starts step kt + 1 behind that barrier), end of step kt: its A(kt + 1) landed.
+            auto run_steps = [&](auto grp_tag) {
+                constexpr int GRP = decltype(grp_tag)::value;
+                auto bar = [] { asm volatile("s_barrier" ::: "memory"); };
+                if (nk > 1) issueW(1, 1);
+                if (GRP == 1) bar();                              // half step 0: group 0 alone
+                int sw = 0;
+                for (int kt = 0; kt < nk; ++kt) {
+                    const int sw1 = sw + 1 == 3 ? 0 : sw + 1, sw2 = sw1 + 1 == 3 ? 0 : sw1 + 1;
+                    int offsA = a_slot(kt & 1), offsW = w_slot(sw);
+                    asm volatile("" : "+s"(offsA), "+s"(offsW));
+                    const unsigned char* stA = smem + offsA;
+                    const unsigned char* stW = smem + offsW;
+                    const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+                    if (n1) issueA(kt + 1, (kt + 1) & 1);
+                    if (GRP == 1 && n2) issueW(kt + 2, sw2);
+                    bf16x8_t fb[2][NT], fa[4];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) fb[0][j] = ldB(stW, 0, j);
+                    fa[0] = ldA(stA, 0);
+                    fa[1] = ldA(stA, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, NT + 2, 0);
+#pragma unroll
+                    for (int s_ = 0; s_ < 2 * MT; ++s_) {
+                        const int kk = s_ / MT, i = s_ % MT;
+                        if (s_ == MT) {                           // ---- middle of the step
+                            if (GRP == 1) {
+                                if (n1 && n2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                                else if (n1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            }
+                            bar();
+                            if (GRP == 0 && n2) issueW(kt + 2, sw2);
+                        }
+                        if (s_ + 2 < 2 * MT) fa[(s_ + 2) & 3] = ldA(stA, s_ + 2);
+                        if (s_ < NT) fb[1][s_] = ldB(stW, 1, s_);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[s_ & 3], acc[i][j], 0, 0, 0);
+                        if (s_ < NT && s_ + 2 < 2 * MT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        else if (s_ < NT || s_ + 2 < 2 * MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+                    }
+                    if (n2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    sw = sw1;
+                }
+                if (GRP == 0) bar();                              // half step 2 nk: group 1 alone
+            };
+            if (__builtin_amdgcn_readfirstlane(wave) >= G::NW / 2) run_steps(std::integral_constant<int, 1>{});
+            else run_steps(std::integral_constant<int, 0>{});
+        } else {
         if (nk > 1) {                                        // (slot 1 was part of the epilogue window until this barrier)
             if (DEEP == 1) issueA(1, 1);
             if (DEEP == 2) issueW(1, 1);
@@ -439,6 +500,7 @@ __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams 
                 __syncthreads();                                    // ... and everybody is done reading this one
             }
             sd = sd1;
+        }
         }
         // the next tile's first K step is requested BEFORE this tile's epilogue: its HBM/L2 latency (and the block
         // re-launch a one-tile-per-block grid would pay) hides under the stores
@@ -500,19 +562,25 @@ __global__ __launch_bounds__(256) void emmax_splitk_reduce_kernel(GemmParams p) 
 
 template <class G, int ACT, bool OUT_F32, bool LN = false, int DEEP = 0>
 int launch_t(const GemmParams& p, hipStream_t stream) {
-    if constexpr (DEEP == 0) {   // (fp32 output included: the split-K slices of the one-frame prefill are 128 x 128 launches)
-        // Third stage by shape (tuning switch gemm_deep = -1; 0 = two stages of both as in rounds 1-3, 1 / 2 = force A / W).  Measured in
-        // the pipeline (tools/stage_bench.py, interleaved runs on one box, profiles/r04_gemm_deep_ab.txt): the ViT stages, whose
-        // activations (137 MB) stream past 2-9 MB of weights, gain 2-4 % end to end with the deep A ring (single shapes +3 .. 14 %); the
-        // 128 x 128 geometry (split-K slices of the one-frame prefill, row remainders) gains 25-30 % per launch; the big-tile LLaMA
-        // prefill GEMMs, where both operands stream, lose 1-4 % with either ring and keep two stages.
+    if constexpr (DEEP == 0) {
+        // Main-loop variant by geometry (tuning switch gemm_deep = -1; 0 = two stages of both operands, one barrier per K step, as in
+        // rounds 1-3; 1 = deep A ring; 3 = staggered wave groups).  Measured, interleaved A/B per shape on one box
+        // (profiles/r04_gemm_deep_ab.txt, r04_gemm_pp_ab.txt): the 256 x 256 tile gains 1-14 % on EVERY shape with the staggered
+        // schedule (8192^3 1385 -> 1493 TFLOP/s, ViT shapes +7 .. 14 %, LLaMA prefill B = 8 +1 .. 4 %), more than with the deep A ring
+        // (ViT +3 .. 10 %, LLaMA -4 %); the 128 x 128 tile (two blocks of four waves per CU: nothing to stagger) gains 25-30 % per launch
+        // with the deep A ring.
         int deep = emmax_tune().gemm_deep;
-        if (deep < 0) deep = (std::is_same<G, GeomSmall>::value || (long long)p.M >= 4ll * p.N) ? 1 : 0;
+        constexpr bool big = std::is_same<G, GeomBig>::value;
+        if (deep < 0) deep = big ? 3 : 1;
+        if (deep == 3 && (!big || OUT_F32)) deep = big ? 0 : 1;
         if (deep == 1) return launch_t<G, ACT, OUT_F32, LN, 1>(p, stream);
-        if (deep == 2 && !LN) return launch_t<G, ACT, OUT_F32, LN, 2>(p, stream);
+        if constexpr (big && !OUT_F32) {
+            if (deep == 3) return launch_t<G, ACT, OUT_F32, LN, 3>(p, stream);
+        }
     }
     auto kern = emmax_gemm_bf16_kernel<G, ACT, OUT_F32, LN, DEEP>;
     constexpr int SMEM = DEEP ? G::SMEM_A3 : G::SMEM;
+    static_assert(DEEP != 2, "the deep W ring (round 4: never faster than the deep A ring) is not instantiated");
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return -4;

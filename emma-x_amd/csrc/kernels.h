@@ -119,7 +119,7 @@ struct EmmaxTune {
     int mfma_xbar;       // 1: decode_mfma.hip orders the activation requests ahead of the weight head with a block barrier
     int gemm_big;        // -1: planned tile geometry; 0 / 1: all small / all big tiles, no split-K
     int gemm_splitk;     // 1: split-K for under-filled long-K GEMMs
-    int gemm_deep;       // GEMM main loop, third LDS stage for the streaming operand: -1 = by shape (A when M >= N, else W), 0 = none, 1 = A, 2 = W
+    int gemm_deep;       // GEMM main loop: -1 = by geometry (256x256: staggered wave groups, 128x128: deep A ring), 0 = two stages + one barrier per step, 1 = third LDS stage for A, 3 = staggered wave groups (256x256 only)
     int gemm_dbg;        // lab: OR-ed into GemmParams::dbg (16 = the second half of the waves requests its slabs mid-step)
     int gemm_lnfuse;     // 1: LayerNorm / RMSNorm applied by the GEMM that consumes the normalised rows (no separate norm pass)
     int attn_resident;   // -1: resident ViT attention kernel where measured faster; 0: never; 2: whenever it fits (tests)
