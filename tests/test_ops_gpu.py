@@ -249,6 +249,32 @@ def test_gemm_with_layernorm_folded_in(device, M, N, K, act):
     assert_elementwise(Cd, ref, atol_frac=1.6e-2, what="gemm + folded LayerNorm")
 
 
+@pytest.mark.parametrize("M,N,K,act", [(256, 256, 64, 0), (1000, 3456, 1152, 0), (2048, 1024, 4096, 1), (768, 4096, 1024, 2), (5000, 512, 192, 0)])
+def test_gemm_main_loop_variants_are_bit_identical(device, tune, M, N, K, act):
+    """The three main loops of the GEMM -- two LDS stages + one barrier per K step (rounds 1-3, tuning switch gemm_deep = 0), the deep A
+    ring (1) and the staggered wave groups with counted waits across bare barriers (3; the default -1 picks by geometry) -- accumulate a
+    tile's K steps in the same order: their outputs must agree BIT FOR BIT, on every repetition.  A DMA / fragment-read race in the
+    counted-wait schedules shows up as a rare differing tile (tools/gemm_race_screen.py is the long form: 30 repetitions, 12 shapes)."""
+    L_, lib = _lib()
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A = bf(torch.randn(M, K, generator=g) * 0.5).to(device)
+    W = bf(torch.randn(N, K, generator=g) * 0.05).to(device)
+    bias = bf(torch.randn(N, generator=g) * 0.1).to(device) if act != 2 else None
+    No = N // 2 if act == 2 else N
+    outs = {}
+    for deep in (0, -1, 1, 3):
+        tune(gemm_deep=deep)
+        for rep in range(4):
+            out = torch.full((M, No), float("nan"), dtype=torch.bfloat16, device=device)
+            L_.check(lib.emmax_op_gemm(A.data_ptr(), K, W.data_ptr(), K, out.data_ptr(), No, M, N, K, L_.ptr(bias), act, None, None, 0, 0, stream()), "gemm")
+            torch.cuda.synchronize()
+            if deep == 0 and rep == 0:
+                outs[0] = out
+                assert torch.isfinite(out.float()).all()
+            else:
+                assert torch.equal(out.view(torch.int16), outs[0].view(torch.int16)), (deep, rep)
+
+
 def test_gemm_rejects_bad_shapes(device):
     L, lib = _lib()
     x = torch.zeros(128, 128, dtype=torch.bfloat16, device=device)

@@ -1,6 +1,6 @@
 """Race screen for the GEMM main-loop variants (lab, through the C ABI): every variant accumulates a tile's K steps in the same order, so the
 staggered / deep-ring loops must reproduce the two-stage loop's output BIT FOR BIT -- on every repetition.  A DMA / fragment-read race
-shows up as a rare differing tile.  usage: python tools/gemm_race_screen.py [reps]"""
+shows up as a rare differing tile.  usage: python tools/gemm_race_screen.py [reps [variants, e.g. -1,1,3]]"""
 import os
 import sys
 
@@ -15,7 +15,9 @@ SHAPES = [(256, 256, 64, 0), (256, 256, 128, 0), (512, 512, 192, 1), (4096, 4096
 
 
 def main():
+    global VARIANTS
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    VARIANTS = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [-1, 1, 3]
     lib = L.load()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
@@ -34,7 +36,7 @@ def main():
         ref = torch.empty(M, No, dtype=torch.bfloat16, device=dev)
         run(ref)
         torch.cuda.synchronize()
-        for deep in (-1, 1, 3):
+        for deep in VARIANTS:
             L.tuning_set("gemm_deep", deep)
             nbad = 0
             for _ in range(reps):
