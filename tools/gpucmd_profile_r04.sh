@@ -23,7 +23,7 @@ for part in $parts; do
                 timeout 600 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex emmax_decode --output-format csv -d $O/pmc_$c -o pmc -- python tools/pmc_probe.py > $O/pmc_$c.log 2>&1
                 rm -f $O/pmc_$c/*/*kernel_trace.csv
               done
-              python tools/pmc_summarize.py $O/pmc_FETCH_SIZE/*/pmc_counter_collection.csv $O/pmc_WRITE_SIZE/*/pmc_counter_collection.csv $O/pmc_traffic.json 2>&1 | tail -2 ;;
+              python tools/pmc_summarize.py $O/pmc_FETCH_SIZE/pmc_counter_collection.csv $O/pmc_WRITE_SIZE/pmc_counter_collection.csv $O/pmc_traffic.json 2>&1 | tail -2 ;;
     pmcgemm)  : > $O/pmc_gemm_mfma.jsonl
               for SH in "8192,8192,8192,0" "66816,3072,1024,0" "66816,4096,1024,1" "65536,1152,4352,0" "6144,22016,4096,2" "6144,12288,4096,0" "768,12288,4096,0" "65536,4096,8704,1"; do
                 D=$O/gemm_$(echo $SH | tr ',' 'x')
