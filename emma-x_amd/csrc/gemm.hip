@@ -116,14 +116,30 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
             }
             sv[jo][r] = (!LN && ACT != 2 && scale && col < n_ok) ? bf2f(scale[col]) : 1.f;   // (LN form: no LayerScale, checked by the launcher)
         }
+    // residual rows (and LN row statistics) of a 64-row half are requested TOGETHER, ahead of the arithmetic: loaded where they are used,
+    // every one of the 16 residual loads of a half was followed by its own vmcnt(0) -- 32 serial trips to L2 / HBM per tile and wave
+    // (which also drained the next tile's operand prefetch each time)
+    const bool fast_res = ACT != 2 && res && vec_r && (n_ok & 3) == 0 && n_ok >= 4;
 #pragma unroll
     for (int h = 0; h < G::MT / 4; ++h) {
+        u32x2_t rres[4][NG];
+        f32x2_t stv[4];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int rowc = min(m0 + wm * (G::MT * 16) + (4 * h + ii) * 16 + li, p.M - 1);   // (rows / columns past the edge: clamped, never stored)
+            if constexpr (LN) stv[ii] = *(const f32x2_t*)(p.ln_stats + (size_t)rowc * 2);
+            else stv[ii] = (f32x2_t){0.f, 1.f};
+            if (fast_res) {   // (rres is only ever read under the same condition)
+#pragma unroll
+                for (int jo = 0; jo < NG; ++jo)
+                    rres[ii][jo] = *(const u32x2_t*)(res + (size_t)rowc * p.ldr + min(ocol0 + jo * 16 + g * 4, n_ok - 4));
+            }
+        }
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
             const int i = 4 * h + ii, rl = ii * 16 + li;          // row inside the 64-row window
             const int row = m0 + wm * (G::MT * 16) + i * 16 + li;
-            f32x2_t st = {0.f, 1.f};                               // LN: (mean, rstd) of this output row
-            if constexpr (LN) st = *(const f32x2_t*)(p.ln_stats + (size_t)min(row, p.M - 1) * 2);
+            const f32x2_t st = stv[ii];                            // LN: (mean, rstd) of this output row
 #pragma unroll
             for (int jo = 0; jo < NG; ++jo) {
                 float v[4];
@@ -138,7 +154,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
                         if constexpr (!LN) v[r] *= sv[jo][r];
                     }
                 }
-                if (ACT != 2 && res && row < p.M) {
+                if (fast_res) {
+                    const u32x2_t rv = rres[ii][jo];
+                    v[0] += bf_lo(rv[0]); v[1] += bf_hi(rv[0]); v[2] += bf_lo(rv[1]); v[3] += bf_hi(rv[1]);
+                } else if (ACT != 2 && res && row < p.M) {
                     const int col = ocol0 + jo * 16 + g * 4;
                     const bf16_t* rp = res + (size_t)row * p.ldr + col;
                     if (col + 3 < n_ok && vec_r) {
