@@ -103,19 +103,38 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
     const int ocol0 = (ACT == 2) ? ((n0 + wn * 64) >> 1) : (n0 + wn * 64);
     const bool vec_r = (p.ldr & 3) == 0;
     float bv[NG][4], sv[NG][4], cs[LN ? NG : 1][4];   // LN: bv = ln_c (fp32), cs = ln_s
+    // a lane's four columns of a group are consecutive: one 8- / 16-byte load per operand and group (were four 2- / 4-byte loads)
+    const bool vec_col = (n_ok & 3) == 0 && (((uintptr_t)bias | (uintptr_t)scale) & 7) == 0;
 #pragma unroll
-    for (int jo = 0; jo < NG; ++jo)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int col = ocol0 + jo * 16 + g * 4 + r;
+    for (int jo = 0; jo < NG; ++jo) {
+        const int col4 = ocol0 + jo * 16 + g * 4;
+        if (vec_col) {
+            const int cc = min(col4, n_ok - 4);            // (columns past the edge: clamped, never stored)
             if constexpr (LN) {
-                bv[jo][r] = col < n_ok ? p.ln_c[col] : 0.f;
-                cs[jo][r] = col < n_ok ? p.ln_s[col] : 0.f;
+                const f32x4_t c4 = *(const f32x4_t*)(p.ln_c + cc), s4 = *(const f32x4_t*)(p.ln_s + cc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { bv[jo][r] = c4[r]; cs[jo][r] = s4[r]; sv[jo][r] = 1.f; }
             } else {
-                bv[jo][r] = (ACT != 2 && bias && col < n_ok) ? bf2f(bias[col]) : 0.f;
+                u32x2_t b2 = {0u, 0u}, s2 = {0x3f803f80u, 0x3f803f80u};   // bf16 1.0 pairs
+                if (ACT != 2 && bias) b2 = *(const u32x2_t*)(bias + cc);
+                if (ACT != 2 && scale) s2 = *(const u32x2_t*)(scale + cc);
+                bv[jo][0] = bf_lo(b2[0]); bv[jo][1] = bf_hi(b2[0]); bv[jo][2] = bf_lo(b2[1]); bv[jo][3] = bf_hi(b2[1]);
+                sv[jo][0] = bf_lo(s2[0]); sv[jo][1] = bf_hi(s2[0]); sv[jo][2] = bf_lo(s2[1]); sv[jo][3] = bf_hi(s2[1]);
             }
-            sv[jo][r] = (!LN && ACT != 2 && scale && col < n_ok) ? bf2f(scale[col]) : 1.f;   // (LN form: no LayerScale, checked by the launcher)
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = col4 + r;
+                if constexpr (LN) {
+                    bv[jo][r] = col < n_ok ? p.ln_c[col] : 0.f;
+                    cs[jo][r] = col < n_ok ? p.ln_s[col] : 0.f;
+                } else {
+                    bv[jo][r] = (ACT != 2 && bias && col < n_ok) ? bf2f(bias[col]) : 0.f;
+                }
+                sv[jo][r] = (!LN && ACT != 2 && scale && col < n_ok) ? bf2f(scale[col]) : 1.f;   // (LN form: no LayerScale, checked by the launcher)
+            }
         }
+    }
     // residual rows (and LN row statistics) of a 64-row half are requested TOGETHER, ahead of the arithmetic: loaded where they are used,
     // every one of the 16 residual loads of a half was followed by its own vmcnt(0) -- 32 serial trips to L2 / HBM per tile and wave
     // (which also drained the next tile's operand prefetch each time)
