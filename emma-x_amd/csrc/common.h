@@ -90,22 +90,22 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
-// exact-erf GELU, 0.5 x (1 + erf(x / sqrt 2)), with erfc(z) = poly(t) exp(-z^2), t = 1 / (1 + p z) (Abramowitz-Stegun
-// 7.1.26, |error| <= 1.5e-7 in erf -- two orders below the bf16 rounding of the output) and no cancellation on the
-// negative side: with h = erfc(z)/2, z = |x| / sqrt 2:  x >= 0: x - |x| h;  x < 0: -|x| h  ==  max(x, 0) - |x| h.
-// Written for the instruction count -- VALU work of a GEMM epilogue does not overlap the MFMAs of its SIMD: z carries the
-// sqrt(log2 e) of the exp2 (so exp(-z^2) is one v_exp_f32 of a product), the 1/2 sits in the polynomial, the sign select is a
-// max: 12 full-rate instructions + rcp + exp2 (the ocml erff is ~40, the first version of this one 17 + v_exp_f32's scale).
+// exact-erf GELU, x Phi(x) = max(x, 0) - |x| h(|x|) with h = erfc(|x| / sqrt 2) / 2 (no cancellation on the negative side), and
+// h = exp2(Q(|x|)): log2 of erfc is smooth (-1 at 0, ~ -x^2 log2(e) / 2 far out), a degree-6 polynomial weighted for the error of
+// |x| h reproduces x Phi(x) to 2.8e-7 absolute in fp32 arithmetic (1.7 % of a bf16 ulp of the result at worst; tools/fit_gelu.py).
+// Written for the instruction count -- VALU work of a GEMM epilogue does not overlap the MFMAs of its SIMD, and the quarter-rate
+// transcendentals weigh four full-rate instructions each: min, 6 fma (packed two per instruction by hipcc), v_exp_f32, max, fma =
+// 9 full-rate + ONE transcendental (rounds 2-4: Abramowitz-Stegun 7.1.26 with rcp + exp2, 12 + two; the ocml erff is ~40).  Beyond
+// |x| = 6 (h < 1e-9) the argument of Q is clamped: its leading coefficient is positive.
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float a = fabsf(x);
-    const float zs = a * 0.84932180028801904272f;                   // z sqrt(log2 e) = |x| sqrt(log2 e / 2)
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.2727374809f, zs, 1.0f));   // 1 / (1 + p z),  p / sqrt(log2 e)
-    float pl = fmaf(0.5307027145f, t, -0.7265760135f);             // the A-S coefficients halved
-    pl = fmaf(pl, t, 0.7107068705f);
-    pl = fmaf(pl, t, -0.142248368f);
-    pl = fmaf(pl, t, 0.127414796f);
-    const float h = pl * t * __builtin_amdgcn_exp2f(-(zs * zs));   // erfc(z) / 2
-    return fmaxf(x, 0.f) - a * h;
+    const float a = fminf(fabsf(x), 6.0f);
+    float q = fmaf(3.3092673036e-05f, a, -7.6921858316e-04f);
+    q = fmaf(q, a, 8.0807131948e-03f);
+    q = fmaf(q, a, -5.3412099418e-02f);
+    q = fmaf(q, a, -4.5877097672e-01f);
+    q = fmaf(q, a, -1.1512017009e+00f);
+    q = fmaf(q, a, -9.9999306113e-01f);
+    return fmaf(-fabsf(x), __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 

@@ -311,8 +311,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4_t
 // of K step t + 2 goes out during step t and is waited for by COUNT (vmcnt(4): its four slab requests stay in flight across the
 // step barrier, a bare s_barrier); the resident operand keeps one step of lead.  Measured (round 4, interleaved A/B on one box):
 // ViT shapes +3 .. 8 % with DEEP = 1 and -3 % with it on the LLaMA shapes, where the weights are the stream.
+// Two waves per SIMD in both geometries (one 8-wave block or two 4-wave blocks per CU), stated to the compiler: left to the
+// block size alone, the 4-wave kernels may take up to 512 registers, and the LN + GELU instantiation took 260 -- ONE block per CU.
 template <class G, int ACT, bool OUT_F32, bool LN = false, int DEEP = 0>
-__global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams p) {
+__global__ __launch_bounds__(G::NW * 64, 2) void emmax_gemm_bf16_kernel(GemmParams p) {
     constexpr int BM = G::BM, BN = G::BN, MT = G::MT, NT = G::NT, STAGE_BYTES = G::STAGE, OP_BYTES = G::OPA;
     static_assert(G::OPA == G::OPB, "the stage slots of A and W are interchangeable");
     constexpr int NSA = DEEP == 1 ? 3 : 2, NSW = DEEP >= 2 ? 3 : 2;
@@ -420,6 +422,7 @@ __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams 
         // freshly issued requests of the next steps with it -- in the middle of every tile's first K step
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
+        GEMM_STAMP();
         if constexpr (PP) {
             // ---- DEEP = 3, lab: the two wave groups of the block -- waves 0 .. NW/2-1 (tile rows 0 .. BM/2) and their SIMD partners
             // NW/2 .. NW-1 -- run HALF A K STEP APART, with a bare s_barrier per half step, so that one group's DMA issue and first
@@ -484,7 +487,6 @@ __global__ __launch_bounds__(G::NW * 64) void emmax_gemm_bf16_kernel(GemmParams 
             if (DEEP == 1) issueA(1, 1);
             if (DEEP == 2) issueW(1, 1);
         }
-        GEMM_STAMP();
         int sd = 0;                                          // slot of the three-stage operand for the current K step (the other: kt & 1)
         for (int kt = 0; kt < nk; ++kt) {
             const int sd1 = sd + 1 == 3 ? 0 : sd + 1, sd2 = sd1 + 1 == 3 ? 0 : sd1 + 1;
@@ -762,7 +764,13 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.act != 2 && n1 > 0 && n1 < p.N) {
         long m1a = 0;
         const double left = plan_rows(p.M, n1, &m1a);
-        const double right = cost_small((long)cdiv(p.M, GeomSmall::BM) * cdiv(p.N - n1, GeomSmall::BN)) + 0.03;
+        // the narrow launch re-reads ALL of A for 128 columns of output: at long K it is bound by that stream, not by its tiles
+        // (SigLIP fc2, K = 4352: 570 MB in 144 us measured against 67 us modelled -- the split was 7.6 % behind all-big,
+        // `gemm_bench --ab gemm_big=-1,0,1`, round 4).  One big round takes ~1.44 us per K step + ~9 us (section 6); A streams at ~4.5 TB/s.
+        const double round_us = 1.44 * (p.K / BK) + 9.0, stream_us = (double)p.M * p.K * 2.0 / 4.5e6;
+        double right = cost_small((long)cdiv(p.M, GeomSmall::BM) * cdiv(p.N - n1, GeomSmall::BN));
+        if (stream_us / round_us > right) right = stream_us / round_us;
+        right += 0.03;
         if (left + right < whole - 1e-9) {
             GemmParams a = p, b = p;
             a.N = n1;

@@ -58,8 +58,11 @@ def main():
             for v in ab[1]:          # first launch of each variant (attribute set-up) outside the timing
                 L.tuning_set(ab[0], v)
                 run()
-            for _ in range(4):       # 4 interleaved rounds of `reps` launches per variant
-                for v in ab[1]:
+            # interleaved rounds of `reps` launches per variant, the order ROTATED from round to round: a variant that always ran behind a
+            # slower (cooler) one measured 2-4 % faster than the identical code path in front of it (power management; round 4)
+            nround = 2 * len(ab[1])
+            for rnd in range(nround):
+                for v in ab[1][rnd % len(ab[1]):] + ab[1][:rnd % len(ab[1])]:
                     L.tuning_set(ab[0], v)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -67,7 +70,7 @@ def main():
                         run()
                     e1.record()
                     torch.cuda.synchronize()
-                    tot[v] += e0.elapsed_time(e1) / reps / 4
+                    tot[v] += e0.elapsed_time(e1) / reps / nround
             tfs = {v: 2.0 * M * N * K / tot[v] / 1e9 for v in ab[1]}
             out[name] = {f"{ab[0]}={v}": round(tfs[v], 1) for v in ab[1]}
             print(f"{name:18s} M={M:6d} N={N:6d} K={K:6d} act={act}  " + "  ".join(f"{ab[0]}={v}: {tot[v]:8.4f} ms {tfs[v]:7.1f} TF/s" for v in ab[1]), flush=True)
