@@ -101,7 +101,6 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
     const bf16_t* res = (const bf16_t*)p.residual;
     const int n_ok = (ACT == 2) ? p.N / 2 : min(p.N, p.N_store);
     const int ocol0 = (ACT == 2) ? ((n0 + wn * 64) >> 1) : (n0 + wn * 64);
-    const bool vec_r = (p.ldr & 3) == 0;
     float bv[NG][4], sv[NG][4], cs[LN ? NG : 1][4];   // LN: bv = ln_c (fp32), cs = ln_s
     // a lane's four columns of a group are consecutive: one 8- / 16-byte load per operand and group (were four 2- / 4-byte loads)
     const bool vec_col = (n_ok & 3) == 0 && (((uintptr_t)bias | (uintptr_t)scale) & 7) == 0;
@@ -135,74 +134,84 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
             }
         }
     }
-    // residual rows (and LN row statistics) of a 64-row half are requested TOGETHER, ahead of the arithmetic: loaded where they are used,
-    // every one of the 16 residual loads of a half was followed by its own vmcnt(0) -- 32 serial trips to L2 / HBM per tile and wave
-    // (which also drained the next tile's operand prefetch each time)
-    const bool fast_res = ACT != 2 && res && vec_r && (n_ok & 3) == 0 && n_ok >= 4;
-#pragma unroll
-    for (int h = 0; h < G::MT / 4; ++h) {
-        u32x2_t rres[4][NG];
-        f32x2_t stv[4];
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
+    // ---- the rows.  The residual is always the vectorised form here (8 bytes per lane and column group, requested ahead; any other
+    // residual layout takes the direct epilogue): with a second, element-wise form chosen per (row tile, column group) hipcc had
+    // interleaved both behind 64 branches per tile.  Rows / columns of an edge tile that lie outside C: requests clamped, stores
+    // masked -- and the window reads unconditional AHEAD of the stores: inside the row check they were serialised (ds_read,
+    // lgkmcnt(0), store: eight LDS round trips per half).
+    const bool has_res = !LN && ACT != 2 && res != nullptr;   // (8-byte requests possible: staged_ok in the kernel; LN form: no residual, checked by the launcher)
+    {
+        constexpr int NH = G::MT / 4;
+        u32x2_t rres[4][NG];       // residual: one 64-row half at a time (both halves at once: 64 registers, spilled)
+        f32x2_t stv[G::MT];   // LN: (mean, rstd) of every output row of the wave, all requested up front (8 bytes per row)
+        // residual rows of a 64-row half are requested TOGETHER, ahead of the arithmetic (loaded where they are used, each of the 16
+        // residual loads of a half was followed by its own vmcnt(0)), and the SECOND half's as soon as the arithmetic of the first
+        // has consumed the registers, i.e. BEFORE the first half's window reads and stores: requested behind the stores, their wait
+        // also waited for the stores' acknowledgements (the counter is in order)
+        auto request_rows = [&](int h, int ii, u32x2_t (&rr)[NG]) {
             const int rowc = min(m0 + wm * (G::MT * 16) + (4 * h + ii) * 16 + li, p.M - 1);   // (rows / columns past the edge: clamped, never stored)
-            if constexpr (LN) stv[ii] = *(const f32x2_t*)(p.ln_stats + (size_t)rowc * 2);
-            else stv[ii] = (f32x2_t){0.f, 1.f};
-            if (fast_res) {   // (rres is only ever read under the same condition)
+            if (has_res) {   // (rres is only ever read under the same condition)
 #pragma unroll
-                for (int jo = 0; jo < NG; ++jo)
-                    rres[ii][jo] = *(const u32x2_t*)(res + (size_t)rowc * p.ldr + min(ocol0 + jo * 16 + g * 4, n_ok - 4));
+                for (int jo = 0; jo < NG; ++jo) rr[jo] = *(const u32x2_t*)(res + (size_t)rowc * p.ldr + min(ocol0 + jo * 16 + g * 4, n_ok - 4));
             }
+        };
+#pragma unroll
+        for (int i = 0; i < G::MT; ++i) {
+            if constexpr (LN) stv[i] = *(const f32x2_t*)(p.ln_stats + (size_t)min(m0 + wm * (G::MT * 16) + i * 16 + li, p.M - 1) * 2);
+            else stv[i] = (f32x2_t){0.f, 1.f};
         }
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int i = 4 * h + ii, rl = ii * 16 + li;          // row inside the 64-row window
-            const int row = m0 + wm * (G::MT * 16) + i * 16 + li;
-            const f32x2_t st = stv[ii];                            // LN: (mean, rstd) of this output row
+        for (int ii = 0; ii < 4; ++ii) request_rows(0, ii, rres[ii]);
 #pragma unroll
-            for (int jo = 0; jo < NG; ++jo) {
-                float v[4];
+        for (int h = 0; h < NH; ++h) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (ACT == 2) {
-                        v[r] = silu(acc[i][2 * jo][r]) * acc[i][2 * jo + 1][r];
-                    } else {
-                        if constexpr (LN) v[r] = (acc[i][jo][r] - st[0] * cs[jo][r]) * st[1] + bv[jo][r];
-                        else v[r] = acc[i][jo][r] + bv[jo][r];
-                        if (ACT == 1) v[r] = gelu_erf(v[r]);
-                        if constexpr (!LN) v[r] *= sv[jo][r];
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = 4 * h + ii, rl = ii * 16 + li;          // row inside the 64-row window
+                const int row = m0 + wm * (G::MT * 16) + i * 16 + li;
+                const f32x2_t st = stv[i];                             // LN: (mean, rstd) of this output row
+#pragma unroll
+                for (int jo = 0; jo < NG; ++jo) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (ACT == 2) {
+                            v[r] = silu(acc[i][2 * jo][r]) * acc[i][2 * jo + 1][r];
+                        } else {
+                            if constexpr (LN) v[r] = (acc[i][jo][r] - st[0] * cs[jo][r]) * st[1] + bv[jo][r];
+                            else v[r] = acc[i][jo][r] + bv[jo][r];
+                            if (ACT == 1) v[r] = gelu_erf(v[r]);
+                            if constexpr (!LN) v[r] *= sv[jo][r];
+                        }
                     }
-                }
-                if (fast_res) {
-                    const u32x2_t rv = rres[ii][jo];
-                    v[0] += bf_lo(rv[0]); v[1] += bf_hi(rv[0]); v[2] += bf_lo(rv[1]); v[3] += bf_hi(rv[1]);
-                } else if (ACT != 2 && res && row < p.M) {
-                    const int col = ocol0 + jo * 16 + g * 4;
-                    const bf16_t* rp = res + (size_t)row * p.ldr + col;
-                    if (col + 3 < n_ok && vec_r) {
-                        const u32x2_t rv = *(const u32x2_t*)rp;
+                    if (has_res) {
+                        const u32x2_t rv = rres[ii][jo];
                         v[0] += bf_lo(rv[0]); v[1] += bf_hi(rv[0]); v[2] += bf_lo(rv[1]); v[3] += bf_hi(rv[1]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (col + r < n_ok) v[r] += bf2f(rp[r]);
                     }
+                    const int c = jo * 2 + (g >> 1);                  // 16-byte chunk of the row, half g & 1
+                    *(u32x2_t*)(wl + rl * (WC * 2) + ((c ^ (rl & (CH - 1))) << 4) + (g & 1) * 8) =
+                        (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 }
-                const int c = jo * 2 + (g >> 1);                  // 16-byte chunk of the row, half g & 1
-                *(u32x2_t*)(wl + rl * (WC * 2) + ((c ^ (rl & (CH - 1))) << 4) + (g & 1) * 8) =
-                    (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             }
-        }
-        // whole rows back out: lane -> (row, chunk); LDS executes a wave's accesses in order, no barrier needed
+            if (h + 1 < NH) {   // the next half's residual rows: the registers are free, and the request stays AHEAD of this half's stores
 #pragma unroll
-        for (int itr = 0; itr < CH; ++itr) {
-            const int idx = itr * 64 + lane;
-            const int rr = idx / CH, cl = idx % CH;
-            const u32x4_t val = *(const u32x4_t*)(wl + rr * (WC * 2) + ((cl ^ (rr & (CH - 1))) << 4));
-            const int row = m0 + wm * (G::MT * 16) + h * 64 + rr, col = ocol0 + cl * 8;
-            if (row < p.M) {
+                for (int ii = 0; ii < 4; ++ii) request_rows(h + 1, ii, rres[ii]);
+            }
+            // whole rows back out: lane -> (row, chunk); LDS executes a wave's accesses in order, no barrier needed
+            u32x4_t val[CH];
+#pragma unroll
+            for (int itr = 0; itr < CH; ++itr) {
+                const int idx = itr * 64 + lane;
+                const int rr = idx / CH, cl = idx % CH;
+                val[itr] = *(const u32x4_t*)(wl + rr * (WC * 2) + ((cl ^ (rr & (CH - 1))) << 4));
+            }
+#pragma unroll
+            for (int itr = 0; itr < CH; ++itr) {
+                const int idx = itr * 64 + lane;
+                const int rr = idx / CH, cl = idx % CH;
+                const int row = m0 + wm * (G::MT * 16) + h * 64 + rr, col = ocol0 + cl * 8;
                 bf16_t* dst = (bf16_t*)p.C + (size_t)row * p.ldc + col;
-                if (col + 7 < n_ok) *(u32x4_t*)dst = val;   // (the launcher routes a column count that is not a multiple of 8 to the direct epilogue)
+                // (the launcher routes a column count that is not a multiple of 8 to the direct epilogue)
+                if (row < p.M && col + 7 < n_ok) *(u32x4_t*)dst = val[itr];
             }
         }
     }
@@ -397,7 +406,8 @@ __global__ __launch_bounds__(G::NW * 64, 2) void emmax_gemm_bf16_kernel(GemmPara
     auto ldB = [&](const unsigned char* st, int kk, int j) { return *(const bf16x8_t*)(st + offB + j * 2048 + (kk ? (c0 ^ 64) : c0)); };
 
     const bool staged_ok = (p.ldc & 7) == 0 && (((size_t)p.C) & 15) == 0 && !(p.dbg & 8) &&
-                           (ACT == 2 ? (p.N & 15) == 0 : (min(p.N, p.N_store) & 7) == 0);   // 16-byte row-layout stores possible
+                           (ACT == 2 ? (p.N & 15) == 0 : (min(p.N, p.N_store) & 7) == 0) &&   // 16-byte row-layout stores possible
+                           (!p.residual || ((p.ldr & 3) == 0 && (((size_t)p.residual) & 7) == 0));   // ... and 8-byte residual requests
     int it = blockIdx.x >> 3;
     if (it >= run_n) return;
 #ifdef GEMM_LAB_TRACE
@@ -657,7 +667,7 @@ int launch_gemm_geom(const GemmParams& p, int big, hipStream_t stream) {
     if (p.M <= 0) return 0;
     if (p.K % BK != 0 || p.N % 128 != 0 || p.K <= 0 || p.N <= 0) return -1;
     if ((p.lda % 8) || (p.ldw % 8)) return -1;
-    if (p.ln_stats && (!p.ln_s || !p.ln_c || p.bias || p.scale || p.act == 2 || p.ksplit > 1)) return -1;
+    if (p.ln_stats && (!p.ln_s || !p.ln_c || p.bias || p.scale || p.residual || p.act == 2 || p.ksplit > 1)) return -1;
     return big ? launch_geom<GeomBig>(p, stream) : launch_geom<GeomSmall>(p, stream);
 }
 
