@@ -107,6 +107,22 @@ __device__ __forceinline__ float gelu_erf(float x) {
     q = fmaf(q, a, -9.9999306113e-01f);
     return fmaf(-fabsf(x), __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
 }
+// Two values at once on the packed fp32 pipe (v_pk_fma_f32: two fmas per issue slot).  From the scalar form hipcc builds the Horner
+// chain out of v_fmaak_f32 with literal coefficients -- one slot per fma; as 2-vectors the six fmas of a PAIR take six slots.  Same
+// operations in the same order: bit-identical to gelu_erf per element.
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
+    const f32x2_t ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2_t a = {fminf(ax[0], 6.0f), fminf(ax[1], 6.0f)};
+    f32x2_t q = __builtin_elementwise_fma((f32x2_t){3.3092673036e-05f, 3.3092673036e-05f}, a, (f32x2_t){-7.6921858316e-04f, -7.6921858316e-04f});
+    q = __builtin_elementwise_fma(q, a, (f32x2_t){8.0807131948e-03f, 8.0807131948e-03f});
+    q = __builtin_elementwise_fma(q, a, (f32x2_t){-5.3412099418e-02f, -5.3412099418e-02f});
+    q = __builtin_elementwise_fma(q, a, (f32x2_t){-4.5877097672e-01f, -4.5877097672e-01f});
+    q = __builtin_elementwise_fma(q, a, (f32x2_t){-1.1512017009e+00f, -1.1512017009e+00f});
+    q = __builtin_elementwise_fma(q, a, (f32x2_t){-9.9999306113e-01f, -9.9999306113e-01f});
+    const f32x2_t e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+    const f32x2_t m = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+    return __builtin_elementwise_fma(-ax, e, m);
+}
 // x sigmoid(x) as x * rcp(1 + exp2(-x log2 e)): mul, v_exp_f32, add, v_rcp_f32, mul.  Written as a quotient it compiled to the IEEE division
 // sequence (two v_div_scale, rcp, five fma, v_div_fmas, v_div_fixup): 13 instructions per element of a SwiGLU epilogue for a last-bit
 // difference that the bf16 rounding of the product erases (v_rcp_f32: 1 ulp).

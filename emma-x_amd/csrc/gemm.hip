@@ -179,8 +179,16 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
                         } else {
                             if constexpr (LN) v[r] = (acc[i][jo][r] - st[0] * cs[jo][r]) * st[1] + bv[jo][r];
                             else v[r] = acc[i][jo][r] + bv[jo][r];
-                            if (ACT == 1) v[r] = gelu_erf(v[r]);
-                            if constexpr (!LN) v[r] *= sv[jo][r];
+                        }
+                    }
+                    if (ACT == 1) {   // GELU two values per packed-fp32 instruction
+                        const f32x2_t g0 = gelu_erf2((f32x2_t){v[0], v[1]}), g1 = gelu_erf2((f32x2_t){v[2], v[3]});
+                        v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
+                    }
+                    if constexpr (!LN) {
+                        if (ACT != 2) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] *= sv[jo][r];
                         }
                     }
                     if (has_res) {
@@ -576,19 +584,25 @@ __global__ __launch_bounds__(G::NW * 64, 2) void emmax_gemm_bf16_kernel(GemmPara
     }
 }
 
-// split-K second pass: C[m, n..n+8) = epi(sum over slices of ws[s][m][n..n+8)); one thread per 8 columns, whole rows in order
+// split-K second pass: C[m, n..n+8) = epi(sum over slices of ws[s][m][..)); one thread per 8 OUTPUT columns, whole rows in order.
+// ACT = 2 (SwiGLU): the partial tiles hold the interleaved (gate, up) 16-column groups of the weight order; output column o of
+// group o / 16 pairs partial columns (o / 16) * 32 + o % 16 and + 16.  Eight consecutive output columns never straddle a group.
 template <int ACT>
 __global__ __launch_bounds__(256) void emmax_splitk_reduce_kernel(GemmParams p) {
-    const int nc = p.N >> 3;   // 8-column groups per row (N % 128 == 0)
+    const int n_out = ACT == 2 ? p.N >> 1 : p.N;
+    const int nc = n_out >> 3;   // 8-column groups per output row (N % 128 == 0)
     const size_t total = (size_t)p.M * nc, slab = (size_t)p.M * p.N;
     const bf16_t* bias = (const bf16_t*)p.bias;
     const bf16_t* scale = (const bf16_t*)p.scale;
     const bf16_t* res = (const bf16_t*)p.residual;
-    const int n_ok = min(p.N, p.N_store);
+    const int n_ok = ACT == 2 ? n_out : min(p.N, p.N_store);
+    const bool vec_c = !p.out_f32 && (p.ldc & 7) == 0 && (((size_t)p.C) & 15) == 0;
+    const bool vec_r = res && (p.ldr & 7) == 0 && (((size_t)res) & 15) == 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int row = (int)(i / nc), col = (int)(i - (size_t)row * nc) * 8;
-        const float* src = p.ws + (size_t)row * p.N + col;
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int pcol = ACT == 2 ? (col >> 4) * 32 + (col & 15) : col;
+        const float* src = p.ws + (size_t)row * p.N + pcol;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, u[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s < p.ksplit; ++s) {
             const f32x4_t a = *(const f32x4_t*)(src + s * slab), b = *(const f32x4_t*)(src + s * slab + 4);
 #pragma unroll
@@ -596,16 +610,43 @@ __global__ __launch_bounds__(256) void emmax_splitk_reduce_kernel(GemmParams p) 
                 v[e] += a[e];
                 v[4 + e] += b[e];
             }
+            if (ACT == 2) {
+                const f32x4_t c = *(const f32x4_t*)(src + s * slab + 16), d = *(const f32x4_t*)(src + s * slab + 20);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u[e] += c[e];
+                    u[4 + e] += d[e];
+                }
+            }
         }
+        const bool full = col + 7 < n_ok;
+        u32x4_t rv = {0u, 0u, 0u, 0u};
+        if (ACT != 2 && vec_r && full) rv = *(const u32x4_t*)(res + (size_t)row * p.ldr + col);
+        float x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            if (col + e >= n_ok) continue;
-            float x = v[e] + (bias ? bf2f(bias[col + e]) : 0.f);
-            if (ACT == 1) x = gelu_erf(x);
-            if (scale) x *= bf2f(scale[col + e]);
-            if (res) x += bf2f(res[(size_t)row * p.ldr + col + e]);
-            if (p.out_f32) ((float*)p.C)[(size_t)row * p.ldc + col + e] = x;
-            else ((bf16_t*)p.C)[(size_t)row * p.ldc + col + e] = f2bf(x);
+            if (ACT == 2) {
+                x[e] = silu(v[e]) * u[e];
+            } else {
+                x[e] = v[e] + ((bias && col + e < n_ok) ? bf2f(bias[col + e]) : 0.f);
+                if (ACT == 1) x[e] = gelu_erf(x[e]);
+                if (scale && col + e < n_ok) x[e] *= bf2f(scale[col + e]);
+                if (res) {
+                    if (vec_r && full) x[e] += (e & 1) ? bf_hi(rv[e >> 1]) : bf_lo(rv[e >> 1]);
+                    else if (col + e < n_ok) x[e] += bf2f(res[(size_t)row * p.ldr + col + e]);
+                }
+            }
+        }
+        if (vec_c && full) {
+            *(u32x4_t*)((bf16_t*)p.C + (size_t)row * p.ldc + col) =
+                (u32x4_t){pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7])};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (col + e >= n_ok) continue;
+                if (p.out_f32) ((float*)p.C)[(size_t)row * p.ldc + col + e] = x[e];
+                else ((bf16_t*)p.C)[(size_t)row * p.ldc + col + e] = f2bf(x[e]);
+            }
         }
     }
 }
@@ -687,6 +728,19 @@ static double cost_small(long tiles) {
     return (double)(r - 1) * 0.63 + ((tiles - (r - 1) * 512) <= 256 ? 0.45 : 0.63);
 }
 
+// slices for launch_gemm_splitk, or 0 when splitting does not pay
+static int splitk_plan(const GemmParams& p) {
+    if (!p.ws || p.ln_stats || (p.act == 2 && p.out_f32)) return 0;
+    const int nk = p.K / BK;
+    const long ts = (long)cdiv(p.M, GeomSmall::BM) * cdiv(p.N, GeomSmall::BN);
+    if (nk < 32 || ts > 224) return 0;              // K >= 2048, at most ~1 block per CU without the split
+    int ks = (int)(512 / ts);
+    if (ks > nk / 8) ks = nk / 8;
+    if (ks > 8) ks = 8;
+    while (ks >= 2 && (long long)ks * p.M * p.N * 4 > p.ws_bytes) --ks;
+    return ks >= 2 ? ks : 0;
+}
+
 // rows [r0, r0 + rows) of the problem as one launch of the given geometry
 static int launch_rows(const GemmParams& p, size_t r0, int rows, int big, hipStream_t stream) {
     if (rows <= 0) return 0;
@@ -728,36 +782,56 @@ static int launch_planned_rows(const GemmParams& p, long m1, hipStream_t stream)
 // Split-K for under-filled problems with a long K: fewer small tiles than CUs-and-a-half means one 4-wave block per CU
 // grinding through K alone (M = 768 prefill o / down: 192 tiles, 64-172 K steps at ~0.75 us; batch-1 ViT fc2: 24 tiles).
 // ks slices per tile fill the chip (<= 512 resident blocks), each >= 8 K steps; the partial tiles meet in a second pass.
-int launch_gemm_splitk(const GemmParams& p, int ks, hipStream_t stream) {
-    if (ks < 2 || p.act == 2 || !p.ws || p.K % BK || p.N % 128 || p.ln_stats) return -1;
+int launch_gemm_splitk(const GemmParams& p, int ks, hipStream_t stream, int big) {
+    if (ks < 2 || !p.ws || p.K % BK || p.N % 128 || p.ln_stats) return -1;
+    if (p.act == 2 && (p.out_f32 || (p.N & 31))) return -1;
     if ((long long)ks * p.M * p.N * 4 > p.ws_bytes) return -1;
     if (p.K / BK < ks) return -1;
     GemmParams a = p;
     a.ksplit = ks;
     a.C = p.ws; a.ldc = p.N; a.N_store = p.N; a.out_f32 = 1; a.act = 0;
     a.bias = nullptr; a.scale = nullptr; a.residual = nullptr;
-    int r = launch_gemm_geom(a, 0, stream);
+    int r = launch_gemm_geom(a, big, stream);
     if (r) return r;
     GemmParams b = p;
     b.ksplit = ks;
-    const size_t groups = (size_t)p.M * (p.N >> 3);
+    const size_t groups = (size_t)p.M * ((p.act == 2 ? p.N >> 1 : p.N) >> 3);
     const int grid = (int)((groups + 255) / 256 < 2048 ? (groups + 255) / 256 : 2048);
-    if (p.act == 1) hipLaunchKernelGGL(emmax_splitk_reduce_kernel<1>, dim3(grid), dim3(256), 0, stream, b);
+    if (p.act == 2) hipLaunchKernelGGL(emmax_splitk_reduce_kernel<2>, dim3(grid), dim3(256), 0, stream, b);
+    else if (p.act == 1) hipLaunchKernelGGL(emmax_splitk_reduce_kernel<1>, dim3(grid), dim3(256), 0, stream, b);
     else hipLaunchKernelGGL(emmax_splitk_reduce_kernel<0>, dim3(grid), dim3(256), 0, stream, b);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-// slices for launch_gemm_splitk, or 0 when splitting does not pay
-static int splitk_plan(const GemmParams& p) {
-    if (!p.ws || p.act == 2 || p.ln_stats) return 0;
+// Column remainder through split-K (round 4, late).  A short, wide problem whose big tiles are a few more than whole rounds -- the
+// one-frame prefill gate/up: 3 x 86 = 258 tiles = one round + 2 tiles, i.e. a second round for 1 % of the work (or 1032 small
+// tiles, 2.02 rounds) -- cannot use the row split (three tile rows).  Instead: columns [0, n1) = as many whole tile columns as fit
+// the whole rounds (85 x 3 = 255 tiles, one round), and the remaining columns as K-split 128 x 128 tiles that fill the chip for a
+// few K steps each + the reduce / epilogue pass (SwiGLU included).  Returns the slices (0: not applicable) and n1.
+static int hybrid_cols_plan(const GemmParams& p, int* n1_out, double* cost_out) {
+    if (!p.ws || p.ln_stats || p.out_f32) return 0;
     const int nk = p.K / BK;
-    const long ts = (long)cdiv(p.M, GeomSmall::BM) * cdiv(p.N, GeomSmall::BN);
-    if (nk < 32 || ts > 224) return 0;              // K >= 2048, at most ~1 block per CU without the split
+    const long tm = cdiv(p.M, GeomBig::BM), tn = cdiv(p.N, GeomBig::BN), tiles = tm * tn;
+    const long rounds = tiles / 256;
+    if (nk < 32 || rounds < 1 || tiles == rounds * 256 || tm > 256) return 0;
+    const long c1 = rounds * 256 / tm;
+    if (c1 <= 0 || c1 >= tn) return 0;
+    const int n1 = (int)c1 * GeomBig::BN, nr = p.N - n1;
+    const long ts = (long)cdiv(p.M, GeomSmall::BM) * cdiv(nr, GeomSmall::BN);
+    if (ts > 224) return 0;
     int ks = (int)(512 / ts);
     if (ks > nk / 8) ks = nk / 8;
     if (ks > 8) ks = 8;
-    while (ks >= 2 && (long long)ks * p.M * p.N * 4 > p.ws_bytes) --ks;
-    return ks >= 2 ? ks : 0;
+    while (ks >= 2 && (long long)ks * p.M * nr * 4 > p.ws_bytes) --ks;
+    if (ks < 2) return 0;
+    // cost in rounds of the big geometry: one round = 1.44 us per K step + ~9 us; a small block runs a K step in ~0.65 us alone
+    // on its CU, ~0.91 us next to a second one; + fp32 tile stores and ramp, two kernel boundaries, the reduce pass at ~3 TB/s
+    const double round_us = 1.44 * nk + 9.0;
+    const double right_us = (double)cdiv(nk, ks) * (ts * ks > 256 ? 0.91 : 0.65) + 8.0 + 8.0 + (double)ks * p.M * nr * 4.0 / 3.0e6;
+    long m1 = 0;
+    *cost_out = plan_rows(p.M, n1, &m1) + right_us / round_us;
+    *n1_out = n1;
+    return ks;
 }
 
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
@@ -768,6 +842,28 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (const int ks = no_splitk ? 0 : splitk_plan(p)) return launch_gemm_splitk(p, ks, stream);
     long m1 = 0;
     const double whole = plan_rows(p.M, p.N, &m1);
+    if (!no_splitk && emmax_tune().gemm_hybrid != 0) {
+        int hn1 = 0;
+        double hcost = 0.0;
+        const int hks = hybrid_cols_plan(p, &hn1, &hcost);
+        if (hks && hcost < whole - 0.02) {
+            GemmParams a = p, b = p;
+            a.N = hn1;
+            a.N_store = p.N_store < hn1 ? p.N_store : hn1;
+            b.N = p.N - hn1;
+            b.N_store = p.N_store > hn1 ? p.N_store - hn1 : 0;
+            b.W = (const bf16_t*)p.W + (size_t)hn1 * p.ldw;
+            b.C = (void*)((bf16_t*)p.C + (p.act == 2 ? hn1 / 2 : hn1));
+            if (p.bias) b.bias = (const bf16_t*)p.bias + hn1;
+            if (p.scale) b.scale = (const bf16_t*)p.scale + hn1;
+            if (p.residual) b.residual = (const bf16_t*)p.residual + hn1;
+            long m1a = 0;
+            plan_rows(p.M, hn1, &m1a);
+            const int r = launch_planned_rows(a, m1a, stream);
+            if (r) return r;
+            return (p.act == 2 || b.N_store > 0) ? launch_gemm_splitk(b, hks, stream) : 0;
+        }
+    }
     // a half-empty last tile column (N = 1152, 3456: 4.5 / 13.5 big tiles wide) can go to the small geometry instead:
     // columns [0, n1) planned as above + columns [n1, N) as one all-small launch
     const int n1 = p.N / GeomBig::BN * GeomBig::BN;

@@ -39,7 +39,7 @@ struct GemmParams {
 int launch_gemm(const GemmParams& p, hipStream_t stream);                     // picks the 256x256 or the 128x128 tile geometry
 int launch_gemm_geom(const GemmParams& p, int big, hipStream_t stream);       // explicit geometry (tools, tests)
 int gemm_big_tiles(const GemmParams& p);
-int launch_gemm_splitk(const GemmParams& p, int ksplit, hipStream_t stream);  // 128x128 geometry, ksplit K slices + reduce pass (needs p.ws)
+int launch_gemm_splitk(const GemmParams& p, int ksplit, hipStream_t stream, int big = 0);  // ksplit K slices per tile (128x128; big: 256x256) + reduce / epilogue pass (needs p.ws)
 
 // ---- norm.hip ----
 int launch_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, int ldx, int ldy, float eps,
@@ -119,6 +119,7 @@ struct EmmaxTune {
     int mfma_xbar;       // 1: decode_mfma.hip orders the activation requests ahead of the weight head with a block barrier
     int gemm_big;        // -1: planned tile geometry; 0 / 1: all small / all big tiles, no split-K
     int gemm_splitk;     // 1: split-K for under-filled long-K GEMMs
+    int gemm_hybrid;     // 1: a column remainder behind whole rounds of big tiles goes through K-split small tiles when K is long (one-frame prefill gate/up)
     int gemm_deep;       // GEMM main loop: -1 = by geometry (256x256: staggered wave groups, 128x128: deep A ring), 0 = two stages + one barrier per step, 1 = third LDS stage for A, 3 = staggered wave groups (256x256 only)
     int gemm_dbg;        // lab: OR-ed into GemmParams::dbg (16 = the second half of the waves requests its slabs mid-step)
     int gemm_lnfuse;     // 1: LayerNorm / RMSNorm applied by the GEMM that consumes the normalised rows (no separate norm pass)

@@ -57,6 +57,7 @@ const TuneEntry kTune[] = {
     {"gemm_big", &EmmaxTune::gemm_big, -1},    {"gemm_splitk", &EmmaxTune::gemm_splitk, 1},
     {"gemm_deep", &EmmaxTune::gemm_deep, -1},       {"gemm_dbg", &EmmaxTune::gemm_dbg, 0},
     {"gemm_lnfuse", &EmmaxTune::gemm_lnfuse, 1}, {"attn_resident", &EmmaxTune::attn_resident, -1},
+    {"gemm_hybrid", &EmmaxTune::gemm_hybrid, 1},
 };
 EmmaxTune g_tune;
 std::once_flag g_tune_once;
@@ -1501,9 +1502,10 @@ int emmax_op_gemm_splitk(const void* A, int lda, const void* W, int ldw, void* C
     GemmParams p = gp(A, lda, W, ldw, C, ldc, M, N, K);
     p.bias = bias; p.act = act; p.scale = scale; p.residual = residual; p.ldr = ldr; p.out_f32 = out_f32;
     p.ws = (float*)ws; p.ws_bytes = ws_bytes;
-    int r = launch_gemm_splitk(p, ksplit, (hipStream_t)st);
+    // ksplit = 0: the launch plan of a session stage with this scratch (whole tiles, split-K, or a column remainder through split-K)
+    int r = ksplit == 0 ? launch_gemm(p, (hipStream_t)st) : launch_gemm_splitk(p, ksplit, (hipStream_t)st);
     if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID,
-                       "emmax_op_gemm_splitk: unsupported (2 <= ksplit <= K/64, act in {0,1}, ws >= ksplit*M*N*4 bytes, K%%64, N%%128)");
+                       "emmax_op_gemm_splitk: unsupported (ksplit = 0 or 2 <= ksplit <= K/64, ws >= ksplit*M*N*4 bytes, K%%64, N%%128; SwiGLU: bf16 output)");
     return 0;
 }
 int emmax_op_gemm_ln(const void* X, int ldx, void* W, int ldw, void* C, int ldc, int M, int N, int K, const void* gamma, const void* beta,

@@ -82,7 +82,8 @@ int emmax_config_size(void);
  * environment variable EMMAX_<NAME> for each of them ONCE, the first time any value is needed; afterwards only emmax_tuning_set
  * changes them (no launcher reads the environment).  Every default is the product path; the other values are the A/B partners
  * DESIGN.md quotes.  Names: graph (1 = hipGraph replay of the decode step, BASELINE configs[4]), ks, ks_oproj, ks_oproj_grid, km,
- * km_down, streamk, fp8_gemv, attn_nsplit, attn_direct, fold_embed, mfma_xbar, gemm_big, gemm_splitk, gemm_deep, gemm_lnfuse, attn_resident.
+ * km_down, streamk, fp8_gemv, attn_nsplit, attn_direct, fold_embed, mfma_xbar, gemm_big, gemm_splitk, gemm_hybrid, gemm_deep, gemm_lnfuse,
+ * attn_resident.
  * Not thread-safe against concurrent launches; a session re-captures its decode graph after a change. */
 int emmax_tuning_set(const char* name, int value);
 int emmax_tuning_get(const char* name, int* value_out);
@@ -213,7 +214,8 @@ int emmax_op_gemm(const void* A_dev, int lda, const void* W_dev, int ldw, void* 
                   emmax_stream stream);
 /* The same GEMM with `ksplit` K slices per 128x128 tile (fp32 partial tiles in ws_dev, >= ksplit*M*N*4 bytes) and a reduce +
  * epilogue pass: the path the session takes by itself for under-filled problems with a long K (prefill o / down at one
- * frame, batch-1 ViT fc2).  act in {0, 1}. */
+ * frame, batch-1 ViT fc2).  act in {0, 1, 2}.  ksplit = 0: the launch plan a session stage runs with this scratch -- whole
+ * tiles, split-K, or whole rounds of 256x256 tiles + the remaining tile columns K-split (one-frame prefill gate/up). */
 int emmax_op_gemm_splitk(const void* A_dev, int lda, const void* W_dev, int ldw, void* C_dev, int ldc, int M, int N, int K,
                          const void* bias_dev, int act, const void* scale_dev, const void* residual_dev, int ldr, int out_f32,
                          int ksplit, void* ws_dev, int64_t ws_bytes, emmax_stream stream);

@@ -212,6 +212,74 @@ def test_gemm_splitk(device, M, N, K, ks, variant):
                                     ws.data_ptr(), ws.numel() * 4, stream()) != 0
 
 
+def _swiglu_case(device, M, inter, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    A = bf(torch.randn(M, K, generator=g)).to(device)
+    Wg = bf(torch.randn(inter, K, generator=g) * 0.03).to(device)
+    Wu = bf(torch.randn(inter, K, generator=g) * 0.03).to(device)
+    ref = F.silu(A.float() @ Wg.float().t()) * (A.float() @ Wu.float().t())
+    Wi = torch.stack([Wg.view(inter // 16, 16, K), Wu.view(inter // 16, 16, K)], dim=1).reshape(2 * inter, K).contiguous()
+    return A, Wi, ref
+
+
+@pytest.mark.parametrize("M,inter,K,ks", [(768, 128, 4096, 8), (300, 192, 640, 3), (768, 2048, 2048, 2)])
+def test_gemm_splitk_swiglu(device, M, inter, K, ks):
+    """SwiGLU through the split-K path: fp32 partial tiles in the interleaved (gate, up) column order, pairing in the reduce pass."""
+    L, lib = _lib()
+    A, Wi, ref = _swiglu_case(device, M, inter, K, M + inter + K)
+    N = 2 * inter
+    Cd = torch.full((M, inter), float("nan"), dtype=torch.bfloat16, device=device)
+    ws = torch.empty(ks * M * N, dtype=torch.float32, device=device)
+    L.check(lib.emmax_op_gemm_splitk(A.data_ptr(), K, Wi.data_ptr(), K, Cd.data_ptr(), inter, M, N, K, None, 2, None, None, 0, 0, ks,
+                                     ws.data_ptr(), ws.numel() * 4, stream()), "splitk swiglu")
+    torch.cuda.synchronize()
+    assert torch.isfinite(Cd.float()).all()
+    assert relerr(Cd, ref) < TOL
+    assert_elementwise(Cd, ref)
+    # the same launch without the split: equal up to the fp32 summation order
+    C1 = torch.empty_like(Cd)
+    L.check(lib.emmax_op_gemm(A.data_ptr(), K, Wi.data_ptr(), K, C1.data_ptr(), inter, M, N, K, None, 2, None, None, 0, 0, stream()), "gemm")
+    torch.cuda.synchronize()
+    assert relerr(Cd, C1.float()) < 4e-3
+
+
+@pytest.mark.parametrize("act", [2, 0])
+def test_gemm_hybrid_column_remainder_plan(device, act):
+    """One-frame prefill gate/up (M = 768, N = 22016 = 86 tile columns, K = 4096): 3 x 86 = 258 big tiles = one round + 2 tiles.
+    The session's launch plan (emmax_op_gemm_splitk with ksplit = 0) runs 85 tile columns as one round of 256x256 tiles and the last
+    256 columns K-split on 128x128 tiles + the reduce / epilogue pass; against fp32, and against the plan with the switch off."""
+    L, lib = _lib()
+    M, N, K = 768, 22016, 4096
+    if act == 2:
+        A, W, ref = _swiglu_case(device, M, N // 2, K, 5)
+        nout = N // 2
+        res = None
+    else:
+        g = torch.Generator().manual_seed(6)
+        A = bf(torch.randn(M, K, generator=g)).to(device)
+        W = bf(torch.randn(N, K, generator=g) * 0.03).to(device)
+        res = bf(torch.randn(M, N, generator=g)).to(device)
+        ref = A.float() @ W.float().t() + res.float()
+        nout = N
+    ws = torch.empty(16 << 20, dtype=torch.float32, device=device)
+    outs = []
+    for hybrid in (1, 0):
+        with L.tuning(gemm_hybrid=hybrid):
+            Cd = torch.full((M, nout), float("nan"), dtype=torch.bfloat16, device=device)
+            L.check(lib.emmax_op_gemm_splitk(A.data_ptr(), K, W.data_ptr(), K, Cd.data_ptr(), nout, M, N, K, None, act, None, L.ptr(res), N, 0, 0,
+                                             ws.data_ptr(), ws.numel() * 4, stream()), "planned gemm")
+            torch.cuda.synchronize()
+        assert torch.isfinite(Cd.float()).all()
+        assert relerr(Cd, ref) < TOL
+        assert_elementwise(Cd, ref)
+        outs.append(Cd)
+    # whole-tile columns: the K order of an output element does not depend on the tile geometry; the K-split columns differ from the
+    # unsplit launch by the fp32 summation order only
+    n1 = 85 * 256 // (2 if act == 2 else 1)
+    assert torch.equal(outs[0][:, :n1], outs[1][:, :n1])
+    assert relerr(outs[0][:, n1:], outs[1][:, n1:].float()) < 4e-3
+
+
 @pytest.mark.parametrize("M,N,K,act", [(261 * 3, 3072, 1024, 0), (256 * 5 + 17, 4352, 1152, 1), (40, 384, 128, 0), (66816 // 8, 4096, 1024, 1)])
 def test_gemm_with_layernorm_folded_in(device, M, N, K, act):
     """timm Block: norm1 -> attn.qkv and norm2 -> mlp.fc1 as ONE GEMM over the raw rows (W' = bf16(W .* gamma), row statistics from a

@@ -36,19 +36,68 @@ def main():
         name, vals = argv[i + 1].split("=")
         ab = (name, [int(v) for v in vals.split(",")])
         del argv[i:i + 2]
-    if argv:   # custom shapes: "M,N,K,act;M,N,K,act;..."
+    argv0 = list(argv)
+    if "--interleave" in argv:
+        argv.remove("--interleave")
+    plan = "--session-plan" in argv   # launch plan of a session stage (64 MB split-K scratch: emmax_op_gemm_splitk with ksplit = 0)
+    if plan:
+        argv.remove("--session-plan")
+    if argv:   # custom shapes: "M,N,K,act[,lda[,ldw[,ldc]]];..."  (row pitches of A, W, C in elements; 0 / absent: dense)
         SHAPES = [(f"custom{i}",) + tuple(int(v) for v in t.split(",")) for i, t in enumerate(argv[0].split(";"))]
     lib = L.load()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
+    if "--interleave" in argv0:
+        # every listed shape allocated up front, then rounds over all of them in ROTATED order (clock / power state drifts inside a
+        # process: consecutive one-shot timings of different variants do not compare); mean ms per shape over the rounds
+        cases = []
+        for name, M, N, K, act, *rest in SHAPES:
+            rest = list(rest) + [0] * (3 - len(rest))
+            lda, ldw, ldc = rest[0] or K, rest[1] or K, rest[2] or (N // 2 if act == 2 else N)
+            A = (torch.randn(M, lda, device=dev) * 0.5).to(torch.bfloat16)
+            W = (torch.randn(N, ldw, device=dev) * 0.05).to(torch.bfloat16)
+            C = torch.empty(M, ldc, dtype=torch.bfloat16, device=dev)
+            cases.append((name, M, N, K, act, lda, ldw, ldc, A, W, C))
+
+        def go(c):
+            name, M, N, K, act, lda, ldw, ldc, A, W, C = c
+            L.check(lib.emmax_op_gemm(A.data_ptr(), lda, W.data_ptr(), ldw, C.data_ptr(), ldc, M, N, K, None, act, None, None, 0, 0, st), "gemm")
+
+        for c in cases:
+            go(c)
+        torch.cuda.synchronize()
+        tot = [0.0] * len(cases)
+        nround, reps = 3 * len(cases), 5
+        for rnd in range(nround):
+            order = list(range(len(cases)))
+            order = order[rnd % len(cases):] + order[:rnd % len(cases)]
+            for i in order:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    go(cases[i])
+                e1.record()
+                torch.cuda.synchronize()
+                tot[i] += e0.elapsed_time(e1) / reps / nround
+        for c, ms in zip(cases, tot):
+            name, M, N, K, act, lda, ldw, ldc = c[:8]
+            print(f"M={M:6d} N={N:6d} K={K:6d} act={act} ld={lda:5d},{ldw:5d},{ldc:5d}  {ms:8.4f} ms  {2.0 * M * N * K / ms / 1e9:7.1f} TF/s", flush=True)
+        return
     out = {}
-    for name, M, N, K, act in SHAPES:
-        A = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
-        W = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
-        C = torch.empty(M, N // 2 if act == 2 else N, dtype=torch.bfloat16, device=dev)
+    ws = torch.empty(16 << 20, dtype=torch.float32, device=dev) if plan else None
+    for name, M, N, K, act, *rest in SHAPES:
+        rest = list(rest) + [0] * (3 - len(rest))
+        lda, ldw, ldc = rest[0] or K, rest[1] or K, rest[2] or (N // 2 if act == 2 else N)   # row pitches in elements (0: dense)
+        A = (torch.randn(M, lda, device=dev) * 0.5).to(torch.bfloat16)
+        W = (torch.randn(N, ldw, device=dev) * 0.05).to(torch.bfloat16)
+        C = torch.empty(M, ldc, dtype=torch.bfloat16, device=dev)
 
         def run():
-            L.check(lib.emmax_op_gemm(A.data_ptr(), K, W.data_ptr(), K, C.data_ptr(), C.shape[1], M, N, K, None, act, None, None, 0, 0, st), "gemm")
+            if plan:
+                L.check(lib.emmax_op_gemm_splitk(A.data_ptr(), lda, W.data_ptr(), ldw, C.data_ptr(), ldc, M, N, K, None, act, None, None, 0, 0, 0,
+                                                 ws.data_ptr(), ws.numel() * 4, st), "gemm")
+                return
+            L.check(lib.emmax_op_gemm(A.data_ptr(), lda, W.data_ptr(), ldw, C.data_ptr(), ldc, M, N, K, None, act, None, None, 0, 0, st), "gemm")
 
         run()
         torch.cuda.synchronize()
@@ -85,7 +134,7 @@ def main():
         ms = e0.elapsed_time(e1) / reps
         tf = 2.0 * M * N * K / ms / 1e9
         out[name] = {"ms": round(ms, 4), "tflops": round(tf, 1)}
-        print(f"{name:18s} M={M:6d} N={N:6d} K={K:6d} act={act}  {ms:8.4f} ms  {tf:7.1f} TF/s", flush=True)
+        print(f"{name:18s} M={M:6d} N={N:6d} K={K:6d} act={act}  {ms:8.4f} ms  {tf:7.1f} TF/s" + (f"  ld={lda},{ldw},{ldc}" if any(rest) else ""), flush=True)
         del A, W, C
     print(json.dumps(out))
 
