@@ -651,6 +651,84 @@ __global__ __launch_bounds__(256) void emmax_splitk_reduce_kernel(GemmParams p) 
     }
 }
 
+// The same second pass with the RMSNorm that consumes its result (HF LlamaRMSNorm: fp32 statistics of the bf16 row, normalise, round,
+// multiply by the weight): ONE WAVE PER ROW with the lane -> chunk map, the accumulation order and the arithmetic of
+// emmax_rownorm_kernel<8, true> (norm.hip), so C and norm_out are bit-identical to the reduce pass followed by that kernel -- the row is
+// summed, finished (bias / LayerScale / residual), rounded and stored, and its rounded values stay in registers for the statistics.
+// One launch and one read of the row less per o-proj / down projection of a one-frame prefill.  N = 4096 (512 NV), act 0, bf16 C.
+template <int NV>   // 16-byte chunks per lane: N = 512 NV exactly, so that no access is predicated and a slice's 2 NV loads go out together
+__global__ __launch_bounds__(256) void emmax_splitk_reduce_norm_kernel(GemmParams p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const size_t slab = (size_t)p.M * p.N;
+    const bf16_t* bias = (const bf16_t*)p.bias;
+    const bf16_t* scale = (const bf16_t*)p.scale;
+    const bf16_t* res = (const bf16_t*)p.residual;
+    const float* src = p.ws + (size_t)row * p.N + lane * 8;
+    u32x4_t rv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) rv[i] = res ? *(const u32x4_t*)(res + (size_t)row * p.ldr + (lane + 64 * i) * 8) : (u32x4_t){0u, 0u, 0u, 0u};
+    float a8[NV][8];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a8[i][e] = 0.f;
+    for (int sl = 0; sl < p.ksplit; ++sl) {
+        f32x4_t a[NV], b[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            a[i] = *(const f32x4_t*)(src + sl * slab + i * 512);
+            b[i] = *(const f32x4_t*)(src + sl * slab + i * 512 + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a8[i][e] += a[i][e];
+                a8[i][4 + e] += b[i][e];
+            }
+    }
+    u32x4_t v[NV];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (lane + 64 * i) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = a8[i][e] + (bias ? bf2f(bias[col + e]) : 0.f);
+            if (scale) x *= bf2f(scale[col + e]);
+            if (res) x += (e & 1) ? bf_hi(rv[i][e >> 1]) : bf_lo(rv[i][e >> 1]);
+            a8[i][e] = x;
+        }
+        v[i] = (u32x4_t){pack_bf16x2(a8[i][0], a8[i][1]), pack_bf16x2(a8[i][2], a8[i][3]), pack_bf16x2(a8[i][4], a8[i][5]), pack_bf16x2(a8[i][6], a8[i][7])};
+        *(u32x4_t*)((bf16_t*)p.C + (size_t)row * p.ldc + col) = v[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = bf_lo(v[i][j]), bb = bf_hi(v[i][j]);
+            ss += a * a + bb * bb;
+        }
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)p.N + p.norm_eps);
+    const bf16_t* w = (const bf16_t*)p.norm_w;
+    bf16_t* yr = (bf16_t*)p.norm_out + (size_t)row * p.ld_norm;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        const u32x4_t wv = *(const u32x4_t*)(w + c * 8);
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = bf_lo(v[i][j]) * rstd, bb = bf_hi(v[i][j]) * rstd;
+            a = bf2f(f2bf(a)) * bf_lo(wv[j]);
+            bb = bf2f(f2bf(bb)) * bf_hi(wv[j]);
+            o[j] = pack_bf16x2(a, bb);
+        }
+        *(u32x4_t*)(yr + c * 8) = o;
+    }
+}
+
 template <class G, int ACT, bool OUT_F32, bool LN = false, int DEEP = 0>
 int launch_t(const GemmParams& p, hipStream_t stream) {
     if constexpr (DEEP == 0) {
@@ -782,6 +860,13 @@ static int launch_planned_rows(const GemmParams& p, long m1, hipStream_t stream)
 // Split-K for under-filled problems with a long K: fewer small tiles than CUs-and-a-half means one 4-wave block per CU
 // grinding through K alone (M = 768 prefill o / down: 192 tiles, 64-172 K steps at ~0.75 us; batch-1 ViT fc2: 24 tiles).
 // ks slices per tile fill the chip (<= 512 resident blocks), each >= 8 K steps; the partial tiles meet in a second pass.
+// the reduce pass can apply p.norm_*: whole rows of 4096 bf16 columns (the LLaMA-2-7B hidden size; other widths keep the separate norm), 16-byte accesses
+static bool splitk_norm_ok(const GemmParams& p) {
+    return p.norm_out && p.norm_w && p.act == 0 && !p.out_f32 && !p.ln_stats && p.N == 4096 && p.N_store >= p.N &&
+           (p.ldc & 7) == 0 && (p.ld_norm & 7) == 0 && (((size_t)p.C | (size_t)p.norm_out | (size_t)p.norm_w) & 15) == 0 &&
+           (!p.residual || ((p.ldr & 7) == 0 && (((size_t)p.residual) & 15) == 0));
+}
+
 int launch_gemm_splitk(const GemmParams& p, int ks, hipStream_t stream, int big) {
     if (ks < 2 || !p.ws || p.K % BK || p.N % 128 || p.ln_stats) return -1;
     if (p.act == 2 && (p.out_f32 || (p.N & 31))) return -1;
@@ -797,7 +882,10 @@ int launch_gemm_splitk(const GemmParams& p, int ks, hipStream_t stream, int big)
     b.ksplit = ks;
     const size_t groups = (size_t)p.M * ((p.act == 2 ? p.N >> 1 : p.N) >> 3);
     const int grid = (int)((groups + 255) / 256 < 2048 ? (groups + 255) / 256 : 2048);
-    if (p.act == 2) hipLaunchKernelGGL(emmax_splitk_reduce_kernel<2>, dim3(grid), dim3(256), 0, stream, b);
+    if (p.norm_out) {
+        if (!splitk_norm_ok(p)) return -1;
+        hipLaunchKernelGGL(emmax_splitk_reduce_norm_kernel<8>, dim3((p.M + 3) / 4), dim3(256), 0, stream, b);
+    } else if (p.act == 2) hipLaunchKernelGGL(emmax_splitk_reduce_kernel<2>, dim3(grid), dim3(256), 0, stream, b);
     else if (p.act == 1) hipLaunchKernelGGL(emmax_splitk_reduce_kernel<1>, dim3(grid), dim3(256), 0, stream, b);
     else hipLaunchKernelGGL(emmax_splitk_reduce_kernel<0>, dim3(grid), dim3(256), 0, stream, b);
     return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -834,8 +922,14 @@ static int hybrid_cols_plan(const GemmParams& p, int* n1_out, double* cost_out) 
     return ks;
 }
 
+bool gemm_fuses_norm(const GemmParams& p) {
+    if (p.M <= 0 || emmax_tune().gemm_big >= 0 || emmax_tune().gemm_splitk == 0 || emmax_tune().gemm_normfuse == 0) return false;
+    return splitk_norm_ok(p) && splitk_plan(p) != 0;
+}
+
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0) return 0;
+    if (p.norm_out && !gemm_fuses_norm(p)) return -1;   // (the caller asks first)
     const int force = emmax_tune().gemm_big;   // 0 / 1: one geometry, no split
     if (force >= 0) return launch_gemm_geom(p, force != 0, stream);
     const bool no_splitk = emmax_tune().gemm_splitk == 0;

@@ -33,12 +33,20 @@ struct GemmParams {
     const float* ln_stats;
     const float* ln_s;
     const float* ln_c;
+    // RMSNorm of the RESULT rows fused into the split-K reduce pass (one-frame prefill: o-proj -> post-attention norm, down -> the next
+    // layer's input norm): norm_out bf16 [M, ld_norm] = RMSNorm(C; norm_w, norm_eps), written next to C.  Only honoured on the whole-problem
+    // split-K path -- ask gemm_fuses_norm(p) first, and run launch_rmsnorm yourself when it says no.
+    const void* norm_w;
+    void* norm_out;
+    int ld_norm;
+    float norm_eps;
     int dbg;               // tools only: 1 = skip the operand DMA after K step 1 (LDS + MFMA time alone), 2 = skip the stores
     long long* trace;      // tools only (tools/gemm_trace.hip): block 0 writes wall_clock64() stamps per tile phase; null in the product
 };
 int launch_gemm(const GemmParams& p, hipStream_t stream);                     // picks the 256x256 or the 128x128 tile geometry
 int launch_gemm_geom(const GemmParams& p, int big, hipStream_t stream);       // explicit geometry (tools, tests)
 int gemm_big_tiles(const GemmParams& p);
+bool gemm_fuses_norm(const GemmParams& p);                                    // launch_gemm(p) will apply p.norm_* (see GemmParams)
 int launch_gemm_splitk(const GemmParams& p, int ksplit, hipStream_t stream, int big = 0);  // ksplit K slices per tile (128x128; big: 256x256) + reduce / epilogue pass (needs p.ws)
 
 // ---- norm.hip ----
@@ -120,6 +128,7 @@ struct EmmaxTune {
     int gemm_big;        // -1: planned tile geometry; 0 / 1: all small / all big tiles, no split-K
     int gemm_splitk;     // 1: split-K for under-filled long-K GEMMs
     int gemm_hybrid;     // 1: a column remainder behind whole rounds of big tiles goes through K-split small tiles when K is long (one-frame prefill gate/up)
+    int gemm_normfuse;   // 1: the split-K reduce pass of the one-frame prefill o-proj / down also applies the RMSNorm that follows
     int gemm_deep;       // GEMM main loop: -1 = by geometry (256x256: staggered wave groups, 128x128: deep A ring), 0 = two stages + one barrier per step, 1 = third LDS stage for A, 3 = staggered wave groups (256x256 only)
     int gemm_dbg;        // lab: OR-ed into GemmParams::dbg (16 = the second half of the waves requests its slabs mid-step)
     int gemm_lnfuse;     // 1: LayerNorm / RMSNorm applied by the GEMM that consumes the normalised rows (no separate norm pass)

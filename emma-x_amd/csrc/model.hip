@@ -57,7 +57,7 @@ const TuneEntry kTune[] = {
     {"gemm_big", &EmmaxTune::gemm_big, -1},    {"gemm_splitk", &EmmaxTune::gemm_splitk, 1},
     {"gemm_deep", &EmmaxTune::gemm_deep, -1},       {"gemm_dbg", &EmmaxTune::gemm_dbg, 0},
     {"gemm_lnfuse", &EmmaxTune::gemm_lnfuse, 1}, {"attn_resident", &EmmaxTune::attn_resident, -1},
-    {"gemm_hybrid", &EmmaxTune::gemm_hybrid, 1},
+    {"gemm_hybrid", &EmmaxTune::gemm_hybrid, 1}, {"gemm_normfuse", &EmmaxTune::gemm_normfuse, 1},
 };
 EmmaxTune g_tune;
 std::once_flag g_tune_once;
@@ -643,9 +643,18 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
     s->total_rows = total; s->max_seqlen = maxS;
 
     KCHK(launch_embed_splice(ids, P_max, s->cu, m->embed, patches, s->ph, B, maxS, np, m->H, m->vocab, st));
+    // the RMSNorm behind a projection whose partial tiles meet in a split-K reduce pass (one-frame prefill: o-proj, down) is applied
+    // by that pass (gemm_fuses_norm); otherwise it is its own launch
+    auto with_norm = [&](GemmParams& g, const void* w) {
+        g.norm_w = w; g.norm_out = s->pxn; g.ld_norm = m->H; g.norm_eps = c.rms_eps;
+        if (gemm_fuses_norm(g)) return true;
+        g.norm_w = nullptr; g.norm_out = nullptr;
+        return false;
+    };
+    bool normed = false;   // s->pxn already holds ln1 of the current layer
     for (int li = 0; li < c.n_layers; ++li) {
         const LayerW& L = m->layers[li];
-        KCHK(launch_rmsnorm(s->ph, s->pxn, L.ln1, total, m->H, m->H, m->H, c.rms_eps, st));
+        if (!normed) KCHK(launch_rmsnorm(s->ph, s->pxn, L.ln1, total, m->H, m->H, m->H, c.rms_eps, st));
         GemmParams g = gps(s, s->pxn, m->H, L.wqkv, m->H, s->pqkv, m->qkv_dim, total, m->qkv_dim, m->H);
         KCHK(launch_gemm(g, st));
         KCHK(launch_rope_kv_write(s->pqkv, m->qkv_dim, 0, m->q_dim, m->q_dim + m->kv_dim, s->cu, B, total, s->cos_t, s->sin_t,
@@ -659,13 +668,15 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
         KCHK(launch_attention(a, c.head_dim, st));
         g = gps(s, s->patt, m->q_dim, L.wo, m->q_dim, s->ph, m->H, total, m->H, m->q_dim);
         g.residual = s->ph; g.ldr = m->H;
+        normed = with_norm(g, L.ln2);
         KCHK(launch_gemm(g, st));
-        KCHK(launch_rmsnorm(s->ph, s->pxn, L.ln2, total, m->H, m->H, m->H, c.rms_eps, st));
+        if (!normed) KCHK(launch_rmsnorm(s->ph, s->pxn, L.ln2, total, m->H, m->H, m->H, c.rms_eps, st));
         g = gps(s, s->pxn, m->H, L.wgu, m->H, s->pact, m->inter_p, total, 2 * m->inter_p, m->H);
         g.act = 2;
         KCHK(launch_gemm(g, st));
         g = gps(s, s->pact, m->inter_p, L.wdown, m->inter_p, s->ph, m->H, total, m->H, m->inter_p);
         g.residual = s->ph; g.ldr = m->H;
+        normed = li + 1 < c.n_layers && with_norm(g, m->layers[li + 1].ln1);
         KCHK(launch_gemm(g, st));
     }
     KCHK(launch_gather_last_rows(s->ph, s->dh + (size_t)r0 * m->H, s->cu, B, m->H, st));

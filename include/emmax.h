@@ -82,7 +82,7 @@ int emmax_config_size(void);
  * environment variable EMMAX_<NAME> for each of them ONCE, the first time any value is needed; afterwards only emmax_tuning_set
  * changes them (no launcher reads the environment).  Every default is the product path; the other values are the A/B partners
  * DESIGN.md quotes.  Names: graph (1 = hipGraph replay of the decode step, BASELINE configs[4]), ks, ks_oproj, ks_oproj_grid, km,
- * km_down, streamk, fp8_gemv, attn_nsplit, attn_direct, fold_embed, mfma_xbar, gemm_big, gemm_splitk, gemm_hybrid, gemm_deep, gemm_lnfuse,
+ * km_down, streamk, fp8_gemv, attn_nsplit, attn_direct, fold_embed, mfma_xbar, gemm_big, gemm_splitk, gemm_hybrid, gemm_normfuse, gemm_deep, gemm_lnfuse,
  * attn_resident.
  * Not thread-safe against concurrent launches; a session re-captures its decode graph after a change. */
 int emmax_tuning_set(const char* name, int value);

@@ -80,7 +80,7 @@ def test_tuning_switches_are_a_table_with_a_setter(lib):
     """The library reads EMMAX_<NAME> once; afterwards only emmax_tuning_set moves a switch (no launcher calls getenv)."""
     L, so = lib
     names = ["graph", "ks", "ks_oproj", "ks_oproj_grid", "km", "km_down", "streamk", "fp8_gemv", "attn_nsplit", "attn_direct", "fold_embed",
-             "mfma_xbar", "gemm_big", "gemm_splitk", "gemm_hybrid", "gemm_deep", "gemm_lnfuse", "attn_resident"]
+             "mfma_xbar", "gemm_big", "gemm_splitk", "gemm_hybrid", "gemm_normfuse", "gemm_deep", "gemm_lnfuse", "attn_resident"]
     header = open(os.path.join(ROOT, "include", "emmax.h")).read()
     for n in names:
         assert re.search(r"\b%s\b" % n, header), n

@@ -173,6 +173,23 @@ def test_bf16_prefill_512_every_logit_row(device, setup, model_bf16):
     assert per_row.max().item() < TOL, per_row.max().item()
 
 
+def test_prefill_768_reduce_pass_with_the_norm_is_bit_identical(device, setup, model_bf16, tune):
+    """One-frame prefill at 7B layer dims: the split-K reduce pass of o-proj / down that also applies the RMSNorm behind it
+    (gemm_normfuse, gemm.hip emmax_splitk_reduce_norm_kernel) against the reduce pass + emmax_rownorm_kernel: every logit bit-identical.
+    The K-split column remainder of gate/up (gemm_hybrid) against whole tiles: equal up to the fp32 summation order of 256 columns."""
+    cfg, _, _, frames, rows = setup
+    fr = torch.from_numpy(frames[:1]).to(device)
+    tune(gemm_normfuse=1, gemm_hybrid=1)
+    a = model_bf16.forward(input_ids=[rows[0]], frames_u8=fr).logits[0].float().clone()
+    tune(gemm_normfuse=0)
+    b = model_bf16.forward(input_ids=[rows[0]], frames_u8=fr).logits[0].float().clone()
+    assert torch.equal(a, b)
+    tune(gemm_hybrid=0)
+    c = model_bf16.forward(input_ids=[rows[0]], frames_u8=fr).logits[0].float().clone()
+    rel = ((a - c).abs().amax(dim=1) / c.abs().amax(dim=1)).max().item()
+    assert rel < 2e-2, rel
+
+
 def test_bf16_long_context_crosses_1024_and_ends_at_1280(device, setup):
     """B = 2, prompts of 760 and 1000 tokens: contexts 1016 -> 1046 (page boundary 1024) and 1256 -> 1286 (1280 = the context of
     the bench's 512th token).  Same tolerance."""
