@@ -617,15 +617,24 @@ __global__ __launch_bounds__(RC::NT, RC::MINW) void emmax_attention_resident_ker
                 // head_dim 72, where the two register copies of the accumulators the branch makes hipcc keep do not fit)
                 constexpr float LAZY = 8.0f;
                 const bool move = m_tile * c > m_run * c + LAZY;   // finite m_tile: key 0 is visible to every query
-                if (NDB > 2 || __builtin_amdgcn_ballot_w64(move) != 0) {
+                if (__builtin_amdgcn_ballot_w64(move) != 0) {
                     const float m_new = move ? m_tile : m_run;
                     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);   // 1 for the rows that stay
                     l_run *= alpha;
                     m_run = m_new;
+                    if (NDB > 2) {
+                        // head_dim 72 (168 registers at three waves per SIMD): as C++ the branch made hipcc keep a second copy of the 48
+                        // accumulator registers and spill; multiplied IN PLACE by asm statements there is nothing to copy
 #pragma unroll
-                    for (int i = 0; i < NDB; ++i)
+                        for (int i = 0; i < NDB; ++i)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+                            for (int r = 0; r < 16; ++r) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(o[i][r]) : "v"(alpha));
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+                    }
                 }
                 const float mc = m_run * c;
                 float psum = 0.f;
