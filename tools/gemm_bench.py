@@ -52,16 +52,20 @@ def main():
         # process: consecutive one-shot timings of different variants do not compare); mean ms per shape over the rounds
         cases = []
         for name, M, N, K, act, *rest in SHAPES:
-            rest = list(rest) + [0] * (3 - len(rest))
+            rest = list(rest) + [0] * (4 - len(rest))
             lda, ldw, ldc = rest[0] or K, rest[1] or K, rest[2] or (N // 2 if act == 2 else N)
+            epi = rest[3]      # 5th optional field: 1 = bias + LayerScale + in-place residual (the ViT proj / fc2 epilogue), 2 = bias only
             A = (torch.randn(M, lda, device=dev) * 0.5).to(torch.bfloat16)
             W = (torch.randn(N, ldw, device=dev) * 0.05).to(torch.bfloat16)
-            C = torch.empty(M, ldc, dtype=torch.bfloat16, device=dev)
-            cases.append((name, M, N, K, act, lda, ldw, ldc, A, W, C))
+            C = (torch.randn(M, ldc, device=dev) * 0.5).to(torch.bfloat16)
+            bias = torch.randn(N, device=dev).to(torch.bfloat16) if epi else None
+            scale = torch.rand(N, device=dev).to(torch.bfloat16) if epi == 1 else None
+            cases.append((name, M, N, K, act, lda, ldw, ldc, A, W, C, bias, scale, epi))
 
         def go(c):
-            name, M, N, K, act, lda, ldw, ldc, A, W, C = c
-            L.check(lib.emmax_op_gemm(A.data_ptr(), lda, W.data_ptr(), ldw, C.data_ptr(), ldc, M, N, K, None, act, None, None, 0, 0, st), "gemm")
+            name, M, N, K, act, lda, ldw, ldc, A, W, C, bias, scale, epi = c
+            L.check(lib.emmax_op_gemm(A.data_ptr(), lda, W.data_ptr(), ldw, C.data_ptr(), ldc, M, N, K, L.ptr(bias), act, L.ptr(scale),
+                                      C.data_ptr() if epi == 1 else None, ldc, 0, st), "gemm")
 
         for c in cases:
             go(c)
@@ -81,23 +85,27 @@ def main():
                 tot[i] += e0.elapsed_time(e1) / reps / nround
         for c, ms in zip(cases, tot):
             name, M, N, K, act, lda, ldw, ldc = c[:8]
-            print(f"M={M:6d} N={N:6d} K={K:6d} act={act} ld={lda:5d},{ldw:5d},{ldc:5d}  {ms:8.4f} ms  {2.0 * M * N * K / ms / 1e9:7.1f} TF/s", flush=True)
+            print(f"M={M:6d} N={N:6d} K={K:6d} act={act} epi={c[13]} ld={lda:5d},{ldw:5d},{ldc:5d}  {ms:8.4f} ms  {2.0 * M * N * K / ms / 1e9:7.1f} TF/s", flush=True)
         return
     out = {}
     ws = torch.empty(16 << 20, dtype=torch.float32, device=dev) if plan else None
     for name, M, N, K, act, *rest in SHAPES:
-        rest = list(rest) + [0] * (3 - len(rest))
+        rest = list(rest) + [0] * (4 - len(rest))
         lda, ldw, ldc = rest[0] or K, rest[1] or K, rest[2] or (N // 2 if act == 2 else N)   # row pitches in elements (0: dense)
         A = (torch.randn(M, lda, device=dev) * 0.5).to(torch.bfloat16)
         W = (torch.randn(N, ldw, device=dev) * 0.05).to(torch.bfloat16)
-        C = torch.empty(M, ldc, dtype=torch.bfloat16, device=dev)
+        C = (torch.randn(M, ldc, device=dev) * 0.5).to(torch.bfloat16)
+        epi = rest[3] if len(rest) > 3 else 0     # 1 = bias + LayerScale + in-place residual, 2 = bias
+        bias = torch.randn(N, device=dev).to(torch.bfloat16) if epi else None
+        scale = torch.rand(N, device=dev).to(torch.bfloat16) if epi == 1 else None
 
         def run():
             if plan:
                 L.check(lib.emmax_op_gemm_splitk(A.data_ptr(), lda, W.data_ptr(), ldw, C.data_ptr(), ldc, M, N, K, None, act, None, None, 0, 0, 0,
                                                  ws.data_ptr(), ws.numel() * 4, st), "gemm")
                 return
-            L.check(lib.emmax_op_gemm(A.data_ptr(), lda, W.data_ptr(), ldw, C.data_ptr(), ldc, M, N, K, None, act, None, None, 0, 0, st), "gemm")
+            L.check(lib.emmax_op_gemm(A.data_ptr(), lda, W.data_ptr(), ldw, C.data_ptr(), ldc, M, N, K, L.ptr(bias), act, L.ptr(scale),
+                                      C.data_ptr() if epi == 1 else None, ldc, 0, st), "gemm")
 
         run()
         torch.cuda.synchronize()
