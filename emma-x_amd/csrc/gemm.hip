@@ -927,13 +927,20 @@ bool gemm_fuses_norm(const GemmParams& p) {
     return splitk_norm_ok(p) && splitk_plan(p) != 0;
 }
 
-int launch_gemm(const GemmParams& p, hipStream_t stream) {
-    if (p.M <= 0) return 0;
-    if (p.norm_out && !gemm_fuses_norm(p)) return -1;   // (the caller asks first)
+// The launch plan of launch_gemm, as data (gemm_plan_describe prints it: the CPU tests pin the plans of the shapes of the hot path).
+//   GEOM    one geometry, forced by the tuning switch gemm_big
+//   SPLITK  the whole problem K-split on 128 x 128 tiles + reduce pass (ks slices)
+//   HYBRID  columns [0, n1): rows plan m1 (big tile rows, the rest small); columns [n1, N): K-split (ks) + reduce pass
+//   COLS    columns [0, n1): rows plan m1; columns [n1, N): one all-small launch (half-empty last tile column)
+//   ROWS    m1 big tile rows, the remaining rows in small tiles (m1 = all: one big launch; 0: one small launch)
+struct GemmPlan { enum Kind { GEOM, SPLITK, HYBRID, COLS, ROWS } kind; int big, ks, n1; long m1; };
+
+static GemmPlan plan_gemm(const GemmParams& p) {
+    GemmPlan pl = {GemmPlan::ROWS, 0, 0, 0, 0};
     const int force = emmax_tune().gemm_big;   // 0 / 1: one geometry, no split
-    if (force >= 0) return launch_gemm_geom(p, force != 0, stream);
+    if (force >= 0) { pl.kind = GemmPlan::GEOM; pl.big = force != 0; return pl; }
     const bool no_splitk = emmax_tune().gemm_splitk == 0;
-    if (const int ks = no_splitk ? 0 : splitk_plan(p)) return launch_gemm_splitk(p, ks, stream);
+    if (const int ks = no_splitk ? 0 : splitk_plan(p)) { pl.kind = GemmPlan::SPLITK; pl.ks = ks; return pl; }
     long m1 = 0;
     const double whole = plan_rows(p.M, p.N, &m1);
     if (!no_splitk && emmax_tune().gemm_hybrid != 0) {
@@ -941,21 +948,9 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
         double hcost = 0.0;
         const int hks = hybrid_cols_plan(p, &hn1, &hcost);
         if (hks && hcost < whole - 0.02) {
-            GemmParams a = p, b = p;
-            a.N = hn1;
-            a.N_store = p.N_store < hn1 ? p.N_store : hn1;
-            b.N = p.N - hn1;
-            b.N_store = p.N_store > hn1 ? p.N_store - hn1 : 0;
-            b.W = (const bf16_t*)p.W + (size_t)hn1 * p.ldw;
-            b.C = (void*)((bf16_t*)p.C + (p.act == 2 ? hn1 / 2 : hn1));
-            if (p.bias) b.bias = (const bf16_t*)p.bias + hn1;
-            if (p.scale) b.scale = (const bf16_t*)p.scale + hn1;
-            if (p.residual) b.residual = (const bf16_t*)p.residual + hn1;
-            long m1a = 0;
-            plan_rows(p.M, hn1, &m1a);
-            const int r = launch_planned_rows(a, m1a, stream);
-            if (r) return r;
-            return (p.act == 2 || b.N_store > 0) ? launch_gemm_splitk(b, hks, stream) : 0;
+            pl.kind = GemmPlan::HYBRID; pl.ks = hks; pl.n1 = hn1;
+            plan_rows(p.M, hn1, &pl.m1);
+            return pl;
         }
     }
     // a half-empty last tile column (N = 1152, 3456: 4.5 / 13.5 big tiles wide) can go to the small geometry instead:
@@ -972,21 +967,57 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
         if (stream_us / round_us > right) right = stream_us / round_us;
         right += 0.03;
         if (left + right < whole - 1e-9) {
-            GemmParams a = p, b = p;
-            a.N = n1;
-            a.N_store = p.N_store < n1 ? p.N_store : n1;
-            b.N = p.N - n1;
-            b.N_store = p.N_store > n1 ? p.N_store - n1 : 0;
-            b.W = (const bf16_t*)p.W + (size_t)n1 * p.ldw;
-            b.C = p.out_f32 ? (void*)((float*)p.C + n1) : (void*)((bf16_t*)p.C + n1);
-            if (p.bias) b.bias = (const bf16_t*)p.bias + n1;
-            if (p.scale) b.scale = (const bf16_t*)p.scale + n1;
-            if (p.residual) b.residual = (const bf16_t*)p.residual + n1;
-            if (p.ln_stats) { b.ln_s = p.ln_s + n1; b.ln_c = p.ln_c + n1; }
-            const int r = launch_planned_rows(a, m1a, stream);
-            if (r) return r;
-            return b.N_store > 0 ? launch_gemm_geom(b, 0, stream) : 0;
+            pl.kind = GemmPlan::COLS; pl.n1 = n1; pl.m1 = m1a;
+            return pl;
         }
     }
-    return launch_planned_rows(p, m1, stream);
+    pl.m1 = m1;
+    return pl;
+}
+
+int gemm_plan_describe(const GemmParams& p, char* buf, int len) {
+    if (p.M <= 0 || p.K % BK != 0 || p.N % 128 != 0 || p.K <= 0 || p.N <= 0) return -1;
+    const GemmPlan pl = plan_gemm(p);
+    const long tm = cdiv(p.M, GeomBig::BM);
+    auto rows = [&](long m1, char* o, int n) {
+        if (m1 >= tm) snprintf(o, n, "big");
+        else if (m1 <= 0) snprintf(o, n, "small");
+        else snprintf(o, n, "big rows 0..%ld + small rows %ld..%d", m1 * GeomBig::BM, m1 * GeomBig::BM, p.M);
+    };
+    char r[96];
+    switch (pl.kind) {
+        case GemmPlan::GEOM: snprintf(buf, len, "forced %s", pl.big ? "big" : "small"); break;
+        case GemmPlan::SPLITK: snprintf(buf, len, "splitk ks=%d%s", pl.ks, gemm_fuses_norm(p) ? " +norm" : ""); break;
+        case GemmPlan::HYBRID: rows(pl.m1, r, sizeof r); snprintf(buf, len, "hybrid cols 0..%d: %s | cols %d..%d: splitk ks=%d", pl.n1, r, pl.n1, p.N, pl.ks); break;
+        case GemmPlan::COLS: rows(pl.m1, r, sizeof r); snprintf(buf, len, "cols 0..%d: %s | cols %d..%d: small", pl.n1, r, pl.n1, p.N); break;
+        case GemmPlan::ROWS: rows(pl.m1, r, sizeof r); snprintf(buf, len, "%s", r); break;
+    }
+    return (int)pl.kind;
+}
+
+int launch_gemm(const GemmParams& p, hipStream_t stream) {
+    if (p.M <= 0) return 0;
+    if (p.norm_out && !gemm_fuses_norm(p)) return -1;   // (the caller asks first)
+    const GemmPlan pl = plan_gemm(p);
+    if (pl.kind == GemmPlan::GEOM) return launch_gemm_geom(p, pl.big, stream);
+    if (pl.kind == GemmPlan::SPLITK) return launch_gemm_splitk(p, pl.ks, stream);
+    if (pl.kind == GemmPlan::ROWS) return launch_planned_rows(p, pl.m1, stream);
+    // column parts: a = columns [0, n1), b = columns [n1, N)
+    const int n1 = pl.n1;
+    GemmParams a = p, b = p;
+    a.N = n1;
+    a.N_store = p.N_store < n1 ? p.N_store : n1;
+    b.N = p.N - n1;
+    b.N_store = p.N_store > n1 ? p.N_store - n1 : 0;
+    b.W = (const bf16_t*)p.W + (size_t)n1 * p.ldw;
+    const int c1 = p.act == 2 ? n1 / 2 : n1;
+    b.C = p.out_f32 ? (void*)((float*)p.C + c1) : (void*)((bf16_t*)p.C + c1);
+    if (p.bias) b.bias = (const bf16_t*)p.bias + n1;
+    if (p.scale) b.scale = (const bf16_t*)p.scale + n1;
+    if (p.residual) b.residual = (const bf16_t*)p.residual + n1;
+    if (p.ln_stats) { b.ln_s = p.ln_s + n1; b.ln_c = p.ln_c + n1; }
+    const int r = launch_planned_rows(a, pl.m1, stream);
+    if (r) return r;
+    if (pl.kind == GemmPlan::HYBRID) return (p.act == 2 || b.N_store > 0) ? launch_gemm_splitk(b, pl.ks, stream) : 0;
+    return b.N_store > 0 ? launch_gemm_geom(b, 0, stream) : 0;
 }

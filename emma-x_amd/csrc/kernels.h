@@ -46,6 +46,7 @@ struct GemmParams {
 int launch_gemm(const GemmParams& p, hipStream_t stream);                     // picks the 256x256 or the 128x128 tile geometry
 int launch_gemm_geom(const GemmParams& p, int big, hipStream_t stream);       // explicit geometry (tools, tests)
 int gemm_big_tiles(const GemmParams& p);
+int gemm_plan_describe(const GemmParams& p, char* buf, int len);              // the plan launch_gemm would run, as text (host only); returns its kind or -1
 bool gemm_fuses_norm(const GemmParams& p);                                    // launch_gemm(p) will apply p.norm_* (see GemmParams)
 int launch_gemm_splitk(const GemmParams& p, int ksplit, hipStream_t stream, int big = 0);  // ksplit K slices per tile (128x128; big: 256x256) + reduce / epilogue pass (needs p.ws)
 

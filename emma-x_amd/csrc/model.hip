@@ -1519,6 +1519,21 @@ int emmax_op_gemm_splitk(const void* A, int lda, const void* W, int ldw, void* C
                        "emmax_op_gemm_splitk: unsupported (ksplit = 0 or 2 <= ksplit <= K/64, ws >= ksplit*M*N*4 bytes, K%%64, N%%128; SwiGLU: bf16 output)");
     return 0;
 }
+int emmax_gemm_plan(int M, int N, int K, int act, int out_f32, int has_ln, int has_residual, int with_norm, int64_t ws_bytes, char* text_out,
+                    int text_len) {
+    if (!text_out || text_len < 16) return fail(EMMAX_ERR_INVALID, "emmax_gemm_plan: text buffer of at least 16 bytes");
+    void* const any = (void*)(uintptr_t)256;   // the plan looks at sizes, alignments and which operands exist -- never through a pointer
+    GemmParams p = gp(any, K, any, K, any, act == 2 ? N / 2 : N, M, N, K);
+    p.act = act; p.out_f32 = out_f32;
+    if (has_residual) { p.residual = any; p.ldr = N; }
+    if (has_ln) { p.ln_stats = (const float*)any; p.ln_s = (const float*)any; p.ln_c = (const float*)any; }
+    if (ws_bytes > 0) { p.ws = (float*)any; p.ws_bytes = ws_bytes; }
+    if (with_norm) { p.norm_w = any; p.norm_out = any; p.ld_norm = N; p.norm_eps = 1e-5f; }
+    if (with_norm && !gemm_fuses_norm(p)) { p.norm_w = nullptr; p.norm_out = nullptr; }   // (what the prefill does: a separate norm launch)
+    const int r = gemm_plan_describe(p, text_out, text_len);
+    if (r < 0) return fail(EMMAX_ERR_INVALID, "emmax_gemm_plan: unsupported shape (K%%64, N%%128)");
+    return 0;
+}
 int emmax_op_gemm_ln(const void* X, int ldx, void* W, int ldw, void* C, int ldc, int M, int N, int K, const void* gamma, const void* beta,
                      const void* bias, float eps, int act, float* stats_ws, float* ln_s_ws, float* ln_c_ws, emmax_stream stream) {
     if (!X || !W || !C || !gamma || !stats_ws || !ln_s_ws || !ln_c_ws) return fail(EMMAX_ERR_INVALID, "emmax_op_gemm_ln: null argument");

@@ -89,6 +89,7 @@ SIGNATURES = {
                                 C.c_int, C.c_int, _vp]),
     "emmax_op_gemm_splitk": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp,
                                        C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp]),
+    "emmax_gemm_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_char_p, C.c_int]),
     "emmax_op_gemm_ln": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_float, C.c_int, _vp, _vp, _vp, _vp]),
     "emmax_op_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp]),
     "emmax_op_rmsnorm": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp]),
@@ -143,6 +144,14 @@ def tuning_get(name: str) -> int:
     v = C.c_int(0)
     check(load().emmax_tuning_get(name.encode(), C.byref(v)), f"emmax_tuning_get({name})")
     return int(v.value)
+
+
+def gemm_plan(M: int, N: int, K: int, act: int = 0, out_f32: bool = False, ln: bool = False, residual: bool = False, norm: bool = False,
+              ws_bytes: int = 64 << 20) -> str:
+    """The GEMM launch plan for a problem, as text (include/emmax.h: emmax_gemm_plan; host only -- runs without a GPU)."""
+    buf = C.create_string_buffer(256)
+    check(load().emmax_gemm_plan(M, N, K, act, int(out_f32), int(ln), int(residual), int(norm), ws_bytes, buf, 256), "emmax_gemm_plan")
+    return buf.value.decode()
 
 
 class tuning:

@@ -219,6 +219,12 @@ int emmax_op_gemm(const void* A_dev, int lda, const void* W_dev, int ldw, void* 
 int emmax_op_gemm_splitk(const void* A_dev, int lda, const void* W_dev, int ldw, void* C_dev, int ldc, int M, int N, int K,
                          const void* bias_dev, int act, const void* scale_dev, const void* residual_dev, int ldr, int out_f32,
                          int ksplit, void* ws_dev, int64_t ws_bytes, emmax_stream stream);
+/* The launch plan emmax_op_gemm / a session stage would run for this problem, as text (host only, no device work): which tile
+ * geometry, row / column parts, split-K slices, and whether the split-K reduce pass also applies the RMSNorm behind the projection
+ * (with_norm; one-frame prefill o-proj / down).  ws_bytes = size of the split-K scratch (0: none).  e.g. M = 768, N = 22016, K = 4096,
+ * act = 2, 64 MB scratch: "hybrid cols 0..21760: big | cols 21760..22016: splitk ks=8". */
+int emmax_gemm_plan(int M, int N, int K, int act, int out_f32, int has_ln, int has_residual, int with_norm, int64_t ws_bytes, char* text_out,
+                    int text_len);
 /* LayerNorm folded into the projection that consumes it, as the ViT qkv / fc1 stages run (timm Block: norm1 -> attn.qkv, norm2 ->
  * mlp.fc1): C[M,N] = act(LN(X; gamma, beta, eps) @ W^T + bias) without materialising LN(X).  W_dev bf16 [N, ldw] is REWRITTEN in
  * place to bf16(W .* gamma) (what emmax_model_finalize does once per model); stats_ws f32 [M][2], ln_s_ws / ln_c_ws f32 [N] are

@@ -151,3 +151,35 @@ def test_null_arguments_are_errors(lib):
     assert so.emmax_model_create(None, None) == -1
     assert so.emmax_decode_step(None, None) == -1
     assert so.emmax_generate(None, 4, 1, None, None, None) == -1
+
+
+def test_gemm_launch_plans_of_the_hot_path(lib):
+    """emmax_gemm_plan (host only): the launch plans of the GEMM shapes of the hot path, pinned -- one-frame prefill (M = 768: gate/up =
+    one round of 256x256 tiles + a K-split column remainder, qkv one under-filled round, o / down K-split with the RMSNorm in the reduce
+    pass), eight frames (M = 6144), ViT at 256 frames (row plan, the half-empty SigLIP tile column), and what the switches turn off."""
+    L, so = lib
+    assert L.gemm_plan(768, 22016, 4096, act=2) == "hybrid cols 0..21760: big | cols 21760..22016: splitk ks=8"
+    assert L.gemm_plan(768, 22016, 4096, act=2, ws_bytes=0) == "big rows 0..512 + small rows 512..768"      # no scratch: never split
+    assert L.gemm_plan(768, 12288, 4096) == "big"
+    assert L.gemm_plan(768, 4096, 4096, residual=True, norm=True) == "splitk ks=2 +norm"
+    assert L.gemm_plan(768, 4096, 11008, residual=True, norm=True) == "splitk ks=2 +norm"
+    assert L.gemm_plan(768, 4096, 11008, residual=True) == "splitk ks=2"
+    assert L.gemm_plan(768, 2048, 4096, residual=True, norm=True) == "splitk ks=5"                             # the fused norm is for 4096-wide rows
+    assert L.gemm_plan(6144, 22016, 4096, act=2) == "hybrid cols 0..21760: big | cols 21760..22016: splitk ks=5"
+    assert L.gemm_plan(6144, 4096, 4096, residual=True, norm=True) == "big rows 0..4096 + small rows 4096..6144"
+    assert L.gemm_plan(66816, 1024, 4096, residual=True) == "big rows 0..62720 + small rows 62720..66816"
+    assert L.gemm_plan(66816, 4096, 1024, act=1, ln=True) == "big rows 0..64768 + small rows 64768..66816"
+    assert L.gemm_plan(65536, 1152, 1152, residual=True) == "cols 0..1024: big | cols 1024..1152: small"
+    assert L.gemm_plan(65536, 1152, 4352, residual=True) == "big"                                              # the narrow launch would re-read all of A
+    assert L.gemm_plan(261, 1024, 4096, residual=True) == "splitk ks=8"                                        # batch-1 ViT fc2
+    assert L.gemm_plan(8192, 8192, 8192) == "big"
+    with L.tuning(gemm_hybrid=0):
+        assert L.gemm_plan(768, 22016, 4096, act=2) == "big rows 0..512 + small rows 512..768"
+    with L.tuning(gemm_normfuse=0):
+        assert L.gemm_plan(768, 4096, 4096, residual=True, norm=True) == "splitk ks=2"
+    with L.tuning(gemm_splitk=0):
+        assert L.gemm_plan(768, 4096, 4096, residual=True, norm=True) == "small"
+        assert L.gemm_plan(768, 22016, 4096, act=2) == "big rows 0..512 + small rows 512..768"
+    with L.tuning(gemm_big=1):
+        assert L.gemm_plan(768, 4096, 4096) == "forced big"
+    assert so.emmax_gemm_plan(768, 100, 4096, 0, 0, 0, 0, 0, 0, None, 0) != 0 and so.emmax_gemm_plan(768, 100, 4096, 0, 0, 0, 0, 0, 0, b" " * 64, 64) != 0
