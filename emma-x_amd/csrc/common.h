@@ -90,6 +90,17 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
+// 8 consecutive elements of an fp32 row (the decode step's fp32 residual stream)
+struct f32x8_t { f32x4_t lo, hi; };
+__device__ __forceinline__ f32x8_t ld_f32x8(const float* p) { return {*(const f32x4_t*)p, *(const f32x4_t*)(p + 4)}; }
+__device__ __forceinline__ u32x4_t f32x8_to_bf16(const f32x8_t& v) {
+    return (u32x4_t){pack_bf16x2(v.lo[0], v.lo[1]), pack_bf16x2(v.lo[2], v.lo[3]), pack_bf16x2(v.hi[0], v.hi[1]), pack_bf16x2(v.hi[2], v.hi[3])};
+}
+__device__ __forceinline__ f32x8_t bf16x8_to_f32(const u32x4_t& v) {
+    return {(f32x4_t){bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1])}, (f32x4_t){bf_lo(v[2]), bf_hi(v[2]), bf_lo(v[3]), bf_hi(v[3])}};
+}
+__device__ __forceinline__ float f32x8_at(const f32x8_t& v, int i) { return i < 4 ? v.lo[i] : v.hi[i - 4]; }
+
 // exact-erf GELU, x Phi(x) = max(x, 0) - |x| h(|x|) with h = erfc(|x| / sqrt 2) / 2 (no cancellation on the negative side), and
 // h = exp2(Q(|x|)): log2 of erfc is smooth (-1 at 0, ~ -x^2 log2(e) / 2 far out), a degree-6 polynomial weighted for the error of
 // |x| h reproduces x Phi(x) to 2.8e-7 absolute in fp32 arithmetic (1.7 % of a bf16 ulp of the result at worst; tools/fit_gelu.py).

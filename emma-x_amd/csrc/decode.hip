@@ -240,6 +240,12 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 && F8 != 1 && F8 != 2 ? 4 : 2)) vo
     const bool head_first = !((one_pass && (MODE == MODE_QKV || FP8)) || XATTN || plain_first);
     if (head_first) issue_head(false);
 
+    // chunk c (8 elements) of activation row b of a NORM mode: from the fp32 residual stream when the step keeps one (GemvParams::h32;
+    // rounded to bf16 here, once per read -- decode_ks.hip, the product path at these batches, keeps statistics and x g in fp32)
+    auto ld_x8 = [&](int b, int c) -> u32x4_t {
+        if (p.h32) return f32x8_to_bf16(ld_f32x8(p.h32 + (size_t)b * p.ldh + (size_t)c * 8));
+        return ld_act16((const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx) + c, coh);
+    };
     // ---- RMSNorm statistics ----
     float rstd[B];
     // single-pass prologue: when the whole row fits one 16-byte chunk per thread, x and the norm weight are read ONCE
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 && F8 != 1 && F8 != 2 ? 4 : 2)) vo
         u32x4_t xv[B];
         const u32x4_t wv = *((const u32x4_t*)p.norm_w + ct);
 #pragma unroll
-        for (int b = 0; b < B; ++b) xv[b] = ld_act16((const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx) + ct, coh);
+        for (int b = 0; b < B; ++b) xv[b] = ld_x8(b, ct);
         if (!head_first) issue_head(true);
 #pragma unroll
         for (int b = 0; b < B; ++b)
@@ -294,9 +300,8 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 && F8 != 1 && F8 != 2 ? 4 : 2)) vo
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             float ss = 0.f;
-            const u32x4_t* xr = (const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx);
             for (int c = tid; c < (K >> 3); c += NT) {
-                const u32x4_t v = ld_act16(xr + c, coh);
+                const u32x4_t v = ld_x8(b, c);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float a = bf_lo(v[j]), bb = bf_hi(v[j]);
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 && F8 != 1 && F8 != 2 ? 4 : 2)) vo
                     const float* pp = p.attn_part + (size_t)(b * p.Hq + (cg >> 4)) * p.nsplit * PSTRIDE;
                     v = attn_merge_chunk_loop(pp, (cg & 15) * 8, p.nsplit, coh);
                 } else {
-                    v = ld_act16(xr + c, coh);
+                    v = NORM ? ld_x8(b, (kc0 >> 3) + c) : ld_act16(xr + c, coh);
                 }
                 if (NORM) {
                     const u32x4_t wv = *((const u32x4_t*)((const bf16_t*)p.norm_w + kc0) + c);
@@ -468,9 +473,14 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 && F8 != 1 && F8 != 2 ? 4 : 2)) vo
             if (MODE == MODE_RESID) {
                 int r0, r1;
                 pair_rows(pg, r0, r1);
-                const bf16_t* hp = (const bf16_t*)p.y + (size_t)eb * p.ldy;
-                pre_a[i] = bf2f(ld_act_bf16(hp + r0, coh));
-                pre_b[i] = bf2f(ld_act_bf16(hp + r1, coh));
+                if (p.h32) {
+                    pre_a[i] = p.h32[(size_t)eb * p.ldh + r0];
+                    pre_b[i] = p.h32[(size_t)eb * p.ldh + r1];
+                } else {
+                    const bf16_t* hp = (const bf16_t*)p.y + (size_t)eb * p.ldy;
+                    pre_a[i] = bf2f(ld_act_bf16(hp + r0, coh));
+                    pre_b[i] = bf2f(ld_act_bf16(hp + r1, coh));
+                }
             } else if (MODE == MODE_QKV) {
                 const int half = p.head_dim >> 1;
                 const int hb = pg / half, d = pg - hb * half;
@@ -600,6 +610,11 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 && F8 != 1 && F8 != 2 ? 4 : 2)) vo
 #pragma unroll
             for (int b = 0; b < B; ++b)
                 if (lane == b) {
+                    if (p.h32) {   // fp32 master copy of the residual stream; the bf16 rows below mirror it
+                        float* hq = p.h32 + (size_t)b * p.ldh;
+                        hq[r0] = pre_a[i] + red0[b];
+                        if (2 * pg + 1 < p.n_rows) hq[r1] = pre_b[i] + red1[b];
+                    }
                     bf16_t* hp = (bf16_t*)p.y + (size_t)b * p.ldy;
                     st_act_bf16(hp + r0, f2bf(pre_a[i] + red0[b]), coh);
                     if (2 * pg + 1 < p.n_rows) st_act_bf16(hp + r1, f2bf(pre_b[i] + red1[b]), coh);
@@ -691,13 +706,21 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 && F8 != 1 && F8 != 2 ? 4 : 2)) vo
 // h[b] = E[cur_tok[b]]
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void emmax_decode_embed_kernel(const int32_t* __restrict__ cur_tok, const bf16_t* __restrict__ E,
-                                                                bf16_t* __restrict__ h, int hidden, int vocab) {
+                                                                bf16_t* __restrict__ h, int hidden, int vocab, float* __restrict__ h32) {
     const int b = blockIdx.x;
     int id = cur_tok[b];
     id = min(max(id, 0), vocab - 1);
     const u32x4_t* s = (const u32x4_t*)(E + (size_t)id * hidden);
     u32x4_t* o = (u32x4_t*)(h + (size_t)b * hidden);
     constexpr bool coh = false;
+    if (h32) {   // fp32 residual stream: the embedding row widened (exact), beside the bf16 row
+        for (int c = threadIdx.x; c < hidden / 8; c += blockDim.x) {
+            const f32x8_t f = bf16x8_to_f32(s[c]);
+            float* hp = h32 + (size_t)b * hidden + (size_t)c * 8;
+            *(f32x4_t*)hp = f.lo;
+            *(f32x4_t*)(hp + 4) = f.hi;
+        }
+    }
     for (int c = threadIdx.x; c < hidden / 8; c += blockDim.x) st_act16(o + c, s[c], coh);
 }
 
@@ -714,9 +737,11 @@ __global__ __launch_bounds__(256) void emmax_decode_embed_kernel(const int32_t* 
 // normalises it and writes the bf16 row the o-proj reads (the arithmetic of a one-split merge), no partials, no o-proj prologue.
 // (Round 3 also measured a cross-split merge INSIDE this launch for 2-8 splits -- sc1 partials, arrival counter, last arriver
 // merges: 12.6 against 5.7 us per launch at B = 1; removed from the product source in round 4)
-template <int HD, int G, bool DIRECT = false>
-__global__ __launch_bounds__(256) void emmax_decode_attn_kernel(DecodeAttnParams p) {
-    constexpr int NW = 4, NT = NW * 64;   // waves per block (8-wave blocks were measured no faster)
+template <int HD, int G, bool DIRECT = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void emmax_decode_attn_kernel(DecodeAttnParams p) {
+    // waves per block: 4 (8-wave blocks were measured no faster at batch 1-2, where 512 four-wave blocks already put 8 waves on a CU,
+    // DESIGN.md section 6); the one-split form of batch 5-8 is 256 blocks = ONE per CU: NW = 8 there (tuning switch attn_nw, round 5)
+    constexpr int NT = NW * 64;
     static_assert(HD == 128, "decode attention maps 16 lanes x 8 elements onto one 128-wide K/V row");
     constexpr int KU = G <= 2 ? 4 : 2;    // keys per lane group per chunk (block chunk = 16 * KU keys), two chunks in flight
     constexpr int SP = 512;  // page ids kept in LDS = the longest page table the launcher accepts (32 K tokens at 64 per page)
@@ -1114,8 +1139,8 @@ int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream,
     }
 }
 
-int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, hipStream_t stream) {
-    hipLaunchKernelGGL(emmax_decode_embed_kernel, dim3(B), dim3(256), 0, stream, cur_tok, (const bf16_t*)E, (bf16_t*)h, hidden, vocab);
+int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, hipStream_t stream, float* h32) {
+    hipLaunchKernelGGL(emmax_decode_embed_kernel, dim3(B), dim3(256), 0, stream, cur_tok, (const bf16_t*)E, (bf16_t*)h, hidden, vocab, h32);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
@@ -1147,10 +1172,13 @@ int launch_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_dim
     if (p.o_out && nsplit != 1) return -1;   // the direct form exists for one split only (nothing to merge)
     const int G = Hq / p.Hkv;
     dim3 grid(nsplit, p.Hkv, B), block(256);
+    const int nw = emmax_tune().attn_nw;
+    const bool nw8 = nw == 8 || (nw == 0 && p.o_out && (long)p.Hkv * B <= 256);
     switch (G) {
 #define ATTN_CASE(GG)                                                                                                   \
     case GG:                                                                                                           \
-        if (p.o_out) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true>), grid, block, 0, stream, p);          \
+        if (p.o_out && nw8) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true, 8>), grid, dim3(512), 0, stream, p); \
+        else if (p.o_out) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true>), grid, block, 0, stream, p);     \
         else hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG>), grid, block, 0, stream, p);                         \
         break
         ATTN_CASE(1); ATTN_CASE(2); ATTN_CASE(4); ATTN_CASE(8);

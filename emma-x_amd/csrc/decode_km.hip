@@ -82,7 +82,17 @@ __device__ __forceinline__ void km_merge_rows(const float* __restrict__ attn_par
 // ---------------------------------------------------------------------------------------------------------------------
 // (v_mfma_f32_16x16x32_fp8_fp8 on e4m3-quantised activations was measured in round 3: no faster -- the kernel is memory-bound by 14x --
 // and 1.0e-1 of max|logit| from the oracle; removed from the product source)
-template <int MODE, bool NORM, bool XATTN, bool FP8>
+// R32 (RESID modes): the residual stream's master copy is the fp32 buffer p.h32 (GemvParams) -- the epilogue adds into it and mirrors
+// the sum into the bf16 rows p.y, which is what the NORM modes of this file read (fetching the fp32 rows instead cost the batch-8
+// step 1.5 %: twice the prologue bytes in front of every qkv / gate-up / lm-head launch; the rounding that matters -- the one that
+// used to accumulate over the 64 additions of a token -- is gone either way)
+// NB: batch rows the prologue stages (8: batch <= 8; 16: batch 9-16 -- round 5: the batch is the 16-wide N side of the MFMA, columns 8-15
+// were zeros until then).  LDS (not XATTN): ONE region per wave -- its activation window [NB][XPITCH] during the prologue, its partial
+// tiles [tiles_cap][64][4] afterwards (the window is dead once the wave holds its fragments; nobody else touches the region before
+// the block's only barrier) -- then sumsq[8][16]: 8 x 16.25 KiB at NB = 16, where window + partial tiles side by side would not fit.
+// ROLL (tuning switch km_roll): a weight register is refilled with its step of the tile two ahead as soon as its MFMA has issued (32 KiB
+// per wave in flight at all times) instead of all sixteen once the tile is done (16-32 KiB)
+template <int MODE, bool NORM, bool XATTN, bool FP8, bool R32, int NB, bool ROLL>
 __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char km_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -93,9 +103,12 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
     const int KT = K / KS;                        // load steps of a whole row
     const int KTW = KT / KM_WAVES;                // ... of this wave's slice (launcher: K % (8 * KS) == 0, KTW <= NSTEP)
     const int tiles_cap = p.kc;                   // launcher
-    float* part = (float*)km_smem;                                   // [KM_WAVES][tiles_cap][64][4]
-    float* sumsq = part + (size_t)KM_WAVES * tiles_cap * 256;        // [KM_WAVES][16]
-    unsigned char* xlds = (unsigned char*)(sumsq + KM_WAVES * 16);   // XATTN: the merged rows [B][K] bf16; else 8 wave-private windows
+    constexpr int XPITCH = KM_STEPS * 64 + 16;    // bytes per staged row slice (+16: the four k-groups of a fragment read hit different banks)
+    // bytes of a wave's region: XATTN: its partial tiles only (the merged rows [B][K] bf16 follow the regions and sumsq)
+    const int wreg = XATTN ? tiles_cap * 1024 : max(NB * XPITCH, tiles_cap * 1024);
+    auto part_of = [&](int w) { return (float*)(km_smem + (size_t)w * wreg); };   // [tiles_cap][64][4]
+    float* sumsq = (float*)(km_smem + (size_t)KM_WAVES * wreg);      // [KM_WAVES][16]
+    unsigned char* xlds = (unsigned char*)(sumsq + KM_WAVES * 16);   // XATTN: the merged rows [B][K] bf16
 
     const int G = gridDim.x, bid = blockIdx.x;
     const int n_tiles = p.n_groups;
@@ -112,9 +125,15 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
     int pre_pos = 0, pre_pg = 0;
     if (e_on) {
         if (MODE == GEMV_RESID) {
-            const bf16_t* hp = (const bf16_t*)p.y + (size_t)e_c * p.ldy + e_tile * 16 + 4 * e_rq;
+            if constexpr (R32) {
+                const f32x4_t hv = *(const f32x4_t*)(p.h32 + (size_t)e_c * p.ldh + e_tile * 16 + 4 * e_rq);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pre_a[j] = bf2f(hp[j]);
+                for (int j = 0; j < 4; ++j) pre_a[j] = hv[j];
+            } else {
+                const bf16_t* hp = (const bf16_t*)p.y + (size_t)e_c * p.ldy + e_tile * 16 + 4 * e_rq;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pre_a[j] = bf2f(hp[j]);
+            }
         } else if (MODE == GEMV_QKV) {
             pre_pos = p.ctx_len[e_c];
             pre_pg = p.page_table[(size_t)e_c * p.max_pages + pre_pos / p.page];
@@ -135,13 +154,14 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)w_bytes, 0x00020000);
     const unsigned voff = (unsigned)lane * 16u;
     u32x4_t wa[NSTEP], wb[NSTEP];   // two tiles in flight
-    auto issue = [&](u32x4_t (&w)[NSTEP], int tl) {   // tile tl of the block (uniform); past the end: out of range = zeros, no traffic
+    auto issue_one = [&](u32x4_t (&w)[NSTEP], int tl, int s) {   // step s of tile tl of the block (uniform); past the end: out of range = zeros, no traffic
+        const int ok = (tl < ntb && s < KTW) ? -1 : 0;
+        const unsigned so = ((unsigned)(((t_lo + tl) * KT + wave * KTW + s) * 1024) & (unsigned)ok) | (w_bytes & (unsigned)~ok);
+        w[s] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, so, 2));   // aux 2 = nt
+    };
+    auto issue = [&](u32x4_t (&w)[NSTEP], int tl) {
 #pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-            const int ok = (tl < ntb && s < KTW) ? -1 : 0;
-            const unsigned so = ((unsigned)(((t_lo + tl) * KT + wave * KTW + s) * 1024) & (unsigned)ok) | (w_bytes & (unsigned)~ok);
-            w[s] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, so, 2));   // aux 2 = nt
-        }
+        for (int s = 0; s < NSTEP; ++s) issue_one(w, tl, s);
     };
 
     // ---- activations: this wave's K slice as MFMA B fragments (batch row = lane & 15, k = 8 (lane >> 4) .. + 8 of a 32-step) ----
@@ -151,7 +171,6 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
     // lines and held the CU's address path for ~3 us: qkv 28.8 us against 22.4 for decode_mfma.hip at B = 8.
     bf16x8_t xf[KM_STEPS];
     const int ksl = K / KM_WAVES / 32;   // 32-element fragments in the wave's slice
-    constexpr int XPITCH = KM_STEPS * 64 + 16;   // bytes per staged row slice (+16: the four k-groups of a fragment read hit different banks)
     if constexpr (XATTN) {
         // o-proj: the block merges the attention split partials once (every thread one 8-element chunk per row), through LDS
         issue(wa, 0);
@@ -177,18 +196,17 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
             xf[s] = __builtin_bit_cast(bf16x8_t, v);
         }
     } else {
-        unsigned char* xw = xlds + (size_t)wave * EMMAX_MAX_DECODE_BATCH * XPITCH;   // this wave's window: [8 rows][XPITCH]
+        unsigned char* xw = km_smem + (size_t)wave * wreg;                           // this wave's window: [NB rows][XPITCH]
         const bool mine = lane < ksl * 4;                                            // 16-byte chunks of the slice
         const int ch = min(lane, ksl * 4 - 1);
-        u32x4_t xr[EMMAX_MAX_DECODE_BATCH];
+        u32x4_t xr[NB];
 #pragma unroll
-        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b)
-            xr[b] = *((const u32x4_t*)((const bf16_t*)p.x + (size_t)min(b, B - 1) * p.ldx + wave * ksl * 32) + ch);
+        for (int b = 0; b < NB; ++b) xr[b] = *((const u32x4_t*)((const bf16_t*)p.x + (size_t)min(b, B - 1) * p.ldx + wave * ksl * 32) + ch);
         u32x4_t nwv = {0u, 0u, 0u, 0u};
         if constexpr (NORM) nwv = *((const u32x4_t*)((const bf16_t*)p.norm_w + wave * ksl * 32) + ch);
         issue(wa, 0);   // behind the activation requests: those are waited for by count while the first tile is in flight
 #pragma unroll
-        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b) {
+        for (int b = 0; b < NB; ++b) {
             float ss = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -226,11 +244,14 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
             } else {
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[s]), xf[s], acc, 0, 0, 0);
             }
+            if constexpr (ROLL) issue_one(w, tl + 2, s);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        issue(w, tl + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (tl < ntb) *(f32x4_t*)(part + ((size_t)(wave * tiles_cap + tl) * 64 + lane) * 4) = acc;
+        if constexpr (!ROLL) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue(w, tl + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tl < ntb) *(f32x4_t*)(part_of(wave) + ((size_t)tl * 64 + lane) * 4) = acc;
     };
     for (int tl = 0; tl < ntb; tl += 2) {
         run_tile(wa, tl);
@@ -243,11 +264,11 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
     if (e_on) {
 #pragma unroll
         for (int w = 0; w < KM_WAVES; ++w) {
-            const f32x4_t a = *(const f32x4_t*)(part + ((size_t)(w * tiles_cap + e_tl) * 64 + e_l) * 4);
+            const f32x4_t a = *(const f32x4_t*)(part_of(w) + ((size_t)e_tl * 64 + e_l) * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += a[j];
             if (e_pairs) {
-                const f32x4_t b2 = *(const f32x4_t*)(part + ((size_t)(w * tiles_cap + e_tl) * 64 + e_l + 32) * 4);
+                const f32x4_t b2 = *(const f32x4_t*)(part_of(w) + ((size_t)e_tl * 64 + e_l + 32) * 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) u[j] += b2[j];
             }
@@ -279,6 +300,8 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
 #pragma unroll
             for (int j = 0; j < 4; ++j) yp[j] = f2bf(v[j]);
         } else if (MODE == GEMV_RESID) {
+            if constexpr (R32)
+                *(f32x4_t*)(p.h32 + (size_t)e_c * p.ldh + row0) = (f32x4_t){pre_a[0] + v[0], pre_a[1] + v[1], pre_a[2] + v[2], pre_a[3] + v[3]};
             bf16_t* hp = (bf16_t*)p.y + (size_t)e_c * p.ldy + row0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) hp[j] = f2bf(pre_a[j] + v[j]);
@@ -325,8 +348,8 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
     if (MODE == GEMV_LMHEAD) {
         // block best per batch column: the 32 slots (tile, row quarter) of a column through LDS; first index wins ties
         __syncthreads();                      // every thread has read its partial sums
-        float* bv = part;                     // [512]
-        int* bi = (int*)(part + KM_NT);       // [512]
+        float* bv = part_of(0);               // [512] + [512]: 4 KiB of wave 0's region (>= its 8.1 KiB window)
+        int* bi = (int*)(bv + KM_NT);         // [512]
         bv[tid] = best;
         bi[tid] = besti;
         __syncthreads();
@@ -347,85 +370,99 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The down projection at batch 3-8 (K = 11008: 43 k-steps per wave -- 172 registers of activation fragments, or 176 KB of LDS for
-// eight rows, neither exists).  One 16-row tile per block; the wave's K slice runs in TWO phases of <= 22 fragments: the row slices
-// of a phase go through the wave-private LDS window (row-shaped requests, no barrier), the fragments are read just in time, one
-// ds_read_b128 per MFMA; the second phase's row slices wait in registers and replace the first's in the window when its MFMAs are
-// done.  Weights: the phase-A steps in flight from the start (22 KiB per wave, 176 KB per CU), every register refilled with the
-// phase-B step as soon as its MFMA has issued.  y = h + W x in place (+ the per-row scale with fp8 weights).
+// The down projection at batch 3-16 (K = 11008: 43 k-steps per wave -- 172 registers of activation fragments, or 176 KB of LDS for
+// eight rows, neither exists).  One 16-row tile per block; the wave's K slice runs in PHASES of FR fragments (NB = 8 rows: two phases
+// of 22; NB = 16 rows, round 5: four of 12): the row slices of a phase go through the wave-private LDS window (row-shaped requests,
+// no barrier), the fragments are read just in time, one ds_read_b128 per MFMA; the row slices of the next two phases wait in two
+// register sets and replace the window's contents when the phase's MFMAs are done.  Weights: the first phase's steps in flight from
+// the start (22 / 12 KiB per wave), every register refilled with the next phase's step as soon as its MFMA has issued.
+// y = h + W x in place (+ the per-row scale with fp8 weights).
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int KD_FRAGS = 22;                    // fragments (32 elements) per phase and wave
-constexpr int KD_XP = KD_FRAGS * 64 + 16;       // bytes per staged row slice
-template <bool FP8>
+template <int NB> struct KdShape {
+    static constexpr int FR = NB == 8 ? 22 : 12;      // fragments (32 elements) per phase and wave
+    static constexpr int NPH = NB == 8 ? 2 : 4;       // phases: K <= 8 waves x NPH x FR x 32 = 11264 / 12288
+    static constexpr int XP = FR * 64 + 16;           // bytes per staged row slice
+    static constexpr int CH = (FR * 4 + 63) / 64;     // 16-byte chunks per lane and row of a phase
+};
+template <bool FP8, bool R32, int NB>
 __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_kmd_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char km_smem[];
+    using S = KdShape<NB>;
+    constexpr int FR = S::FR, NPH = S::NPH, XP = S::XP, CH = S::CH;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g4 = lane >> 4, c16 = lane & 15;
     const int B = p.batch, K = p.K;
     constexpr int KS = FP8 ? 64 : 32, FPS = FP8 ? 2 : 1;   // elements / fragments per load step
-    constexpr int NST = KD_FRAGS / FPS;                      // load steps per phase
+    constexpr int NST = FR / FPS;                            // load steps per phase
     const int KT = K / KS;
     const int kq = KT / KM_WAVES, kr = KT % KM_WAVES;
-    const int k_lo = wave * kq + min(wave, kr), k_n = kq + (wave < kr ? 1 : 0);   // this wave's load steps
-    const int nA = min(NST, k_n), nB = k_n - nA;                                   // launcher: k_n <= 2 NST
+    const int k_lo = wave * kq + min(wave, kr), k_n = kq + (wave < kr ? 1 : 0);   // this wave's load steps (launcher: k_n <= NPH NST)
     float* part = (float*)km_smem;                                                 // [KM_WAVES][64][4]
-    unsigned char* xw = km_smem + KM_WAVES * 1024 + (size_t)wave * EMMAX_MAX_DECODE_BATCH * KD_XP;   // this wave's window
+    unsigned char* xw = km_smem + KM_WAVES * 1024 + (size_t)wave * NB * XP;        // this wave's window
     const int tile = blockIdx.x;
 
     // epilogue operands of thread (lane l of wave 0): rows 4 (l >> 4) + j, batch column l & 15
     const bool e_on = tid < 64 && c16 < B;
     float pre[4] = {0.f, 0.f, 0.f, 0.f};
     if (e_on) {
-        const bf16_t* hp = (const bf16_t*)p.y + (size_t)c16 * p.ldy + tile * 16 + 4 * g4;
+        if constexpr (R32) {
+            const f32x4_t hv = *(const f32x4_t*)(p.h32 + (size_t)c16 * p.ldh + tile * 16 + 4 * g4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pre[j] = bf2f(hp[j]);
+            for (int j = 0; j < 4; ++j) pre[j] = hv[j];
+        } else {
+            const bf16_t* hp = (const bf16_t*)p.y + (size_t)c16 * p.ldy + tile * 16 + 4 * g4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pre[j] = bf2f(hp[j]);
+        }
     }
 
-    // ---- activation row slices of both phases: lane l holds chunks l and l + 64 of the phase's slice, for every batch row ----
-    auto load_rows = [&](int step0, int nstep, u32x4_t (&r)[EMMAX_MAX_DECODE_BATCH][2]) {
-        const int nch = nstep * (KS / 8);                       // 16-byte chunks in the slice
-        const bf16_t* base = (const bf16_t*)p.x + (size_t)(k_lo + step0) * KS;
+    // ---- activation row slices of a phase: lane l holds chunks l (and l + 64) of the phase's slice, for every batch row ----
+    auto phase_steps = [&](int ph) { return max(0, min(NST, k_n - ph * NST)); };
+    auto load_rows = [&](int ph, u32x4_t (&r)[NB][CH]) {
+        const int nch = phase_steps(ph) * (KS / 8);             // 16-byte chunks in the slice
+        const bf16_t* base = (const bf16_t*)p.x + (size_t)(k_lo + ph * NST) * KS;
 #pragma unroll
-        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < CH; ++h) {
                 const int c = min(lane + 64 * h, max(nch - 1, 0));
                 r[b][h] = *((const u32x4_t*)(base + (size_t)min(b, B - 1) * p.ldx) + c);
             }
     };
-    auto store_rows = [&](int nstep, const u32x4_t (&r)[EMMAX_MAX_DECODE_BATCH][2]) {
-        const int nch = nstep * (KS / 8);
+    auto store_rows = [&](int ph, const u32x4_t (&r)[NB][CH]) {
+        const int nch = phase_steps(ph) * (KS / 8);
 #pragma unroll
-        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < CH; ++h) {
                 const int c = lane + 64 * h;
-                if (c < KD_FRAGS * 4) {   // chunks past the slice / rows past the batch: zeros
+                if (c < FR * 4) {   // chunks past the slice / rows past the batch: zeros
                     const bool live = c < nch && b < B;
-                    *(u32x4_t*)(xw + (size_t)b * KD_XP + (size_t)c * 16) = live ? r[b][h] : (u32x4_t){0u, 0u, 0u, 0u};
+                    *(u32x4_t*)(xw + (size_t)b * XP + (size_t)c * 16) = live ? r[b][h] : (u32x4_t){0u, 0u, 0u, 0u};
                 }
             }
     };
-    u32x4_t xa[EMMAX_MAX_DECODE_BATCH][2], xb[EMMAX_MAX_DECODE_BATCH][2];
-    load_rows(0, nA, xa);
-    load_rows(nA, nB, xb);
+    u32x4_t xa[NB][CH], xb[NB][CH];   // even / odd phases
+    load_rows(0, xa);
+    load_rows(1, xb);
 
-    // ---- weights: phase A in flight now, phase B refilled register by register ----
+    // ---- weights: phase 0 in flight now, later phases refilled register by register ----
     const unsigned w_bytes = (unsigned)((size_t)p.n_groups * 16 * (size_t)K * (FP8 ? 1 : 2));
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)w_bytes, 0x00020000);
     const unsigned voff = (unsigned)lane * 16u;
     u32x4_t w[NST];
-#pragma unroll
-    for (int s = 0; s < NST; ++s) {
-        const int ok = s < nA ? -1 : 0;
-        const unsigned so = ((unsigned)((tile * KT + k_lo + s) * 1024) & (unsigned)ok) | (w_bytes & (unsigned)~ok);
+    auto issue_w = [&](int ph, int s) {   // load step s of phase ph (past the wave's slice: out of range = zeros, no traffic)
+        const int ok = (ph * NST + s < k_n) ? -1 : 0;
+        const unsigned so = ((unsigned)((tile * KT + k_lo + ph * NST + s) * 1024) & (unsigned)ok) | (w_bytes & (unsigned)~ok);
         w[s] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, so, 2));
-    }
-    store_rows(nA, xa);   // waits for the phase-A rows only (counted: the phase-B rows and the weights stay in flight)
+    };
+#pragma unroll
+    for (int s = 0; s < NST; ++s) issue_w(0, s);
+    store_rows(0, xa);   // waits for the phase-0 rows only (counted: the phase-1 rows and the weights stay in flight)
 
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    // batch column = lane & 15; columns past the batch are zero (their window rows hold zeros; columns 8-15 have no row at all)
-    const unsigned char* xcol = xw + (size_t)min(c16, EMMAX_MAX_DECODE_BATCH - 1) * KD_XP + (size_t)g4 * 16;
+    // batch column = lane & 15; columns past the batch are zero (their window rows hold zeros; NB = 8: columns 8-15 have no row at all)
+    const unsigned char* xcol = xw + (size_t)min(c16, NB - 1) * XP + (size_t)g4 * 16;
     auto frag = [&](int f) {
         const u32x4_t v = *(const u32x4_t*)(xcol + (size_t)f * 64);
         return __builtin_bit_cast(bf16x8_t, c16 < B ? v : (u32x4_t){0u, 0u, 0u, 0u});
@@ -439,15 +476,17 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_kmd_kernel(GemvParams p
         }
     };
 #pragma unroll
-    for (int s = 0; s < NST; ++s) {
-        mfma_step(s);
-        const int ok = s < nB ? -1 : 0;   // the register's phase-B step
-        const unsigned so = ((unsigned)((tile * KT + k_lo + nA + s) * 1024) & (unsigned)ok) | (w_bytes & (unsigned)~ok);
-        w[s] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, so, 2));
-    }
-    store_rows(nB, xb);   // same wave, in order behind the fragment reads above
+    for (int ph = 0; ph < NPH; ++ph) {
+        // the register set this phase's rows came from is free since they went into the window: request the rows two phases ahead
+        if (ph + 2 < NPH) { if (ph & 1) load_rows(ph + 2, xb); else load_rows(ph + 2, xa); }
 #pragma unroll
-    for (int s = 0; s < NST; ++s) mfma_step(s);
+        for (int s = 0; s < NST; ++s) {
+            mfma_step(s);
+            if (ph + 1 < NPH) issue_w(ph + 1, s);   // the register's step of the next phase
+        }
+        // same wave, in order behind the fragment reads above: the next phase's rows replace this phase's
+        if (ph + 1 < NPH) { if ((ph + 1) & 1) store_rows(ph + 1, xb); else store_rows(ph + 1, xa); }
+    }
 
     *(f32x4_t*)(part + ((size_t)wave * 64 + lane) * 4) = acc;
     __syncthreads();
@@ -459,30 +498,35 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_kmd_kernel(GemvParams p
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += a[j];
         }
-        bf16_t* hp = (bf16_t*)p.y + (size_t)c16 * p.ldy + tile * 16 + 4 * g4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if constexpr (FP8) v[j] *= p.wscale[tile * 16 + 4 * g4 + j];
-            hp[j] = f2bf(pre[j] + v[j]);
+            v[j] += pre[j];
         }
+        if constexpr (R32) *(f32x4_t*)(p.h32 + (size_t)c16 * p.ldh + tile * 16 + 4 * g4) = (f32x4_t){v[0], v[1], v[2], v[3]};
+        bf16_t* hp = (bf16_t*)p.y + (size_t)c16 * p.ldy + tile * 16 + 4 * g4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hp[j] = f2bf(v[j]);
     }
 }
 
-template <bool FP8>
+template <bool FP8, int NB>
 int kmd_launch(GemvParams p, int B, hipStream_t stream) {
+    using S = KdShape<NB>;
     constexpr int KS = FP8 ? 64 : 32, FPS = FP8 ? 2 : 1;
     if (p.K % KS || p.n_rows % 16 || p.attn_part) return -2;
     p.batch = B;
     p.n_groups = p.n_rows / 16;
-    if (cdiv(p.K / KS, KM_WAVES) > 2 * (KD_FRAGS / FPS)) return -2;   // two phases of 22 fragments per wave: K <= 11264
+    if (cdiv(p.K / KS, KM_WAVES) > S::NPH * (S::FR / FPS)) return -2;   // NPH phases of FR fragments per wave
     if (p.K / KS < KM_WAVES) return -2;
-    const size_t smem = (size_t)KM_WAVES * 1024 + (size_t)KM_WAVES * EMMAX_MAX_DECODE_BATCH * KD_XP;
-    hipLaunchKernelGGL((emmax_decode_kmd_kernel<FP8>), dim3(p.n_groups), dim3(KM_NT), smem, stream, p);
+    const size_t smem = (size_t)KM_WAVES * 1024 + (size_t)KM_WAVES * NB * S::XP;
+    if (p.h32) hipLaunchKernelGGL((emmax_decode_kmd_kernel<FP8, true, NB>), dim3(p.n_groups), dim3(KM_NT), smem, stream, p);
+    else hipLaunchKernelGGL((emmax_decode_kmd_kernel<FP8, false, NB>), dim3(p.n_groups), dim3(KM_NT), smem, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-template <int MODE, bool NORM, bool XATTN, bool FP8>
-int km_launch_t(GemvParams p, int B, hipStream_t stream, int* grid_out) {
+template <int MODE, bool NORM, bool XATTN, bool FP8, int NB, bool ROLL>
+int km_launch_nb(GemvParams p, int B, hipStream_t stream, int* grid_out) {
     constexpr int KS = FP8 ? 64 : 32;
     if (p.K % (KM_WAVES * KS) || p.K > KM_WAVES * KM_STEPS * 32 || p.n_rows % 16) return -2;
     if (MODE == GEMV_QKV && (p.head_dim % 16 || p.head_dim < 16)) return -2;
@@ -494,13 +538,25 @@ int km_launch_t(GemvParams p, int B, hipStream_t stream, int* grid_out) {
     p.kc = cdiv(p.n_groups, grid);
     if (p.kc > KM_MAX_TILES) return -2;
     if (p.kc & 1) p.kc += 1;   // the loop runs tiles in pairs
-    const size_t smem = (size_t)KM_WAVES * p.kc * 1024 + KM_WAVES * 16 * 4 +
-                        (XATTN ? (size_t)B * p.K * 2 : (size_t)KM_WAVES * EMMAX_MAX_DECODE_BATCH * (KM_STEPS * 64 + 16));
+    // one region per wave (kernel: window [NB][XPITCH] overlaid by the partial tiles) + sumsq (+ XATTN: the merged rows)
+    const size_t wreg = XATTN ? (size_t)p.kc * 1024 : std::max((size_t)NB * (KM_STEPS * 64 + 16), (size_t)p.kc * 1024);
+    const size_t smem = (size_t)KM_WAVES * wreg + KM_WAVES * 16 * 4 + (XATTN ? (size_t)B * p.K * 2 : 0);
     if (smem > 150 * 1024) return -2;
     if (grid_out) *grid_out = grid;
-    auto kern = emmax_decode_km_kernel<MODE, NORM, XATTN, FP8>;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(KM_NT), smem, stream, p);
+    if constexpr (MODE == GEMV_RESID) {   // (NORM modes read the bf16 mirror: h32 is ignored there)
+        if (p.h32) {
+            hipLaunchKernelGGL((emmax_decode_km_kernel<MODE, NORM, XATTN, FP8, true, NB, ROLL>), dim3(grid), dim3(KM_NT), smem, stream, p);
+            return hipGetLastError() == hipSuccess ? 0 : -4;
+        }
+    }
+    hipLaunchKernelGGL((emmax_decode_km_kernel<MODE, NORM, XATTN, FP8, false, NB, ROLL>), dim3(grid), dim3(KM_NT), smem, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+template <int MODE, bool NORM, bool XATTN, bool FP8>
+int km_launch_t(const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
+    if (emmax_tune().km_roll)
+        return B <= 8 ? km_launch_nb<MODE, NORM, XATTN, FP8, 8, true>(p, B, stream, grid_out) : km_launch_nb<MODE, NORM, XATTN, FP8, 16, true>(p, B, stream, grid_out);
+    return B <= 8 ? km_launch_nb<MODE, NORM, XATTN, FP8, 8, false>(p, B, stream, grid_out) : km_launch_nb<MODE, NORM, XATTN, FP8, 16, false>(p, B, stream, grid_out);
 }
 
 template <bool FP8>
@@ -532,15 +588,24 @@ int decode_km_init() {
     if (done == 0) return 0;
     const int lim = 150 * 1024;
     hipError_t e = hipSuccess;
-#define KM_SET1(M, N_, X, F) \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_km_kernel<M, N_, X, F>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
+#define KM_SET4(M, N_, X, F, R, NB_, RL) \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_km_kernel<M, N_, X, F, R, NB_, RL>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
+#define KM_SET3(M, N_, X, F, R, NB_) KM_SET4(M, N_, X, F, R, NB_, false); KM_SET4(M, N_, X, F, R, NB_, true)
+#define KM_SET2(M, N_, X, F, R) KM_SET3(M, N_, X, F, R, 8); KM_SET3(M, N_, X, F, R, 16)
+#define KM_SET1(M, N_, X, F) KM_SET2(M, N_, X, F, false); if (M == GEMV_RESID) KM_SET2(M, N_, X, F, true)
 #define KM_SET(M, N_, X) KM_SET1(M, N_, X, false); KM_SET1(M, N_, X, true)
     KM_SET(GEMV_QKV, true, false); KM_SET1(GEMV_RESID, false, true, true); KM_SET(GEMV_RESID, false, false); KM_SET(GEMV_GATEUP, true, false);
     KM_SET(GEMV_LMHEAD, true, false); KM_SET(GEMV_PLAIN, false, false);
 #undef KM_SET
 #undef KM_SET1
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_kmd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_kmd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+#undef KM_SET2
+#undef KM_SET3
+#undef KM_SET4
+#define KD_SET(F, R, NB_) \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_kmd_kernel<F, R, NB_>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
+    KD_SET(false, false, 8); KD_SET(true, false, 8); KD_SET(false, true, 8); KD_SET(true, true, 8);
+    KD_SET(false, false, 16); KD_SET(true, false, 16); KD_SET(false, true, 16); KD_SET(true, true, 16);
+#undef KD_SET
     done = (e == hipSuccess) ? 0 : -4;
     return done;
 }
@@ -564,7 +629,8 @@ int launch_decode_km(int mode, const GemvParams& p, int B, hipStream_t stream, i
     if (decode_km_init() != 0) return -4;
     if (mode == GEMV_RESID && !p.attn_part && p.K > KM_WAVES * KM_STEPS * 32) {   // the down projection: two K phases (natural row order copy)
         if (!emmax_tune().km_down) return -2;   // A/B partner: decode_mfma.hip
-        return p.wscale ? kmd_launch<true>(p, B, stream) : kmd_launch<false>(p, B, stream);
+        if (B <= 8) return p.wscale ? kmd_launch<true, 8>(p, B, stream) : kmd_launch<false, 8>(p, B, stream);
+        return p.wscale ? kmd_launch<true, 16>(p, B, stream) : kmd_launch<false, 16>(p, B, stream);
     }
     return p.wscale ? km_launch_mode<true>(mode, p, B, stream, grid_out) : km_launch_mode<false>(mode, p, B, stream, grid_out);
 }

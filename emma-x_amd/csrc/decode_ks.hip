@@ -102,7 +102,7 @@ template <int B, int CPL> struct KsShape { static constexpr int RB = (B == 1 ? 1
 // weight registers of a wave: one flat array
 template <int B> struct KsRegs { static constexpr int N = B == 1 ? 16 : 8; };
 
-enum { XS_GLOBAL = 0, XS_ATTN = 1 };
+enum { XS_GLOBAL = 0, XS_ATTN = 1, XS_EMBED = 2 };   // XS_EMBED: x row b = the embedding of token x_tok[b] (layer 0's qkv, the embed launch folded in)
 #ifdef DECODE_LAB_TRACE
 // lab builds only (tools/ks_trace.py): s_memrealtime stamps (100 MHz) of waves 0 and 7 of every block:
 // [block][wave 0 | 7][op = 0][0 entered, 1 activations in registers, 2 unused, 3 stream done, 4 barrier passed, 5 epilogue done]
@@ -174,11 +174,12 @@ __device__ __forceinline__ void ks_chunks(int K, int wave, int lane, int (&coff)
 // ---------------------------------------------------------------------------------------------------------------------
 // One projection.  The first batch of its weights is requested right behind the activation loads / the split merge (whose ~60
 // registers the head would otherwise have to share).  part / sumsq: the launch's LDS scratch.
-//   XS: where the activations come from (global row, attention split partials)
+//   XS: where the activations come from (global row, attention split partials, embedding rows)
+//   R32: the residual stream is the fp32 buffer p.h32 (GemvParams): NORM modes read it, RESID modes add into it
 // (Round 3 chained four of these in one persistent launch with in-kernel mailbox hand-offs: bit-identical and 18 % slower --
 // DESIGN.md section 6; that variant lives in the history, commit 61d5036, not in the product source.)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int B, int MODE, bool NORM, int XS, int CPL>
+template <int B, int MODE, bool NORM, int XS, int CPL, bool R32>
 __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsRegs<B>::N], float* part, float* sumsq, int rows_cap,
                                           int trace_op = -1) {
     constexpr int RB = KsShape<B, CPL>::RB;
@@ -199,9 +200,15 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
     int pre_pos = 0, pre_pg = 0;
     if (epi) {
         if (MODE == GEMV_RESID) {
-            const bf16_t* hp = (const bf16_t*)p.y + (size_t)eb * p.ldy;
-            pre_a = bf2f(hp[er0]);
-            pre_b = bf2f(hp[er1]);
+            if constexpr (R32) {
+                const float* hp = p.h32 + (size_t)eb * p.ldh;
+                pre_a = hp[er0];
+                pre_b = hp[er1];
+            } else {
+                const bf16_t* hp = (const bf16_t*)p.y + (size_t)eb * p.ldy;
+                pre_a = bf2f(hp[er0]);
+                pre_b = bf2f(hp[er1]);
+            }
         } else if (MODE == GEMV_QKV) {
             pre_pos = p.ctx_len[eb];
             pre_pg = p.page_table[(size_t)eb * p.max_pages + pre_pos / p.page];
@@ -242,38 +249,68 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
 #pragma unroll
             for (int j = 0; j < CPL; ++j) nw[j] = *((const u32x4_t*)p.norm_w + coff[j]);
         }
-        {
+        float ss[B];
+        if constexpr (R32 && NORM && XS != XS_EMBED) {
+            // fp32 residual stream: the wave's slice as 8 floats per chunk; statistics and x g in fp32, ONE rounding to bf16
+            f32x8_t xq[B][CPL];
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) xq[b][j] = ld_f32x8(p.h32 + (size_t)b * p.ldh + (size_t)coff[j] * 8);
+            ks_issue<B, MODE, CPL>(p, g_lo, nrows, 0, voff, wr);
 #pragma unroll
             for (int b = 0; b < B; ++b) {
-                // layer 0: the row is the embedding of the current token (the embed launch folded in); block 0 leaves a copy in the
-                // residual stream for the o-proj's "+ residual"
+                ss[b] = 0.f;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = cok[j] ? f32x8_at(xq[b][j], 2 * e) : 0.f, c = cok[j] ? f32x8_at(xq[b][j], 2 * e + 1) : 0.f;
+                        ss[b] += a * a + c * c;
+                        xr[b][j][e] = pack_bf16x2(a * bf_lo(nw[j][e]), c * bf_hi(nw[j][e]));
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                // layer 0 (XS_EMBED): the row is the embedding of the current token (the embed launch folded in); block 0 leaves a
+                // copy in the residual stream for the o-proj's "+ residual"
                 size_t row = (size_t)b;
-                if (p.x_tok) row = (size_t)min(max(p.x_tok[b], 0), p.x_vocab - 1);
+                if constexpr (XS == XS_EMBED) row = (size_t)min(max(p.x_tok[b], 0), p.x_vocab - 1);
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) {
                     xr[b][j] = *((const u32x4_t*)((const bf16_t*)p.x + row * p.ldx) + coff[j]);
-                    if (p.x_tok && blockIdx.x == 0 && cok[j]) *((u32x4_t*)((bf16_t*)p.x_copy + (size_t)b * p.ldx) + coff[j]) = xr[b][j];
+                    if constexpr (XS == XS_EMBED) {
+                        if (blockIdx.x == 0 && cok[j]) {
+                            *((u32x4_t*)((bf16_t*)p.x_copy + (size_t)b * p.ldx) + coff[j]) = xr[b][j];
+                            if constexpr (R32) {   // ... and in the fp32 stream (exact)
+                                const f32x8_t f = bf16x8_to_f32(xr[b][j]);
+                                float* hp = p.h32 + (size_t)b * p.ldh + (size_t)coff[j] * 8;
+                                *(f32x4_t*)hp = f.lo;
+                                *(f32x4_t*)(hp + 4) = f.hi;
+                            }
+                        }
+                    }
                 }
             }
-        }
-        // right behind the activations: they are waited for by count while the head of the stream is in flight
-        ks_issue<B, MODE, CPL>(p, g_lo, nrows, 0, voff, wr);
-        float ss[B];
+            // right behind the activations: they are waited for by count while the head of the stream is in flight
+            ks_issue<B, MODE, CPL>(p, g_lo, nrows, 0, voff, wr);
 #pragma unroll
-        for (int b = 0; b < B; ++b) {
-            ss[b] = 0.f;
+            for (int b = 0; b < B; ++b) {
+                ss[b] = 0.f;
 #pragma unroll
-            for (int j = 0; j < CPL; ++j)
+                for (int j = 0; j < CPL; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    uint32_t v = cok[j] ? xr[b][j][e] : 0u;
-                    if constexpr (NORM) {
-                        const float a = bf_lo(v), c = bf_hi(v);
-                        ss[b] += a * a + c * c;
-                        v = pack_bf16x2(a * bf_lo(nw[j][e]), c * bf_hi(nw[j][e]));
+                    for (int e = 0; e < 4; ++e) {
+                        uint32_t v = cok[j] ? xr[b][j][e] : 0u;
+                        if constexpr (NORM) {
+                            const float a = bf_lo(v), c = bf_hi(v);
+                            ss[b] += a * a + c * c;
+                            v = pack_bf16x2(a * bf_lo(nw[j][e]), c * bf_hi(nw[j][e]));
+                        }
+                        xr[b][j][e] = v;
                     }
-                    xr[b][j][e] = v;
-                }
+            }
         }
         if constexpr (NORM) {
 #pragma unroll
@@ -345,6 +382,11 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
         }
     } else if (MODE == GEMV_RESID) {
         if (epi) {
+            if constexpr (R32) {   // the fp32 stream is the master; the bf16 rows below mirror it (batch >= 3 / fp8 kernels read those)
+                float* hq = p.h32 + (size_t)eb * p.ldh;
+                hq[er0] = pre_a + red0;
+                if (has1) hq[er1] = pre_b + red1;
+            }
             const uint32_t hv = pack_bf16x2(pre_a + red0, pre_b + red1);
             bf16_t* hp = (bf16_t*)p.y + (size_t)eb * p.ldy;
             hp[er0] = (bf16_t)(hv & 0xffffu);
@@ -406,7 +448,7 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
 // work on pairs: (d, d + hd/2) of a head for QKV, (gate_i, up_i) for GATEUP, two consecutive rows otherwise).
 // Dynamic LDS: float part[8 waves][B][rows_cap] + float sumsq[8][B].
 // ---------------------------------------------------------------------------------------------------------------------
-template <int B, int MODE, bool NORM, bool XATTN, int CPL>
+template <int B, int MODE, bool NORM, int XS, int CPL, bool R32>
 __global__ __launch_bounds__(KS_NT, 4) void emmax_decode_ks_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -414,11 +456,11 @@ __global__ __launch_bounds__(KS_NT, 4) void emmax_decode_ks_kernel(GemvParams p)
     float* part = (float*)ks_smem;          // [KS_WAVES][B][rows_cap]
     float* sumsq = part + KS_WAVES * B * rows_cap;   // [KS_WAVES][B]
     u32x4_t wr[KsRegs<B>::N];
-    ks_run_op<B, MODE, NORM, XATTN ? XS_ATTN : XS_GLOBAL, CPL>(p, wr, part, sumsq, rows_cap, 0);
+    ks_run_op<B, MODE, NORM, XS, CPL, R32>(p, wr, part, sumsq, rows_cap, 0);
 }
 
-template <int B, int MODE, bool NORM, bool XATTN, int CPL>
-int ks_launch_t(GemvParams p, hipStream_t stream, int* grid_out) {
+template <int B, int MODE, bool NORM, int XS, int CPL, bool R32>
+int ks_launch_r(GemvParams p, hipStream_t stream, int* grid_out) {
     constexpr int RB = KsShape<B, CPL>::RB;
     int grid = min(512, p.n_groups);
     if (p.max_grid > 0) grid = min(grid, p.max_grid);
@@ -429,8 +471,20 @@ int ks_launch_t(GemvParams p, hipStream_t stream, int* grid_out) {
     p.kc = cdiv(2 * pairs_max, RB) * RB;
     const size_t smem = (size_t)(KS_WAVES * B * p.kc + KS_WAVES * B) * sizeof(float);
     if (grid_out) *grid_out = grid;
-    hipLaunchKernelGGL((emmax_decode_ks_kernel<B, MODE, NORM, XATTN, CPL>), dim3(grid), dim3(KS_NT), smem, stream, p);
+    hipLaunchKernelGGL((emmax_decode_ks_kernel<B, MODE, NORM, XS, CPL, R32>), dim3(grid), dim3(KS_NT), smem, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+// the fp32 residual stream concerns the modes that read (NORM) or update (RESID) the hidden rows; the embedding gather exists for qkv only
+template <int B, int MODE, bool NORM, bool XATTN, int CPL>
+int ks_launch_t(const GemvParams& p, hipStream_t stream, int* grid_out) {
+    constexpr bool touches_h = NORM || MODE == GEMV_RESID;
+    if constexpr (MODE == GEMV_QKV) {
+        if (p.x_tok) return p.h32 ? ks_launch_r<B, MODE, NORM, XS_EMBED, CPL, true>(p, stream, grid_out) : ks_launch_r<B, MODE, NORM, XS_EMBED, CPL, false>(p, stream, grid_out);
+    } else if (p.x_tok) return -2;
+    if constexpr (touches_h) {
+        if (p.h32) return ks_launch_r<B, MODE, NORM, XATTN ? XS_ATTN : XS_GLOBAL, CPL, true>(p, stream, grid_out);
+    } else if (p.h32) return -2;
+    return ks_launch_r<B, MODE, NORM, XATTN ? XS_ATTN : XS_GLOBAL, CPL, false>(p, stream, grid_out);
 }
 
 // pairs / shift of a mode

@@ -20,6 +20,7 @@ namespace {
 
 enum { MODE_QKV = 0, MODE_RESID = 1, MODE_GATEUP = 2, MODE_LMHEAD = 3, MODE_PLAIN = 4 };
 constexpr int PSTRIDE = EMMAX_PSTRIDE;
+constexpr int MFMA_MAX_B = 8;   // this kernel stages at most 8 batch rows (batch 9-16 run on decode_km.hip only)
 constexpr int GW = 8;
 __device__ __forceinline__ u32x4_t ld_nt(const u32x4_t* p) { return __builtin_nontemporal_load(p); }
 
@@ -266,20 +267,20 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
     // from those registers and the normalised rows go straight to LDS
     const bool one_pass = NORM && !XATTN && n_phase == 1 && (K >> 3) <= NT;
     if (one_pass) {
-        __shared__ __attribute__((aligned(16))) float rsum1[GW][EMMAX_MAX_DECODE_BATCH];
+        __shared__ __attribute__((aligned(16))) float rsum1[GW][MFMA_MAX_B];
         const bool mine = tid < (K >> 3);
-        u32x4_t xv[EMMAX_MAX_DECODE_BATCH];
+        u32x4_t xv[MFMA_MAX_B];
         // unconditional (clamped) loads, masked afterwards: hipcc can then count them and waits for exactly these nine loads
         // -- behind predicated loads it waited for the whole first ring as well (the prologue ended when 32 MB of weights had
         // landed, ~10 us into the launch, with HBM idle for half of that)
         const int ct = min(tid, (K >> 3) - 1);
         u32x4_t wv = *((const u32x4_t*)p.norm_w + ct);
 #pragma unroll
-        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b)
+        for (int b = 0; b < MFMA_MAX_B; ++b)
             xv[b] = *((const u32x4_t*)((const bf16_t*)p.x + (size_t)min(b, B - 1) * p.ldx) + ct);
         issue_head();
 #pragma unroll
-        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b) {
+        for (int b = 0; b < MFMA_MAX_B; ++b) {
             if (b >= B) break;   // block-uniform: rows the batch does not have cost nothing (fp8 runs this kernel at B = 1 too)
             float ss = 0.f;
 #pragma unroll
@@ -293,10 +294,10 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
         }
         __syncthreads();
         // the 8 x 8 wave partials as sixteen broadcast 16-byte LDS reads per thread (64 scalar reads cost ~2 us)
-        static_assert(EMMAX_MAX_DECODE_BATCH == 8, "row statistics are read as two float4 per wave");
-        float tot[EMMAX_MAX_DECODE_BATCH];
+        static_assert(MFMA_MAX_B == 8, "row statistics are read as two float4 per wave");
+        float tot[MFMA_MAX_B];
 #pragma unroll
-        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b) tot[b] = 0.f;
+        for (int b = 0; b < MFMA_MAX_B; ++b) tot[b] = 0.f;
 #pragma unroll
         for (int w = 0; w < GW; ++w) {
             const f32x4_t lo = *(const f32x4_t*)&rsum1[w][0], hi = *(const f32x4_t*)&rsum1[w][4];
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
             }
         }
 #pragma unroll
-        for (int b = 0; b < EMMAX_MAX_DECODE_BATCH; ++b) {
+        for (int b = 0; b < MFMA_MAX_B; ++b) {
             if (b < B) {   // block-uniform: a scalar branch, no exec-mask juggling per row
                 const float rs = rsqrtf(tot[b] / (float)K + p.eps);
                 u32x4_t v = xv[b];
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
         }
         if (mine) *(u32x4_t*)(smem + (size_t)B * pitch + (size_t)tid * 16) = (u32x4_t){0u, 0u, 0u, 0u};
     } else if (NORM) {
-        __shared__ float rsum[GW][EMMAX_MAX_DECODE_BATCH];
+        __shared__ float rsum[GW][MFMA_MAX_B];
         for (int b = 0; b < B; ++b) {
             float ss = 0.f;
             const u32x4_t* xr = (const u32x4_t*)((const bf16_t*)p.x + (size_t)b * p.ldx);
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
         if (tid >= 256 || ec >= B || cs.gb != 0) return;   // segments that only publish partial sums have no epilogue
         const int row_in = 4 * ((tid & 63) >> 4) + (tid >> 6);
         if (MODE == MODE_RESID) {
-            pf_a = bf2f(((const bf16_t*)p.y)[(size_t)ec * p.ldy + cs.t * 16 + row_in]);
+            pf_a = p.h32 ? p.h32[(size_t)ec * p.ldh + cs.t * 16 + row_in] : bf2f(((const bf16_t*)p.y)[(size_t)ec * p.ldy + cs.t * 16 + row_in]);
         } else if (MODE == MODE_QKV) {
             const int half = p.head_dim >> 1;
             const int hb = cs.t >> p.qk_shift, d = (cs.t & ((1 << p.qk_shift) - 1)) * 16 + row_in;
@@ -504,6 +505,8 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
                 if (MODE == MODE_PLAIN) {
                     ((bf16_t*)p.y)[(size_t)c * p.ldy + t * 16 + row_in] = f2bf(v[0]);
                 } else if (MODE == MODE_RESID) {
+                    // fp32 residual stream (GemvParams::h32): the master copy + its bf16 mirror (what the NORM modes read)
+                    if (p.h32) p.h32[(size_t)c * p.ldh + t * 16 + row_in] = pf_a + v[0];
                     bf16_t* hp = (bf16_t*)p.y + (size_t)c * p.ldy + t * 16 + row_in;
                     *hp = f2bf(pf_a + v[0]);
                 } else if (MODE == MODE_GATEUP) {
@@ -726,7 +729,7 @@ static int launch_mfma_mode(int mode, const GemvParams& p, int B, hipStream_t st
 }
 
 int launch_decode_mfma(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
-    if (B < 1 || B > EMMAX_MAX_DECODE_BATCH) return -1;
+    if (B < 1 || B > MFMA_MAX_B) return -1;
     return p.wscale ? launch_mfma_mode<true>(mode, p, B, stream, grid_out) : launch_mfma_mode<false>(mode, p, B, stream, grid_out);
 }
 

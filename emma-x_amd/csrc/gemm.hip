@@ -287,7 +287,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4_t
                 if (ACT == 1) v[r] = gelu_erf(v[r]);
                 v[r] *= sv[r];
             }
-            if (res) {
+            if (OUT_F32 && res && p.res_f32) {   // fp32 residual stream (C may alias it)
+                const float* rq = (const float*)p.residual + (size_t)row * p.ldr + col;
+                if (full && vec_r) {
+                    const f32x4_t rv = *(const f32x4_t*)rq;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col + r < n_ok) v[r] += rq[r];
+                }
+            } else if (res) {
                 const bf16_t* rp = res + (size_t)row * p.ldr + col;
                 if (full && vec_r) {
                     const u32x2_t rv = *(const u32x2_t*)rp;
@@ -597,7 +608,9 @@ __global__ __launch_bounds__(256) void emmax_splitk_reduce_kernel(GemmParams p) 
     const bf16_t* res = (const bf16_t*)p.residual;
     const int n_ok = ACT == 2 ? n_out : min(p.N, p.N_store);
     const bool vec_c = !p.out_f32 && (p.ldc & 7) == 0 && (((size_t)p.C) & 15) == 0;
-    const bool vec_r = res && (p.ldr & 7) == 0 && (((size_t)res) & 15) == 0;
+    const bool vec_c32 = p.out_f32 && (p.ldc & 3) == 0 && (((size_t)p.C) & 15) == 0;
+    const bool vec_r = res && !p.res_f32 && (p.ldr & 7) == 0 && (((size_t)res) & 15) == 0;
+    const bool vec_r32 = res && p.res_f32 && (p.ldr & 3) == 0 && (((size_t)res) & 15) == 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int row = (int)(i / nc), col = (int)(i - (size_t)row * nc) * 8;
         const int pcol = ACT == 2 ? (col >> 4) * 32 + (col & 15) : col;
@@ -622,6 +635,12 @@ __global__ __launch_bounds__(256) void emmax_splitk_reduce_kernel(GemmParams p) 
         const bool full = col + 7 < n_ok;
         u32x4_t rv = {0u, 0u, 0u, 0u};
         if (ACT != 2 && vec_r && full) rv = *(const u32x4_t*)(res + (size_t)row * p.ldr + col);
+        f32x4_t rf0 = {0.f, 0.f, 0.f, 0.f}, rf1 = {0.f, 0.f, 0.f, 0.f};   // fp32 residual stream
+        if (ACT != 2 && vec_r32 && full) {
+            const float* rq = (const float*)p.residual + (size_t)row * p.ldr + col;
+            rf0 = *(const f32x4_t*)rq;
+            rf1 = *(const f32x4_t*)(rq + 4);
+        }
         float x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -633,13 +652,18 @@ __global__ __launch_bounds__(256) void emmax_splitk_reduce_kernel(GemmParams p) 
                 if (scale && col + e < n_ok) x[e] *= bf2f(scale[col + e]);
                 if (res) {
                     if (vec_r && full) x[e] += (e & 1) ? bf_hi(rv[e >> 1]) : bf_lo(rv[e >> 1]);
-                    else if (col + e < n_ok) x[e] += bf2f(res[(size_t)row * p.ldr + col + e]);
+                    else if (vec_r32 && full) x[e] += e < 4 ? rf0[e & 3] : rf1[e & 3];
+                    else if (col + e < n_ok) x[e] += p.res_f32 ? ((const float*)p.residual)[(size_t)row * p.ldr + col + e] : bf2f(res[(size_t)row * p.ldr + col + e]);
                 }
             }
         }
         if (vec_c && full) {
             *(u32x4_t*)((bf16_t*)p.C + (size_t)row * p.ldc + col) =
                 (u32x4_t){pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7])};
+        } else if (vec_c32 && full) {
+            float* cp = (float*)p.C + (size_t)row * p.ldc + col;
+            *(f32x4_t*)cp = (f32x4_t){x[0], x[1], x[2], x[3]};
+            *(f32x4_t*)(cp + 4) = (f32x4_t){x[4], x[5], x[6], x[7]};
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -656,7 +680,10 @@ __global__ __launch_bounds__(256) void emmax_splitk_reduce_kernel(GemmParams p) 
 // emmax_rownorm_kernel<8, true> (norm.hip), so C and norm_out are bit-identical to the reduce pass followed by that kernel -- the row is
 // summed, finished (bias / LayerScale / residual), rounded and stored, and its rounded values stay in registers for the statistics.
 // One launch and one read of the row less per o-proj / down projection of a one-frame prefill.  N = 4096 (512 NV), act 0, bf16 C.
-template <int NV>   // 16-byte chunks per lane: N = 512 NV exactly, so that no access is predicated and a slice's 2 NV loads go out together
+// F32 (round 5): the fp32 residual stream of the prefill -- `residual` and C are f32 rows (C may alias the residual), the statistics and
+// the normalise take the fp32 sums (HF's arithmetic on an fp32 hidden state: normalise, round to bf16, multiply by the weight, round);
+// nothing of the stream is rounded to bf16 except the normalised row the next GEMM consumes.
+template <int NV, bool F32>   // 16-byte chunks per lane: N = 512 NV exactly, so that no access is predicated and a slice's 2 NV loads go out together
 __global__ __launch_bounds__(256) void emmax_splitk_reduce_norm_kernel(GemmParams p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -665,10 +692,15 @@ __global__ __launch_bounds__(256) void emmax_splitk_reduce_norm_kernel(GemmParam
     const bf16_t* bias = (const bf16_t*)p.bias;
     const bf16_t* scale = (const bf16_t*)p.scale;
     const bf16_t* res = (const bf16_t*)p.residual;
+    const float* res32 = (const float*)p.residual;
     const float* src = p.ws + (size_t)row * p.N + lane * 8;
-    u32x4_t rv[NV];
+    u32x4_t rv[F32 ? 1 : NV];
+    f32x8_t rq[F32 ? NV : 1];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) rv[i] = res ? *(const u32x4_t*)(res + (size_t)row * p.ldr + (lane + 64 * i) * 8) : (u32x4_t){0u, 0u, 0u, 0u};
+    for (int i = 0; i < NV; ++i) {
+        if constexpr (F32) rq[i] = p.residual ? ld_f32x8(res32 + (size_t)row * p.ldr + (lane + 64 * i) * 8) : f32x8_t{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        else rv[i] = res ? *(const u32x4_t*)(res + (size_t)row * p.ldr + (lane + 64 * i) * 8) : (u32x4_t){0u, 0u, 0u, 0u};
+    }
     float a8[NV][8];
 #pragma unroll
     for (int i = 0; i < NV; ++i)
@@ -689,7 +721,7 @@ __global__ __launch_bounds__(256) void emmax_splitk_reduce_norm_kernel(GemmParam
                 a8[i][4 + e] += b[i][e];
             }
     }
-    u32x4_t v[NV];
+    u32x4_t v[F32 ? 1 : NV];
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -698,15 +730,24 @@ __global__ __launch_bounds__(256) void emmax_splitk_reduce_norm_kernel(GemmParam
         for (int e = 0; e < 8; ++e) {
             float x = a8[i][e] + (bias ? bf2f(bias[col + e]) : 0.f);
             if (scale) x *= bf2f(scale[col + e]);
-            if (res) x += (e & 1) ? bf_hi(rv[i][e >> 1]) : bf_lo(rv[i][e >> 1]);
+            if constexpr (F32) x += f32x8_at(rq[i], e);
+            else if (res) x += (e & 1) ? bf_hi(rv[i][e >> 1]) : bf_lo(rv[i][e >> 1]);
             a8[i][e] = x;
         }
-        v[i] = (u32x4_t){pack_bf16x2(a8[i][0], a8[i][1]), pack_bf16x2(a8[i][2], a8[i][3]), pack_bf16x2(a8[i][4], a8[i][5]), pack_bf16x2(a8[i][6], a8[i][7])};
-        *(u32x4_t*)((bf16_t*)p.C + (size_t)row * p.ldc + col) = v[i];
+        if constexpr (F32) {
+            float* cp = (float*)p.C + (size_t)row * p.ldc + col;
+            *(f32x4_t*)cp = (f32x4_t){a8[i][0], a8[i][1], a8[i][2], a8[i][3]};
+            *(f32x4_t*)(cp + 4) = (f32x4_t){a8[i][4], a8[i][5], a8[i][6], a8[i][7]};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float a = bf_lo(v[i][j]), bb = bf_hi(v[i][j]);
-            ss += a * a + bb * bb;
+            for (int e = 0; e < 8; ++e) ss += a8[i][e] * a8[i][e];
+        } else {
+            v[i] = (u32x4_t){pack_bf16x2(a8[i][0], a8[i][1]), pack_bf16x2(a8[i][2], a8[i][3]), pack_bf16x2(a8[i][4], a8[i][5]), pack_bf16x2(a8[i][6], a8[i][7])};
+            *(u32x4_t*)((bf16_t*)p.C + (size_t)row * p.ldc + col) = v[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = bf_lo(v[i][j]), bb = bf_hi(v[i][j]);
+                ss += a * a + bb * bb;
+            }
         }
     }
     ss = wave_sum(ss);
@@ -720,7 +761,9 @@ __global__ __launch_bounds__(256) void emmax_splitk_reduce_norm_kernel(GemmParam
         u32x4_t o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float a = bf_lo(v[i][j]) * rstd, bb = bf_hi(v[i][j]) * rstd;
+            float a, bb;
+            if constexpr (F32) { a = a8[i][2 * j] * rstd; bb = a8[i][2 * j + 1] * rstd; }
+            else { a = bf_lo(v[i][j]) * rstd; bb = bf_hi(v[i][j]) * rstd; }
             a = bf2f(f2bf(a)) * bf_lo(wv[j]);
             bb = bf2f(f2bf(bb)) * bf_hi(wv[j]);
             o[j] = pack_bf16x2(a, bb);
@@ -787,6 +830,7 @@ int launch_gemm_geom(const GemmParams& p, int big, hipStream_t stream) {
     if (p.K % BK != 0 || p.N % 128 != 0 || p.K <= 0 || p.N <= 0) return -1;
     if ((p.lda % 8) || (p.ldw % 8)) return -1;
     if (p.ln_stats && (!p.ln_s || !p.ln_c || p.bias || p.scale || p.residual || p.act == 2 || p.ksplit > 1)) return -1;
+    if (p.res_f32 && (!p.out_f32 || !p.residual || p.act == 2)) return -1;   // the fp32 residual stream yields an fp32 result
     return big ? launch_geom<GeomBig>(p, stream) : launch_geom<GeomSmall>(p, stream);
 }
 
@@ -826,7 +870,7 @@ static int launch_rows(const GemmParams& p, size_t r0, int rows, int big, hipStr
     q.M = rows;
     q.A = (const bf16_t*)p.A + r0 * p.lda;
     q.C = p.out_f32 ? (void*)((float*)p.C + r0 * p.ldc) : (void*)((bf16_t*)p.C + r0 * p.ldc);
-    if (p.residual) q.residual = (const bf16_t*)p.residual + r0 * p.ldr;
+    if (p.residual) q.residual = p.res_f32 ? (const void*)((const float*)p.residual + r0 * p.ldr) : (const void*)((const bf16_t*)p.residual + r0 * p.ldr);
     if (p.ln_stats) q.ln_stats = p.ln_stats + r0 * 2;
     return launch_gemm_geom(q, big, stream);
 }
@@ -862,8 +906,9 @@ static int launch_planned_rows(const GemmParams& p, long m1, hipStream_t stream)
 // ks slices per tile fill the chip (<= 512 resident blocks), each >= 8 K steps; the partial tiles meet in a second pass.
 // the reduce pass can apply p.norm_*: whole rows of 4096 bf16 columns (the LLaMA-2-7B hidden size; other widths keep the separate norm), 16-byte accesses
 static bool splitk_norm_ok(const GemmParams& p) {
-    return p.norm_out && p.norm_w && p.act == 0 && !p.out_f32 && !p.ln_stats && p.N == 4096 && p.N_store >= p.N &&
-           (p.ldc & 7) == 0 && (p.ld_norm & 7) == 0 && (((size_t)p.C | (size_t)p.norm_out | (size_t)p.norm_w) & 15) == 0 &&
+    // (out_f32: only as the fp32 residual stream -- fp32 residual in, fp32 C out)
+    return p.norm_out && p.norm_w && p.act == 0 && (!p.out_f32 || p.res_f32) && (!p.res_f32 || p.out_f32) && !p.ln_stats && p.N == 4096 &&
+           p.N_store >= p.N && (p.ldc & 7) == 0 && (p.ld_norm & 7) == 0 && (((size_t)p.C | (size_t)p.norm_out | (size_t)p.norm_w) & 15) == 0 &&
            (!p.residual || ((p.ldr & 7) == 0 && (((size_t)p.residual) & 15) == 0));
 }
 
@@ -875,7 +920,7 @@ int launch_gemm_splitk(const GemmParams& p, int ks, hipStream_t stream, int big)
     GemmParams a = p;
     a.ksplit = ks;
     a.C = p.ws; a.ldc = p.N; a.N_store = p.N; a.out_f32 = 1; a.act = 0;
-    a.bias = nullptr; a.scale = nullptr; a.residual = nullptr;
+    a.bias = nullptr; a.scale = nullptr; a.residual = nullptr; a.res_f32 = 0;
     int r = launch_gemm_geom(a, big, stream);
     if (r) return r;
     GemmParams b = p;
@@ -884,7 +929,8 @@ int launch_gemm_splitk(const GemmParams& p, int ks, hipStream_t stream, int big)
     const int grid = (int)((groups + 255) / 256 < 2048 ? (groups + 255) / 256 : 2048);
     if (p.norm_out) {
         if (!splitk_norm_ok(p)) return -1;
-        hipLaunchKernelGGL(emmax_splitk_reduce_norm_kernel<8>, dim3((p.M + 3) / 4), dim3(256), 0, stream, b);
+        if (p.res_f32) hipLaunchKernelGGL((emmax_splitk_reduce_norm_kernel<8, true>), dim3((p.M + 3) / 4), dim3(256), 0, stream, b);
+        else hipLaunchKernelGGL((emmax_splitk_reduce_norm_kernel<8, false>), dim3((p.M + 3) / 4), dim3(256), 0, stream, b);
     } else if (p.act == 2) hipLaunchKernelGGL(emmax_splitk_reduce_kernel<2>, dim3(grid), dim3(256), 0, stream, b);
     else if (p.act == 1) hipLaunchKernelGGL(emmax_splitk_reduce_kernel<1>, dim3(grid), dim3(256), 0, stream, b);
     else hipLaunchKernelGGL(emmax_splitk_reduce_kernel<0>, dim3(grid), dim3(256), 0, stream, b);
@@ -1014,7 +1060,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     b.C = p.out_f32 ? (void*)((float*)p.C + c1) : (void*)((bf16_t*)p.C + c1);
     if (p.bias) b.bias = (const bf16_t*)p.bias + n1;
     if (p.scale) b.scale = (const bf16_t*)p.scale + n1;
-    if (p.residual) b.residual = (const bf16_t*)p.residual + n1;
+    if (p.residual) b.residual = p.res_f32 ? (const void*)((const float*)p.residual + n1) : (const void*)((const bf16_t*)p.residual + n1);
     if (p.ln_stats) { b.ln_s = p.ln_s + n1; b.ln_c = p.ln_c + n1; }
     const int r = launch_planned_rows(a, pl.m1, stream);
     if (r) return r;

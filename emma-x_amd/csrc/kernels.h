@@ -16,6 +16,8 @@ struct GemmParams {
     const void* residual;  // bf16 [M, ldr] or null
     int M, N, K;
     int lda, ldw, ldc, ldr;
+    int res_f32;           // 1: `residual` is f32 [M, ldr] -- the fp32 residual stream of the prefill (round 5); needs out_f32 (C may alias it: every
+                           //    element is read and written by the same thread).  Honoured by the direct epilogue and the split-K reduce passes
     int N_store;           // columns >= N_store are not written
     int act;               // 0 none, 1 gelu(erf), 2 swiglu over 16-col interleaved (gate,up)
     int out_f32;
@@ -54,6 +56,7 @@ int launch_gemm_splitk(const GemmParams& p, int ksplit, hipStream_t stream, int 
 int launch_layernorm(const void* x, void* y, const void* w, const void* b, int rows, int D, int ldx, int ldy, float eps,
                      hipStream_t stream);
 int launch_rmsnorm(const void* x, void* y, const void* w, int rows, int D, int ldx, int ldy, float eps, hipStream_t stream);
+int launch_rmsnorm_f32(const float* x, void* y, const void* w, int rows, int D, int ldx, int ldy, float eps, hipStream_t stream);   // fp32 rows in, bf16 out
 // LayerNorm statistics alone: stats f32 [rows][2] = (mean, rstd) of every bf16 row (two-pass variance from registers, as launch_layernorm)
 int launch_row_stats(const void* x, float* stats, int rows, int D, int ldx, float eps, hipStream_t stream);
 // fold a LayerNorm into the [N, ldw] bf16 weight of the projection that consumes it (in place): W[n, k] <- bf16(W[n, k] * gamma[k]),
@@ -80,7 +83,7 @@ int launch_assemble_tokens(const void* pe, const void* pos, const void* cls, con
                            int n_patches, int n_prefix, int has_cls, int D, int ld, hipStream_t stream);
 int launch_copy_rows(const void* in, int ld_in, void* out, int B, int rows_in, int r_off, int rows_out, int D, int ld_out,
                      int col_off, hipStream_t stream);
-#define EMMAX_MAX_DECODE_BATCH 8
+#define EMMAX_MAX_DECODE_BATCH 16   // rows of a decode step: the 16-wide N side of v_mfma_f32_16x16x32_bf16 (decode_km.hip); rounds 1-4: 8
 #define EMMAX_MAX_STOP_IDS 16
 struct PrefillState {
     int B;
@@ -101,13 +104,14 @@ int launch_set_int(int32_t* p, int32_t v, hipStream_t stream);
 int launch_set_ints(int32_t* p, int n, int32_t v, hipStream_t stream);
 int launch_slots_idle(int n, int32_t* cur_tok, int32_t* ctx_len, int32_t* done, int32_t* n_out, int32_t pad_id, hipStream_t stream);
 int launch_embed_splice(const int32_t* ids, int P_max, const int32_t* cu, const void* E, const void* patches, void* h, int B,
-                        int max_seqlen, int n_patches, int hidden, int vocab, hipStream_t stream);
+                        int max_seqlen, int n_patches, int hidden, int vocab, hipStream_t stream, float* h32 = nullptr);   // h32: the rows also as fp32
 int launch_rope_kv_write(void* qkv, int ld, int q_off, int k_off, int v_off, const int32_t* cu, int B, int total_rows,
                          const float* cos_t, const float* sin_t, void* kcache, void* vcache, const int32_t* page_table,
                          int max_pages, int Hq, int Hkv, int hd, int page, hipStream_t stream);
 int launch_resize_bicubic_u8(const uint8_t* src, int B, int H, int W, uint8_t* dst, int OH, int OW, uint8_t* tmp, const int32_t* bounds_h,
                              const int32_t* kk_h, int ksize_h, const int32_t* bounds_v, const int32_t* kk_v, int ksize_v, hipStream_t stream);
-int launch_gather_last_rows(const void* in, void* out, const int32_t* cu, int B, int D, hipStream_t stream);
+// out32: the rows also as fp32; in32 != null: the source rows are fp32 (`in` unused)
+int launch_gather_last_rows(const void* in, void* out, const int32_t* cu, int B, int D, hipStream_t stream, float* out32 = nullptr, const float* in32 = nullptr);
 
 // ---- tuning switches (model.hip) ----
 // ONE table of named integers, read from the environment (EMMAX_<NAME>) ONCE, when the library first needs a value; after that only
@@ -120,6 +124,8 @@ struct EmmaxTune {
     int ks_oproj_grid;   // grid cap of that o-proj launch (256)
     int km;              // 1: batch >= 3 (and fp8) projections on decode_km.hip; 0: decode_mfma.hip
     int km_down;         // 1: ... including the two-phase down projection
+    int km_roll;         // 1: decode_km.hip refills a weight register as soon as its MFMA has issued (rolling ring); 0: a tile's sixteen refills together
+    int attn_nw;         // waves per decode-attention block: 0 = by shape (4; 8 for the one-split form when that leaves <= 256 blocks), 4 / 8 forced
     int streamk;         // 1: stream-K work split in decode_mfma.hip; 0: whole tasks per block
     int fp8_gemv;        // -1: default routing of the batch 1-2 fp8 projections; >= 0: bit mask (1 qkv, 2 o-proj, 4 gate/up, 8 down, 16 lm-head) on the row GEMV
     int attn_nsplit;     // 0: KV splits of the decode attention chosen from (B, kv heads); > 0: forced (rounded down to 2^k, <= 16)
@@ -134,6 +140,7 @@ struct EmmaxTune {
     int gemm_dbg;        // lab: OR-ed into GemmParams::dbg (16 = the second half of the waves requests its slabs mid-step)
     int gemm_lnfuse;     // 1: LayerNorm / RMSNorm applied by the GEMM that consumes the normalised rows (no separate norm pass)
     int attn_resident;   // -1: resident ViT attention kernel where measured faster; 0: never; 2: whenever it fits (tests)
+    int resid32;         // 1: prefill and decode step keep the residual stream in fp32 (GemmParams::res_f32, GemvParams::h32); 2: the decode step only; 0: bf16 rows (rounds 1-4)
     int epoch;           // bumped by every emmax_tuning_set: sessions drop captured graphs when it moves
 };
 const EmmaxTune& emmax_tune();
@@ -179,6 +186,13 @@ struct GemvParams {
     const int32_t* x_tok;   // K-split kernel, non-null: x row b = x[x_tok[b]] (p.x = embedding table, ids clamped to x_vocab): the embed launch
     void* x_copy;           //   folded into layer 0's qkv; block 0 also copies the rows to x_copy [B, ldx] (the residual stream)
     int x_vocab;
+    // fp32 residual stream (round 5, tuning switch resid32): h32 f32 [B, ldh] is the MASTER copy of the hidden rows of a decode step, the
+    // bf16 rows (p.x of the NORM modes = p.y of the RESID modes) its mirror.  RESID modes (o-proj, down) add into h32 in place and store
+    // bf16(sum) in the mirror; NORM modes (qkv, gate/up, lm-head) read either -- the batch 1-2 kernels the fp32 rows (free there: statistics
+    // and x g in fp32, one rounding), the batch >= 3 / fp8 MFMA kernels the mirror (the fp32 rows cost them 1.5 % of a step).  Either way
+    // the stream is no longer rounded after each of the 64 additions of a token: the mirror is re-derived from fp32 every time.
+    float* h32;
+    int ldh;
 };
 int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
 // decode_ks.hip: the batch 1-2 bf16 projections with K split across the waves of a block (activation slice in registers, no
@@ -186,7 +200,7 @@ int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream,
 int launch_decode_ks(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
 bool decode_ks_enabled();
 int decode_gemv_init();   // raise the dynamic-LDS limit of every GEMV instantiation (call once, outside graph capture)
-int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, hipStream_t stream);
+int launch_decode_embed(const int32_t* cur_tok, const void* E, void* h, int B, int hidden, int vocab, hipStream_t stream, float* h32 = nullptr);
 
 struct DecodeAttnParams {
     const void* q;          // bf16 [B, ldq] rotated queries

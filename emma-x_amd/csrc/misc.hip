@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void emmax_copy_rows_kernel(const bf16_t* __re
 __global__ __launch_bounds__(256) void emmax_embed_splice_kernel(const int32_t* __restrict__ ids, int P_max,
                                                                 const int32_t* __restrict__ cu, const bf16_t* __restrict__ E,
                                                                 const bf16_t* __restrict__ patches, bf16_t* __restrict__ h,
-                                                                int n_patches, int hidden, int vocab) {
+                                                                int n_patches, int hidden, int vocab, float* __restrict__ h32) {
     const int b = blockIdx.y, s = blockIdx.x;
     const int start = cu[b], len = cu[b + 1] - start;
     if (s >= len) return;
@@ -84,7 +84,16 @@ __global__ __launch_bounds__(256) void emmax_embed_splice_kernel(const int32_t* 
         src = (const u32x4_t*)(E + (size_t)id * hidden);
     }
     u32x4_t* o = (u32x4_t*)(h + (size_t)(start + s) * hidden);
-    for (int c = threadIdx.x; c < hidden / 8; c += blockDim.x) o[c] = src[c];
+    for (int c = threadIdx.x; c < hidden / 8; c += blockDim.x) {
+        const u32x4_t v = src[c];
+        o[c] = v;
+        if (h32) {   // the fp32 residual stream of the prefill starts from the same values (exact)
+            const f32x8_t f = bf16x8_to_f32(v);
+            float* hp = h32 + (size_t)(start + s) * hidden + (size_t)c * 8;
+            *(f32x4_t*)hp = f.lo;
+            *(f32x4_t*)(hp + 4) = f.hi;
+        }
+    }
 }
 
 // Prefill RoPE (rotate-half convention) on q,k in place + K/V append into the paged cache.
@@ -176,10 +185,34 @@ __global__ __launch_bounds__(256) void emmax_rope_kv_write_vec_kernel(bf16_t* __
 }
 
 // gather the last row of every packed sequence: out[b] = in[cu[b+1]-1]
+// out32 != null: the rows also widened to fp32 (the decode step's fp32 residual stream); in32 != null: the source rows are fp32 (the
+// prefill's fp32 residual stream): out32 = the row, out = its bf16 rounding
 __global__ __launch_bounds__(256) void emmax_gather_last_rows_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
-                                                                    const int32_t* __restrict__ cu, int D) {
+                                                                    const int32_t* __restrict__ cu, int D, float* __restrict__ out32,
+                                                                    const float* __restrict__ in32) {
     const int b = blockIdx.x;
+    if (in32) {
+        const float* sp = in32 + (size_t)(cu[b + 1] - 1) * D;
+        for (int c = threadIdx.x; c < D / 8; c += blockDim.x) {
+            const f32x8_t f = ld_f32x8(sp + (size_t)c * 8);
+            *((u32x4_t*)(out + (size_t)b * D) + c) = f32x8_to_bf16(f);
+            if (out32) {
+                float* hp = out32 + (size_t)b * D + (size_t)c * 8;
+                *(f32x4_t*)hp = f.lo;
+                *(f32x4_t*)(hp + 4) = f.hi;
+            }
+        }
+        return;
+    }
     const u32x4_t* s = (const u32x4_t*)(in + (size_t)(cu[b + 1] - 1) * D);
+    if (out32) {
+        for (int c = threadIdx.x; c < D / 8; c += blockDim.x) {
+            const f32x8_t f = bf16x8_to_f32(s[c]);
+            float* hp = out32 + (size_t)b * D + (size_t)c * 8;
+            *(f32x4_t*)hp = f.lo;
+            *(f32x4_t*)(hp + 4) = f.hi;
+        }
+    }
     u32x4_t* o = (u32x4_t*)(out + (size_t)b * D);
     for (int c = threadIdx.x; c < D / 8; c += blockDim.x) o[c] = s[c];
 }
@@ -348,11 +381,11 @@ int launch_copy_rows(const void* in, int ld_in, void* out, int B, int rows_in, i
 }
 
 int launch_embed_splice(const int32_t* ids, int P_max, const int32_t* cu, const void* E, const void* patches, void* h, int B,
-                        int max_seqlen, int n_patches, int hidden, int vocab, hipStream_t stream) {
+                        int max_seqlen, int n_patches, int hidden, int vocab, hipStream_t stream, float* h32) {
     if (hidden % 8) return -1;
     dim3 grid(max_seqlen, B), block(256);
     hipLaunchKernelGGL(emmax_embed_splice_kernel, grid, block, 0, stream, ids, P_max, cu, (const bf16_t*)E,
-                       (const bf16_t*)patches, (bf16_t*)h, n_patches, hidden, vocab);
+                       (const bf16_t*)patches, (bf16_t*)h, n_patches, hidden, vocab, h32);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
@@ -372,8 +405,8 @@ int launch_rope_kv_write(void* qkv, int ld, int q_off, int k_off, int v_off, con
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-int launch_gather_last_rows(const void* in, void* out, const int32_t* cu, int B, int D, hipStream_t stream) {
+int launch_gather_last_rows(const void* in, void* out, const int32_t* cu, int B, int D, hipStream_t stream, float* out32, const float* in32) {
     dim3 grid(B), block(256);
-    hipLaunchKernelGGL(emmax_gather_last_rows_kernel, grid, block, 0, stream, (const bf16_t*)in, (bf16_t*)out, cu, D);
+    hipLaunchKernelGGL(emmax_gather_last_rows_kernel, grid, block, 0, stream, (const bf16_t*)in, (bf16_t*)out, cu, D, out32, in32);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }

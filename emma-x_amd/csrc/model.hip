@@ -51,6 +51,7 @@ const TuneEntry kTune[] = {
     {"graph", &EmmaxTune::graph, 0},           {"ks", &EmmaxTune::ks, 1},
     {"ks_oproj", &EmmaxTune::ks_oproj, 1},     {"ks_oproj_grid", &EmmaxTune::ks_oproj_grid, 256},
     {"km", &EmmaxTune::km, 1},                 {"km_down", &EmmaxTune::km_down, 1},
+    {"km_roll", &EmmaxTune::km_roll, 0},       {"attn_nw", &EmmaxTune::attn_nw, 4},
     {"streamk", &EmmaxTune::streamk, 1},       {"fp8_gemv", &EmmaxTune::fp8_gemv, -1},
     {"attn_nsplit", &EmmaxTune::attn_nsplit, 0}, {"attn_direct", &EmmaxTune::attn_direct, 1},
     {"fold_embed", &EmmaxTune::fold_embed, 1}, {"mfma_xbar", &EmmaxTune::mfma_xbar, 1},
@@ -58,6 +59,7 @@ const TuneEntry kTune[] = {
     {"gemm_deep", &EmmaxTune::gemm_deep, -1},       {"gemm_dbg", &EmmaxTune::gemm_dbg, 0},
     {"gemm_lnfuse", &EmmaxTune::gemm_lnfuse, 1}, {"attn_resident", &EmmaxTune::attn_resident, -1},
     {"gemm_hybrid", &EmmaxTune::gemm_hybrid, 1}, {"gemm_normfuse", &EmmaxTune::gemm_normfuse, 1},
+    {"resid32", &EmmaxTune::resid32, 1},
 };
 EmmaxTune g_tune;
 std::once_flag g_tune_once;
@@ -314,15 +316,21 @@ struct emmax_session {
     int32_t* cu_vit[2];
     // prefill scratch
     bf16 *ph, *pxn, *pqkv, *patt, *pact;
+    float* ph32;                // the prefill's residual stream in fp32 (tuning switch resid32 = 1), [max_rows][H]
+    bool p32 = false;           // the last prefill ran on ph32 (what emmax_prefill_logits normalises)
     int32_t* cu;
     // decode
     bf16 *dh, *dq, *datt, *dact;
+    float* dh32;                // the decode step's residual stream in fp32 (tuning switch resid32; GemvParams::h32), [rows_total][H]
     float *part, *part_val, *logits, *part_val2 /* lm-head argmax partials of a staged prefill */;
     int32_t *part_idx2;
     int32_t *part_idx, *cur_tok, *ctx_len, *done, *n_out, *out_ids, *max_new_d /* [max_batch] */, *page_table;
     float* splitk_ws;           // fp32 partial tiles of split-K GEMMs (gemm.hip)
     int64_t splitk_bytes;
     unsigned long long* sk_ws = nullptr;     // device: stream-K granules of the MFMA decode projections (decode_mfma.hip), all zero between launches
+    unsigned long long* sk_ws2 = nullptr;    // ... of a STAGED prefill's lm-head: it runs on a second stream beside the live decode steps, and the
+                                             // granules are indexed by block id only -- two concurrent launches on one workspace would consume or
+                                             // clear each other's partial sums
     int32_t *stop_ids /* [EMMAX_MAX_STOP_IDS] */, *stop_cfg /* {n_trigger, n_after} */, *stop_m, *stop_after;
     bool slots_open = false;    // slot serving mode: rows are independent request slots (emmax_slots_open)
     float *cos_t, *sin_t;
@@ -387,6 +395,7 @@ static void plan_session(emmax_session* s, SBump& b) {
     for (int t = 0; t < 2; ++t) s->cu_vit[t] = (int32_t*)b.take((Bv + 1) * 4);
     const int64_t R = s->max_rows;
     s->ph = (bf16*)b.take(R * m->H * 2);
+    s->ph32 = (float*)b.take(R * m->H * 4);
     s->pxn = (bf16*)b.take(R * m->H * 2);
     s->pqkv = (bf16*)b.take(R * m->qkv_dim * 2);
     s->patt = (bf16*)b.take(R * m->q_dim * 2);
@@ -394,6 +403,7 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->cu = (int32_t*)b.take((s->max_batch + 1) * 4);
     const int Bd = s->max_batch, Br = s->rows_total;   // decode batch rows / all rows incl. the staging rows
     s->dh = (bf16*)b.take((int64_t)Br * m->H * 2);
+    s->dh32 = (float*)b.take((int64_t)Br * m->H * 4);
     s->dq = (bf16*)b.take((int64_t)Bd * m->q_dim * 2);
     s->datt = (bf16*)b.take((int64_t)Bd * m->q_dim * 2);
     s->dact = (bf16*)b.take((int64_t)Bd * m->inter_p * 2);
@@ -416,6 +426,7 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->stop_after = (int32_t*)b.take(Br * 4);
     s->page_table = (int32_t*)b.take((int64_t)Br * s->max_pages * 4);
     s->sk_ws = (unsigned long long*)b.take((int64_t)256 * 2 * 256 * 8);
+    s->sk_ws2 = (unsigned long long*)b.take((int64_t)256 * 2 * 256 * 8);
     s->splitk_bytes = (int64_t)64 << 20;   // e.g. 4 slices of a 768 x 4096 prefill GEMM = 50 MB; smaller budgets just split less
     s->splitk_ws = (float*)b.take(s->splitk_bytes);
     s->cos_t = (float*)b.take((int64_t)s->max_ctx * (m->cfg.head_dim / 2) * 4);
@@ -562,6 +573,22 @@ static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_
     return launch_decode_gemv(mode, p, B, st, grid_out);
 }
 
+// the hidden rows of a decode step: the fp32 stream (tuning switch resid32, the default) or the bf16 rows of rounds 1-4
+// (resid32: 0 = bf16 rows everywhere, 1 = fp32 stream in the prefill and the decode step, 2 = in the decode step only)
+static float* h32_of(emmax_session* s, int slot0 = 0) { return emmax_tune().resid32 ? s->dh32 + (size_t)slot0 * s->m->H : nullptr; }
+
+// Decode batches of 9-16 rows exist on decode_km.hip only (decode_mfma.hip, the fallback for other shapes, stages eight rows): the
+// model's projections must be shapes that kernel takes -- K a multiple of 256 and <= 4096 for qkv / o-proj / gate-up / lm-head, at
+// most 8 tiles per block (N <= 32768), the down projection within four phases of 12 fragments per wave (K <= 12288).
+static int model_max_decode_batch(const emmax_model* m) {
+    const auto& c = m->cfg;
+    const bool k_ok = m->H % 256 == 0 && m->H <= 4096 && m->q_dim % 256 == 0 && m->q_dim <= 4096;
+    const bool n_ok = m->qkv_dim % 16 == 0 && m->qkv_dim <= 32768 && 2 * m->inter_p <= 32768 && m->vocab_p <= 32768 && m->H % 16 == 0 && c.head_dim % 16 == 0;
+    const int kd = m->fp8 ? 64 : 32;
+    const bool d_ok = m->inter_p % kd == 0 && m->inter_p / kd >= 8 && (m->inter_p / kd + 7) / 8 <= (m->fp8 ? 24 : 48) && m->inter_p > 4096;
+    return (k_ok && n_ok && d_ok && decode_km_enabled() && emmax_tune().km_down) ? EMMAX_MAX_DECODE_BATCH : 8;
+}
+
 static bf16* kcache_of(emmax_session* s, int layer) { return s->kv + (size_t)layer * s->kv_layer_stride; }
 static bf16* vcache_of(emmax_session* s, int layer) { return s->kv + (size_t)layer * s->kv_layer_stride + s->kv_layer_stride / 2; }
 
@@ -607,8 +634,9 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
     emmax_model* m = s->m;
     const auto& c = m->cfg;
     if (!m->finalized) return fail(EMMAX_ERR_STATE, "model not finalized");
-    if (B <= 0 || B > s->max_batch || B > EMMAX_MAX_DECODE_BATCH)
-        return fail(EMMAX_ERR_INVALID, "prefill batch %d outside 1..min(max_batch=%d, %d)", B, s->max_batch, EMMAX_MAX_DECODE_BATCH);
+    if (B <= 0 || B > s->max_batch || B > model_max_decode_batch(m))
+        return fail(EMMAX_ERR_INVALID, "prefill batch %d outside 1..min(max_batch=%d, %d) (decode batches above 8 need the shapes decode_km.hip takes: emmax_model_max_decode_batch)",
+                    B, s->max_batch, model_max_decode_batch(m));
     if (B >= EMMAX_MFMA_MIN_BATCH && !m->aux_built)
         return fail(EMMAX_ERR_STATE, "batch %d decodes on the fragment-major weight copies: call emmax_model_build_aux first", B);
     const int np = patches ? m->tw[0].n_patches : 0;
@@ -642,7 +670,21 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
     if (!slot_mode) { s->cur_B = B; s->dec_steps = 0; }
     s->total_rows = total; s->max_seqlen = maxS;
 
-    KCHK(launch_embed_splice(ids, P_max, s->cu, m->embed, patches, s->ph, B, maxS, np, m->H, m->vocab, st));
+    // fp32 residual stream (tuning switch resid32 = 1; 2 = the decode step only): o-proj and down add into fp32 rows -- through the
+    // split-K reduce passes of a one-frame prefill, through the direct fp32 epilogue of the big GEMMs otherwise -- and the RMSNorms read
+    // them; the stream is rounded to bf16 only where a GEMM consumes the normalised rows
+    const bool p32 = emmax_tune().resid32 == 1;
+    s->p32 = p32;
+    KCHK(launch_embed_splice(ids, P_max, s->cu, m->embed, patches, s->ph, B, maxS, np, m->H, m->vocab, st, p32 ? s->ph32 : nullptr));
+    auto input_norm = [&](const void* w) {
+        return p32 ? launch_rmsnorm_f32(s->ph32, s->pxn, w, total, m->H, m->H, m->H, c.rms_eps, st)
+                   : launch_rmsnorm(s->ph, s->pxn, w, total, m->H, m->H, m->H, c.rms_eps, st);
+    };
+    auto into_stream = [&](GemmParams& g) {   // C = residual stream += A W^T
+        if (p32) { g.C = s->ph32; g.out_f32 = 1; g.residual = s->ph32; g.res_f32 = 1; }
+        else { g.residual = s->ph; }
+        g.ldr = m->H;
+    };
     // the RMSNorm behind a projection whose partial tiles meet in a split-K reduce pass (one-frame prefill: o-proj, down) is applied
     // by that pass (gemm_fuses_norm); otherwise it is its own launch
     auto with_norm = [&](GemmParams& g, const void* w) {
@@ -654,7 +696,7 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
     bool normed = false;   // s->pxn already holds ln1 of the current layer
     for (int li = 0; li < c.n_layers; ++li) {
         const LayerW& L = m->layers[li];
-        if (!normed) KCHK(launch_rmsnorm(s->ph, s->pxn, L.ln1, total, m->H, m->H, m->H, c.rms_eps, st));
+        if (!normed) KCHK(input_norm(L.ln1));
         GemmParams g = gps(s, s->pxn, m->H, L.wqkv, m->H, s->pqkv, m->qkv_dim, total, m->qkv_dim, m->H);
         KCHK(launch_gemm(g, st));
         KCHK(launch_rope_kv_write(s->pqkv, m->qkv_dim, 0, m->q_dim, m->q_dim + m->kv_dim, s->cu, B, total, s->cos_t, s->sin_t,
@@ -667,19 +709,19 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
         a.scale = 1.0f / sqrtf((float)c.head_dim); a.causal = 1;
         KCHK(launch_attention(a, c.head_dim, st));
         g = gps(s, s->patt, m->q_dim, L.wo, m->q_dim, s->ph, m->H, total, m->H, m->q_dim);
-        g.residual = s->ph; g.ldr = m->H;
+        into_stream(g);
         normed = with_norm(g, L.ln2);
         KCHK(launch_gemm(g, st));
-        if (!normed) KCHK(launch_rmsnorm(s->ph, s->pxn, L.ln2, total, m->H, m->H, m->H, c.rms_eps, st));
+        if (!normed) KCHK(input_norm(L.ln2));
         g = gps(s, s->pxn, m->H, L.wgu, m->H, s->pact, m->inter_p, total, 2 * m->inter_p, m->H);
         g.act = 2;
         KCHK(launch_gemm(g, st));
         g = gps(s, s->pact, m->inter_p, L.wdown, m->inter_p, s->ph, m->H, total, m->H, m->inter_p);
-        g.residual = s->ph; g.ldr = m->H;
+        into_stream(g);
         normed = li + 1 < c.n_layers && with_norm(g, m->layers[li + 1].ln1);
         KCHK(launch_gemm(g, st));
     }
-    KCHK(launch_gather_last_rows(s->ph, s->dh + (size_t)r0 * m->H, s->cu, B, m->H, st));
+    KCHK(launch_gather_last_rows(s->ph, s->dh + (size_t)r0 * m->H, s->cu, B, m->H, st, h32_of(s, r0), p32 ? s->ph32 : nullptr));
     int r = run_lm_head_step(s, B, true, nullptr, true, st, r0);
     if (r) return r;
     s->prefilled = true;
@@ -701,6 +743,7 @@ static void stage_params(emmax_session* s, int B, int li, int stage, GemvParams&
     const LayerW& L = m->layers[li];
     memset(&p, 0, sizeof(p));
     p.sk_ws = streamk_on() ? s->sk_ws : nullptr;
+    if (stage != STAGE_ATTN) { p.h32 = h32_of(s); p.ldh = m->H; }   // qkv / gate-up read the hidden rows, o-proj / down add into them
     switch (stage) {
         case STAGE_QKV:
             p.x = s->dh; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln1; p.eps = c.rms_eps;
@@ -728,8 +771,9 @@ static void stage_params(emmax_session* s, int B, int li, int stage, GemvParams&
 static void lmhead_params(emmax_session* s, int slot0, float* logits_out, GemvParams& p) {
     emmax_model* m = s->m;
     memset(&p, 0, sizeof(p));
-    p.sk_ws = streamk_on() ? s->sk_ws : nullptr;
+    p.sk_ws = streamk_on() ? (slot0 >= s->stg0 ? s->sk_ws2 : s->sk_ws) : nullptr;
     p.x = s->dh + (size_t)slot0 * m->H; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = m->final_norm; p.eps = m->cfg.rms_eps;
+    p.h32 = h32_of(s, slot0); p.ldh = m->H;
     const bool stg = slot0 >= s->stg0;
     p.n_rows = m->vocab; p.max_parts = s->n_lm_blocks; p.part_val = stg ? s->part_val2 : s->part_val; p.part_idx = stg ? s->part_idx2 : s->part_idx;
     p.logits_out = logits_out;
@@ -784,7 +828,7 @@ static int run_qkv0_with_embed(emmax_session* s, int B, hipStream_t st) {
     p.x = m->embed; p.x_tok = s->cur_tok; p.x_copy = s->dh; p.x_vocab = m->vocab;
     int r = launch_decode_ks(GEMV_QKV, p, B, st, nullptr);
     if (r == -2) {
-        KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st));
+        KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st, h32_of(s)));
         return run_decode_stage(s, B, 0, STAGE_QKV, st);
     }
     return r ? fail(EMMAX_ERR_HIP, "qkv launch of layer 0 failed (code %d)", r) : 0;
@@ -795,7 +839,7 @@ static int run_decode_step(emmax_session* s, int B, hipStream_t st) {
     // batch 1-2 on bf16 weights: the embedding row is read by layer 0's qkv launch itself (K-split kernel) -- one launch fewer
     const bool fold_embed = B < EMMAX_MFMA_MIN_BATCH && !m->fp8 && decode_ks_enabled() && m->H % 64 == 0 && m->H <= 12288 &&
                             emmax_tune().fold_embed != 0;
-    if (!fold_embed) KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st));
+    if (!fold_embed) KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st, h32_of(s)));
     for (int li = 0; li < m->cfg.n_layers; ++li)
         for (int stage = STAGE_QKV; stage <= STAGE_DOWN; ++stage) {
             int r = (li == 0 && stage == STAGE_QKV && fold_embed) ? run_qkv0_with_embed(s, B, st) : run_decode_stage(s, B, li, stage, st);
@@ -1012,6 +1056,8 @@ int emmax_model_finalize(emmax_model* m, void* arena, int64_t arena_bytes, emmax
     return 0;
 }
 
+int emmax_model_max_decode_batch(const emmax_model* m) { return m ? model_max_decode_batch(m) : -1; }
+
 int64_t emmax_model_aux_bytes(const emmax_model* m) {
     if (!m) return -1;
     if (m->fp8) return 0;
@@ -1062,14 +1108,26 @@ static int session_dims(const emmax_model* m, int max_batch, int max_prompt, int
     return 0;
 }
 
+// stage_rows: staging rows for overlapped admissions (emmax_slots_prefill_staged), 0 .. min(max_batch, EMMAX_MAX_DECODE_BATCH).  They
+// cost per-row state AND their share of the paged KV region; a session that never stages (emmax_prefill / emmax_generate, the bench)
+// asks for none (round 4 gave every session min(max_batch, 8) of them and doubled the KV region of small sessions).
+static int check_stage_rows(int max_batch, int stage_rows) {
+    if (stage_rows < 0 || stage_rows > max_batch || stage_rows > EMMAX_MAX_DECODE_BATCH)
+        return fail(EMMAX_ERR_INVALID, "stage_rows %d outside 0..min(max_batch=%d, %d)", stage_rows, max_batch, EMMAX_MAX_DECODE_BATCH);
+    return 0;
+}
 int emmax_session_bytes(const emmax_model* m, int max_batch, int max_prompt, int max_ctx, int64_t* ws, int64_t* kv) {
+    return emmax_session_bytes_ex(m, max_batch, max_prompt, max_ctx, 0, ws, kv);
+}
+int emmax_session_bytes_ex(const emmax_model* m, int max_batch, int max_prompt, int max_ctx, int stage_rows, int64_t* ws, int64_t* kv) {
     int mp, mr, r;
     if ((r = session_dims(m, max_batch, max_prompt, max_ctx, &mp, &mr))) return r;
+    if ((r = check_stage_rows(max_batch, stage_rows))) return r;
     emmax_session tmp;
     tmp.m = const_cast<emmax_model*>(m);
     tmp.max_batch = max_batch; tmp.max_prompt = max_prompt; tmp.max_ctx = max_ctx; tmp.max_pages = mp; tmp.max_rows = mr;
     tmp.max_out = max_ctx;
-    tmp.n_stg = std::min(max_batch, EMMAX_MAX_DECODE_BATCH); tmp.stg0 = max_batch; tmp.rows_total = max_batch + tmp.n_stg;
+    tmp.n_stg = stage_rows; tmp.stg0 = max_batch; tmp.rows_total = max_batch + tmp.n_stg;
     SBump b{nullptr};
     plan_session(&tmp, b);
     if (ws) *ws = b.off + 256;
@@ -1079,10 +1137,15 @@ int emmax_session_bytes(const emmax_model* m, int max_batch, int max_prompt, int
 
 int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_ctx, void* ws, int64_t ws_bytes, void* kv,
                          int64_t kvb, emmax_session** out) {
+    return emmax_session_create_ex(m, max_batch, max_prompt, max_ctx, 0, ws, ws_bytes, kv, kvb, out);
+}
+int emmax_session_stage_rows(const emmax_session* s) { return s ? s->n_stg : -1; }
+int emmax_session_create_ex(emmax_model* m, int max_batch, int max_prompt, int max_ctx, int stage_rows, void* ws, int64_t ws_bytes, void* kv,
+                            int64_t kvb, emmax_session** out) {
     if (!m || !ws || !kv || !out) return fail(EMMAX_ERR_INVALID, "null argument");
     if (!m->finalized) return fail(EMMAX_ERR_STATE, "model not finalized");
     int64_t need_ws, need_kv;
-    int r = emmax_session_bytes(m, max_batch, max_prompt, max_ctx, &need_ws, &need_kv);
+    int r = emmax_session_bytes_ex(m, max_batch, max_prompt, max_ctx, stage_rows, &need_ws, &need_kv);
     if (r) return r;
     if (ws_bytes < need_ws || kvb < need_kv)
         return fail(EMMAX_ERR_NOMEM, "session memory too small: workspace %lld/%lld, kv %lld/%lld", (long long)ws_bytes,
@@ -1094,7 +1157,7 @@ int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_
     s->max_batch = max_batch; s->max_prompt = max_prompt; s->max_ctx = max_ctx;
     session_dims(m, max_batch, max_prompt, max_ctx, &s->max_pages, &s->max_rows);
     s->max_out = max_ctx;
-    s->n_stg = std::min(max_batch, EMMAX_MAX_DECODE_BATCH); s->stg0 = max_batch; s->rows_total = max_batch + s->n_stg;
+    s->n_stg = stage_rows; s->stg0 = max_batch; s->rows_total = max_batch + s->n_stg;
     SBump b{(char*)ws};
     plan_session(s, b);
     s->kv = (bf16*)kv;
@@ -1181,7 +1244,8 @@ int emmax_prefill_logits(emmax_session* s, float* out, emmax_stream stream) {
     if (!s->prefilled) return fail(EMMAX_ERR_STATE, "prefill has not run");
     emmax_model* m = s->m;
     hipStream_t st = (hipStream_t)stream;
-    KCHK(launch_rmsnorm(s->ph, s->pxn, m->final_norm, s->total_rows, m->H, m->H, m->H, m->cfg.rms_eps, st));
+    if (s->p32) KCHK(launch_rmsnorm_f32(s->ph32, s->pxn, m->final_norm, s->total_rows, m->H, m->H, m->H, m->cfg.rms_eps, st));
+    else KCHK(launch_rmsnorm(s->ph, s->pxn, m->final_norm, s->total_rows, m->H, m->H, m->H, m->cfg.rms_eps, st));
     GemmParams g = gps(s, s->pxn, m->H, m->lm_head, m->H, out, m->vocab, s->total_rows, m->vocab_p, m->H);
     g.N_store = m->vocab; g.out_f32 = 1;
     KCHK(launch_gemm(g, st));
@@ -1318,8 +1382,8 @@ int emmax_session_set_stop(emmax_session* s, const int32_t* trigger_ids, int n_t
 
 int emmax_slots_open(emmax_session* s, int n_slots, emmax_stream stream) {
     if (!s) return fail(EMMAX_ERR_INVALID, "null argument");
-    if (n_slots < 1 || n_slots > s->max_batch || n_slots > EMMAX_MAX_DECODE_BATCH)
-        return fail(EMMAX_ERR_INVALID, "%d slots outside 1..min(max_batch=%d, %d)", n_slots, s->max_batch, EMMAX_MAX_DECODE_BATCH);
+    if (n_slots < 1 || n_slots > s->max_batch || n_slots > model_max_decode_batch(s->m))
+        return fail(EMMAX_ERR_INVALID, "%d slots outside 1..min(max_batch=%d, %d)", n_slots, s->max_batch, model_max_decode_batch(s->m));
     if (n_slots >= EMMAX_MFMA_MIN_BATCH && !s->m->aux_built)
         return fail(EMMAX_ERR_STATE, "%d slots decode on the fragment-major weight copies: call emmax_model_build_aux first", n_slots);
     hipStream_t user = (hipStream_t)stream, st;
@@ -1368,7 +1432,8 @@ int emmax_slots_prefill_staged(emmax_session* s, int n, const int32_t* ids, int 
                                const int32_t* max_new_host, emmax_stream stream) {
     if (!s || !ids || !lens_host || !max_new_host) return fail(EMMAX_ERR_INVALID, "null argument");
     if (!s->slots_open) return fail(EMMAX_ERR_STATE, "emmax_slots_prefill_staged before emmax_slots_open");
-    if (n < 1 || n > s->n_stg) return fail(EMMAX_ERR_INVALID, "%d staged requests outside 1..%d", n, s->n_stg);
+    if (n < 1 || n > s->n_stg)
+        return fail(EMMAX_ERR_INVALID, "%d staged requests outside 1..%d (the session's staging rows: emmax_session_create_ex)", n, s->n_stg);
     if ((uintptr_t)stream <= 2) return fail(EMMAX_ERR_INVALID, "a staged prefill needs its own (non-default) stream: it runs beside the decode steps");
     for (int i = 0; i < n; ++i)
         if (max_new_host[i] < 1 || max_new_host[i] > s->max_out)
@@ -1525,7 +1590,7 @@ int emmax_gemm_plan(int M, int N, int K, int act, int out_f32, int has_ln, int h
     void* const any = (void*)(uintptr_t)256;   // the plan looks at sizes, alignments and which operands exist -- never through a pointer
     GemmParams p = gp(any, K, any, K, any, act == 2 ? N / 2 : N, M, N, K);
     p.act = act; p.out_f32 = out_f32;
-    if (has_residual) { p.residual = any; p.ldr = N; }
+    if (has_residual) { p.residual = any; p.ldr = N; p.res_f32 = has_residual == 2; }   // 2: the fp32 residual stream (with out_f32)
     if (has_ln) { p.ln_stats = (const float*)any; p.ln_s = (const float*)any; p.ln_c = (const float*)any; }
     if (ws_bytes > 0) { p.ws = (float*)any; p.ws_bytes = ws_bytes; }
     if (with_norm) { p.norm_w = any; p.norm_out = any; p.ld_norm = N; p.norm_eps = 1e-5f; }
@@ -1659,8 +1724,14 @@ int emmax_op_gemm_small_km(const void* x, const void* W_km, void* y, int B, int 
     GemvParams p;
     memset(&p, 0, sizeof(p));
     p.x = x; p.ldx = K; p.W = W_km; p.ldw = K; p.K = K; p.y = y; p.ldy = N; p.n_rows = N;
-    int r = launch_decode_km(GEMV_PLAIN, p, B, (hipStream_t)st);
-    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_gemm_small_km: unsupported shape (1 <= B <= 8, N %% 16, K %% 256, K <= 4096, N <= 32768)");
+    int r;
+    if (K > 4096) {   // the phased kernel of the down projection (y = h + W x): h = 0
+        HIPCHK(hipMemsetAsync(y, 0, (size_t)B * N * 2, (hipStream_t)st));
+        r = launch_decode_km(GEMV_RESID, p, B, (hipStream_t)st);
+    } else {
+        r = launch_decode_km(GEMV_PLAIN, p, B, (hipStream_t)st);
+    }
+    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_gemm_small_km: unsupported shape (1 <= B <= 16, N %% 16; K %% 256 and K <= 4096 and N <= 32768, or the phased form: K %% 32, K <= 11264 at B <= 8, 12288 at B <= 16)");
     return 0;
 }
 int emmax_op_gemm_small(const void* x, const void* W_fm, void* y, int B, int N, int K, emmax_stream st) {

@@ -82,6 +82,45 @@ __global__ __launch_bounds__(256) void emmax_rownorm_kernel(const bf16_t* __rest
     }
 }
 
+// RMSNorm of fp32 rows (the fp32 residual stream of the prefill, round 5): HF LlamaRMSNorm on an fp32 hidden state -- statistics and
+// normalise in fp32, round to bf16, multiply by the weight, round.  D % 8 == 0, D <= 8 * 64 * MAXV
+template <int MAXV>
+__global__ __launch_bounds__(256) void emmax_rmsnorm_f32_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, const bf16_t* __restrict__ w,
+                                                               int rows, int D, int ldx, int ldy, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = D >> 3;
+    const float* xr = x + (size_t)row * ldx;
+    f32x8_t v[MAXV];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < nchunk ? ld_f32x8(xr + c * 8) : f32x8_t{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += f32x8_at(v[i], e) * f32x8_at(v[i], e);
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)D + eps);
+    bf16_t* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            const u32x4_t wv = *(const u32x4_t*)(w + c * 8);
+            u32x4_t o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = bf2f(f2bf(f32x8_at(v[i], 2 * j) * rstd)) * bf_lo(wv[j]);
+                const float bb = bf2f(f2bf(f32x8_at(v[i], 2 * j + 1) * rstd)) * bf_hi(wv[j]);
+                o[j] = pack_bf16x2(a, bb);
+            }
+            *(u32x4_t*)(yr + c * 8) = o;
+        }
+    }
+}
+
 // LayerNorm statistics of every row, nothing else: one wave per row, the row read once
 template <int MAXV>
 __global__ __launch_bounds__(256) void emmax_row_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats, int rows, int D, int ldx, float eps) {
@@ -199,4 +238,18 @@ int launch_layernorm(const void* x, void* y, const void* w, const void* b, int r
 }
 int launch_rmsnorm(const void* x, void* y, const void* w, int rows, int D, int ldx, int ldy, float eps, hipStream_t stream) {
     return launch_rownorm(true, x, y, w, nullptr, rows, D, ldx, ldy, eps, stream);
+}
+int launch_rmsnorm_f32(const float* x, void* y, const void* w, int rows, int D, int ldx, int ldy, float eps, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    if (D % 8 != 0 || D > 8 * 64 * 16 || ldx % 4 || ldy % 8) return -1;
+    dim3 grid(cdiv(rows, 4)), block(256);
+    const int nv = cdiv(D / 8, 64);
+#define LAUNCH(MAXV) hipLaunchKernelGGL((emmax_rmsnorm_f32_kernel<MAXV>), grid, block, 0, stream, x, (bf16_t*)y, (const bf16_t*)w, rows, D, ldx, ldy, eps)
+    if (nv <= 1) LAUNCH(1);
+    else if (nv <= 2) LAUNCH(2);
+    else if (nv <= 4) LAUNCH(4);
+    else if (nv <= 8) LAUNCH(8);
+    else LAUNCH(16);
+#undef LAUNCH
+    return hipGetLastError() == hipSuccess ? 0 : -4;
 }

@@ -43,7 +43,7 @@ class ConfigC(C.Structure):
     ]
 
 
-ABI_VERSION = 3   # EMMAX_ABI_VERSION of include/emmax.h this binding was written against
+ABI_VERSION = 4   # EMMAX_ABI_VERSION of include/emmax.h this binding was written against
 
 # name -> (restype, argtypes): exactly the entry points of include/emmax.h
 SIGNATURES = {
@@ -57,11 +57,15 @@ SIGNATURES = {
     "emmax_model_destroy": (None, [_vp]),
     "emmax_model_bind_weight": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int, _c_i64p, C.c_int]),
     "emmax_model_arena_bytes": (C.c_int64, [_vp]),
+    "emmax_model_max_decode_batch": (C.c_int, [_vp]),
     "emmax_model_finalize": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "emmax_model_aux_bytes": (C.c_int64, [_vp]),
     "emmax_model_build_aux": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "emmax_session_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _c_i64p, _c_i64p]),
     "emmax_session_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp, C.c_int64, C.POINTER(_vp)]),
+    "emmax_session_bytes_ex": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _c_i64p, _c_i64p]),
+    "emmax_session_create_ex": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp, C.c_int64, C.POINTER(_vp)]),
+    "emmax_session_stage_rows": (C.c_int, [_vp]),
     "emmax_session_destroy": (None, [_vp]),
     "emmax_vision_encode": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     "emmax_vision_encode_pixels": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
@@ -146,7 +150,7 @@ def tuning_get(name: str) -> int:
     return int(v.value)
 
 
-def gemm_plan(M: int, N: int, K: int, act: int = 0, out_f32: bool = False, ln: bool = False, residual: bool = False, norm: bool = False,
+def gemm_plan(M: int, N: int, K: int, act: int = 0, out_f32: bool = False, ln: bool = False, residual: int = 0, norm: bool = False,
               ws_bytes: int = 64 << 20) -> str:
     """The GEMM launch plan for a problem, as text (include/emmax.h: emmax_gemm_plan; host only -- runs without a GPU)."""
     buf = C.create_string_buffer(256)

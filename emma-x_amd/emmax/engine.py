@@ -93,7 +93,9 @@ class EmmaxEngine:
         self.new_session(max_batch, max_prompt, max_ctx)
 
     # ------------------------------------------------------------------------------------------------------------------
-    def new_session(self, max_batch: int, max_prompt: int, max_ctx: Optional[int] = None) -> None:
+    def new_session(self, max_batch: int, max_prompt: int, max_ctx: Optional[int] = None, stage_rows: int = 0) -> None:
+        """(Re)create the session.  `stage_rows` staging rows (overlapped slot admissions, include/emmax.h) cost per-row state and
+        their share of the paged KV region: only slot serving asks for them (ensure_stage_rows)."""
         if self._session:
             self.lib.emmax_session_destroy(self._session)
             self._session = C.c_void_p()
@@ -101,14 +103,20 @@ class EmmaxEngine:
         if max_ctx is None:
             max_ctx = np_ + max_prompt + 512 + 1
         ws, kv = C.c_int64(), C.c_int64()
-        _lib.check(self.lib.emmax_session_bytes(self._model, max_batch, max_prompt, max_ctx, C.byref(ws), C.byref(kv)),
-                   "emmax_session_bytes")
+        _lib.check(self.lib.emmax_session_bytes_ex(self._model, max_batch, max_prompt, max_ctx, int(stage_rows), C.byref(ws), C.byref(kv)),
+                   "emmax_session_bytes_ex")
         self.workspace = torch.empty(ws.value, dtype=torch.uint8, device=self.device)
         self.kv = torch.empty(kv.value, dtype=torch.uint8, device=self.device)
-        _lib.check(self.lib.emmax_session_create(self._model, max_batch, max_prompt, max_ctx, self.workspace.data_ptr(),
-                                                 ws.value, self.kv.data_ptr(), kv.value, C.byref(self._session)),
-                   "emmax_session_create")
-        self.max_batch, self.max_prompt, self.max_ctx = max_batch, max_prompt, max_ctx
+        _lib.check(self.lib.emmax_session_create_ex(self._model, max_batch, max_prompt, max_ctx, int(stage_rows), self.workspace.data_ptr(),
+                                                    ws.value, self.kv.data_ptr(), kv.value, C.byref(self._session)),
+                   "emmax_session_create_ex")
+        self.max_batch, self.max_prompt, self.max_ctx, self.stage_rows = max_batch, max_prompt, max_ctx, int(stage_rows)
+
+    def ensure_stage_rows(self, n: int) -> None:
+        """Slot serving with overlapped admission stages up to `n` requests at a time: re-create the session with that many staging
+        rows if it has fewer (drops any state of the current session -- call before slots_open)."""
+        if n > getattr(self, "stage_rows", 0):
+            self.new_session(self.max_batch, self.max_prompt, self.max_ctx, stage_rows=int(n))
 
     def ensure_decode_batch(self, batch: int) -> None:
         """Decode batches >= 3 read MFMA-fragment-major weight copies that live in a second arena (include/emmax.h:
@@ -123,13 +131,18 @@ class EmmaxEngine:
         _lib.check(self.lib.emmax_model_build_aux(self._model, self.aux_arena.data_ptr(), n, _lib.current_stream()), "emmax_model_build_aux")
         self.aux_build_s = time.perf_counter() - t0
 
+    def max_decode_batch(self) -> int:
+        """Rows of one decode batch this model can run (16 for LLaMA-2-7B shapes, 8 for shapes outside decode_km.hip)."""
+        return int(self.lib.emmax_model_max_decode_batch(self._model))
+
     def weight_bytes(self) -> int:
         return int(self.arena.numel()) + (int(self.aux_arena.numel()) if self.aux_arena is not None else 0)
 
     def ensure_capacity(self, batch: int, prompt: int, max_new: int) -> None:
         need_ctx = self.cfg.n_patches + prompt + max_new + 1
         if batch > self.max_batch or prompt > self.max_prompt or need_ctx > self.max_ctx:
-            self.new_session(max(batch, self.max_batch), max(prompt, self.max_prompt), max(need_ctx, self.max_ctx))
+            self.new_session(max(batch, self.max_batch), max(prompt, self.max_prompt), max(need_ctx, self.max_ctx),
+                             stage_rows=getattr(self, "stage_rows", 0))
 
     def close(self) -> None:
         if getattr(self, "_session", None):

@@ -50,6 +50,9 @@ class _Active:
     t_admit: float
 
 
+MAX_SLOTS = 16   # EMMAX_MAX_DECODE_BATCH (emma-x_amd/csrc/kernels.h): rows of a decode step
+
+
 class SlotScheduler:
     """Greedy slot scheduler.
 
@@ -57,7 +60,7 @@ class SlotScheduler:
              (emmax.engine.EmmaxEngine, or a fake in the CPU tests)
     encode   frames (list) -> patch embeddings, one [n_patches, hidden] bf16 tensor per frame; called once per admission
              round with every frame admitted in that round, so the ViT runs batched
-    n_slots  decode batch (<= 8)
+    n_slots  decode batch (<= 16)
     poll_every   decode steps between two device polls (a poll is one tiny D2H copy + sync; default 4 = ~13 ms at 7B shapes: a retired
                  slot is refilled within 4 steps -- 32 requests / 8 slots: 22.9 actions/s polling every 16 steps, 24.2 every 4)
     encode_ahead frames encoded per `encode` call: the frames being admitted plus the next ones in the queue, so the ViT
@@ -68,8 +71,8 @@ class SlotScheduler:
     def __init__(self, engine, encode: Callable[[List[Any]], List[Any]], n_slots: int = 8, poll_every: int = 4,
                  stop_trigger: Sequence[int] = (), stop_after: int = 0, clock: Callable[[], float] = time.perf_counter,
                  encode_ahead: int = 0, overlap: Optional[bool] = None, stage_batch: Optional[int] = None) -> None:
-        if not 1 <= n_slots <= 8:
-            raise ValueError(f"n_slots {n_slots} outside 1..8")
+        if not 1 <= n_slots <= MAX_SLOTS:
+            raise ValueError(f"n_slots {n_slots} outside 1..{MAX_SLOTS}")
         if poll_every < 1:
             raise ValueError("poll_every must be >= 1")
         self.engine = engine
@@ -96,6 +99,10 @@ class SlotScheduler:
         self.stage_batch = max(1, min(int(stage_batch) if stage_batch else max(1, n_slots // 2), n_slots))
         self._pending = None                         # [staged handle, [(request, t_submit), ...], committed so far] of the staged batch
         self.overlapped_admissions = 0
+        # a staged batch is at most max(stage_batch, free slots) <= n_slots requests: the session needs that many staging rows
+        # (they cost KV pages, so a session only has them when a scheduler asks: engine.ensure_stage_rows re-creates it if needed)
+        if self.overlap and hasattr(engine, "ensure_stage_rows"):
+            engine.ensure_stage_rows(n_slots)
         engine.set_stop(list(stop_trigger), stop_after)
         engine.slots_open(n_slots)
 
@@ -151,10 +158,18 @@ class SlotScheduler:
         free = sum(1 for s in range(self.n_slots) if s not in self.active)
         take = min(len(self.queue), max(self.stage_batch, free))
         batch = [self.queue.popleft() for _ in range(take)]
-        with self.engine.admission():
-            embeds = self._encode_for(batch)
-            staged = self.engine.slots_prefill_staged([list(r.prompt_ids) for r, _ in batch], embeds if embeds[0] is not None else None,
-                                                      [r.max_new_tokens for r, _ in batch])
+        try:
+            with self.engine.admission():
+                embeds = self._encode_for(batch)
+                staged = self.engine.slots_prefill_staged([list(r.prompt_ids) for r, _ in batch], embeds if embeds[0] is not None else None,
+                                                          [r.max_new_tokens for r, _ in batch])
+        except Exception:
+            # nothing was staged: the requests go back to the head of the queue in their order and the error reaches the caller
+            # (they were popped and then neither requeued nor reported)
+            for item in reversed(batch):
+                self._embeds.pop(id(item[0]), None)
+                self.queue.appendleft(item)
+            raise
         self._pending = [staged, batch, 0]
         return True
 

@@ -34,8 +34,9 @@ extern "C" {
 
 /* Bumped whenever emmax_config / emmax_tower_config change layout or an entry point changes signature.
  *   1: rounds 1-2;  2: emmax_config grew `decode_fp8` (round 2, not bumped then);  3: round 4 -- emmax_config_size / emmax_tuning_*
- *   added, the lab-only entry points (persistent layer chain, in-attention split merge) removed. */
-#define EMMAX_ABI_VERSION 3
+ *   added, the lab-only entry points (persistent layer chain, in-attention split merge) removed;  4: round 5 -- emmax_session_*_ex (staging rows
+ *   are asked for, the plain calls give none), decode batches / slot counts up to 16. */
+#define EMMAX_ABI_VERSION 4
 
 typedef enum emmax_status {
     EMMAX_OK = 0,
@@ -98,6 +99,9 @@ void emmax_model_destroy(emmax_model* m);
 int emmax_model_bind_weight(emmax_model* m, const char* hf_key, const void* ptr_dev, int dtype,
                             const int64_t* shape, int ndim);
 int64_t emmax_model_arena_bytes(const emmax_model* m);
+/* rows of one decode batch / slot set this model can run: 16 when every LLM projection is a shape the K-split MFMA kernels take
+ * (K % 256 == 0 and <= 4096, N <= 32768, intermediate size <= 12288: LLaMA-2-7B is), else 8 (round 5; rounds 1-4: 8) */
+int emmax_model_max_decode_batch(const emmax_model* m);
 int emmax_model_finalize(emmax_model* m, void* arena_dev, int64_t arena_bytes, emmax_stream stream);
 /* bf16 models: decode batches >= 3 stream the LLM projections from MFMA-fragment-major copies that a model serving batches 1-2
  * never reads.  They live in a SECOND caller-owned arena, built on demand from the finalized main arena (no bound tensors
@@ -113,6 +117,14 @@ int emmax_session_bytes(const emmax_model* m, int max_batch, int max_prompt, int
 int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_ctx,
                          void* workspace_dev, int64_t workspace_bytes, void* kv_dev, int64_t kv_bytes,
                          emmax_session** out);
+/* ... plus `stage_rows` STAGING rows (0 .. min(max_batch, 16)) for overlapped admissions, emmax_slots_prefill_staged below: each costs per-row
+ * state and its share of the paged KV region.  The plain calls above are stage_rows = 0. */
+int emmax_session_bytes_ex(const emmax_model* m, int max_batch, int max_prompt, int max_ctx, int stage_rows,
+                           int64_t* workspace_bytes, int64_t* kv_bytes);
+int emmax_session_create_ex(emmax_model* m, int max_batch, int max_prompt, int max_ctx, int stage_rows,
+                            void* workspace_dev, int64_t workspace_bytes, void* kv_dev, int64_t kv_bytes,
+                            emmax_session** out);
+int emmax_session_stage_rows(const emmax_session* s);
 void emmax_session_destroy(emmax_session* s);
 
 /* frames_u8_dev: uint8 [B,224,224,3] RGB (normalisation fused into the patch gather);  out: bf16 [B,256,hidden]. */
@@ -168,7 +180,7 @@ int emmax_profile_decode_stage(emmax_session* s, int stage, int reps, float* avg
  * followed by n_after more tokens (the emitted prefix is exactly the prefix of the full greedy generation).  n_trigger = 0
  * clears the rule; at most 16 ids; a mismatch restarts the match at the current token (no overlapping-prefix handling). */
 int emmax_session_set_stop(emmax_session* s, const int32_t* trigger_ids_host, int n_trigger, int n_after, emmax_stream stream);
-/* Turn the first n_slots rows of the session into independent, idle request slots (n_slots <= max_batch, <= 8). */
+/* Turn the first n_slots rows of the session into independent, idle request slots (n_slots <= max_batch, <= 16). */
 int emmax_slots_open(emmax_session* s, int n_slots, emmax_stream stream);
 /* Prefill ONE request into `slot` without disturbing the other slots: prompt ids (device int32[len]), its
  * [n_patches, hidden] bf16 patch embeddings (device; NULL = language-only) and its token budget.  The first generated
@@ -182,8 +194,8 @@ int emmax_slot_prefill(emmax_session* s, int slot, const int32_t* ids_dev, int l
 int emmax_slots_prefill(emmax_session* s, int slot0, int n, const int32_t* ids_dev, int P_max, const int32_t* lens_host,
                         const void* patch_embeds_dev, const int32_t* max_new_host, emmax_stream stream);
 /* Overlapped admission.  emmax_slot_prefill and emmax_slots_prefill run on the stream the slots decode on: while a request is prefilled (16 ms for one
- * 7B row, 70 ms for eight) the other slots stand still.  The staged pair removes that stall: every session holds min(max_batch, 8)
- * STAGING rows beside its decode rows (per-row state, output row, KV pages: emmax_session_bytes accounts for them).
+ * 7B row, 70 ms for eight) the other slots stand still.  The staged pair removes that stall: a session created with
+ * emmax_session_create_ex holds `stage_rows` STAGING rows beside its decode rows (per-row state, output row, KV pages).
  *   emmax_slots_prefill_staged  prefills n requests into the staging rows on `stream`, which must be a stream of its own (not the
  *                               default stream, not the one the decode steps run on): the call touches nothing a decode step reads,
  *                               so decode steps may run beside it.  Arguments as emmax_slots_prefill without slot0.
@@ -222,7 +234,8 @@ int emmax_op_gemm_splitk(const void* A_dev, int lda, const void* W_dev, int ldw,
 /* The launch plan emmax_op_gemm / a session stage would run for this problem, as text (host only, no device work): which tile
  * geometry, row / column parts, split-K slices, and whether the split-K reduce pass also applies the RMSNorm behind the projection
  * (with_norm; one-frame prefill o-proj / down).  ws_bytes = size of the split-K scratch (0: none).  e.g. M = 768, N = 22016, K = 4096,
- * act = 2, 64 MB scratch: "hybrid cols 0..21760: big | cols 21760..22016: splitk ks=8". */
+ * act = 2, 64 MB scratch: "hybrid cols 0..21760: big | cols 21760..22016: splitk ks=8".  has_residual = 2 (with out_f32): the residual and the
+ * result are fp32 rows -- the prefill's fp32 residual stream (round 5). */
 int emmax_gemm_plan(int M, int N, int K, int act, int out_f32, int has_ln, int has_residual, int with_norm, int64_t ws_bytes, char* text_out,
                     int text_len);
 /* LayerNorm folded into the projection that consumes it, as the ViT qkv / fc1 stages run (timm Block: norm1 -> attn.qkv, norm2 ->
@@ -269,8 +282,6 @@ int emmax_op_resize_bicubic_u8(const uint8_t* src_dev, int B, int H, int W, uint
                                const int32_t* bounds_h_dev, const int32_t* kk_h_dev, int ksize_h, const int32_t* bounds_v_dev,
                                const int32_t* kk_v_dev, int ksize_v, emmax_stream stream);
 
-/* Small-batch decode projection on MFMA: y[b,n] = sum_k x[b,k] W[n,k], weights in the MFMA-fragment-major layout that
- * emmax_op_repack_fm produces from a row-major [N,ld] matrix (N % 16 == 0, K % 32 == 0); 1 <= B <= 8. */
 /* fp8 variant: quantise a row-major bf16 [N,ld] matrix to e4m3 fragment-major tiles + fp32 per-row scales (N % 16, K % 64),
  * and the matching small-batch projection (activations bf16, weights de-quantised in registers). */
 int emmax_op_quant_fm8(const void* W_dev, int ld, void* W8_fm_out_dev, float* scales_out_dev, int N, int K, emmax_stream stream);
@@ -287,6 +298,8 @@ int emmax_op_gemm_small_km(const void* x_dev, const void* W_km_dev, void* y_dev,
 int emmax_op_quant_rm8(const void* W_dev, int ld, void* W8_rows_out_dev, float* scales_out_dev, int N, int K, emmax_stream stream);
 int emmax_op_gemv_fp8(const void* x_dev, const void* W8_rows_dev, const float* scales_dev, void* y_dev, int B, int N, int K,
                       emmax_stream stream);
+/* Small-batch decode projection on MFMA: y[b,n] = sum_k x[b,k] W[n,k], weights in the MFMA-fragment-major layout that
+ * emmax_op_repack_fm produces from a row-major [N,ld] matrix (N % 16 == 0, K % 32 == 0); 1 <= B <= 8. */
 int emmax_op_repack_fm(const void* W_dev, int ld, void* W_fm_out_dev, int N, int K, emmax_stream stream);
 int emmax_op_gemm_small(const void* x_dev, const void* W_fm_dev, void* y_dev, int B, int N, int K, emmax_stream stream);
 

@@ -297,6 +297,18 @@ def predict_action_tail(generated_ids: np.ndarray, stats: dict, vocab_size: int 
     return unnormalize_actions(decode_token_ids_to_actions(generated_ids[-dim:], vocab_size, n_bins), stats)
 
 
+def generate_actions_pos_tail(require_unorm, delta_position, proprio_stats: dict):
+    """prismatic/models/vlms/prismatic.py:686-696, the `type == "pos"` tail of `generate_actions`, branch for branch -- INCLUDING its
+    defect: `proprio_norm` is only assigned under `if require_unorm:`, so a textual movement line (require_unorm False, solver.py:57-58)
+    or an unparsable one (require_unorm None, solver.py:43 / the catch-all) ends in the reference's `UnboundLocalError`.  The product
+    (emmax/modeling.py `_postprocess`) returns the Solver's delta unchanged on that branch instead."""
+    if require_unorm:
+        mask = proprio_stats.get("mask", np.ones_like(proprio_stats["Q1"], dtype=bool))
+        hi, lo = np.array(proprio_stats["Q99"]), np.array(proprio_stats["Q1"])
+        proprio_norm = np.where(mask, 0.5 * (np.array(delta_position) + 1) * (hi - lo) + lo, delta_position)
+    return proprio_norm   # noqa: F821 -- unbound when require_unorm is falsy, as in the reference
+
+
 class Solver:
     """Restatement of prismatic/vla/solver.py:8-137 (`tokenizer` = object with __call__(text, add_special_tokens) ->
     .input_ids; never raises: parse failures yield zeros / -100s exactly as the reference)."""

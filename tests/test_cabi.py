@@ -131,8 +131,14 @@ def test_config_validation_and_sizing(lib):
     so.emmax_model_destroy(h8)
     ws, kv = C.c_int64(), C.c_int64()
     assert so.emmax_session_bytes(h, 8, 512, 1281, C.byref(ws), C.byref(kv)) == 0
-    # paged KV: 32 layers x 2 x (8 decode rows + 8 staging rows of the overlapped admission) x 21 pages x 32 heads x 64 x 128 bf16
-    assert kv.value == 32 * 2 * 16 * 21 * 32 * 64 * 128 * 2
+    # paged KV: 32 layers x 2 x 8 decode rows x 21 pages x 32 heads x 64 x 128 bf16 -- a plain session holds NO staging rows (ADVICE r04:
+    # round 4 gave every session min(max_batch, 8) of them and doubled this region); slot serving asks for them through the _ex calls
+    assert kv.value == 32 * 2 * 8 * 21 * 32 * 64 * 128 * 2
+    ws2, kv2 = C.c_int64(), C.c_int64()
+    assert so.emmax_session_bytes_ex(h, 8, 512, 1281, 4, C.byref(ws2), C.byref(kv2)) == 0
+    assert kv2.value == 32 * 2 * (8 + 4) * 21 * 32 * 64 * 128 * 2 and ws2.value > ws.value
+    assert so.emmax_session_bytes_ex(h, 8, 512, 1281, 9, C.byref(ws2), C.byref(kv2)) != 0 and b"stage_rows" in so.emmax_last_error()
+    assert so.emmax_session_bytes_ex(h, 16, 512, 1281, 16, C.byref(ws2), C.byref(kv2)) == 0     # decode batches up to 16 (round 5)
     assert so.emmax_session_bytes(h, 8, 512, 700, C.byref(ws), C.byref(kv)) != 0
     assert b"max_ctx" in so.emmax_last_error()
     so.emmax_model_destroy(h)
@@ -164,6 +170,10 @@ def test_gemm_launch_plans_of_the_hot_path(lib):
     assert L.gemm_plan(768, 4096, 4096, residual=True, norm=True) == "splitk ks=2 +norm"
     assert L.gemm_plan(768, 4096, 11008, residual=True, norm=True) == "splitk ks=2 +norm"
     assert L.gemm_plan(768, 4096, 11008, residual=True) == "splitk ks=2"
+    # round 5: the prefill's fp32 residual stream (fp32 residual in, fp32 C out) takes the same plans, the norm still in the reduce pass
+    assert L.gemm_plan(768, 4096, 4096, out_f32=True, residual=2, norm=True) == "splitk ks=2 +norm"
+    assert L.gemm_plan(768, 4096, 11008, out_f32=True, residual=2, norm=True) == "splitk ks=2 +norm"
+    assert L.gemm_plan(6144, 4096, 11008, out_f32=True, residual=2, norm=True) == "big rows 0..4096 + small rows 4096..6144"
     assert L.gemm_plan(768, 2048, 4096, residual=True, norm=True) == "splitk ks=5"                             # the fused norm is for 4096-wide rows
     assert L.gemm_plan(6144, 22016, 4096, act=2) == "hybrid cols 0..21760: big | cols 21760..22016: splitk ks=5"
     assert L.gemm_plan(6144, 4096, 4096, residual=True, norm=True) == "big rows 0..4096 + small rows 4096..6144"

@@ -286,11 +286,16 @@ def test_how_often_an_id_could_flip_over_a_512_token_generation(device, full, de
     reproducible where margin > 2 x error; the fraction of steps below that is how often a greedy id COULD differ from the fp32
     reference on weights with THESE margins (random weights: the thinnest margins there are -- a trained checkpoint's action
     tokens sit far above).  Asserted: the argmax is right on every step above the line; the numbers go to
-    gpurun_out/r04_margin_statistic.json and are printed."""
+    gpurun_out/r05_margin_statistic.json and are printed.
+
+    Round 5: run twice -- with the decode step's residual stream in fp32 (tuning switch resid32 = 1, the
+    default: the hidden rows are rounded to bf16 once per consumer instead of after each of the 64 additions of a token) and with
+    the bf16 rows of rounds 1-4 (resid32 = 0) -- same prefill, same teacher-forced ids, same oracle trace."""
     import json
     import os
 
     from conftest import ROOT
+    from emmax import _lib
 
     cfg, model, _, _ = full
     frames, row, _, _ = oracle_trace
@@ -299,37 +304,47 @@ def test_how_often_an_id_could_flip_over_a_512_token_generation(device, full, de
     model.engine.new_session(1, 512, 256 + 512 + T + 1)
     gen, trace = _dev_trace(cfg, ref, ref, frames, row, T, device)
     eng = model.engine
-    model._prefill([list(row)], None, torch.from_numpy(frames).to(device), max_new=T + 1)
-    errs, margins, could_flip, flipped, wrong_above = [], [], 0, 0, 0
-    for t in range(T):
-        got = eng.last_logits().float().cpu()[0]
-        r = trace[t]
-        scale = r.abs().max().item()
-        err = (got - r).abs().max().item()
-        top2 = torch.topk(r, 2).values
-        margin = (top2[0] - top2[1]).item()
-        errs.append(err / scale)
-        margins.append(margin / scale)
-        same = int(got.argmax()) == gen[t]
-        if margin > 2 * err:
-            wrong_above += int(not same)
-        else:
-            could_flip += 1
-            flipped += int(not same)
-        eng.set_current_tokens([gen[t]])
-        eng.decode_step()
-    e, m = np.array(errs), np.array(margins)
-    out = {"steps": T, "contexts": [768, 768 + T - 1], "rel_err_median": float(np.median(e)), "rel_err_p95": float(np.percentile(e, 95)),
-           "rel_err_max": float(e.max()), "margin_median": float(np.median(m)), "margin_p05": float(np.percentile(m, 5)),
-           "steps_margin_below_2x_err": could_flip, "fraction_could_flip": could_flip / T, "steps_actually_flipped": flipped,
-           "wrong_above_the_line": wrong_above,
-           "what": "Emma-X-7B shape, 32 layers, RANDOM weights (seed 33), bf16 HIP path B=1 teacher-forced against the fp32 restatement; "
-                   "errors and margins relative to max|logit| of the step"}
+
+    def run_mode():
+        model._prefill([list(row)], None, torch.from_numpy(frames).to(device), max_new=T + 1)
+        errs, margins, could_flip, flipped, wrong_above = [], [], 0, 0, 0
+        for t in range(T):
+            got = eng.last_logits().float().cpu()[0]
+            r = trace[t]
+            scale = r.abs().max().item()
+            err = (got - r).abs().max().item()
+            top2 = torch.topk(r, 2).values
+            margin = (top2[0] - top2[1]).item()
+            errs.append(err / scale)
+            margins.append(margin / scale)
+            same = int(got.argmax()) == gen[t]
+            if margin > 2 * err:
+                wrong_above += int(not same)
+            else:
+                could_flip += 1
+                flipped += int(not same)
+            eng.set_current_tokens([gen[t]])
+            eng.decode_step()
+        e, m = np.array(errs), np.array(margins)
+        return {"steps": T, "contexts": [768, 768 + T - 1], "rel_err_median": float(np.median(e)), "rel_err_p95": float(np.percentile(e, 95)),
+                "rel_err_max": float(e.max()), "margin_median": float(np.median(m)), "margin_p05": float(np.percentile(m, 5)),
+                "steps_margin_below_2x_err": could_flip, "fraction_could_flip": could_flip / T, "steps_actually_flipped": flipped,
+                "wrong_above_the_line": wrong_above}
+
+    out = {"what": "Emma-X-7B shape, 32 layers, RANDOM weights (seed 33), bf16 HIP path B=1 teacher-forced against the fp32 restatement; "
+                   "errors and margins relative to max|logit| of the step; resid32 = the decode step's residual stream kept in fp32"}
+    for mode in (1, 0):
+        with _lib.tuning(resid32=mode):
+            out[f"resid32_{mode}"] = run_mode()
     print("\n512-step margin statistic:", json.dumps(out))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r04_margin_statistic.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r05_margin_statistic.json"), "w") as f:
         json.dump(out, f, indent=1)
-    assert wrong_above == 0
-    assert e.max() < TOL
-    assert flipped <= could_flip
+    for mode in (1, 0):
+        o = out[f"resid32_{mode}"]
+        assert o["wrong_above_the_line"] == 0, o
+        assert o["rel_err_max"] < TOL, o
+        assert o["steps_actually_flipped"] <= o["steps_margin_below_2x_err"]
+    # the fp32 stream must not be further from the fp32 reference than the bf16 rows it replaces
+    assert out["resid32_1"]["rel_err_median"] <= out["resid32_0"]["rel_err_median"] * 1.05, out
     model.engine.new_session(8, 512, 256 + 512 + 32)

@@ -457,11 +457,15 @@ def test_gemm_small_mfma(device, B, N, K):
     assert_elementwise(y, ref)
 
 
-@pytest.mark.parametrize("B", [3, 5, 8])
-@pytest.mark.parametrize("N,K", [(256, 256), (4096, 4096), (12288, 4096), (32064, 4096), (1008, 1024), (48, 2048)])
+@pytest.mark.parametrize("B", [3, 5, 8, 9, 13, 16])
+@pytest.mark.parametrize("N,K", [(256, 256), (4096, 4096), (12288, 4096), (32064, 4096), (1008, 1024), (48, 2048), (4096, 11008), (64, 8192), (64, 4352),
+                                 (48, 11264)])
 def test_gemm_small_km(device, B, N, K):
-    """Batch 3-8 decode projection on the K-split MFMA kernel (decode_km.hip): activations as register fragments, two tiles in
-    flight per wave, partial tiles of the eight K slices meeting in LDS.  N covers 1 .. 8 tiles per block and ragged shares."""
+    """Batch 3-16 decode projection on the K-split MFMA kernel (decode_km.hip): activations as register fragments, two tiles in
+    flight per wave, partial tiles of the eight K slices meeting in LDS.  N covers 1 .. 8 tiles per block and ragged shares.
+    Round 5: batches 9-16 (the MFMA's N side is 16 wide: sixteen staged rows per wave, window and partial tiles sharing one LDS
+    region) and, for K > 4096, the phased kernel of the down projection (two phases of 22 fragments at B <= 8, four of 12 above;
+    K = 11264 = its limit at B <= 8, K = 4352: a slice shorter than one phase at B <= 8)."""
     L, lib = _lib()
     g = torch.Generator().manual_seed(B * 11 + N + K)
     x = bf(torch.randn(B, K, generator=g))
@@ -479,10 +483,10 @@ def test_gemm_small_km(device, B, N, K):
 
 def test_gemm_small_km_refuses_shapes_outside_it(device):
     L, lib = _lib()
-    x = torch.zeros(8, 11008, dtype=torch.bfloat16, device=device)
-    W = torch.zeros(64 * 11008, dtype=torch.bfloat16, device=device)
-    y = torch.zeros(8, 64, dtype=torch.bfloat16, device=device)
-    for B, N, K in [(4, 64, 11008), (4, 64, 320), (9, 64, 256), (4, 40, 256)]:
+    x = torch.zeros(17, 12320, dtype=torch.bfloat16, device=device)
+    W = torch.zeros(64 * 12320, dtype=torch.bfloat16, device=device)
+    y = torch.zeros(17, 64, dtype=torch.bfloat16, device=device)
+    for B, N, K in [(4, 64, 11296), (4, 64, 320), (17, 64, 256), (4, 40, 256), (16, 64, 12320)]:
         assert lib.emmax_op_gemm_small_km(x.data_ptr(), W.data_ptr(), y.data_ptr(), B, N, K, stream()) != 0, (B, N, K)
     torch.cuda.synchronize()
 
