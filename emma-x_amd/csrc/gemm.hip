@@ -595,6 +595,196 @@ __global__ __launch_bounds__(G::NW * 64, 2) void emmax_gemm_bf16_kernel(GemmPara
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 128 x 256 x 32 tile, TWO independent 4-wave blocks per CU (round 5; VERDICT r04 next #1a).
+// The 256 x 256 tile keeps both waves of a SIMD in ONE block: they meet the same barriers, issue their DMA requests at the same time and
+// run their epilogues together -- for ~9 of the ~32 us of a K = 1024 tile no MFMA of the CU runs.  Here a block is four waves side by
+// side (wave tile 128 x 64: the same 128 accumulator registers and the same 0.375 fragment reads per MFMA as the big tile), one per
+// SIMD, and TWO blocks share the CU: whatever stalls one block -- a step barrier, DMA issue, LDS latency, the whole epilogue and the
+// tile-top wait -- leaves the SIMDs to the other block's MFMAs, and the two blocks' tile boundaries drift apart by themselves.
+// K steps are 32 deep (64-byte rows) so that THREE stages of (8 + 16) KiB fit twice into the CU's 160 KiB: the request of K step t + 2
+// goes out at the top of step t (into the stage step t - 1 read), ONE bare s_barrier per step, waits counted (vmcnt(6): the six
+// requests of step t + 1 stay in flight).  Price: 0.0117 instead of 0.0078 L2 -> LDS bytes per FLOP.
+// LDS image of a stage: A rows 0..127 then W rows 0..255, 64 bytes each = 4 chunks of 16 bytes; a wave-level DMA writes 1 KiB = 16 whole
+// rows in lane order, the swizzle is applied to the SOURCE address: physical chunk c of row r holds logical chunk c ^ F((r >> 2) & 3),
+// F = (0, 2, 3, 1).  A ds_read_b128 fragment read (lane (g, li): row li of a 16-row tile, logical chunk g) is serviced in four groups
+// of 16 lanes {g: li 0-3, 12-15; g ^ 1: li 4-11}: per row residue mod 4 the four lanes see chunks F(0), F(3), 1 ^ F(1), 1 ^ F(2)
+// (resp. F(1), F(2), 1 ^ F(0), 1 ^ F(3)) -- all different with this F: sixteen distinct 16-byte slots of the 256-byte bank row.
+// ---------------------------------------------------------------------------------------------------------------------
+using GeomK32 = Geom<1, 4, 8, 4>;   // (for the epilogues: 4 waves side by side, MT x NT = 8 x 4 MFMA tiles per wave)
+constexpr int K32_BK = 32;
+constexpr int K32_OPA = 128 * 64, K32_OPB = 256 * 64, K32_STAGE = K32_OPA + K32_OPB, K32_NS = 3, K32_SMEM = K32_NS * K32_STAGE;
+static_assert(K32_STAGE + GeomK32::NW * GeomK32::WIN <= K32_SMEM, "the epilogue windows live behind stage 0");
+
+__device__ __forceinline__ void glds16_group2(unsigned int lds_base, unsigned int v0, unsigned int v1, unsigned long long sbase) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3 offset:0\n\t"
+                 "global_load_lds_dwordx4 %2, %3 offset:1024"
+                 ::"s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(v0), "v"(v1), "s"(sbase)
+                 : "m0", "memory");
+}
+__device__ __forceinline__ int k32_swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
+
+template <int ACT, bool OUT_F32, bool LN>
+__global__ __launch_bounds__(256, 2) void emmax_gemm_k32_kernel(GemmParams p) {
+    using G = GeomK32;
+    constexpr int BM = G::BM, BN = G::BN, MT = G::MT, NT = G::NT;
+    static_assert(BM == 128 && BN == 256, "stage image");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = 0, wn = wave;
+    const int g = lane >> 4, li = lane & 15;
+
+    // ---- persistent tile walk: as emmax_gemm_bf16_kernel (banded, XCD-aware; split-K units slice-major) ----
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int ntile = tiles_m * tiles_n;
+    const int ks = p.ksplit > 1 ? p.ksplit : 1;
+    const int nwg = ntile * ks;
+    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+    const int rq = nwg >> 3, rr = nwg & 7;
+    const int run0 = xcd < rr ? xcd * (rq + 1) : rr * (rq + 1) + (xcd - rr) * rq, run_n = rq + (xcd < rr ? 1 : 0);
+    const int nk_all = p.K / K32_BK;
+    const int nk_slice = (nk_all + ks - 1) / ks;
+    int kidx = 0, kbeg = 0, nk = nk_all;
+    auto tile_origin = [&](int it, int& m0, int& n0) {
+        const int unit = run0 + it;
+        kidx = unit / ntile;
+        kbeg = kidx * nk_slice;
+        nk = min(nk_slice, nk_all - kbeg);
+        const int bid = unit - kidx * ntile;
+        const int band = bid / (BAND * tiles_m), in_band = bid - band * (BAND * tiles_m);
+        const int bw = min(BAND, tiles_n - band * BAND);
+        const int tm = in_band / bw, tn = band * BAND + (in_band - tm * bw);
+        m0 = tm * BM;
+        n0 = tn * BN;
+    };
+
+    // ---- DMA sources: wave w fills slabs (16 rows of 64 bytes) 2 w, 2 w + 1 of the A image and 4 w .. 4 w + 3 of the W image ----
+    unsigned int offA_l[2], offB_l[4];
+    unsigned long long baseA = 0, baseB = 0;
+    const unsigned int lds0 = __builtin_amdgcn_readfirstlane((unsigned int)(uintptr_t)(__attribute__((address_space(3))) void*)smem);
+    auto set_sources = [&](int m0, int n0) {
+        baseA = (unsigned long long)(uintptr_t)((const bf16_t*)p.A + (size_t)m0 * p.lda) - DMA_BIAS;
+        baseB = (unsigned long long)(uintptr_t)((const bf16_t*)p.W + (size_t)n0 * p.ldw) - DMA_BIAS;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (wave * 2 + j) * 16 + (lane >> 2);
+            const int gm = min(m0 + row, p.M - 1) - m0;   // edge tiles re-read the last row (never stored)
+            offA_l[j] = (unsigned int)gm * (unsigned int)(p.lda * 2) + ((lane & 3) ^ k32_swz(row)) * 16 + (DMA_BIAS - j * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (wave * 4 + j) * 16 + (lane >> 2);
+            const int gn = min(n0 + row, p.N - 1) - n0;
+            offB_l[j] = (unsigned int)gn * (unsigned int)(p.ldw * 2) + ((lane & 3) ^ k32_swz(row)) * 16 + (DMA_BIAS - j * 1024);
+        }
+    };
+    auto issue = [&](int kt, int slot) {   // K step kt of the current tile into stage `slot`: this wave's six slabs
+        const unsigned long long ko = (unsigned long long)(kbeg + kt) * (K32_BK * 2);
+        glds16_group2(lds0 + slot * K32_STAGE + wave * 2048, offA_l[0], offA_l[1], baseA + ko);
+        glds16_group4(lds0 + slot * K32_STAGE + K32_OPA + wave * 4096, offB_l[0], offB_l[1], offB_l[2], offB_l[3], baseB + ko);
+    };
+
+    // ---- fragment reads: lane (g, li) = row li of a 16-row tile, logical chunk g ----
+    const int c0 = (g ^ k32_swz(li)) << 4;
+    const int offA = li * 64 + c0, offB = K32_OPA + (wn * (NT * 16) + li) * 64 + c0;
+    auto ldA = [&](const unsigned char* st, int i) { return *(const bf16x8_t*)(st + offA + i * 1024); };
+    auto ldB = [&](const unsigned char* st, int j) { return *(const bf16x8_t*)(st + offB + j * 1024); };
+
+    const bool staged_ok = (p.ldc & 7) == 0 && (((size_t)p.C) & 15) == 0 &&
+                           (ACT == 2 ? (p.N & 15) == 0 : (min(p.N, p.N_store) & 7) == 0) &&
+                           (!p.residual || ((p.ldr & 3) == 0 && (((size_t)p.residual) & 7) == 0));
+    int it = blockIdx.x >> 3;
+    if (it >= run_n) return;
+    int m0, n0;
+    tile_origin(it, m0, n0);
+    set_sources(m0, n0);
+    issue(0, 0);
+    auto bar = [] { asm volatile("s_barrier" ::: "memory"); };
+    while (true) {
+        f32x4_t acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        // K step 0 has landed, the previous tile's stores have retired (the builtin: see emmax_gemm_bf16_kernel), and behind the barrier
+        // every wave has left its epilogue window: stages 1 and 2 may be written again
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        if (nk > 1) issue(1, 1);
+        int st_i = 0;   // stage of the current K step
+        for (int kt = 0; kt < nk; ++kt) {
+            const int st_2 = st_i >= 1 ? st_i - 1 : 2;   // (st_i + 2) % 3: the stage step kt - 1 read
+            if (kt > 0) {
+                // this wave's requests of step kt have landed (those of step kt + 1 stay in flight); behind the barrier everybody's have,
+                // and everybody is done reading step kt - 1
+                if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bar();
+            }
+            if (kt + 2 < nk) issue(kt + 2, st_2);
+            int offs = st_i * K32_STAGE;
+            asm volatile("" : "+s"(offs));
+            const unsigned char* st = smem + offs;
+            bf16x8_t fb[NT], fa[4];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = ldB(st, j);
+            fa[0] = ldA(st, 0);
+            fa[1] = ldA(st, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, NT + 2, 0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if (i + 2 < MT) fa[(i + 2) & 3] = ldA(st, i + 2);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i & 3], acc[i][j], 0, 0, 0);
+                if (i + 2 < MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+            }
+            st_i = st_i == 2 ? 0 : st_i + 1;
+        }
+        // every wave is done reading the last stage (it may be stage 0, which the next tile's first request overwrites, or lie under an
+        // epilogue window)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bar();
+        const int cm0 = m0, cn0 = n0;
+        const size_t c_off = ks > 1 ? (size_t)kidx * p.M * p.ldc : 0;
+        it += per_xcd;
+        const bool more = it < run_n;
+        if (more) {   // the next tile's first K step is requested BEFORE this tile's epilogue
+            tile_origin(it, m0, n0);
+            set_sources(m0, n0);
+            issue(0, 0);
+        }
+        if (!OUT_F32 && staged_ok) gemm_epilogue_staged<G, ACT, LN>(p, acc, cm0, cn0, wm, wn, g, li, lane, smem + K32_STAGE + wave * G::WIN);
+        else gemm_epilogue<G, ACT, OUT_F32>(p, acc, cm0, cn0, wm, wn, g, li, c_off);
+        if (!more) break;
+    }
+}
+
+template <int ACT, bool OUT_F32, bool LN = false>
+int launch_k32_t(const GemmParams& p, hipStream_t stream) {
+    auto kern = emmax_gemm_k32_kernel<ACT, OUT_F32, LN>;
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, K32_SMEM) != hipSuccess) return -4;
+        attr_done = true;
+    }
+    const int tiles = cdiv(p.M, GeomK32::BM) * cdiv(p.N, GeomK32::BN) * (p.ksplit > 1 ? p.ksplit : 1);
+    const int resident = 512;   // two blocks per CU
+    const int grid = tiles < resident ? (tiles + 7) / 8 * 8 : resident;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), K32_SMEM, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+int launch_k32(const GemmParams& p, hipStream_t stream) {
+    if (p.K % K32_BK) return -1;
+    if (p.act == 2) return p.out_f32 ? -1 : launch_k32_t<2, false>(p, stream);
+    if (p.ln_stats && !p.out_f32) return p.act == 1 ? launch_k32_t<1, false, true>(p, stream) : launch_k32_t<0, false, true>(p, stream);
+    if (p.act == 1) return p.out_f32 ? launch_k32_t<1, true>(p, stream) : launch_k32_t<1, false>(p, stream);
+    return p.out_f32 ? launch_k32_t<0, true>(p, stream) : launch_k32_t<0, false>(p, stream);
+}
+
 // split-K second pass: C[m, n..n+8) = epi(sum over slices of ws[s][m][..)); one thread per 8 OUTPUT columns, whole rows in order.
 // ACT = 2 (SwiGLU): the partial tiles hold the interleaved (gate, up) 16-column groups of the weight order; output column o of
 // group o / 16 pairs partial columns (o / 16) * 32 + o % 16 and + 16.  Eight consecutive output columns never straddle a group.
@@ -739,7 +929,7 @@ __global__ __launch_bounds__(256) void emmax_splitk_reduce_norm_kernel(GemmParam
             *(f32x4_t*)cp = (f32x4_t){a8[i][0], a8[i][1], a8[i][2], a8[i][3]};
             *(f32x4_t*)(cp + 4) = (f32x4_t){a8[i][4], a8[i][5], a8[i][6], a8[i][7]};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ss += a8[i][e] * a8[i][e];
+            for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(a8[i][e], a8[i][e], ss);   // spelled out: emmax_rmsnorm_f32_kernel must round identically
         } else {
             v[i] = (u32x4_t){pack_bf16x2(a8[i][0], a8[i][1]), pack_bf16x2(a8[i][2], a8[i][3]), pack_bf16x2(a8[i][4], a8[i][5]), pack_bf16x2(a8[i][6], a8[i][7])};
             *(u32x4_t*)((bf16_t*)p.C + (size_t)row * p.ldc + col) = v[i];
@@ -784,9 +974,11 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
         int deep = emmax_tune().gemm_deep;
         constexpr bool big = std::is_same<G, GeomBig>::value;
         if (deep < 0) deep = big ? 3 : 1;
-        if (deep == 3 && (!big || OUT_F32)) deep = big ? 0 : 1;
+        // (round 5: fp32 results take the staggered loop too -- the direct epilogue needs no LDS window; they had been left on the
+        // two-stage loop, which cost the fp32 residual stream of an eight-frame prefill 4 %)
+        if (deep == 3 && !big) deep = 1;
         if (deep == 1) return launch_t<G, ACT, OUT_F32, LN, 1>(p, stream);
-        if constexpr (big && !OUT_F32) {
+        if constexpr (big) {
             if (deep == 3) return launch_t<G, ACT, OUT_F32, LN, 3>(p, stream);
         }
     }
@@ -831,6 +1023,7 @@ int launch_gemm_geom(const GemmParams& p, int big, hipStream_t stream) {
     if ((p.lda % 8) || (p.ldw % 8)) return -1;
     if (p.ln_stats && (!p.ln_s || !p.ln_c || p.bias || p.scale || p.residual || p.act == 2 || p.ksplit > 1)) return -1;
     if (p.res_f32 && (!p.out_f32 || !p.residual || p.act == 2)) return -1;   // the fp32 residual stream yields an fp32 result
+    if (big == 2) return launch_k32(p, stream);   // 128 x 256 x 32, two blocks per CU
     return big ? launch_geom<GeomBig>(p, stream) : launch_geom<GeomSmall>(p, stream);
 }
 
@@ -984,7 +1177,7 @@ struct GemmPlan { enum Kind { GEOM, SPLITK, HYBRID, COLS, ROWS } kind; int big, 
 static GemmPlan plan_gemm(const GemmParams& p) {
     GemmPlan pl = {GemmPlan::ROWS, 0, 0, 0, 0};
     const int force = emmax_tune().gemm_big;   // 0 / 1: one geometry, no split
-    if (force >= 0) { pl.kind = GemmPlan::GEOM; pl.big = force != 0; return pl; }
+    if (force >= 0) { pl.kind = GemmPlan::GEOM; pl.big = force > 2 ? 1 : force; return pl; }   // 0 small, 1 big, 2 = 128 x 256 x 32
     const bool no_splitk = emmax_tune().gemm_splitk == 0;
     if (const int ks = no_splitk ? 0 : splitk_plan(p)) { pl.kind = GemmPlan::SPLITK; pl.ks = ks; return pl; }
     long m1 = 0;
@@ -1032,7 +1225,7 @@ int gemm_plan_describe(const GemmParams& p, char* buf, int len) {
     };
     char r[96];
     switch (pl.kind) {
-        case GemmPlan::GEOM: snprintf(buf, len, "forced %s", pl.big ? "big" : "small"); break;
+        case GemmPlan::GEOM: snprintf(buf, len, "forced %s", pl.big == 2 ? "k32" : pl.big ? "big" : "small"); break;
         case GemmPlan::SPLITK: snprintf(buf, len, "splitk ks=%d%s", pl.ks, gemm_fuses_norm(p) ? " +norm" : ""); break;
         case GemmPlan::HYBRID: rows(pl.m1, r, sizeof r); snprintf(buf, len, "hybrid cols 0..%d: %s | cols %d..%d: splitk ks=%d", pl.n1, r, pl.n1, p.N, pl.ks); break;
         case GemmPlan::COLS: rows(pl.m1, r, sizeof r); snprintf(buf, len, "cols 0..%d: %s | cols %d..%d: small", pl.n1, r, pl.n1, p.N); break;

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void emmax_rmsnorm_f32_kernel(const float* __r
         const int c = lane + 64 * i;
         v[i] = c < nchunk ? ld_f32x8(xr + c * 8) : f32x8_t{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ss += f32x8_at(v[i], e) * f32x8_at(v[i], e);
+        for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(f32x8_at(v[i], e), f32x8_at(v[i], e), ss);   // spelled out: the split-K reduce pass with the norm (gemm.hip) must round identically
     }
     ss = wave_sum(ss);
     const float rstd = rsqrtf(ss / (float)D + eps);

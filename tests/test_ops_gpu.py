@@ -105,11 +105,13 @@ def test_gemm_swiglu(device):
     assert_elementwise(Cd, ref)
 
 
+@pytest.mark.parametrize("geom", [-1, 2], ids=["planned", "k32"])
 @pytest.mark.parametrize("variant", ["plain", "gelu", "scale_res", "f32", "swiglu"])
-def test_gemm_big_tile(device, variant):
+def test_gemm_big_tile(device, tune, variant, geom):
     """>= 512 tiles of 256x256 route to the 256x256x64 geometry of the GEMM kernel (gemm.hip): ragged M (4100 = 16 tiles + 4
     rows), N = 65 * 128 (the last tile column is half empty), every epilogue; reference = fp32 matmul on the same device."""
     L, lib = _lib()
+    tune(gemm_big=geom)   # 2: the 128 x 256 x 32 tile of round 5 (K = 192 = six 32-deep steps: the three-stage ring wraps twice)
     M, N, K = 4100, 8320, 192
     g = torch.Generator().manual_seed(11)
     A = bf(torch.randn(M, K, generator=g)).to(device)
@@ -280,13 +282,15 @@ def test_gemm_hybrid_column_remainder_plan(device, act):
     assert relerr(outs[0][:, n1:], outs[1][:, n1:].float()) < 4e-3
 
 
+@pytest.mark.parametrize("geom", [-1, 2], ids=["planned", "k32"])
 @pytest.mark.parametrize("M,N,K,act", [(261 * 3, 3072, 1024, 0), (256 * 5 + 17, 4352, 1152, 1), (40, 384, 128, 0), (66816 // 8, 4096, 1024, 1)])
-def test_gemm_with_layernorm_folded_in(device, M, N, K, act):
+def test_gemm_with_layernorm_folded_in(device, tune, M, N, K, act, geom):
     """timm Block: norm1 -> attn.qkv and norm2 -> mlp.fc1 as ONE GEMM over the raw rows (W' = bf16(W .* gamma), row statistics from a
     stats-only pass, y = rstd (acc - mean * colsum(W')) + (W beta + bias) in the epilogue) against LayerNorm + linear (+ exact-erf
     GELU) in fp32.  Rows carry a large common offset and a few massive channels (what ViT token streams look like): the mean term
     must cancel exactly, not approximately.  Every launch plan: big tiles, small tiles, row split, column split (N = 4352)."""
     L_, lib = _lib()
+    tune(gemm_big=geom)
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g) * 0.7 + 3.0 * torch.randn(M, 1, generator=g)
     x[:, 5] += 40.0
@@ -341,6 +345,17 @@ def test_gemm_main_loop_variants_are_bit_identical(device, tune, M, N, K, act):
                 assert torch.isfinite(out.float()).all()
             else:
                 assert torch.equal(out.view(torch.int16), outs[0].view(torch.int16)), (deep, rep)
+    # round 5: the 128 x 256 x 32 tile (two blocks per CU, three 32-deep stages, one counted-wait barrier per step; tuning switch
+    # gemm_big = 2) accumulates a tile's K in the same order too -- against the 256 x 256 tile forced the same way (no split-K on either)
+    tune(gemm_deep=-1, gemm_big=1)
+    ref = torch.full((M, No), float("nan"), dtype=torch.bfloat16, device=device)
+    L_.check(lib.emmax_op_gemm(A.data_ptr(), K, W.data_ptr(), K, ref.data_ptr(), No, M, N, K, L_.ptr(bias), act, None, None, 0, 0, stream()), "gemm")
+    tune(gemm_big=2)
+    for rep in range(6):
+        out = torch.full((M, No), float("nan"), dtype=torch.bfloat16, device=device)
+        L_.check(lib.emmax_op_gemm(A.data_ptr(), K, W.data_ptr(), K, out.data_ptr(), No, M, N, K, L_.ptr(bias), act, None, None, 0, 0, stream()), "gemm k32")
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), ("k32", rep, (out.float() - ref.float()).abs().max().item())
 
 
 def test_gemm_rejects_bad_shapes(device):

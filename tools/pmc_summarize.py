@@ -11,8 +11,10 @@ import sys
 
 STAGE_OF = [  # (substring of the kernel name, stage)
     # round 3: the K-split kernel of decode_ks.hip <B, MODE, NORM, XATTN, CPL> serves batch 1-2 on bf16 weights
-    ("emmax_decode_ks_kernel<1, 0,", "qkv_gemv"), ("emmax_decode_ks_kernel<1, 1, false, true,", "oproj_gemv"),
-    ("emmax_decode_ks_kernel<1, 2,", "gateup_gemv"), ("emmax_decode_ks_kernel<1, 1, false, false,", "down_gemv"),
+    # (round 5: <B, MODE, NORM, XS, CPL, R32> with XS = 0 global rows / 1 attention split partials / 2 embedding rows)
+    ("emmax_decode_ks_kernel<1, 0,", "qkv_gemv"), ("emmax_decode_ks_kernel<1, 1, false, 1,", "oproj_gemv"),
+    ("emmax_decode_ks_kernel<1, 2,", "gateup_gemv"), ("emmax_decode_ks_kernel<1, 1, false, 0,", "down_gemv"),
+    ("emmax_decode_ks_kernel<1, 1, false, true,", "oproj_gemv"), ("emmax_decode_ks_kernel<1, 1, false, false,", "down_gemv"),   # rounds 3-4
     ("emmax_decode_ks_kernel<1, 3,", "lmhead_argmax"),
     ("emmax_decode_gemv_kernel<1, 0,", "qkv_gemv"), ("emmax_decode_attn_kernel", "paged_attn"),
     ("emmax_decode_gemv_kernel<1, 1, false, true,", "oproj_gemv"), ("emmax_decode_gemv_kernel<1, 2,", "gateup_gemv"),
