@@ -83,7 +83,7 @@ int launch_assemble_tokens(const void* pe, const void* pos, const void* cls, con
                            int n_patches, int n_prefix, int has_cls, int D, int ld, hipStream_t stream);
 int launch_copy_rows(const void* in, int ld_in, void* out, int B, int rows_in, int r_off, int rows_out, int D, int ld_out,
                      int col_off, hipStream_t stream);
-#define EMMAX_MAX_DECODE_BATCH 16   // rows of a decode step: the 16-wide N side of v_mfma_f32_16x16x32_bf16 (decode_km.hip); rounds 1-4: 8
+#define EMMAX_MAX_DECODE_BATCH 32   // rows of a decode step: two 16-wide MFMA batch tiles (decode_kmp.hip; one: decode_km.hip, 16 rows); rounds 1-4: 8
 #define EMMAX_MAX_STOP_IDS 16
 struct PrefillState {
     int B;
@@ -250,6 +250,9 @@ int launch_repack_km(const void* src, int ld, void* dst, int N, int K, int perm,
 int launch_decode_km(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
 bool decode_km_enabled();
 int decode_km_init();   // raise the dynamic-LDS limit of every instantiation (call once, outside graph capture)
+// decode_kmp.hip: batch 17-32 (two batch tiles per weight tile, the K slice in phases), bf16 weights, same copies; launch_decode_km routes there
+int launch_decode_kmp(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
+int decode_kmp_init();
 
 // ---- decode_mfma.hip: small-batch (B >= 3) projections on MFMA over the fragment-major weight copy ----
 int launch_repack_fm(const void* src, int ld, void* dst, int N, int K, hipStream_t stream);

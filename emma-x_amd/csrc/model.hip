@@ -586,7 +586,10 @@ static int model_max_decode_batch(const emmax_model* m) {
     const bool n_ok = m->qkv_dim % 16 == 0 && m->qkv_dim <= 32768 && 2 * m->inter_p <= 32768 && m->vocab_p <= 32768 && m->H % 16 == 0 && c.head_dim % 16 == 0;
     const int kd = m->fp8 ? 64 : 32;
     const bool d_ok = m->inter_p % kd == 0 && m->inter_p / kd >= 8 && (m->inter_p / kd + 7) / 8 <= (m->fp8 ? 24 : 48) && m->inter_p > 4096;
-    return (k_ok && n_ok && d_ok && decode_km_enabled() && emmax_tune().km_down) ? EMMAX_MAX_DECODE_BATCH : 8;
+    if (!(k_ok && n_ok && d_ok && decode_km_enabled() && emmax_tune().km_down)) return 8;
+    // 17-32 rows: decode_kmp.hip -- bf16 weights, the down projection within eleven phases of four k-steps per wave (K <= 11264, K % 256 == 0)
+    const bool p_ok = !m->fp8 && m->inter_p % 256 == 0 && m->inter_p <= 11264 && m->H <= 4096 && m->H / 16 <= 256;
+    return p_ok ? EMMAX_MAX_DECODE_BATCH : 16;
 }
 
 static bf16* kcache_of(emmax_session* s, int layer) { return s->kv + (size_t)layer * s->kv_layer_stride; }
@@ -1151,7 +1154,8 @@ int emmax_session_create_ex(emmax_model* m, int max_batch, int max_prompt, int m
         return fail(EMMAX_ERR_NOMEM, "session memory too small: workspace %lld/%lld, kv %lld/%lld", (long long)ws_bytes,
                     (long long)need_ws, (long long)kvb, (long long)need_kv);
     if (((uintptr_t)ws % 256) || ((uintptr_t)kv % 256)) return fail(EMMAX_ERR_INVALID, "workspace / kv must be 256-byte aligned");
-    if (decode_mfma_init() != 0 || decode_km_init() != 0) return fail(EMMAX_ERR_HIP, "could not raise the dynamic LDS limit of the MFMA decode kernels");
+    if (decode_mfma_init() != 0 || decode_km_init() != 0 || decode_kmp_init() != 0)
+        return fail(EMMAX_ERR_HIP, "could not raise the dynamic LDS limit of the MFMA decode kernels");
     emmax_session* s = new emmax_session();
     s->m = m;
     s->max_batch = max_batch; s->max_prompt = max_prompt; s->max_ctx = max_ctx;
@@ -1731,7 +1735,7 @@ int emmax_op_gemm_small_km(const void* x, const void* W_km, void* y, int B, int 
     } else {
         r = launch_decode_km(GEMV_PLAIN, p, B, (hipStream_t)st);
     }
-    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_gemm_small_km: unsupported shape (1 <= B <= 16, N %% 16; K %% 256 and K <= 4096 and N <= 32768, or the phased form: K %% 32, K <= 11264 at B <= 8, 12288 at B <= 16)");
+    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_gemm_small_km: unsupported shape (1 <= B <= 32, N %% 16; K %% 256 and K <= 4096 and N <= 32768, or the phased form: K %% 32, K <= 11264 at B <= 8, 12288 at B <= 16; B > 16: K %% 256, K <= 11264, N <= 4096 there)");
     return 0;
 }
 int emmax_op_gemm_small(const void* x, const void* W_fm, void* y, int B, int N, int K, emmax_stream st) {

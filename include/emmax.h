@@ -35,7 +35,7 @@ extern "C" {
 /* Bumped whenever emmax_config / emmax_tower_config change layout or an entry point changes signature.
  *   1: rounds 1-2;  2: emmax_config grew `decode_fp8` (round 2, not bumped then);  3: round 4 -- emmax_config_size / emmax_tuning_*
  *   added, the lab-only entry points (persistent layer chain, in-attention split merge) removed;  4: round 5 -- emmax_session_*_ex (staging rows
- *   are asked for, the plain calls give none), decode batches / slot counts up to 16. */
+ *   are asked for, the plain calls give none), decode batches / slot counts up to 32 (emmax_model_max_decode_batch). */
 #define EMMAX_ABI_VERSION 4
 
 typedef enum emmax_status {
@@ -99,8 +99,9 @@ void emmax_model_destroy(emmax_model* m);
 int emmax_model_bind_weight(emmax_model* m, const char* hf_key, const void* ptr_dev, int dtype,
                             const int64_t* shape, int ndim);
 int64_t emmax_model_arena_bytes(const emmax_model* m);
-/* rows of one decode batch / slot set this model can run: 16 when every LLM projection is a shape the K-split MFMA kernels take
- * (K % 256 == 0 and <= 4096, N <= 32768, intermediate size <= 12288: LLaMA-2-7B is), else 8 (round 5; rounds 1-4: 8) */
+/* rows of one decode batch / slot set this model can run: 32 (bf16 weights) / 16 (fp8) when every LLM projection is a shape the K-split
+ * MFMA kernels take (K % 256 == 0 and <= 4096, N <= 32768, intermediate size % 256 == 0 and <= 11264: LLaMA-2-7B is), else 8 (round 5;
+ * rounds 1-4: 8) */
 int emmax_model_max_decode_batch(const emmax_model* m);
 int emmax_model_finalize(emmax_model* m, void* arena_dev, int64_t arena_bytes, emmax_stream stream);
 /* bf16 models: decode batches >= 3 stream the LLM projections from MFMA-fragment-major copies that a model serving batches 1-2
@@ -117,7 +118,7 @@ int emmax_session_bytes(const emmax_model* m, int max_batch, int max_prompt, int
 int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_ctx,
                          void* workspace_dev, int64_t workspace_bytes, void* kv_dev, int64_t kv_bytes,
                          emmax_session** out);
-/* ... plus `stage_rows` STAGING rows (0 .. min(max_batch, 16)) for overlapped admissions, emmax_slots_prefill_staged below: each costs per-row
+/* ... plus `stage_rows` STAGING rows (0 .. min(max_batch, 32)) for overlapped admissions, emmax_slots_prefill_staged below: each costs per-row
  * state and its share of the paged KV region.  The plain calls above are stage_rows = 0. */
 int emmax_session_bytes_ex(const emmax_model* m, int max_batch, int max_prompt, int max_ctx, int stage_rows,
                            int64_t* workspace_bytes, int64_t* kv_bytes);
@@ -180,7 +181,7 @@ int emmax_profile_decode_stage(emmax_session* s, int stage, int reps, float* avg
  * followed by n_after more tokens (the emitted prefix is exactly the prefix of the full greedy generation).  n_trigger = 0
  * clears the rule; at most 16 ids; a mismatch restarts the match at the current token (no overlapping-prefix handling). */
 int emmax_session_set_stop(emmax_session* s, const int32_t* trigger_ids_host, int n_trigger, int n_after, emmax_stream stream);
-/* Turn the first n_slots rows of the session into independent, idle request slots (n_slots <= max_batch, <= 16). */
+/* Turn the first n_slots rows of the session into independent, idle request slots (n_slots <= max_batch, <= emmax_model_max_decode_batch). */
 int emmax_slots_open(emmax_session* s, int n_slots, emmax_stream stream);
 /* Prefill ONE request into `slot` without disturbing the other slots: prompt ids (device int32[len]), its
  * [n_patches, hidden] bf16 patch embeddings (device; NULL = language-only) and its token budget.  The first generated

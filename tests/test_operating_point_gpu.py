@@ -162,20 +162,23 @@ def test_bf16_decode_residual_stream_variants(device, setup, oracle_bf16, model_
     assert agree == checked, (agree, checked)
 
 
-LENS16 = LENS8 + [509, 33, 512, 500, 128, 512, 7, 256]   # sixteen rows: the decode batch of round 5 (the MFMA's N side is 16 wide)
+LENS16 = LENS8 + [509, 33, 512, 500, 128, 512, 7, 256]   # sixteen rows: one MFMA batch tile (decode_km.hip)
+LENS32 = LENS16 + [64, 511, 12, 300, 512, 200, 505, 31, 450, 512, 90, 128, 512, 5, 333, 508]   # thirty-two: two batch tiles (decode_kmp.hip)
 T16 = 12
 
 
-@pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "fp8"])
-def test_decode_batches_of_nine_to_sixteen_rows(device, setup, tune, fp8):
-    """Round 5: decode batches of 9-16 rows -- decode_km.hip stages sixteen rows per wave (qkv / o-proj / gate-up /
-    lm-head) and runs the down projection in four K phases; the packed prefill takes the sixteen ragged rows in one pass.  Every
-    row's teacher-forced logits against the fp32 oracle of THAT row (bf16 weights; fp8: the de-quantised weights), B = 16 ragged,
-    B = 9 and B = 12 (sub-batches), eager and hipGraph."""
+@pytest.mark.parametrize("nrows,fp8", [(16, False), (16, True), (32, False)], ids=["16-bf16", "16-fp8", "32-bf16"])
+def test_decode_batches_of_nine_to_thirty_two_rows(device, setup, tune, nrows, fp8):
+    """Round 5: decode batches of 9-32 rows.  9-16: decode_km.hip stages sixteen rows per wave (qkv / o-proj /
+    gate-up / lm-head) and runs the down projection in four K phases; 17-32 (bf16 weights): decode_kmp.hip -- two 16-wide batch tiles per
+    weight tile, the K slice in phases through a 32-row window; the packed prefill takes the ragged rows in one pass.  Every row's
+    teacher-forced logits against the fp32 oracle of THAT row (bf16 weights; fp8: the de-quantised weights): the full batch, odd
+    sub-batches, shuffled rows, eager and hipGraph."""
     cfg, sd_bf, sd_ref, frames8, _ = setup
     rng = np.random.default_rng(1616)
-    frames = np.concatenate([frames8, rng.integers(0, 256, size=(8, 224, 224, 3), dtype=np.uint8)])
-    rows = [[1] + [int(x) for x in rng.integers(3, 31744, size=n - 1)] for n in LENS16]
+    lens = LENS16 if nrows == 16 else LENS32
+    frames = np.concatenate([frames8, rng.integers(0, 256, size=(nrows - 8, 224, 224, 3), dtype=np.uint8)])
+    rows = [[1] + [int(x) for x in rng.integers(3, 31744, size=n - 1)] for n in lens]
     if fp8:
         proj = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
         sd_q = {k: (_dequant_e4m3_rows(v) if (any(p in k for p in proj) or k.endswith("lm_head.weight")) else v) for k, v in sd_ref.items()}
@@ -189,10 +192,13 @@ def test_decode_batches_of_nine_to_sixteen_rows(device, setup, tune, fp8):
     c = copy.deepcopy(cfg)
     if fp8:
         c.decode_weight_dtype = "fp8"
-    model = EmmaXForActionPrediction(c, dict(sd_bf)).to(device, max_batch=16, max_prompt=512, max_ctx=256 + 512 + 32)
+    model = EmmaXForActionPrediction(c, dict(sd_bf)).to(device, max_batch=nrows, max_prompt=512, max_ctx=256 + 512 + 32)
+    assert model.engine.max_decode_batch() == (16 if fp8 else 32)
+    sels = [list(range(16)), list(range(3, 12)), [15, 0, 7, 8, 1, 9, 2, 10, 3, 11, 4, 12]] if nrows == 16 else \
+           [list(range(32)), list(range(5, 22)), [31, 0, 30, 1, 29, 2, 28, 3, 27, 4, 26, 5, 25, 6, 24, 7, 23, 8, 22, 9, 21, 10, 20, 11, 19]]
     for graph in (0, 1):
         tune(graph=graph)
-        for sel in (list(range(16)), list(range(3, 12)), [15, 0, 7, 8, 1, 9, 2, 10, 3, 11, 4, 12]):
+        for sel in sels:
             worst, checked, agree = _teacher_forced(model, frames, rows, gens, traces, sel, T16, device)
             assert model.engine.graph_active() == bool(graph)
             assert worst < TOL, (fp8, graph, len(sel), worst)

@@ -472,6 +472,29 @@ def test_gemm_small_mfma(device, B, N, K):
     assert_elementwise(y, ref)
 
 
+@pytest.mark.parametrize("B", [17, 24, 32])
+@pytest.mark.parametrize("N,K", [(256, 256), (4096, 4096), (12288, 4096), (22016, 4096), (32064, 4096), (1008, 1024), (48, 2048), (4096, 11008), (64, 8192),
+                                 (48, 11264), (512, 3072)])
+def test_gemm_small_kmp(device, B, N, K):
+    """Batch 17-32 decode projection (decode_kmp.hip, round 5): two 16-wide batch tiles per weight tile, the wave's K slice in phases of
+    four k-steps through a 32-row LDS window, accumulators of all tiles of the block in registers.  N covers the three block shapes
+    (1, <= 3, <= 6 tiles per block; 32064: more blocks than CUs), K the 4-phase form (<= 4096, incl. slices shorter than four phases)
+    and the 11-phase form of the down projection (K = 11008, 8192, 11264 = its limit)."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(B * 13 + N + K)
+    x = bf(torch.randn(B, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    ref = x.float() @ W.float().t()
+    xd, Wd = x.to(device), W.to(device)
+    Wk = torch.empty_like(Wd)
+    y = torch.full((B, N), float("nan"), dtype=torch.bfloat16, device=device)
+    L.check(lib.emmax_op_repack_km(Wd.data_ptr(), K, Wk.data_ptr(), N, K, 0, 0, stream()), "repack km")
+    L.check(lib.emmax_op_gemm_small_km(xd.data_ptr(), Wk.data_ptr(), y.data_ptr(), B, N, K, stream()), "gemm small kmp")
+    torch.cuda.synchronize()
+    assert relerr(y, ref) < TOL
+    assert_elementwise(y, ref)
+
+
 @pytest.mark.parametrize("B", [3, 5, 8, 9, 13, 16])
 @pytest.mark.parametrize("N,K", [(256, 256), (4096, 4096), (12288, 4096), (32064, 4096), (1008, 1024), (48, 2048), (4096, 11008), (64, 8192), (64, 4352),
                                  (48, 11264)])
@@ -498,10 +521,10 @@ def test_gemm_small_km(device, B, N, K):
 
 def test_gemm_small_km_refuses_shapes_outside_it(device):
     L, lib = _lib()
-    x = torch.zeros(17, 12320, dtype=torch.bfloat16, device=device)
-    W = torch.zeros(64 * 12320, dtype=torch.bfloat16, device=device)
-    y = torch.zeros(17, 64, dtype=torch.bfloat16, device=device)
-    for B, N, K in [(4, 64, 11296), (4, 64, 320), (17, 64, 256), (4, 40, 256), (16, 64, 12320)]:
+    x = torch.zeros(33, 12320, dtype=torch.bfloat16, device=device)
+    W = torch.zeros(8192 * 12320, dtype=torch.bfloat16, device=device)
+    y = torch.zeros(33, 8192, dtype=torch.bfloat16, device=device)
+    for B, N, K in [(4, 64, 11296), (4, 64, 320), (33, 64, 256), (4, 40, 256), (16, 64, 12320), (20, 64, 11520), (20, 8192, 11008), (20, 64, 320)]:
         assert lib.emmax_op_gemm_small_km(x.data_ptr(), W.data_ptr(), y.data_ptr(), B, N, K, stream()) != 0, (B, N, K)
     torch.cuda.synchronize()
 
