@@ -51,6 +51,40 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_move<0x140>(v);   // row_mirror
     return v;
 }
+// max over the 16 lanes of each DPP row, in every lane of the row
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_move<0xB1>(v));
+    v = fmaxf(v, dpp_move<0x4E>(v));
+    v = fmaxf(v, dpp_move<0x141>(v));
+    v = fmaxf(v, dpp_move<0x140>(v));
+    return v;
+}
+// ---- e4m3 (OCP) rows with one fp32 scale per row: the opt-in fp8 KV cache (round 5) ----
+// The row scale is a POWER OF TWO, the smallest one with amax / scale <= 448: v_cvt_scalef32_pk_bf16_fp8 applies only the exponent of its
+// scale operand (measured: an arbitrary fp32 scale came back truncated to 2^floor(log2 s) -- up to 2 x off), and e4m3 being a floating
+// format a power-of-two scale costs no relative precision, only (at most one binade of) range.  Both directions are then exact.
+__device__ __forceinline__ float e4m3_row_scale(float amax) {
+    const float r = amax * (1.0f / 448.0f);
+    if (!(r > 0.f)) return 1.0f;
+    uint32_t u = __float_as_uint(r), e = u & 0x7f800000u;
+    if (u & 0x007fffffu) e += 0x00800000u;
+    return __uint_as_float(e ? e : 0x00800000u);
+}
+// 8 bf16 (u32x4) -> 8 e4m3 (u32x2), values divided by the row's scale first; 8 e4m3 -> 8 bf16 multiplied by the scale
+__device__ __forceinline__ u32x2_t quant8_e4m3(const u32x4_t& v, float inv_scale) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[0]) * inv_scale, bf_hi(v[0]) * inv_scale, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[1]) * inv_scale, bf_hi(v[1]) * inv_scale, lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[2]) * inv_scale, bf_hi(v[2]) * inv_scale, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(v[3]) * inv_scale, bf_hi(v[3]) * inv_scale, hi, true);
+    return (u32x2_t){(uint32_t)lo, (uint32_t)hi};
+}
+__device__ __forceinline__ u32x4_t dequant8_e4m3(const u32x2_t& q, float scale) {
+    return (u32x4_t){__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q[0], scale, false)),
+                     __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q[0], scale, true)),
+                     __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q[1], scale, false)),
+                     __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q[1], scale, true))};
+}
 // exchange across the four rows (lanes with equal lane & 15) with the gfx950 swap instructions:
 //   v_permlane32_swap a, b: a.hi <-> b.lo   => with a = b = v:  a = {v.lo, v.lo}, b = {v.hi, v.hi}
 //   v_permlane16_swap a, b: odd rows of a <-> even rows of b

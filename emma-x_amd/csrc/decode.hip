@@ -641,13 +641,13 @@ __global__ __launch_bounds__(GW * 64, (B <= 2 && F8 != 1 && F8 != 2 ? 4 : 2)) vo
                             st_act_bf16(q + d + half, y1, coh);
                         } else {
                             const int pgid = pre_pg;
-                            bf16_t* kc = (bf16_t*)p.kcache + (((size_t)pgid * p.Hkv + (hb - p.Hq)) * p.page + pos % p.page) * hd;
+                            bf16_t* kc = gemv_kv_row(p, false, b, pgid, pos, hb - p.Hq);
                             st_act_bf16(kc + d, y0, coh);
                             st_act_bf16(kc + d + half, y1, coh);
                         }
                     } else {
                         const int pgid = pre_pg;
-                        bf16_t* vc = (bf16_t*)p.vcache + (((size_t)pgid * p.Hkv + (hb - p.Hq - p.Hkv)) * p.page + pos % p.page) * hd;
+                        bf16_t* vc = gemv_kv_row(p, true, b, pgid, pos, hb - p.Hq - p.Hkv);
                         st_act_bf16(vc + d, f2bf(x0), coh);
                         st_act_bf16(vc + d + half, f2bf(x1), coh);
                     }
@@ -737,7 +737,11 @@ __global__ __launch_bounds__(256) void emmax_decode_embed_kernel(const int32_t* 
 // normalises it and writes the bf16 row the o-proj reads (the arithmetic of a one-split merge), no partials, no o-proj prologue.
 // (Round 3 also measured a cross-split merge INSIDE this launch for 2-8 splits -- sc1 partials, arrival counter, last arriver
 // merges: 12.6 against 5.7 us per launch at B = 1; removed from the product source in round 4)
-template <int HD, int G, bool DIRECT = false, int NW = 4>
+// KV8 (round 5, opt-in fp8 KV cache): K / V pages hold e4m3 rows with one fp32 scale per (token, head) row -- 8 bytes per lane and key
+// instead of 16, de-quantised in registers (v_cvt_scalef32_pk_bf16_fp8 with the row's scale) right before the dot products.  The key the
+// qkv launch of THIS step produced (position L - 1) waits as bf16 in p.kv_stage: every block quantises it itself (so that this step sees
+// the values every later step will read back) and split 0 appends bytes + scale to the cache.
+template <int HD, int G, bool DIRECT = false, int NW = 4, bool KV8 = false>
 __global__ __launch_bounds__(NW * 64) void emmax_decode_attn_kernel(DecodeAttnParams p) {
     // waves per block: 4 (8-wave blocks were measured no faster at batch 1-2, where 512 four-wave blocks already put 8 waves on a CU,
     // DESIGN.md section 6); the one-split form of batch 5-8 is 256 blocks = ONE per CU: NW = 8 there (tuning switch attn_nw, round 5)
@@ -794,8 +798,37 @@ __global__ __launch_bounds__(NW * 64) void emmax_decode_attn_kernel(DecodeAttnPa
 
     const bf16_t* kc = (const bf16_t*)p.kcache;
     const bf16_t* vc = (const bf16_t*)p.vcache;
+    const uint8_t* kc8 = (const uint8_t*)p.kcache;
+    const uint8_t* vc8 = (const uint8_t*)p.vcache;
+    // KV8: the step's new K / V row of this kv head, requested now (one round trip with the page table), quantised below
+    u32x4_t new_k = {0u, 0u, 0u, 0u}, new_v = {0u, 0u, 0u, 0u};
+    if constexpr (KV8) {
+        const bf16_t* st = (const bf16_t*)p.kv_stage + ((size_t)b * p.Hkv + hk) * 2 * HD + ch * 8;
+        new_k = *(const u32x4_t*)st;
+        new_v = *(const u32x4_t*)(st + HD);
+    }
 
     __syncthreads();
+    if constexpr (KV8) {
+        // one scale per row (e4m3_row_scale of the amax) over the 16 lanes of a key group (every group of every wave holds the same row)
+        auto requant = [&](u32x4_t& v, uint8_t* cache, float* scales) {
+            float am = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) am = fmaxf(am, fmaxf(fabsf(bf_lo(v[j])), fabsf(bf_hi(v[j]))));
+            am = row16_max(am);
+            const float sc = e4m3_row_scale(am);
+            const u32x2_t q8 = quant8_e4m3(v, 1.0f / sc);
+            v = dequant8_e4m3(q8, sc);
+            if (split == 0 && tid < 16) {   // append: bytes + scale at position L - 1
+                const int pos = L - 1, pg = s_pages[pos >> p.page_shift];
+                const size_t rowi = (((size_t)pg * p.Hkv + hk) << p.page_shift) + (pos & (p.page - 1));
+                *(u32x2_t*)(cache + rowi * HD + ch * 8) = q8;
+                if (tid == 0) scales[rowi] = sc;
+            }
+        };
+        requant(new_k, (uint8_t*)p.kcache, p.kscale);
+        requant(new_v, (uint8_t*)p.vcache, p.vscale);
+    }
 
     float m[G], l[G], o[G][8];
 #pragma unroll
@@ -809,12 +842,21 @@ __global__ __launch_bounds__(NW * 64) void emmax_decode_attn_kernel(DecodeAttnPa
     // software pipeline: two register chunk buffers; the loads of chunk i+1 are issued before the scores of chunk i are
     // computed, so every wave has K/V requests in flight at all times (a 1/8 split of a 1K context is two chunks: both
     // are requested up front)
+    // KV8: kv / vv carry the raw bytes in [0..1] and the row's scale in [2] until consume_chunk de-quantises them
     auto load_chunk = [&](int kb, u32x4_t (&kv)[KU], u32x4_t (&vv)[KU], bool (&ok)[KU]) {
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int key = kb + u * (4 * NW) + wave * 4 + kg;
             ok[u] = key < k1;
             const int kk = ok[u] ? key : k0;
+            if constexpr (KV8) {
+                const int pg8 = s_pages[kk >> p.page_shift];
+                const size_t rowi = (((size_t)pg8 * p.Hkv + hk) << p.page_shift) + (kk & (p.page - 1));
+                const u32x2_t k8 = *(const u32x2_t*)(kc8 + rowi * HD + ch * 8), v8 = *(const u32x2_t*)(vc8 + rowi * HD + ch * 8);
+                kv[u] = (u32x4_t){k8[0], k8[1], __float_as_uint(p.kscale[rowi]), (uint32_t)key};
+                vv[u] = (u32x4_t){v8[0], v8[1], __float_as_uint(p.vscale[rowi]), 0u};
+                continue;
+            }
             // the page id ALWAYS comes from LDS (the launcher rejects tables longer than SP): a select between the LDS copy and
             // the global table became a FLAT load, whose wait (vmcnt(0) lgkmcnt(0)) also drained the K/V loads in flight --
             // every key's lookup waited for the previous key's rows
@@ -828,7 +870,20 @@ __global__ __launch_bounds__(NW * 64) void emmax_decode_attn_kernel(DecodeAttnPa
             }
         }
     };
-    auto consume_chunk = [&](const u32x4_t (&kv)[KU], const u32x4_t (&vv)[KU], const bool (&ok)[KU]) {
+    auto consume_chunk = [&](u32x4_t (&kv)[KU], u32x4_t (&vv)[KU], const bool (&ok)[KU]) {
+        if constexpr (KV8) {   // bytes -> bf16 x scale; the key of this step comes from the staging row (its cache bytes may not have landed)
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const bool is_new = (int)kv[u][3] == L - 1;
+                const u32x4_t kd = dequant8_e4m3((u32x2_t){kv[u][0], kv[u][1]}, __uint_as_float(kv[u][2]));
+                const u32x4_t vd = dequant8_e4m3((u32x2_t){vv[u][0], vv[u][1]}, __uint_as_float(vv[u][2]));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    kv[u][j] = is_new ? new_k[j] : kd[j];
+                    vv[u][j] = is_new ? new_v[j] : vd[j];
+                }
+            }
+        }
 #pragma unroll
         for (int gq = 0; gq < G; ++gq) {
             float sc[KU];
@@ -865,7 +920,26 @@ __global__ __launch_bounds__(NW * 64) void emmax_decode_attn_kernel(DecodeAttnPa
             m[gq] = mn;
         }
     };
-    {
+    if constexpr (KV8) {
+        // FOUR chunks in flight: at 8 bytes per lane and key two chunks are 8 KiB per wave -- the launch was a latency chain (one chunk
+        // per ~1.1 us round trip: 18.9 us for 53 MB at batch 8); the raw bytes of four chunks take the registers two bf16 chunks did
+        constexpr int CHK = (4 * NW) * KU;
+        u32x4_t kvA[KU], vvA[KU], kvB[KU], vvB[KU], kvC[KU], vvC[KU], kvD[KU], vvD[KU];
+        bool okA[KU], okB[KU], okC[KU], okD[KU];
+        load_chunk(k0, kvA, vvA, okA);
+        if (k0 + CHK < k1) load_chunk(k0 + CHK, kvB, vvB, okB);
+        if (k0 + 2 * CHK < k1) load_chunk(k0 + 2 * CHK, kvC, vvC, okC);
+        for (int kb = k0; kb < k1; kb += 4 * CHK) {               // every condition is block-uniform
+            if (kb + 3 * CHK < k1) load_chunk(kb + 3 * CHK, kvD, vvD, okD);
+            consume_chunk(kvA, vvA, okA);
+            if (kb + 4 * CHK < k1) load_chunk(kb + 4 * CHK, kvA, vvA, okA);
+            if (kb + CHK < k1) consume_chunk(kvB, vvB, okB);
+            if (kb + 5 * CHK < k1) load_chunk(kb + 5 * CHK, kvB, vvB, okB);
+            if (kb + 2 * CHK < k1) consume_chunk(kvC, vvC, okC);
+            if (kb + 6 * CHK < k1) load_chunk(kb + 6 * CHK, kvC, vvC, okC);
+            if (kb + 3 * CHK < k1) consume_chunk(kvD, vvD, okD);
+        }
+    } else {
         u32x4_t kvA[KU], vvA[KU], kvB[KU], vvB[KU];
         bool okA[KU], okB[KU];
         load_chunk(k0, kvA, vvA, okA);
@@ -1170,6 +1244,7 @@ int launch_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_dim
     p.page_shift = 0;
     while ((1 << p.page_shift) < p.page) ++p.page_shift;
     if (p.o_out && nsplit != 1) return -1;   // the direct form exists for one split only (nothing to merge)
+    if (p.kv_stage && (!p.kscale || !p.vscale)) return -1;   // fp8 KV cache: bytes + one scale per row
     const int G = Hq / p.Hkv;
     dim3 grid(nsplit, p.Hkv, B), block(256);
     const int nw = emmax_tune().attn_nw;
@@ -1177,7 +1252,9 @@ int launch_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_dim
     switch (G) {
 #define ATTN_CASE(GG)                                                                                                   \
     case GG:                                                                                                           \
-        if (p.o_out && nw8) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true, 8>), grid, dim3(512), 0, stream, p); \
+        if (p.kv_stage && p.o_out) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true, 4, true>), grid, block, 0, stream, p); \
+        else if (p.kv_stage) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, false, 4, true>), grid, block, 0, stream, p); \
+        else if (p.o_out && nw8) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true, 8>), grid, dim3(512), 0, stream, p); \
         else if (p.o_out) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true>), grid, block, 0, stream, p);     \
         else hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG>), grid, block, 0, stream, p);                         \
         break

@@ -324,12 +324,12 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
                         q[d] = y0;
                         q[d + half] = y1;
                     } else {
-                        bf16_t* kc = (bf16_t*)p.kcache + (((size_t)pre_pg * p.Hkv + (hb - p.Hq)) * p.page + pre_pos % p.page) * hd;
+                        bf16_t* kc = gemv_kv_row(p, false, e_c, pre_pg, pre_pos, hb - p.Hq);
                         kc[d] = y0;
                         kc[d + half] = y1;
                     }
                 } else {
-                    bf16_t* vc = (bf16_t*)p.vcache + (((size_t)pre_pg * p.Hkv + (hb - p.Hq - p.Hkv)) * p.page + pre_pos % p.page) * hd;
+                    bf16_t* vc = gemv_kv_row(p, true, e_c, pre_pg, pre_pos, hb - p.Hq - p.Hkv);
                     vc[d] = f2bf(x0);
                     vc[d + half] = f2bf(x1);
                 }

@@ -281,12 +281,12 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
                         q[d] = y0;
                         q[d + half] = y1;
                     } else {
-                        bf16_t* kc = (bf16_t*)p.kcache + (((size_t)pg * p.Hkv + (hb - p.Hq)) * p.page + pos % p.page) * hd;
+                        bf16_t* kc = gemv_kv_row(p, false, e_c, pg, pos, hb - p.Hq);
                         kc[d] = y0;
                         kc[d + half] = y1;
                     }
                 } else {
-                    bf16_t* vc = (bf16_t*)p.vcache + (((size_t)pg * p.Hkv + (hb - p.Hq - p.Hkv)) * p.page + pos % p.page) * hd;
+                    bf16_t* vc = gemv_kv_row(p, true, e_c, pg, pos, hb - p.Hq - p.Hkv);
                     vc[d] = f2bf(x0);
                     vc[d + half] = f2bf(x1);
                 }

@@ -408,12 +408,12 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
                     q[d] = y0;
                     q[d + half] = y1;
                 } else {
-                    bf16_t* kc = (bf16_t*)p.kcache + (((size_t)pre_pg * p.Hkv + (hb - p.Hq)) * p.page + pre_pos % p.page) * hd;
+                    bf16_t* kc = gemv_kv_row(p, false, eb, pre_pg, pre_pos, hb - p.Hq);
                     kc[d] = y0;
                     kc[d + half] = y1;
                 }
             } else {
-                bf16_t* vc = (bf16_t*)p.vcache + (((size_t)pre_pg * p.Hkv + (hb - p.Hq - p.Hkv)) * p.page + pre_pos % p.page) * hd;
+                bf16_t* vc = gemv_kv_row(p, true, eb, pre_pg, pre_pos, hb - p.Hq - p.Hkv);
                 vc[d] = f2bf(x0);
                 vc[d + half] = f2bf(x1);
             }

@@ -525,13 +525,13 @@ __global__ __launch_bounds__(GW * 64, 2) void emmax_decode_mfma_kernel(GemvParam
                             q[d + half] = y1;
                         } else {
                             const int pg = pre_pg;
-                            bf16_t* kc = (bf16_t*)p.kcache + (((size_t)pg * p.Hkv + (hb - p.Hq)) * p.page + pos % p.page) * hd;
+                            bf16_t* kc = gemv_kv_row(p, false, c, pg, pos, hb - p.Hq);
                             kc[d] = y0;
                             kc[d + half] = y1;
                         }
                     } else {
                         const int pg = pre_pg;
-                        bf16_t* vc = (bf16_t*)p.vcache + (((size_t)pg * p.Hkv + (hb - p.Hq - p.Hkv)) * p.page + pos % p.page) * hd;
+                        bf16_t* vc = gemv_kv_row(p, true, c, pg, pos, hb - p.Hq - p.Hkv);
                         vc[d] = f2bf(x0);
                         vc[d + half] = f2bf(x1);
                     }

@@ -103,7 +103,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, const 
     const int ocol0 = (ACT == 2) ? ((n0 + wn * 64) >> 1) : (n0 + wn * 64);
     float bv[NG][4], sv[NG][4], cs[LN ? NG : 1][4];   // LN: bv = ln_c (fp32), cs = ln_s
     // a lane's four columns of a group are consecutive: one 8- / 16-byte load per operand and group (were four 2- / 4-byte loads)
-    const bool vec_col = (n_ok & 3) == 0 && (((uintptr_t)bias | (uintptr_t)scale) & 7) == 0;
+    // (LN form: ln_c / ln_s take 16-byte loads -- the model's arena keeps them aligned, emmax_op_gemm_ln takes caller workspaces: ADVICE r04)
+    const bool vec_col = (n_ok & 3) == 0 && (((uintptr_t)bias | (uintptr_t)scale) & 7) == 0 &&
+                         (!LN || ((((uintptr_t)p.ln_c | (uintptr_t)p.ln_s) & 15) == 0));
 #pragma unroll
     for (int jo = 0; jo < NG; ++jo) {
         const int col4 = ocol0 + jo * 16 + g * 4;

@@ -108,6 +108,9 @@ int launch_embed_splice(const int32_t* ids, int P_max, const int32_t* cu, const 
 int launch_rope_kv_write(void* qkv, int ld, int q_off, int k_off, int v_off, const int32_t* cu, int B, int total_rows,
                          const float* cos_t, const float* sin_t, void* kcache, void* vcache, const int32_t* page_table,
                          int max_pages, int Hq, int Hkv, int hd, int page, hipStream_t stream);
+// fp8 KV cache: quantise the prefill's K / V rows (K rotated in place by launch_rope_kv_write with null cache pointers) into e4m3 pages + row scales
+int launch_kv_quant_rows(const void* qkv, int ld, int k_off, int v_off, const int32_t* cu, int B, int total_rows, void* k8, void* v8, float* kscale,
+                         float* vscale, const int32_t* page_table, int max_pages, int Hkv, int hd, int page, hipStream_t stream);
 int launch_resize_bicubic_u8(const uint8_t* src, int B, int H, int W, uint8_t* dst, int OH, int OW, uint8_t* tmp, const int32_t* bounds_h,
                              const int32_t* kk_h, int ksize_h, const int32_t* bounds_v, const int32_t* kk_v, int ksize_v, hipStream_t stream);
 // out32: the rows also as fp32; in32 != null: the source rows are fp32 (`in` unused)
@@ -140,6 +143,7 @@ struct EmmaxTune {
     int gemm_dbg;        // lab: OR-ed into GemmParams::dbg (16 = the second half of the waves requests its slabs mid-step)
     int gemm_lnfuse;     // 1: LayerNorm / RMSNorm applied by the GEMM that consumes the normalised rows (no separate norm pass)
     int attn_resident;   // -1: resident ViT attention kernel where measured faster; 0: never; 2: whenever it fits (tests)
+    int kv_fp8;          // 1: sessions created from now on keep the paged KV cache as e4m3 rows + one fp32 scale per (token, head) row (opt-in: half the attention bytes of a decode step, its own error line in the tests); 0: bf16
     int resid32;         // 1: prefill and decode step keep the residual stream in fp32 (GemmParams::res_f32, GemvParams::h32); 2: the decode step only; 0: bf16 rows (rounds 1-4)
     int epoch;           // bumped by every emmax_tuning_set: sessions drop captured graphs when it moves
 };
@@ -174,6 +178,8 @@ struct GemvParams {
     // RESID with x = merged attention output: split partials f32 [B][Hq][nsplit][132] (null: x is a bf16 vector)
     const float* attn_part;
     int nsplit;
+    void* kv_stage;         // QKV, fp8 KV cache (round 5, opt-in): the new K / V rows go to bf16 [B][Hkv][2][head_dim] instead of the paged cache;
+                            //   the attention launch of the step quantises them (one scale per row) and appends them
     const float* wscale;    // per-row fp32 scales when W is an fp8 copy (MFMA path: fragment-major tiles; GEMV: rows in span order); null: bf16
     int n_pairs;            // GEMV, set by the launcher: row pairs (fp8 groups hold two)
     unsigned long long* sk_ws;   // MFMA path: stream-K granules [256 blocks][2 tiles][256] of {f32, tag} (null: whole tasks per block)
@@ -194,6 +200,11 @@ struct GemvParams {
     float* h32;
     int ldh;
 };
+// where the QKV epilogues put element block (head hk, K or V) of batch row b: the paged bf16 cache, or the staging rows of the fp8 KV cache
+__device__ __forceinline__ bf16_t* gemv_kv_row(const GemvParams& p, bool is_v, int b, int pg, int pos, int hk) {
+    if (p.kv_stage) return (bf16_t*)p.kv_stage + (((size_t)b * p.Hkv + hk) * 2 + (is_v ? 1 : 0)) * p.head_dim;
+    return (bf16_t*)(is_v ? p.vcache : p.kcache) + (((size_t)pg * p.Hkv + hk) * p.page + pos % p.page) * p.head_dim;
+}
 int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
 // decode_ks.hip: the batch 1-2 bf16 projections with K split across the waves of a block (activation slice in registers, no
 // block-wide stage); returns -2 for a shape it does not take.  launch_decode_gemv tries it first (tuning switch `ks` = 0: never).
@@ -211,6 +222,12 @@ struct DecodeAttnParams {
     const int32_t* done;    // int32 [B] or null: finished / idle rows read no K/V (their partials are written empty)
     float* part;            // f32 [B][Hq][nsplit][132] = { o[128] un-normalised, m, l, pad }
     void* o_out;            // non-null (one split only): the block normalises its result and writes the bf16 row [B, ldq] itself
+    // fp8 KV cache (kv_stage non-null): kcache / vcache are e4m3 bytes [pages][Hkv][page][hd], kscale / vscale fp32 [pages][Hkv][page]; the
+    // step's new rows come from kv_stage bf16 [B][Hkv][2][hd] (written by the qkv launch): every block that needs key L - 1 quantises it
+    // itself, split 0 appends it to the cache
+    const void* kv_stage;
+    float* kscale;
+    float* vscale;
     int ldq, Hkv, page, max_pages;
     int page_shift;         // log2(page), set by the launcher
     float scale;

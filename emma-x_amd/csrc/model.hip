@@ -59,7 +59,7 @@ const TuneEntry kTune[] = {
     {"gemm_deep", &EmmaxTune::gemm_deep, -1},       {"gemm_dbg", &EmmaxTune::gemm_dbg, 0},
     {"gemm_lnfuse", &EmmaxTune::gemm_lnfuse, 1}, {"attn_resident", &EmmaxTune::attn_resident, -1},
     {"gemm_hybrid", &EmmaxTune::gemm_hybrid, 1}, {"gemm_normfuse", &EmmaxTune::gemm_normfuse, 1},
-    {"resid32", &EmmaxTune::resid32, 1},
+    {"resid32", &EmmaxTune::resid32, 1},       {"kv_fp8", &EmmaxTune::kv_fp8, 0},
 };
 EmmaxTune g_tune;
 std::once_flag g_tune_once;
@@ -337,7 +337,9 @@ struct emmax_session {
     int n_lm_blocks;
     // kv
     bf16* kv;
-    int64_t kv_layer_stride;   // elements between layers; K at +0, V at +kv_layer_stride/2
+    int64_t kv_layer_stride;   // BYTES between layers.  bf16 cache: K at +0, V at +stride/2.  fp8 cache (kv8): K bytes, V bytes, K scales, V scales
+    bool kv8 = false;          // the cache holds e4m3 rows + one fp32 scale per (token, kv head) row (tuning switch kv_fp8 at emmax_session_create)
+    bf16* kv_stage = nullptr;  // kv8: the step's new K / V rows, bf16 [rows_total][Hkv][2][head_dim] (qkv launch -> attention launch)
     // host state
     int cur_B = 0, total_rows = 0, max_seqlen = 0, vision_B = 0;
     int dec_steps = 0;          // decode steps issued since the last full prefill (upper bound of every row's context growth)
@@ -404,6 +406,7 @@ static void plan_session(emmax_session* s, SBump& b) {
     const int Bd = s->max_batch, Br = s->rows_total;   // decode batch rows / all rows incl. the staging rows
     s->dh = (bf16*)b.take((int64_t)Br * m->H * 2);
     s->dh32 = (float*)b.take((int64_t)Br * m->H * 4);
+    s->kv_stage = (bf16*)b.take((int64_t)Br * 2 * m->kv_dim * 2);
     s->dq = (bf16*)b.take((int64_t)Bd * m->q_dim * 2);
     s->datt = (bf16*)b.take((int64_t)Bd * m->q_dim * 2);
     s->dact = (bf16*)b.take((int64_t)Bd * m->inter_p * 2);
@@ -433,8 +436,13 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->sin_t = (float*)b.take((int64_t)s->max_ctx * (m->cfg.head_dim / 2) * 4);
 }
 
-static int64_t kv_bytes_for(const emmax_model* m, int max_batch, int max_pages) {
-    return (int64_t)m->cfg.n_layers * 2 * max_batch * max_pages * m->cfg.n_kv_heads * PAGE * m->cfg.head_dim * 2;
+// paged KV region: per layer K and V, rows x pages x kv heads x 64 tokens x head_dim elements -- bf16, or (kv8) e4m3 bytes + a 4-byte scale per row
+static int64_t kv_rows_per_layer(const emmax_model* m, int rows, int max_pages) { return (int64_t)rows * max_pages * m->cfg.n_kv_heads * PAGE; }
+static int64_t kv_layer_bytes(const emmax_model* m, int rows, int max_pages, bool kv8) {
+    return 2 * kv_rows_per_layer(m, rows, max_pages) * (kv8 ? m->cfg.head_dim + 4 : m->cfg.head_dim * 2);
+}
+static int64_t kv_bytes_for(const emmax_model* m, int max_batch, int max_pages, bool kv8) {
+    return (int64_t)m->cfg.n_layers * kv_layer_bytes(m, max_batch, max_pages, kv8);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -592,8 +600,14 @@ static int model_max_decode_batch(const emmax_model* m) {
     return p_ok ? EMMAX_MAX_DECODE_BATCH : 16;
 }
 
-static bf16* kcache_of(emmax_session* s, int layer) { return s->kv + (size_t)layer * s->kv_layer_stride; }
-static bf16* vcache_of(emmax_session* s, int layer) { return s->kv + (size_t)layer * s->kv_layer_stride + s->kv_layer_stride / 2; }
+static char* kv_layer(emmax_session* s, int layer) { return (char*)s->kv + (size_t)layer * s->kv_layer_stride; }
+static int64_t kv_rows(emmax_session* s) { return kv_rows_per_layer(s->m, s->rows_total, s->max_pages); }
+static bf16* kcache_of(emmax_session* s, int layer) { return (bf16*)kv_layer(s, layer); }
+static bf16* vcache_of(emmax_session* s, int layer) {
+    return (bf16*)(kv_layer(s, layer) + kv_rows(s) * (s->kv8 ? s->m->cfg.head_dim : s->m->cfg.head_dim * 2));
+}
+static float* kscale_of(emmax_session* s, int layer) { return (float*)(kv_layer(s, layer) + 2 * kv_rows(s) * s->m->cfg.head_dim); }   // kv8 only
+static float* vscale_of(emmax_session* s, int layer) { return kscale_of(s, layer) + kv_rows(s); }
 
 static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, int slot0 = 0);
 static int launch_finish_step(emmax_session* s, int B, bool is_prefill, int n_part, int slot0, hipStream_t st);
@@ -702,9 +716,14 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
         if (!normed) KCHK(input_norm(L.ln1));
         GemmParams g = gps(s, s->pxn, m->H, L.wqkv, m->H, s->pqkv, m->qkv_dim, total, m->qkv_dim, m->H);
         KCHK(launch_gemm(g, st));
+        // (fp8 KV cache: the pass rotates q / k in place only, the quantising pass appends K and V as e4m3 rows + scales)
         KCHK(launch_rope_kv_write(s->pqkv, m->qkv_dim, 0, m->q_dim, m->q_dim + m->kv_dim, s->cu, B, total, s->cos_t, s->sin_t,
-                                  kcache_of(s, li), vcache_of(s, li), s->page_table + (size_t)r0 * s->max_pages, s->max_pages, c.n_heads,
-                                  c.n_kv_heads, c.head_dim, PAGE, st));
+                                  s->kv8 ? nullptr : kcache_of(s, li), s->kv8 ? nullptr : vcache_of(s, li), s->page_table + (size_t)r0 * s->max_pages,
+                                  s->max_pages, c.n_heads, c.n_kv_heads, c.head_dim, PAGE, st));
+        if (s->kv8)
+            KCHK(launch_kv_quant_rows(s->pqkv, m->qkv_dim, m->q_dim, m->q_dim + m->kv_dim, s->cu, B, total, kcache_of(s, li), vcache_of(s, li),
+                                      kscale_of(s, li), vscale_of(s, li), s->page_table + (size_t)r0 * s->max_pages, s->max_pages, c.n_kv_heads,
+                                      c.head_dim, PAGE, st));
         AttnParams a;
         a.qkv = s->pqkv; a.out = s->patt; a.cu_seqlens = s->cu;
         a.ld_qkv = m->qkv_dim; a.q_off = 0; a.k_off = m->q_dim; a.v_off = m->q_dim + m->kv_dim; a.ld_out = m->q_dim;
@@ -754,6 +773,7 @@ static void stage_params(emmax_session* s, int B, int li, int stage, GemvParams&
             p.head_dim = c.head_dim; p.Hq = c.n_heads; p.Hkv = c.n_kv_heads; p.page = PAGE; p.max_pages = s->max_pages;
             p.ctx_len = s->ctx_len; p.page_table = s->page_table; p.cos_t = s->cos_t; p.sin_t = s->sin_t;
             p.kcache = kcache_of(s, li); p.vcache = vcache_of(s, li);
+            p.kv_stage = s->kv8 ? s->kv_stage : nullptr;   // fp8 KV cache: the new rows wait as bf16 for the attention launch
             break;
         case STAGE_OPROJ:
             p.x = s->datt; p.ldx = m->q_dim; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
@@ -796,7 +816,9 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             return 0;
         case STAGE_ATTN: {
             DecodeAttnParams a;
+            memset(&a, 0, sizeof(a));
             a.q = s->dq; a.ldq = m->q_dim; a.kcache = kcache_of(s, li); a.vcache = vcache_of(s, li);
+            if (s->kv8) { a.kv_stage = s->kv_stage; a.kscale = kscale_of(s, li); a.vscale = vscale_of(s, li); }
             a.page_table = s->page_table; a.ctx_len = s->ctx_len; a.done = s->done; a.part = s->part; a.Hkv = c.n_kv_heads; a.page = PAGE;
             a.max_pages = s->max_pages; a.scale = 1.0f / sqrtf((float)c.head_dim);
             a.o_out = attn_direct_on(s, B) ? s->datt : nullptr;
@@ -1134,7 +1156,7 @@ int emmax_session_bytes_ex(const emmax_model* m, int max_batch, int max_prompt, 
     SBump b{nullptr};
     plan_session(&tmp, b);
     if (ws) *ws = b.off + 256;
-    if (kv) *kv = kv_bytes_for(m, tmp.rows_total, mp);
+    if (kv) *kv = kv_bytes_for(m, tmp.rows_total, mp, emmax_tune().kv_fp8 != 0);
     return 0;
 }
 
@@ -1165,7 +1187,8 @@ int emmax_session_create_ex(emmax_model* m, int max_batch, int max_prompt, int m
     SBump b{(char*)ws};
     plan_session(s, b);
     s->kv = (bf16*)kv;
-    s->kv_layer_stride = (int64_t)2 * s->rows_total * s->max_pages * m->cfg.n_kv_heads * PAGE * m->cfg.head_dim;
+    s->kv8 = emmax_tune().kv_fp8 != 0;
+    s->kv_layer_stride = kv_layer_bytes(m, s->rows_total, s->max_pages, s->kv8);
     HIPCHK(hipMemset(ws, 0, need_ws));   // padding columns of every activation buffer stay zero forever
     HIPCHK(hipMemset(kv, 0, need_kv));
     HIPCHK(hipDeviceSynchronize());
@@ -1606,6 +1629,8 @@ int emmax_gemm_plan(int M, int N, int K, int act, int out_f32, int has_ln, int h
 int emmax_op_gemm_ln(const void* X, int ldx, void* W, int ldw, void* C, int ldc, int M, int N, int K, const void* gamma, const void* beta,
                      const void* bias, float eps, int act, float* stats_ws, float* ln_s_ws, float* ln_c_ws, emmax_stream stream) {
     if (!X || !W || !C || !gamma || !stats_ws || !ln_s_ws || !ln_c_ws) return fail(EMMAX_ERR_INVALID, "emmax_op_gemm_ln: null argument");
+    if (((uintptr_t)stats_ws & 7) || (((uintptr_t)ln_s_ws | (uintptr_t)ln_c_ws) & 3))   // (mean, rstd) pairs are read as 8 bytes
+        return fail(EMMAX_ERR_INVALID, "emmax_op_gemm_ln: workspaces must be 8-byte (stats) / 4-byte (ln_s, ln_c) aligned");
     hipStream_t st = (hipStream_t)stream;
     KCHK(launch_ln_fold(W, ldw, N, K, gamma, beta, bias, ln_s_ws, ln_c_ws, st));
     KCHK(launch_row_stats(X, stats_ws, M, K, ldx, eps, st));
@@ -1661,6 +1686,23 @@ int emmax_op_decode_attention_direct(const void* q, const void* kcache, const vo
     a.part = nullptr; a.Hkv = Hkv; a.page = page; a.max_pages = max_pages; a.scale = scale; a.o_out = o_out;
     int r = launch_decode_attn(a, B, Hq, 128, 1, (hipStream_t)st);
     if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_decode_attention_direct: unsupported (GQA group in {1,2,4,8}, page = 2^k, max_pages <= 512)");
+    return 0;
+}
+int emmax_op_decode_attention_kv8(const void* q, void* kcache8, void* vcache8, float* kscale, float* vscale, const void* kv_stage,
+                                  const int32_t* page_table, const int32_t* ctx_len, const int32_t* done, float* part_out, void* o_out, int B, int Hq,
+                                  int Hkv, int page, int max_pages, int nsplit, float scale, emmax_stream st) {
+    if (!q || !kcache8 || !vcache8 || !kscale || !vscale || !kv_stage || !page_table || !ctx_len || (!part_out && !o_out))
+        return fail(EMMAX_ERR_INVALID, "emmax_op_decode_attention_kv8: null argument");
+    if (B < 1 || B > EMMAX_MAX_DECODE_BATCH || Hkv < 1 || Hq % Hkv) return fail(EMMAX_ERR_INVALID, "emmax_op_decode_attention_kv8: bad B / heads");
+    DecodeAttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.q = q; a.ldq = Hq * 128; a.kcache = kcache8; a.vcache = vcache8; a.kscale = kscale; a.vscale = vscale; a.kv_stage = kv_stage;
+    a.page_table = page_table; a.ctx_len = ctx_len; a.done = done; a.part = part_out; a.o_out = o_out;
+    a.Hkv = Hkv; a.page = page; a.max_pages = max_pages; a.scale = scale;
+    const int ns = o_out ? 1 : (nsplit > 0 ? nsplit : decode_attn_nsplit(B, Hkv));
+    if (ns > 16) return fail(EMMAX_ERR_INVALID, "emmax_op_decode_attention_kv8: nsplit %d > 16", ns);
+    int r = launch_decode_attn(a, B, Hq, 128, ns, (hipStream_t)st);
+    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_decode_attention_kv8: unsupported (GQA group in {1,2,4,8}, page = 2^k, max_pages <= 512, nsplit = 2^k)");
     return 0;
 }
 int emmax_op_gemv(const void* x, const void* W, void* y, int B, int N, int K, emmax_stream st) {

@@ -102,6 +102,8 @@ SIGNATURES = {
     "emmax_op_decode_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_float, C.POINTER(C.c_int), _vp]),
     "emmax_op_decode_attention_direct": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
+    "emmax_op_decode_attention_kv8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.c_float, _vp]),
     "emmax_op_gemv": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "emmax_op_resize_bicubic_u8": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "emmax_op_quant_fm8": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp]),

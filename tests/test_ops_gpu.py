@@ -725,6 +725,74 @@ def test_decode_attention_paged_matches_oracle(device, Hq, Hkv, ctxs):
     assert_elementwise(om, ref)
 
 
+def _quant_rows_e4m3(x):
+    """[..., 128] float -> (e4m3 bytes as uint8, fp32 scale per row = the smallest power of two with amax / scale <= 448, what the kernels
+    read back: e4m3 x scale, exact in bf16)."""
+    r = (x.abs().amax(dim=-1, keepdim=True).float() / 448.0)
+    sc = torch.where(r > 0, torch.exp2(torch.ceil(torch.log2(r.clamp_min(1e-38)))), torch.ones_like(r)).float()   # power of two (common.h: e4m3_row_scale)
+    q8 = (x.float() / sc).to(torch.float8_e4m3fn)
+    deq = (q8.float() * sc).to(torch.bfloat16).float()
+    return q8.view(torch.uint8), sc.squeeze(-1), deq
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(32, 32), (8, 2)])
+@pytest.mark.parametrize("ctxs", [[63], [64], [767], [1024], [1279], [768, 63, 1279], [1279, 1, 64, 1024, 65, 767, 1025, 300, 5, 900, 64, 128, 333, 1000, 2, 640]])
+def test_decode_attention_over_the_fp8_kv_cache(device, Hq, Hkv, ctxs):
+    """The opt-in fp8 KV cache (round 5, tuning switch kv_fp8): e4m3 K / V rows with one fp32 scale per (token, head) row.  The kernel
+    must (a) attend over bf16(e4m3 x scale) of the cached keys and of the step's NEW key (handed over as bf16 in the staging rows),
+    checked against an fp32 softmax over exactly those values, every split count and the direct form; (b) append the new key's bytes
+    and scale at position ctx_len -- checked against torch's own e4m3 rounding of the staged rows."""
+    L_, lib = _lib()
+    B, page, max_pages = len(ctxs), 64, 21
+    g = torch.Generator().manual_seed(Hq * 77 + sum(ctxs))
+    scale = 128 ** -0.5
+    q = bf(torch.randn(B, Hq, 128, generator=g))
+    K = [bf(torch.randn(c + 1, Hkv, 128, generator=g) * (0.5 + 2.0 * torch.rand(c + 1, Hkv, 1, generator=g))) for c in ctxs]   # keys 0..ctx; row scales vary
+    V = [bf(torch.randn(c + 1, Hkv, 128, generator=g) * (0.5 + 2.0 * torch.rand(c + 1, Hkv, 1, generator=g))) for c in ctxs]
+    K8, KS, KD = zip(*[_quant_rows_e4m3(k) for k in K])
+    V8, VS, VD = zip(*[_quant_rows_e4m3(v) for v in V])
+    rep = Hq // Hkv
+    ref = torch.empty(B, Hq, 128)
+    for b in range(B):
+        kk, vv = KD[b].repeat_interleave(rep, dim=1), VD[b].repeat_interleave(rep, dim=1)
+        att = torch.einsum("hd,lhd->hl", q[b].float(), kk) * scale
+        ref[b] = torch.einsum("hl,lhd->hd", F.softmax(att, dim=-1, dtype=torch.float32), vv)
+    # paged byte caches + scales holding keys 0 .. ctx - 1 (the new key, position ctx, arrives through the staging rows)
+    n_pages = B * max_pages
+    table = torch.randperm(n_pages, generator=g).view(B, max_pages).to(torch.int32)
+    kc = torch.randint(0, 120, (n_pages, Hkv, page, 128), generator=g, dtype=torch.uint8)     # garbage beyond the context must not matter
+    vc = torch.randint(0, 120, (n_pages, Hkv, page, 128), generator=g, dtype=torch.uint8)
+    ks, vs = torch.rand(n_pages, Hkv, page, generator=g), torch.rand(n_pages, Hkv, page, generator=g)
+    for b, c in enumerate(ctxs):
+        for t0 in range(0, c, page):
+            pg, n = int(table[b, t0 // page]), min(page, c - t0)
+            kc[pg, :, :n], vc[pg, :, :n] = K8[b][t0:t0 + n].transpose(0, 1), V8[b][t0:t0 + n].transpose(0, 1)
+            ks[pg, :, :n], vs[pg, :, :n] = KS[b][t0:t0 + n].transpose(0, 1), VS[b][t0:t0 + n].transpose(0, 1)
+    stage = torch.stack([torch.stack([K[b][ctxs[b]], V[b][ctxs[b]]], dim=1) for b in range(B)]).contiguous()   # [B][Hkv][2][128] bf16
+    qd, td, sd = q.view(B, Hq * 128).contiguous().to(device), table.to(device), stage.to(device)
+    ctx_d = torch.tensor(ctxs, dtype=torch.int32, device=device)
+    for nsplit in (1, 2, 8, 0):
+        kcd, vcd, ksd, vsd = kc.to(device), vc.to(device), ks.to(device), vs.to(device)
+        direct = nsplit == 0
+        part = torch.full((B, Hq, 16, 132), float("nan"), dtype=torch.float32, device=device)
+        o = torch.full((B, Hq * 128), float("nan"), dtype=torch.bfloat16, device=device)
+        L_.check(lib.emmax_op_decode_attention_kv8(qd.data_ptr(), kcd.data_ptr(), vcd.data_ptr(), ksd.data_ptr(), vsd.data_ptr(), sd.data_ptr(),
+                                                   td.data_ptr(), ctx_d.data_ptr(), None, None if direct else part.data_ptr(),
+                                                   o.data_ptr() if direct else None, B, Hq, Hkv, page, max_pages, max(nsplit, 1), scale, stream()),
+                 "decode attention kv8")
+        torch.cuda.synchronize()
+        got = o.float().cpu().view(B, Hq, 128) if direct else _merge_partials(part.view(-1)[: B * Hq * nsplit * 132].view(B, Hq, nsplit, 132).cpu(), nsplit)
+        assert torch.isfinite(got).all(), nsplit
+        assert relerr(got, ref) < (8e-3 if direct else 5e-3), (nsplit, relerr(got, ref))
+        # the appended row: bytes and scale at position ctx of every (row, head)
+        kc2, vc2, ks2, vs2 = kcd.cpu(), vcd.cpu(), ksd.cpu(), vsd.cpu()
+        for b, c in enumerate(ctxs):
+            pg, sl = int(table[b, c // page]), c % page
+            for got8, gots, want8, wants, wantd in ((kc2, ks2, K8[b][c], KS[b][c], KD[b][c]), (vc2, vs2, V8[b][c], VS[b][c], VD[b][c])):
+                assert torch.equal(gots[pg, :, sl], wants), (b, "scale")
+                assert torch.equal(got8[pg, :, sl], want8), (b, "bytes")     # power-of-two scale: both roundings are the same exact operation
+
+
 def test_decode_attention_done_rows_read_nothing(device):
     """Rows flagged done (finished / idle slots) must produce empty partials (m = -inf, l = 0) and leave the others untouched."""
     L_, lib = _lib()

@@ -273,3 +273,35 @@ def test_overlapped_admission_keeps_decoding_while_a_request_is_prefilled():
     assert {r.rid: r.ids for r in sch2.run()} == {r.rid: r.ids for r in res}
     with pytest.raises(ValueError):
         SlotScheduler(FakeEngine(plans), _encode_factory([]), n_slots=2, overlap=True)
+
+
+def test_a_failed_staged_prefill_requeues_its_requests_and_asks_for_staging_rows():
+    """`_start_admission` pops its batch off the queue before the engine call; if that call raises, the requests used to
+    be neither requeued nor reported.  Now they go back to the head of the queue in their order and the error reaches the caller --
+    a retry then serves everything.  Round 5 also: an overlapped scheduler asks the engine for as many staging rows as it has slots
+    (sessions hold none unless asked)."""
+    lengths = [5, 7, 3, 9, 4, 6]
+    plans = _plans(lengths)
+
+    class Flaky(FakeStagedEngine):
+        fail_next, asked = True, None
+
+        def ensure_stage_rows(self, n):
+            self.asked = n
+
+        def slots_prefill_staged(self, prompts, embeds, max_new):
+            if self.fail_next:
+                self.fail_next = False
+                raise RuntimeError("staged prefill failed")
+            return super().slots_prefill_staged(prompts, embeds, max_new)
+
+    eng = Flaky(plans, lag=1)
+    sch = SlotScheduler(eng, _encode_factory([]), n_slots=3, poll_every=1)
+    assert sch.overlap and eng.asked == 3
+    for i in range(len(lengths)):
+        sch.submit(Request(rid=i, frame=i, prompt_ids=[1, 9, i + 3]))
+    with pytest.raises(RuntimeError, match="staged prefill failed"):
+        sch.run()
+    assert [r.rid for r, _ in sch.queue] == list(range(len(lengths))) and sch._pending is None and not sch.active   # nothing lost, order kept
+    res = sch.run()                                                                                                   # the retry
+    assert sorted(r.rid for r in res) == list(range(len(lengths))) and all(r.ids == plans[r.rid] for r in res)

@@ -22,6 +22,10 @@ STAGE_OF = [  # (substring of the kernel name, stage)
     # batch >= 3 (PROBE_BATCH=8), round 3: the K-split MFMA kernels of decode_km.hip <MODE, NORM, XATTN, FP8, F8N> / the two-phase down kernel
     ("emmax_decode_km_kernel<0,", "qkv_gemv"), ("emmax_decode_km_kernel<1,", "oproj_gemv"), ("emmax_decode_km_kernel<2,", "gateup_gemv"),
     ("emmax_decode_km_kernel<3,", "lmhead_argmax"), ("emmax_decode_kmd_kernel<", "down_gemv"),
+    # batch 17-32 (round 5): decode_kmp.hip <MODE, NORM, R32, TMAX, NPH>; the down projection is its 11-phase RESID form
+    ("emmax_decode_kmp_kernel<0,", "qkv_gemv"), ("emmax_decode_kmp_kernel<1, false, true, 1, 11>", "down_gemv"),
+    ("emmax_decode_kmp_kernel<1, false, false, 1, 11>", "down_gemv"), ("emmax_decode_kmp_kernel<1,", "oproj_gemv"),
+    ("emmax_decode_kmp_kernel<2,", "gateup_gemv"), ("emmax_decode_kmp_kernel<3,", "lmhead_argmax"),
     # batch >= 3 (PROBE_BATCH=8): the MFMA small-batch kernel <MODE, NORM, XATTN, FP8>
     ("emmax_decode_mfma_kernel<0,", "qkv_gemv"), ("emmax_decode_mfma_kernel<1, false, true,", "oproj_gemv"),
     ("emmax_decode_mfma_kernel<2,", "gateup_gemv"), ("emmax_decode_mfma_kernel<1, false, false,", "down_gemv"),
@@ -35,16 +39,17 @@ def read(path, counter):
         for row in csv.DictReader(f):
             if row["Counter_Name"] != counter:
                 continue
-            for sub, stage in STAGE_OF:
+            for sub, stage in STAGE_OF:   # first match wins (more specific patterns are listed first)
                 if sub in row["Kernel_Name"]:
                     per.setdefault(stage, []).append(float(row["Counter_Value"]))
+                    break
     return {k: statistics.median(v) for k, v in per.items()}
 
 
 def main():
     fetch, write = read(sys.argv[1], "FETCH_SIZE"), read(sys.argv[2], "WRITE_SIZE")
     out = {"how": "rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --kernel-trace --kernel-include-regex emmax_decode "
-                  "-- python tools/pmc_probe.py (B=1, context 768, full-size layer shapes). FETCH_SIZE doubled: on gfx950 it reports 1/2 of a "
+                  "-- python tools/pmc_probe.py (PROBE_BATCH rows, context 768, full-size layer shapes). FETCH_SIZE doubled: on gfx950 it reports 1/2 of a "
                   "wide coalesced stream (MI355X_MICROARCH.md, HBM section); WRITE_SIZE taken as reported (uncalibrated).",
            "batch": int(sys.argv[4]) if len(sys.argv) > 4 else 1, "stages": {}}
     for stage in fetch:
