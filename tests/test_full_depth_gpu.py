@@ -131,12 +131,18 @@ def test_full_depth_random_weights_batch1(device, full, oracle_trace, bf16_yards
         assert e <= 1.25 * y + 2e-3, (t, e, y)
 
 
-def test_full_depth_random_weights_batch8_mfma_path(device, full, oracle_trace):
+@pytest.mark.parametrize("B", [8, 16, 32])
+def test_full_depth_random_weights_batch8_mfma_path(device, full, oracle_trace, B):
+    """B = 8: decode_km.hip; round 5: B = 16 (sixteen staged rows) and B = 32 (decode_kmp.hip: two batch tiles per weight tile) at all 32 layers."""
     _, model, _, _ = full
     frames, row, gen, trace = oracle_trace
-    worst, per_step, checked, agree, mm = _run(model, frames, row, gen, trace, 8, T_B8, device)
-    print("\nfull depth B=8: worst |err|/max|ref| per step:", " ".join(f"{v:.2e}" for v in per_step),
-          f"| argmax checked {checked}/{8 * T_B8} agreed {agree}")
+    if B > 8:
+        model.engine.new_session(B, 512, 256 + 512 + 32)
+    worst, per_step, checked, agree, mm = _run(model, frames, row, gen, trace, B, T_B8, device)
+    print(f"\nfull depth B={B}: worst |err|/max|ref| per step:", " ".join(f"{v:.2e}" for v in per_step),
+          f"| argmax checked {checked}/{B * T_B8} agreed {agree}")
+    if B > 8:
+        model.engine.new_session(8, 512, 256 + 512 + 32)
     assert all(np.isfinite(per_step))
     assert worst < TOL, (worst, per_step)
     assert agree == checked
