@@ -741,7 +741,8 @@ __global__ __launch_bounds__(256) void emmax_decode_embed_kernel(const int32_t* 
 // instead of 16, de-quantised in registers (v_cvt_scalef32_pk_bf16_fp8 with the row's scale) right before the dot products.  The key the
 // qkv launch of THIS step produced (position L - 1) waits as bf16 in p.kv_stage: every block quantises it itself (so that this step sees
 // the values every later step will read back) and split 0 appends bytes + scale to the cache.
-template <int HD, int G, bool DIRECT = false, int NW = 4, bool KV8 = false>
+// DEEP: four chunks of keys in flight per wave instead of two (always with KV8; bf16: tuning switch attn_deep)
+template <int HD, int G, bool DIRECT = false, int NW = 4, bool KV8 = false, bool DEEP = KV8>
 __global__ __launch_bounds__(NW * 64) void emmax_decode_attn_kernel(DecodeAttnParams p) {
     // waves per block: 4 (8-wave blocks were measured no faster at batch 1-2, where 512 four-wave blocks already put 8 waves on a CU,
     // DESIGN.md section 6); the one-split form of batch 5-8 is 256 blocks = ONE per CU: NW = 8 there (tuning switch attn_nw, round 5)
@@ -920,7 +921,7 @@ __global__ __launch_bounds__(NW * 64) void emmax_decode_attn_kernel(DecodeAttnPa
             m[gq] = mn;
         }
     };
-    if constexpr (KV8) {
+    if constexpr (DEEP) {
         // FOUR chunks in flight: at 8 bytes per lane and key two chunks are 8 KiB per wave -- the launch was a latency chain (one chunk
         // per ~1.1 us round trip: 18.9 us for 53 MB at batch 8); the raw bytes of four chunks take the registers two bf16 chunks did
         constexpr int CHK = (4 * NW) * KU;
@@ -1249,11 +1250,14 @@ int launch_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_dim
     dim3 grid(nsplit, p.Hkv, B), block(256);
     const int nw = emmax_tune().attn_nw;
     const bool nw8 = nw == 8 || (nw == 0 && p.o_out && (long)p.Hkv * B <= 256);
+    const bool deep = emmax_tune().attn_deep != 0 && G <= 2;   // (G >= 4: four chunks of K / V next to 4-8 query heads' state do not fit the registers)
     switch (G) {
 #define ATTN_CASE(GG)                                                                                                   \
     case GG:                                                                                                           \
         if (p.kv_stage && p.o_out) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true, 4, true>), grid, block, 0, stream, p); \
         else if (p.kv_stage) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, false, 4, true>), grid, block, 0, stream, p); \
+        else if (p.o_out && deep) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true, 4, false, true>), grid, block, 0, stream, p); \
+        else if (deep) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, false, 4, false, true>), grid, block, 0, stream, p); \
         else if (p.o_out && nw8) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true, 8>), grid, dim3(512), 0, stream, p); \
         else if (p.o_out) hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG, true>), grid, block, 0, stream, p);     \
         else hipLaunchKernelGGL((emmax_decode_attn_kernel<128, GG>), grid, block, 0, stream, p);                         \

@@ -1,4 +1,5 @@
-// decode_km.hip -- batch 3-8 decode projections with K <= 4096 on MFMA, K split across the waves of a block ("km").
+// decode_km.hip -- batch 3-16 decode projections with K <= 4096 on MFMA, K split across the waves of a block ("km"; round 5: rows 9-16 --
+// the batch is the 16-wide N side of the MFMA -- through the template argument NB; batches 17-32 are routed to decode_kmp.hip).
 // Replaces the q_len == 1 linears of HF `LlamaDecoderLayer` at small batch (cached branch of
 // prismatic/extern/hf/modeling_prismatic.py:325-341; the configs[2] per-GPU shard), like decode_mfma.hip, with the structure
 // that made the batch-1 kernel of decode_ks.hip faster:

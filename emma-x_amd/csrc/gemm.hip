@@ -687,6 +687,14 @@ __global__ __launch_bounds__(256, 2) void emmax_gemm_k32_kernel(GemmParams p) {
         glds16_group2(lds0 + slot * K32_STAGE + wave * 2048, offA_l[0], offA_l[1], baseA + ko);
         glds16_group4(lds0 + slot * K32_STAGE + K32_OPA + wave * 4096, offB_l[0], offB_l[1], offB_l[2], offB_l[3], baseB + ko);
     };
+    // lab (gemm_dbg bit 32): the same six requests in three pairs, issued BETWEEN the MFMA groups of the step instead of at its top
+    auto issue_part = [&](int kt, int slot, int part) {
+        const unsigned long long ko = (unsigned long long)(kbeg + kt) * (K32_BK * 2);
+        if (part == 0) glds16_group2(lds0 + slot * K32_STAGE + wave * 2048, offA_l[0], offA_l[1], baseA + ko);
+        else if (part == 1) glds16_group2(lds0 + slot * K32_STAGE + K32_OPA + wave * 4096, offB_l[0], offB_l[1], baseB + ko);
+        else glds16_group2(lds0 + slot * K32_STAGE + K32_OPA + wave * 4096 + 2048, offB_l[2] + 2048, offB_l[3] + 2048, baseB + ko);
+    };
+    const bool spread = (p.dbg & 32) != 0;
 
     // ---- fragment reads: lane (g, li) = row li of a 16-row tile, logical chunk g ----
     const int c0 = (g ^ k32_swz(li)) << 4;
@@ -725,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void emmax_gemm_k32_kernel(GemmParams p) {
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 bar();
             }
-            if (kt + 2 < nk) issue(kt + 2, st_2);
+            if (kt + 2 < nk && !spread) issue(kt + 2, st_2);
             int offs = st_i * K32_STAGE;
             asm volatile("" : "+s"(offs));
             const unsigned char* st = smem + offs;
@@ -743,6 +751,7 @@ __global__ __launch_bounds__(256, 2) void emmax_gemm_k32_kernel(GemmParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i & 3], acc[i][j], 0, 0, 0);
                 if (i + 2 < MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+                if (spread && kt + 2 < nk && (i == 1 || i == 3 || i == 5)) issue_part(kt + 2, st_2, i >> 1);
             }
             st_i = st_i == 2 ? 0 : st_i + 1;
         }
@@ -776,7 +785,9 @@ int launch_k32_t(const GemmParams& p, hipStream_t stream) {
     const int tiles = cdiv(p.M, GeomK32::BM) * cdiv(p.N, GeomK32::BN) * (p.ksplit > 1 ? p.ksplit : 1);
     const int resident = 512;   // two blocks per CU
     const int grid = tiles < resident ? (tiles + 7) / 8 * 8 : resident;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), K32_SMEM, stream, p);
+    GemmParams q = p;
+    q.dbg |= emmax_tune().gemm_dbg;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), K32_SMEM, stream, q);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 int launch_k32(const GemmParams& p, hipStream_t stream) {

@@ -128,6 +128,7 @@ struct EmmaxTune {
     int km;              // 1: batch >= 3 (and fp8) projections on decode_km.hip; 0: decode_mfma.hip
     int km_down;         // 1: ... including the two-phase down projection
     int km_roll;         // 1: decode_km.hip refills a weight register as soon as its MFMA has issued (rolling ring); 0: a tile's sixteen refills together
+    int attn_deep;       // 1: the bf16 decode attention keeps four chunks of keys in flight per wave (the fp8-cache form always does); 0: two
     int attn_nw;         // waves per decode-attention block: 0 = by shape (4; 8 for the one-split form when that leaves <= 256 blocks), 4 / 8 forced
     int streamk;         // 1: stream-K work split in decode_mfma.hip; 0: whole tasks per block
     int fp8_gemv;        // -1: default routing of the batch 1-2 fp8 projections; >= 0: bit mask (1 qkv, 2 o-proj, 4 gate/up, 8 down, 16 lm-head) on the row GEMV
@@ -260,7 +261,7 @@ int launch_set_tokens(int32_t* cur_tok, const int32_t* toks, int B, int32_t* don
                       int budget, hipStream_t stream);
 
 
-// ---- decode_km.hip: batch 3-8 projections with K <= 4096 on MFMA, K split across the waves, activations as register fragments ----
+// ---- decode_km.hip: batch 3-16 projections with K <= 4096 on MFMA, K split across the waves, activations as register fragments ----
 // p.W = the km copy (launch_repack_km: fragment-major tiles; perm 1 / 2 = the row orders that put the qkv RoPE pairs / the
 // (gate, up) pairs inside one 16-row tile).  -2: shape outside the kernel, the caller falls back to launch_decode_mfma.
 int launch_repack_km(const void* src, int ld, void* dst, int N, int K, int perm, int head_dim, hipStream_t stream);

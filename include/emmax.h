@@ -301,7 +301,8 @@ int emmax_op_resize_bicubic_u8(const uint8_t* src_dev, int B, int H, int W, uint
 int emmax_op_quant_fm8(const void* W_dev, int ld, void* W8_fm_out_dev, float* scales_out_dev, int N, int K, emmax_stream stream);
 int emmax_op_gemm_small_fp8(const void* x_dev, const void* W8_fm_dev, const float* scales_dev, void* y_dev, int B, int N, int K,
                             emmax_stream stream);
-/* Batch 3-8 decode projection on the K-split MFMA kernel (decode_km.hip; what emmax_decode_step runs for qkv / o-proj / gate-up /
+/* Batch 3-32 decode projection on the K-split MFMA kernels (decode_km.hip up to 16 rows, decode_kmp.hip above; K > 4096: the phased kernel of the
+ * down projection, y = W x through a zeroed residual; what emmax_decode_step runs for qkv / o-proj / gate-up /
  * lm-head at batch >= 3): W_km = emmax_op_repack_km(W row-major [N, ld]) -- fragment-major 16-row tiles, perm 0 natural row order,
  * 1 = qkv (rows d and d + head_dim/2 of a head in one tile), 2 = gate/up (gate_g and up_g in one tile; source in the 16-row
  * interleaved order of the model arena).  y bf16 [B, N] = x bf16 [B, K] W^T (perm 0).  K % 256 == 0, K <= 4096. */
