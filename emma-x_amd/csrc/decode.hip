@@ -1250,7 +1250,10 @@ int launch_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_dim
     dim3 grid(nsplit, p.Hkv, B), block(256);
     const int nw = emmax_tune().attn_nw;
     const bool nw8 = nw == 8 || (nw == 0 && p.o_out && (long)p.Hkv * B <= 256);
-    const bool deep = emmax_tune().attn_deep != 0 && G <= 2;   // (G >= 4: four chunks of K / V next to 4-8 query heads' state do not fit the registers)
+    // four chunks of keys in flight (bf16 cache): measured on one box (profiles/r05_attn_deep_k32_spread_ab.txt) -- B = 32 (1024 blocks, four
+    // per CU) 73.0 -> 68.5 us per launch, B = 8 / 16 (256 / 512 blocks) 20.0 -> 20.6 / 36.9 -> 37.3: on from 1024 blocks (-1 = that rule)
+    const int deep_sw = emmax_tune().attn_deep;
+    const bool deep = G <= 2 && (deep_sw > 0 || (deep_sw < 0 && (long)nsplit * p.Hkv * B >= 1024));   // (G >= 4: no registers for it)
     switch (G) {
 #define ATTN_CASE(GG)                                                                                                   \
     case GG:                                                                                                           \

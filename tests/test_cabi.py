@@ -80,12 +80,15 @@ def test_tuning_switches_are_a_table_with_a_setter(lib):
     """The library reads EMMAX_<NAME> once; afterwards only emmax_tuning_set moves a switch (no launcher calls getenv)."""
     L, so = lib
     names = ["graph", "ks", "ks_oproj", "ks_oproj_grid", "km", "km_down", "streamk", "fp8_gemv", "attn_nsplit", "attn_direct", "fold_embed",
-             "mfma_xbar", "gemm_big", "gemm_splitk", "gemm_hybrid", "gemm_normfuse", "gemm_deep", "gemm_lnfuse", "attn_resident"]
+             "mfma_xbar", "gemm_big", "gemm_splitk", "gemm_hybrid", "gemm_normfuse", "gemm_deep", "gemm_lnfuse", "attn_resident",
+             "resid32", "kv_fp8", "km_roll", "attn_nw", "attn_deep"]   # (the last five: round 5)
     header = open(os.path.join(ROOT, "include", "emmax.h")).read()
     for n in names:
         assert re.search(r"\b%s\b" % n, header), n
         L.tuning_get(n)
     assert L.tuning_get("graph") == int(os.environ.get("EMMAX_GRAPH", "0")) and L.tuning_get("ks") == int(os.environ.get("EMMAX_KS", "1"))
+    # the product defaults of round 5: fp32 residual stream on, bf16 KV cache
+    assert L.tuning_get("resid32") == int(os.environ.get("EMMAX_RESID32", "1")) and L.tuning_get("kv_fp8") == int(os.environ.get("EMMAX_KV_FP8", "0"))
     with L.tuning(graph=1, attn_nsplit=4):
         assert L.tuning_get("graph") == 1 and L.tuning_get("attn_nsplit") == 4
         os.environ["EMMAX_GRAPH"] = "0"          # the environment is not consulted again
