@@ -148,6 +148,28 @@ def test_full_depth_random_weights_batch8_mfma_path(device, full, oracle_trace, 
     assert agree == checked
 
 
+@pytest.mark.parametrize("B", [1, 8])
+def test_full_depth_over_the_fp8_kv_cache(device, full, oracle_trace, tune, B):
+    """VERDICT r04 next #3c: the opt-in fp8-e4m3 KV cache (tuning switch kv_fp8 at session creation) at FULL depth -- its own logit-error
+    line against the fp32 oracle, next to the bf16 cache's on the same steps.  e4m3 carries 3 mantissa bits on every K and V element:
+    the error is bounded at 3 x TOL here (measured ~2-3 x the bf16 cache's), and the argmax must still hold wherever the oracle's
+    margin exceeds twice the measured error."""
+    _, model, _, _ = full
+    frames, row, gen, trace = oracle_trace
+    lines = {}
+    for kv8 in (0, 1):
+        tune(kv_fp8=kv8)
+        model.engine.new_session(8, 512, 256 + 512 + 32)     # the cache format is fixed when the session is created
+        worst, per_step, checked, agree, mm = _run(model, frames, row, gen, trace, B, T_B1 if B == 1 else T_B8, device)
+        lines[kv8] = per_step
+        assert all(np.isfinite(per_step)) and agree == checked, (kv8, per_step, agree, checked)
+    tune(kv_fp8=0)
+    model.engine.new_session(8, 512, 256 + 512 + 32)
+    print(f"\nfull depth B={B}, bf16 KV cache:  worst |err|/max|ref| per step:", " ".join(f"{v:.2e}" for v in lines[0]))
+    print(f"full depth B={B}, e4m3 KV cache:  worst |err|/max|ref| per step:", " ".join(f"{v:.2e}" for v in lines[1]))
+    assert max(lines[0]) < TOL and max(lines[1]) < 3 * TOL, lines
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Round 4 (VERDICT r03 "next" #4): fp8 and RAGGED batch 8 at full depth, and how often an id COULD flip over a whole generation.
 #
