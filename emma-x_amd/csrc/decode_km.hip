@@ -627,7 +627,7 @@ int launch_repack_km(const void* src, int ld, void* dst, int N, int K, int perm,
 // row order).  -2: shape outside this kernel (K % 256, K > 4096, more than 8 tiles per block) -- the caller uses decode_mfma.hip.
 int launch_decode_km(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
     if (B < 1 || B > EMMAX_MAX_DECODE_BATCH) return -2;
-    if (B > 16) return launch_decode_kmp(mode, p, B, stream, grid_out);   // two batch tiles: decode_kmp.hip (bf16 weights)
+    if (B > 16) return launch_decode_kmp(mode, p, B, stream, grid_out);   // two batch tiles: decode_kmp.hip
     if (decode_km_init() != 0) return -4;
     if (mode == GEMV_RESID && !p.attn_part && p.K > KM_WAVES * KM_STEPS * 32) {   // the down projection: two K phases (natural row order copy)
         if (!emmax_tune().km_down) return -2;   // A/B partner: decode_mfma.hip

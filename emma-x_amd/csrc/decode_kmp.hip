@@ -11,8 +11,11 @@
 // one computes.  The loop nest is (phase, tile, step) and the weight registers form a ring over it: the register of unit (phase, tile,
 // step) is refilled with (phase + LOOK, tile, step) as soon as its two MFMAs have issued, so TMAX x PH x LOOK KiB per wave stay in
 // flight whatever the tile count -- three shapes: TMAX = 6 tiles x 1 phase of lookahead (gate/up, lm-head), 3 x 2 (qkv), 1 x 4 (o-proj:
-// the whole slice at once).  Same weight copies as decode_km.hip (launch_repack_km), same fused prologues / epilogues, same arithmetic
-// (y = rstd * W (x .* g), the eight K-slice partial tiles meet in LDS at the end of the block).
+// the whole slice at once).  Same weight copies as decode_km.hip (launch_repack_km; with fp8 weights the e4m3 tiles of 16 rows x 64 k
+// and a scale per row: a load step is then two fragments, converted to bf16 in registers, and the lookahead counts twice the phases
+// for the same bytes in flight), same fused prologues / epilogues, same arithmetic (y = rstd * W (x .* g), the eight K-slice partial
+// tiles meet in LDS at the end of the block).  The K slices of the waves are whole load steps and may differ by one (the fp8 down
+// projection: 172 steps over 8 waves).
 #include <cstdlib>
 #include <type_traits>
 
@@ -29,19 +32,34 @@ constexpr int KP_ROWS = 32;                 // staged batch rows = two MFMA batc
 constexpr int KP_XP = KP_PH * 64 + 16;      // window pitch in bytes (+16: the rows of a fragment read start on different bank slots)
 constexpr int KP_RPL = KP_ROWS * KP_PH * 4 / 64;   // 16-byte chunks per lane and phase: rows (lane >> 4) + 4 j, chunk lane & 15
 
-template <int TMAX> struct KpLook { static constexpr int L = TMAX >= 4 ? 1 : TMAX >= 2 ? 2 : 4; };   // phases of weights in flight
+// phases of weights in flight (fp8 tiles carry 64 k per KiB: twice the phases for the same bytes)
+template <int TMAX, bool FP8> struct KpLook { static constexpr int L = (TMAX >= 4 ? 1 : TMAX >= 2 ? 2 : 4) * (FP8 ? 2 : 1); };
 
-template <int MODE, bool NORM, bool R32, int TMAX, int NPH>
+// two fp8 e4m3 pairs (the low / high half of a dword) -> two bf16, exact (as decode_km.hip)
+template <bool HI>
+__device__ __forceinline__ uint32_t kp_fp8x2(uint32_t v) {
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, HI));
+}
+__device__ __forceinline__ bf16x8_t kp_fp8x8(uint32_t lo, uint32_t hi) {
+    const u32x4_t v = {kp_fp8x2<false>(lo), kp_fp8x2<true>(lo), kp_fp8x2<false>(hi), kp_fp8x2<true>(hi)};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int MODE, bool NORM, bool R32, int TMAX, int NPH, bool FP8>
 __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvParams p) {
     constexpr int KP_NPH = NPH;
     extern __shared__ __attribute__((aligned(16))) unsigned char kp_smem[];
-    constexpr int LOOK = KpLook<TMAX>::L;
-    constexpr int RING = TMAX * KP_PH * LOOK;          // weight registers (16-byte loads of 1 KiB tiles) of a wave
+    constexpr int LOOK = KpLook<TMAX, FP8>::L;
+    constexpr int KS = FP8 ? 64 : 32;                  // elements per load step (one 1 KiB tile)
+    constexpr int PHS = KP_PH * 32 / KS;               // load steps per phase
+    constexpr int RING = TMAX * PHS * LOOK;            // weight registers (16-byte loads of 1 KiB tiles) of a wave
     constexpr int WREG = TMAX * 2048 > KP_ROWS * KP_XP ? TMAX * 2048 : KP_ROWS * KP_XP;   // a wave's LDS region: window, later its partial tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g4 = lane >> 4, c16 = lane & 15;
     const int B = p.batch, K = p.K;
-    const int KT = K / 32, KTW = KT / KP_WAVES;        // k-steps of a row / of this wave's slice (launcher: K % 256 == 0, KTW <= 4 NPH)
+    const int KT = K / KS;                             // load steps of a row
+    const int kq = KT / KP_WAVES, kr = KT % KP_WAVES;
+    const int k_lo = wave * kq + min(wave, kr), k_n = kq + (wave < kr ? 1 : 0);   // this wave's load steps (launcher: k_n <= NPH PHS)
     unsigned char* xw = kp_smem + (size_t)wave * WREG;                     // this wave's window [32][KP_XP]
     auto part_of = [&](int w) { return (float*)(kp_smem + (size_t)w * WREG); };   // [TMAX][2][64][4]
     float* sumsq = (float*)(kp_smem + (size_t)KP_WAVES * WREG);            // [KP_WAVES][32]
@@ -93,16 +111,16 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
     }
 
     // ---- weight stream: buffer loads, the (tile, step) offset in an SGPR, the lane's 16 bytes in the VGPR offset ----
-    const unsigned w_bytes = (unsigned)((size_t)p.n_groups * 16 * (size_t)K * 2);
+    const unsigned w_bytes = (unsigned)((size_t)p.n_groups * 16 * (size_t)K * (FP8 ? 1 : 2));
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)w_bytes, 0x00020000);
     const unsigned voff = (unsigned)lane * 16u;
     u32x4_t w[RING];
-    // unit (ph, tl, s) lives in register ((ph % LOOK) * TMAX + tl) * KP_PH + s; past the block's tiles / the slice: out of range = zeros, no traffic
+    // unit (ph, tl, s) lives in register ((ph % LOOK) * TMAX + tl) * PHS + s; past the block's tiles / the slice: out of range = zeros, no traffic
     auto issue_w = [&](int ph, int tl, int s) {
-        const int ks = ph * KP_PH + s;
-        const int ok = (ph < KP_NPH && tl < ntb && ks < KTW) ? -1 : 0;
-        const unsigned so = ((unsigned)(((t_lo + tl) * KT + wave * KTW + ks) * 1024) & (unsigned)ok) | (w_bytes & (unsigned)~ok);
-        w[((ph % LOOK) * TMAX + tl) * KP_PH + s] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, so, 2));   // aux 2 = nt
+        const int ks = ph * PHS + s;
+        const int ok = (ph < KP_NPH && tl < ntb && ks < k_n) ? -1 : 0;
+        const unsigned so = ((unsigned)(((t_lo + tl) * KT + k_lo + ks) * 1024) & (unsigned)ok) | (w_bytes & (unsigned)~ok);
+        w[((ph % LOOK) * TMAX + tl) * PHS + s] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, so, 2));   // aux 2 = nt
     };
 
     // ---- activations of a phase: lane l holds chunk l & 15 (8 elements) of rows (l >> 4) + 4 j of the phase's 128-element slice ----
@@ -111,7 +129,7 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
     float ssl[KP_RPL];   // NORM: this lane's running sum of squares of rows r0 + 4 j
 #pragma unroll
     for (int j = 0; j < KP_RPL; ++j) ssl[j] = 0.f;
-    auto phase_live = [&](int ph) { return ph * KP_PH * 4 + c16 < KTW * 4; };   // the lane's chunk lies inside the wave's slice
+    auto phase_live = [&](int ph) { return ph * KP_PH * 4 + c16 < k_n * (KS / 8); };   // the lane's chunk lies inside the wave's slice
     // rows as buffer loads: one descriptor, a 32-bit lane offset per row (8 registers instead of 8 x 64-bit addresses per phase -- the
     // row requests of the three later phases had their addresses precomputed and held), the phase in the scalar offset; a chunk past the
     // slice reads the neighbouring slice or, past the matrix, zeros: it is masked at the store either way
@@ -121,7 +139,7 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
 #pragma unroll
     for (int j = 0; j < KP_RPL; ++j) xvoff[j] = (unsigned)min(r0 + 4 * j, B - 1) * (unsigned)p.ldx * 2u + (unsigned)c16 * 16u;
     auto load_rows = [&](int ph) {
-        const unsigned so = (unsigned)(wave * KTW * 32 + ph * KP_PH * 32) * 2u;   // first byte of the phase inside a row
+        const unsigned so = (unsigned)(k_lo * KS + ph * KP_PH * 32) * 2u;   // first byte of the phase inside a row
 #pragma unroll
         for (int j = 0; j < KP_RPL; ++j) xr[j] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xvoff[j], so, 0));
         if constexpr (NORM) nwv = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(nrsrc, (unsigned)c16 * 16u, so, 0));
@@ -155,7 +173,7 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
 #pragma unroll
         for (int tl = 0; tl < TMAX; ++tl)
 #pragma unroll
-            for (int s = 0; s < KP_PH; ++s) issue_w(ph, tl, s);
+            for (int s = 0; s < PHS; ++s) issue_w(ph, tl, s);
     __builtin_amdgcn_sched_barrier(0);
     store_rows(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -189,11 +207,20 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
         __builtin_amdgcn_sched_barrier(0);                                                                              \
         _Pragma("unroll") for (int tl = 0; tl < TMAX; ++tl) {                                                           \
             if (TMAX <= 3 || tl < ntb) { /* block-uniform; small shapes run straight-line (a missing tile: zero weights) */ \
-                _Pragma("unroll") for (int s = 0; s < KP_PH; ++s) {                                                     \
-                    constexpr int slot0 = (ph % LOOK) * TMAX * KP_PH;                                                   \
-                    const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, w[slot0 + tl * KP_PH + s]);                        \
-                    acc[tl][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[s][0], acc[tl][0], 0, 0, 0);            \
-                    acc[tl][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[s][1], acc[tl][1], 0, 0, 0);            \
+                _Pragma("unroll") for (int s = 0; s < PHS; ++s) {                                                       \
+                    constexpr int slot0 = (ph % LOOK) * TMAX * PHS;                                                     \
+                    const u32x4_t wv = w[slot0 + tl * PHS + s];                                                         \
+                    if constexpr (FP8) { /* a 16 x 64 e4m3 tile: two bf16 fragments */                                  \
+                        const bf16x8_t wlo = kp_fp8x8(wv[0], wv[1]), whi = kp_fp8x8(wv[2], wv[3]);                      \
+                        acc[tl][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xf[2 * s][0], acc[tl][0], 0, 0, 0);   \
+                        acc[tl][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, xf[2 * s][1], acc[tl][1], 0, 0, 0);   \
+                        acc[tl][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xf[2 * s + 1][0], acc[tl][0], 0, 0, 0); \
+                        acc[tl][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, xf[2 * s + 1][1], acc[tl][1], 0, 0, 0); \
+                    } else {                                                                                            \
+                        const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wv);                                           \
+                        acc[tl][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[s][0], acc[tl][0], 0, 0, 0);        \
+                        acc[tl][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[s][1], acc[tl][1], 0, 0, 0);        \
+                    }                                                                                                   \
                     issue_w(ph + LOOK, tl, s); /* the register's unit LOOK phases ahead */                              \
                 }                                                                                                       \
             }                                                                                                           \
@@ -249,6 +276,13 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
             const float sc = rsqrtf(t / (float)K + p.eps);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { v[j] *= sc; u[j] *= sc; }
+        }
+        if constexpr (FP8) {   // per-row weight scales (km row order)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] *= p.wscale[e_tile * 16 + 4 * e_rq + j];
+                if (e_pairs) u[j] *= p.wscale[e_tile * 16 + 8 + 4 * e_rq + j];
+            }
         }
         const int row0 = e_tile * 16 + 4 * e_rq;   // natural-order matrices
         if (MODE == GEMV_PLAIN) {
@@ -334,9 +368,9 @@ template <int TMAX> constexpr size_t kp_smem_bytes() {
     return (size_t)KP_WAVES * (TMAX * 2048 > KP_ROWS * KP_XP ? TMAX * 2048 : KP_ROWS * KP_XP) + KP_WAVES * 32 * 4;
 }
 
-template <int MODE, bool NORM, bool R32, int TMAX, int NPH = 4>
+template <int MODE, bool NORM, bool R32, int TMAX, int NPH, bool FP8>
 int kp_launch_r(const GemvParams& p, int grid, hipStream_t stream) {
-    auto kern = emmax_decode_kmp_kernel<MODE, NORM, R32, TMAX, NPH>;
+    auto kern = emmax_decode_kmp_kernel<MODE, NORM, R32, TMAX, NPH, FP8>;
     static bool attr_done = false;   // per instantiation (first call: outside graph capture -- decode_kmp_init)
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kp_smem_bytes<TMAX>()) != hipSuccess) return -4;
@@ -346,15 +380,23 @@ int kp_launch_r(const GemvParams& p, int grid, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-template <int MODE, bool NORM, int TMAX, int NPH = 4>
-int kp_launch_tm(const GemvParams& p, int grid, bool r32, bool init_only, hipStream_t stream) {
+template <int MODE, bool NORM, int TMAX, int NPH, bool FP8>
+int kp_launch_tf(const GemvParams& p, int grid, bool r32, bool init_only, hipStream_t stream) {
     if constexpr (MODE == GEMV_RESID) {   // (NORM modes read the bf16 mirror of the fp32 residual stream, as in decode_km.hip)
         if (init_only || r32) {
-            const int r = kp_launch_r<MODE, NORM, true, TMAX, NPH>(p, init_only ? 0 : grid, stream);
+            const int r = kp_launch_r<MODE, NORM, true, TMAX, NPH, FP8>(p, init_only ? 0 : grid, stream);
             if (r || !init_only) return r;
         }
     }
-    return kp_launch_r<MODE, NORM, false, TMAX, NPH>(p, init_only ? 0 : grid, stream);
+    return kp_launch_r<MODE, NORM, false, TMAX, NPH, FP8>(p, init_only ? 0 : grid, stream);
+}
+template <int MODE, bool NORM, int TMAX, int NPH = 4>
+int kp_launch_tm(const GemvParams& p, int grid, bool r32, bool init_only, hipStream_t stream) {
+    if (init_only || p.wscale) {
+        const int r = kp_launch_tf<MODE, NORM, TMAX, NPH, true>(p, grid, r32, init_only, stream);
+        if (r || !init_only) return r;
+    }
+    return kp_launch_tf<MODE, NORM, TMAX, NPH, false>(p, grid, r32, init_only, stream);
 }
 
 template <int MODE, bool NORM>
@@ -368,7 +410,9 @@ int kp_launch_t(GemvParams p, int B, hipStream_t stream, int* grid_out, bool ini
         }
         return r;
     }
-    if (p.K % (KP_WAVES * 32) || p.K > KP_WAVES * 11 * KP_PH * 32 || p.n_rows % 16 || p.wscale || p.attn_part) return -2;
+    // K in whole load steps (32 elements; 64 with fp8 tiles), at least one per wave, a wave's share within eleven phases
+    const int ks_el = p.wscale ? 64 : 32;
+    if (p.K % ks_el || p.K / ks_el < KP_WAVES || cdiv(p.K / ks_el, KP_WAVES) * ks_el > 11 * KP_PH * 32 || p.n_rows % 16 || p.attn_part) return -2;
     if (MODE == GEMV_QKV && (p.head_dim % 16 || p.head_dim < 16)) return -2;
     p.batch = B;
     p.n_groups = p.n_rows / 16;   // tiles
@@ -378,7 +422,7 @@ int kp_launch_t(GemvParams p, int B, hipStream_t stream, int* grid_out, bool ini
     if (grid_out) *grid_out = grid;
     const int tpb = cdiv(p.n_groups, grid);
     const bool r32 = MODE == GEMV_RESID && p.h32 != nullptr;
-    if (p.K > KP_WAVES * 4 * KP_PH * 32) {   // the down projection: eleven phases, one tile per block
+    if (cdiv(p.K / ks_el, KP_WAVES) * ks_el > 4 * KP_PH * 32) {   // the down projection: eleven phases, one tile per block
         if constexpr (MODE == GEMV_RESID || MODE == GEMV_PLAIN) {
             if (tpb <= 1) return kp_launch_tm<MODE, NORM, 1, 11>(p, grid, r32, false, stream);
         }
@@ -413,7 +457,8 @@ int decode_kmp_init() {
     return done;
 }
 
-// p.W: the km copy of the matrix (launch_repack_km), bf16.  -2: shape outside this kernel (K % 256, K > 4096, fp8 weights, the o-proj's split merge)
+// p.W: the km copy of the matrix (launch_repack_km; fp8: decode_mfma.hip's e4m3 tiles of the permuted rows + p.wscale in the same row
+// order).  -2: shape outside this kernel (K not in whole load steps, a wave's share beyond eleven phases, the o-proj's split merge)
 int launch_decode_kmp(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
     if (B < 17 || B > 32) return -2;
     if (decode_kmp_init() != 0) return -4;

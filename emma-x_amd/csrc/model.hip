@@ -596,8 +596,9 @@ static int model_max_decode_batch(const emmax_model* m) {
     const int kd = m->fp8 ? 64 : 32;
     const bool d_ok = m->inter_p % kd == 0 && m->inter_p / kd >= 8 && (m->inter_p / kd + 7) / 8 <= (m->fp8 ? 24 : 48) && m->inter_p > 4096;
     if (!(k_ok && n_ok && d_ok && decode_km_enabled() && emmax_tune().km_down)) return 8;
-    // 17-32 rows: decode_kmp.hip -- bf16 weights, the down projection within eleven phases of four k-steps per wave (K <= 11264, K % 256 == 0)
-    const bool p_ok = !m->fp8 && m->inter_p % 256 == 0 && m->inter_p <= 11264 && m->H <= 4096 && m->H / 16 <= 256;
+    // 17-32 rows: decode_kmp.hip -- the down projection within eleven phases of 128 elements per wave (K in whole load steps of 32
+    // elements, 64 with fp8 tiles; the widest wave share <= 1408 elements: K <= 11264), one tile per block there (H <= 4096)
+    const bool p_ok = ((m->inter_p / kd + 7) / 8) * kd <= 11 * 128 && m->H <= 4096 && m->H / 16 <= 256;
     return p_ok ? EMMAX_MAX_DECODE_BATCH : 16;
 }
 
@@ -1752,9 +1753,17 @@ int emmax_op_gemm_small_fp8(const void* x, const void* W8, const float* scales, 
     memset(&p, 0, sizeof(p));
     p.x = x; p.ldx = K; p.W = W8; p.ldw = K; p.K = K; p.y = y; p.ldy = N; p.n_rows = N; p.wscale = scales;
     if (!scales) return fail(EMMAX_ERR_INVALID, "emmax_op_gemm_small_fp8: scales required");
-    if (decode_mfma_init() != 0) return fail(EMMAX_ERR_HIP, "could not raise the dynamic LDS limit of the MFMA decode kernels");
-    int r = launch_decode_mfma(GEMV_PLAIN, p, B, (hipStream_t)st);
-    if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_gemm_small_fp8: unsupported shape (1 <= B <= 8, N %% 16, K %% 64)");
+    int r;
+    if (B <= 8) {   // decode_mfma.hip stages eight rows
+        if (decode_mfma_init() != 0) return fail(EMMAX_ERR_HIP, "could not raise the dynamic LDS limit of the MFMA decode kernels");
+        r = launch_decode_mfma(GEMV_PLAIN, p, B, (hipStream_t)st);
+    } else if (K > 4096) {   // 9-32 rows: the K-split kernels (natural row order: the same e4m3 tiles); the phased down form is y = h + W x: h = 0
+        HIPCHK(hipMemsetAsync(y, 0, (size_t)B * N * 2, (hipStream_t)st));
+        r = launch_decode_km(GEMV_RESID, p, B, (hipStream_t)st);
+    } else {
+        r = launch_decode_km(GEMV_PLAIN, p, B, (hipStream_t)st);
+    }
+    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_gemm_small_fp8: unsupported shape (N %% 16, K %% 64; 1 <= B <= 8; 9 <= B <= 32: the shapes of emmax_op_gemm_small_km)");
     return 0;
 }
 int emmax_op_repack_fm(const void* W, int ld, void* W_fm, int N, int K, emmax_stream st) {
@@ -1778,7 +1787,7 @@ int emmax_op_gemm_small_km(const void* x, const void* W_km, void* y, int B, int 
     } else {
         r = launch_decode_km(GEMV_PLAIN, p, B, (hipStream_t)st);
     }
-    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_gemm_small_km: unsupported shape (1 <= B <= 32, N %% 16; K %% 256 and K <= 4096 and N <= 32768, or the phased form: K %% 32, K <= 11264 at B <= 8, 12288 at B <= 16; B > 16: K %% 256, K <= 11264, N <= 4096 there)");
+    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_gemm_small_km: unsupported shape (1 <= B <= 32, N %% 16; K %% 256 and K <= 4096 and N <= 32768, or the phased form: K %% 32, K <= 11264 at B <= 8, 12288 at B <= 16; B > 16: K %% 32, K <= 11264, N <= 4096 there)");
     return 0;
 }
 int emmax_op_gemm_small(const void* x, const void* W_fm, void* y, int B, int N, int K, emmax_stream st) {

@@ -103,8 +103,8 @@ void emmax_model_destroy(emmax_model* m);
 int emmax_model_bind_weight(emmax_model* m, const char* hf_key, const void* ptr_dev, int dtype,
                             const int64_t* shape, int ndim);
 int64_t emmax_model_arena_bytes(const emmax_model* m);
-/* rows of one decode batch / slot set this model can run: 32 (bf16 weights) / 16 (fp8) when every LLM projection is a shape the K-split
- * MFMA kernels take (K % 256 == 0 and <= 4096, N <= 32768, intermediate size % 256 == 0 and <= 11264: LLaMA-2-7B is), else 8 (round 5;
+/* rows of one decode batch / slot set this model can run: 32 (bf16 or fp8 weights) when every LLM projection is a shape the K-split
+ * MFMA kernels take (K % 256 == 0 and <= 4096, N <= 32768, intermediate size % 32 (fp8: % 64) == 0 and <= 11264: LLaMA-2-7B is), else 8 (round 5;
  * rounds 1-4: 8) */
 int emmax_model_max_decode_batch(const emmax_model* m);
 int emmax_model_finalize(emmax_model* m, void* arena_dev, int64_t arena_bytes, emmax_stream stream);
@@ -297,7 +297,9 @@ int emmax_op_resize_bicubic_u8(const uint8_t* src_dev, int B, int H, int W, uint
                                const int32_t* kk_v_dev, int ksize_v, emmax_stream stream);
 
 /* fp8 variant: quantise a row-major bf16 [N,ld] matrix to e4m3 fragment-major tiles + fp32 per-row scales (N % 16, K % 64),
- * and the matching small-batch projection (activations bf16, weights de-quantised in registers). */
+ * and the matching small-batch projection (activations bf16, weights de-quantised in registers).  B <= 8: decode_mfma.hip; 9-32 rows:
+ * the K-split kernels over the same tiles (decode_km.hip 9-16: K % 512 == 0 up to 4096 or the phased form above; decode_kmp.hip 17-32:
+ * K % 64 == 0, K >= 512, the widest wave share <= 1408 elements), EMMAX_ERR_INVALID outside those shapes. */
 int emmax_op_quant_fm8(const void* W_dev, int ld, void* W8_fm_out_dev, float* scales_out_dev, int N, int K, emmax_stream stream);
 int emmax_op_gemm_small_fp8(const void* x_dev, const void* W8_fm_dev, const float* scales_dev, void* y_dev, int B, int N, int K,
                             emmax_stream stream);

@@ -474,12 +474,13 @@ def test_gemm_small_mfma(device, B, N, K):
 
 @pytest.mark.parametrize("B", [17, 24, 32])
 @pytest.mark.parametrize("N,K", [(256, 256), (4096, 4096), (12288, 4096), (22016, 4096), (32064, 4096), (1008, 1024), (48, 2048), (4096, 11008), (64, 8192),
-                                 (48, 11264), (512, 3072)])
+                                 (48, 11264), (512, 3072), (64, 320), (32, 11040)])
 def test_gemm_small_kmp(device, B, N, K):
     """Batch 17-32 decode projection (decode_kmp.hip, round 5): two 16-wide batch tiles per weight tile, the wave's K slice in phases of
     four k-steps through a 32-row LDS window, accumulators of all tiles of the block in registers.  N covers the three block shapes
     (1, <= 3, <= 6 tiles per block; 32064: more blocks than CUs), K the 4-phase form (<= 4096, incl. slices shorter than four phases)
-    and the 11-phase form of the down projection (K = 11008, 8192, 11264 = its limit)."""
+    and the 11-phase form of the down projection (K = 11008, 8192, 11264 = its limit); K = 320 / 11040: wave slices in whole k-steps
+    that differ by one (10 / 345 steps over eight waves; 11040: the widest slice fills the eleven phases)."""
     L, lib = _lib()
     g = torch.Generator().manual_seed(B * 13 + N + K)
     x = bf(torch.randn(B, K, generator=g))
@@ -524,7 +525,7 @@ def test_gemm_small_km_refuses_shapes_outside_it(device):
     x = torch.zeros(33, 12320, dtype=torch.bfloat16, device=device)
     W = torch.zeros(8192 * 12320, dtype=torch.bfloat16, device=device)
     y = torch.zeros(33, 8192, dtype=torch.bfloat16, device=device)
-    for B, N, K in [(4, 64, 11296), (4, 64, 320), (33, 64, 256), (4, 40, 256), (16, 64, 12320), (20, 64, 11520), (20, 8192, 11008), (20, 64, 320)]:
+    for B, N, K in [(4, 64, 11296), (4, 64, 320), (33, 64, 256), (4, 40, 256), (16, 64, 12320), (20, 64, 11520), (20, 8192, 11008), (20, 64, 336), (20, 64, 224), (20, 64, 11296)]:
         assert lib.emmax_op_gemm_small_km(x.data_ptr(), W.data_ptr(), y.data_ptr(), B, N, K, stream()) != 0, (B, N, K)
     torch.cuda.synchronize()
 
@@ -580,6 +581,35 @@ def test_fp8_weight_projection(device, B, N, K):
     y = torch.full((B, N), float("nan"), dtype=torch.bfloat16, device=device)
     L.check(lib.emmax_op_gemm_small_fp8(xd.data_ptr(), W8.data_ptr(), sc.data_ptr(), y.data_ptr(), B, N, K, stream()), "gemm fp8")
     torch.cuda.synchronize()
+    assert relerr(y, ref) < TOL
+    assert_elementwise(y, ref)
+
+
+@pytest.mark.parametrize("B", [9, 16, 17, 24, 32])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (1008, 11008), (256, 512), (64, 704)])
+def test_fp8_weight_projection_nine_to_thirty_two_rows(device, B, N, K):
+    """The same e4m3 tiles on the K-split kernels: 9-16 rows decode_km.hip (K <= 4096; beyond, its phased down form), 17-32 rows
+    decode_kmp.hip -- two fragments per 1 KiB load step, wave slices in whole load steps that may differ by one (K = 11008: 172
+    steps over eight waves; K = 704: 11).  Against an fp32 matmul over the de-quantised weights."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(B * 7 + N + K)
+    x = bf(torch.randn(B, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    W[5, 3] = 0.6
+    scale_ref = W.float().abs().amax(dim=1).clamp_min(1e-30) / 448.0
+    Wq_ref = (W.float() / scale_ref[:, None]).to(torch.float8_e4m3fn)
+    Wd, xd = W.to(device), x.to(device)
+    W8 = torch.empty(N * K, dtype=torch.uint8, device=device)
+    sc = torch.empty(N, dtype=torch.float32, device=device)
+    L.check(lib.emmax_op_quant_fm8(Wd.data_ptr(), K, W8.data_ptr(), sc.data_ptr(), N, K, stream()), "quant")
+    y = torch.full((B, N), float("nan"), dtype=torch.bfloat16, device=device)
+    rc = lib.emmax_op_gemm_small_fp8(xd.data_ptr(), W8.data_ptr(), sc.data_ptr(), y.data_ptr(), B, N, K, stream())
+    if B <= 16 and K <= 4096 and K % 512:
+        assert rc != 0 and b"emmax_op_gemm_small_fp8" in lib.emmax_last_error()   # decode_km.hip: equal wave slices (K % 512) below the phased form
+        return
+    L.check(rc, "gemm fp8")
+    torch.cuda.synchronize()
+    ref = x.float() @ (Wq_ref.float() * scale_ref[:, None]).t()
     assert relerr(y, ref) < TOL
     assert_elementwise(y, ref)
 
