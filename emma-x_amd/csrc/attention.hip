@@ -39,7 +39,7 @@ namespace {
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
-template <int HD_, int NW_, int QB_, int NBUF_, int BPC_>
+template <int HD_, int NW_, int QB_, int NBUF_, int BPC_, int KSPL_ = 1>
 struct AttnCfg {
     static constexpr int HD = HD_;
     static constexpr int HDK = (HD + 15) / 16 * 16;     // QK^T reduction length (k steps of 16), zero padded
@@ -52,11 +52,20 @@ struct AttnCfg {
     static constexpr int NW = NW_;                      // waves per block
     static constexpr int NT = NW * 64;
     static constexpr int QB = QB_;                      // 32-query blocks per wave
-    static constexpr int QCH = NW * 32 * QB;            // queries per block
+    // KSPL = 2 (round 5, the under-filled causal prefill): the block's waves form two KEY groups over the same NW / 2 query waves --
+    // wave w and wave w + NW / 2 hold the same 32 queries, group g takes the 32-key half g of every 64-key tile, and the two
+    // (m, l, O^T) states meet through LDS after the last tile.  One frame's causal prefill is 6 chunks x 32 heads = 192 blocks
+    // on 256 CUs and lasts as long as its heaviest block (12 tiles behind one another at one wave per SIMD); with the key groups
+    // that chain is half as long per wave and a SIMD holds two waves whose LDS / DMA waits cover each other.
+    static constexpr int KSPL = KSPL_;
+    static constexpr int NQW = NW / KSPL;               // query waves
+    static constexpr int QCH = NQW * 32 * QB;           // queries per block
     static constexpr int NBUF = NBUF_;                  // LDS ring depth: NBUF - 1 tiles of DMA in flight
     static constexpr int KS = KP / 8, VS = VP / 8;      // 16-byte slots per LDS row
     static constexpr int NKI = (TILE * KS + 63) / 64, NVI = (TILE * VS + 63) / 64;   // 1 KiB DMA instructions per tile
-    static constexpr bool GS = HD == 72 || (HD == 128 && QB == 2);   // softmax step = one 32-key group instead of the 64-key tile (registers)
+    static constexpr bool GS = HD == 72 || (HD == 128 && QB == 2) || KSPL == 2;   // softmax step = one 32-key group instead of the 64-key tile (registers; KSPL: the wave's half)
+    static_assert(KSPL == 1 || (KSPL == 2 && NW % 2 == 0 && QB == 1), "key groups: two, one query block per wave");
+    static constexpr bool LZ = HD == 128 && QB == 1;    // lazy reference maximum (round 5; the ViT shapes of this kernel are 4-5 tiles long: mostly first steps)
     static constexpr int MINW = BPC_ * NW / 4;          // waves per SIMD the register budget is planned for (BPC blocks per CU)
 };
 
@@ -82,6 +91,20 @@ __device__ __forceinline__ void glds16_slab(const char* gsrc) {
     asm volatile("global_load_lds_dwordx4 %0, off offset:%1" ::"v"(gsrc - (J - 4) * 1024), "n"((J - 4) * 1024) : "memory");
 }
 
+// slab j (0..7) with j known only after unrolling: the immediate must be a literal, so the eight forms are spelled out
+__device__ __forceinline__ void glds16_slab_j(int j, const char* gsrc) {
+    switch (j) {
+        case 0: glds16_slab<0>(gsrc); break;
+        case 1: glds16_slab<1>(gsrc); break;
+        case 2: glds16_slab<2>(gsrc); break;
+        case 3: glds16_slab<3>(gsrc); break;
+        case 4: glds16_slab<4>(gsrc); break;
+        case 5: glds16_slab<5>(gsrc); break;
+        case 6: glds16_slab<6>(gsrc); break;
+        default: glds16_slab<7>(gsrc); break;
+    }
+}
+
 __device__ __forceinline__ float half_max(float v) {   // max over the two half-waves (lanes l and l ^ 32)
     float a, b;
     swap_halves(v, a, b);
@@ -99,11 +122,23 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
     constexpr int NKK = DM::NKK, NDB = DM::NDB, KP = DM::KP, VP = DM::VP, CH = DM::CH, TILE = DM::TILE, NT = DM::NT, NW = DM::NW;
     constexpr int QB = DM::QB, QCH = DM::QCH, KS = DM::KS, VS = DM::VS, NKI = DM::NKI, NVI = DM::NVI;
     constexpr bool GS = DM::GS;
-    __shared__ __attribute__((aligned(16))) bf16_t sK[NBUF][TILE * KP];
-    __shared__ __attribute__((aligned(16))) bf16_t sV[NBUF][TILE * VP];
+    constexpr int KSPL = DM::KSPL, NQW = DM::NQW;
+    constexpr bool LZ = DM::LZ;
+    // one ring buffer = the K image (NKI slabs of 1 KiB), the V image (NVI slabs) and the surplus slabs of the last wave's share (see
+    // dma_tile), contiguous: slab i of a tile sits 1024 i bytes into its buffer, so a wave's consecutive slabs share one M0
+    constexpr int PTW = (NKI + NVI + NW - 1) / NW, BUFE = NW * PTW * 512;
+    static_assert(TILE * KP * 2 == NKI * 1024 && TILE * VP * 2 == NVI * 1024, "the images are whole 1 KiB slabs");
+    __shared__ __attribute__((aligned(1024))) bf16_t sKV[NBUF][BUFE];
+    auto sK = [&](int buf) -> bf16_t* { return &sKV[buf][0]; };
+    auto sV = [&](int buf) -> bf16_t* { return &sKV[buf][TILE * KP]; };
+    // KSPL: key group 1 hands its state to group 0 here: [query wave][16 NDB + 2 registers][lane] fp32
+    constexpr int MREG = 16 * DM::NDB + 2;
+    __shared__ float sM[KSPL == 2 ? NQW * MREG * 64 : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: an SGPR
     const int ql = lane & 31, hi = lane >> 5;
+    const int wq = KSPL == 2 ? (wave >= NQW ? wave - NQW : wave) : wave;    // query wave
+    const int kg = KSPL == 2 ? (wave >= NQW ? 1 : 0) : 0;                   // key group
     // XCD-aware work map: linear block id L runs on XCD L % 8.  The (sequence, head) items are dealt out in contiguous runs of
     // `per_xcd`, so neighbouring heads of a sequence -- and, when there are many sequences, whole sequences -- stay on one XCD;
     // an item's query chunks occupy consecutive slots of that XCD, heavy (late) causal chunks first
@@ -128,12 +163,12 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
     {
         constexpr int KZ = (KP - HD) / 8, VZ = (VP - HD) / 8;    // 16-byte slots of padding per row (HD % 8 == 0)
         const u32x4_t z = {0u, 0u, 0u, 0u};
-        for (int i = tid; i < NBUF * TILE * KZ; i += NT) *(u32x4_t*)(&sK[0][0] + (i / KZ) * KP + HD + (i % KZ) * 8) = z;
-        for (int i = tid; i < NBUF * TILE * VZ; i += NT) *(u32x4_t*)(&sV[0][0] + (i / VZ) * VP + HD + (i % VZ) * 8) = z;
+        for (int i = tid; i < NBUF * TILE * KZ; i += NT) *(u32x4_t*)(sK(i / (TILE * KZ)) + (i / KZ % TILE) * KP + HD + (i % KZ) * 8) = z;
+        for (int i = tid; i < NBUF * TILE * VZ; i += NT) *(u32x4_t*)(sV(i / (TILE * VZ)) + (i / VZ % TILE) * VP + HD + (i % VZ) * 8) = z;
     }
 
     // Q^T fragments (B operand): lane (ql, hi) holds Q[q_row][16 kk + 8 hi .. +8] of each of its QB query blocks
-    const int q_w0 = q_blk0 + wave * 32 * QB;
+    const int q_w0 = q_blk0 + wq * 32 * QB;
     const bool wave_live = q_w0 < len;
     bf16x8_t qf[QB][NKK];
 #pragma unroll
@@ -164,50 +199,54 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
     const float c = p.scale * 1.44269504088896340736f;                          // exp(x * scale) = exp2(x * c)
     const int ntile = (kv_end + TILE - 1) / TILE;
 
-    // ---- tile staging by LDS-DMA: instruction i of a tile fills the 64 slots 64 i .. 64 i + 63 of the row-major image; slot n is
-    // row n / KS, chunk n % KS; padding chunks are inactive lanes; rows past the sequence end re-read its last row (finite, and
-    // masked where it matters), so every data slot of a tile is rewritten.  Every wave issues exactly PT instructions per tile
-    // (the surplus slots of the last round re-issue instructions 0.. of the same tile: same data to the same place), so the
-    // waits can count: vmcnt(n PT) = "all but the n youngest tiles have landed".  Everything that does not depend on the tile is
-    // computed once: per instruction the lane's row, its source pointer at row 0 and its LDS slab. ----
-    constexpr int TOT = NKI + NVI, PT = (TOT + NW - 1) / NW;
+    // ---- tile staging by LDS-DMA: slab i of a tile fills the 64 slots 64 i .. 64 i + 63 of the row-major images (K: slabs 0 .. NKI - 1,
+    // V: the NVI behind them); slot n is row n / KS, chunk n % KS; padding chunks are inactive lanes; rows past the sequence end re-read
+    // its last row (finite, and masked where it matters), so every data slot of a tile is rewritten.  Wave w issues the PT CONSECUTIVE
+    // slabs w PT .. w PT + PT - 1 of every tile (round 5; it had been slabs w, w + NW, ..): they lie within 8 KiB of each other, so one
+    // M0 serves eight of them through the instruction's immediate offset -- rewriting M0 between two LDS-DMA instructions serialises
+    // them on the first one's data return (tools/dma_issue_rate.hip) and the issuing wave stands still meanwhile.  The last wave's
+    // surplus slabs (NW PT - TOT of them) land in spare LDS behind the images, so every wave issues exactly PT instructions per tile
+    // and the waits can count: vmcnt(n PT) = "all but the n youngest tiles have landed".  Everything that does not depend on the tile
+    // is computed once: per instruction the lane's row and its source byte offset at row 0. ----
+    constexpr int TOT = NKI + NVI, PT = PTW;
     // per instruction: the lane's row inside the tile (-1: padding slot, the lane stays inactive) and its source byte offset
     // from `base` at row 0 (head column + chunk)
     const int k_col0 = p.k_off + hk * HD, v_col0 = p.v_off + hk * HD;   // locals: selecting between two FIELDS of the by-value
                                                                       // argument struct at run time made hipcc copy it to scratch
     auto slot_of = [&](int u, int& row, unsigned int& off) {
-        int idx = wave + u * NW;
-        idx = idx >= TOT ? idx - TOT : idx;
+        const int idx = wave * PT + u;
         const bool isk = idx < NKI;
         const int n = (isk ? idx : idx - NKI) * 64 + lane;
         const int rk = n / KS, rv = n / VS;
         const int r = isk ? rk : rv, ch = isk ? n - rk * KS : n - rv * VS;
         row = (ch < CH && r < TILE) ? r : -1;
         off = (unsigned int)(((isk ? k_col0 : v_col0) + ch * 8) * 2);
+        if (idx >= TOT) { row = 0; off = (unsigned int)(k_col0 * 2); }      // surplus slab: any readable 16 bytes, into the spare LDS
     };
     constexpr bool PRE = PT <= 12;            // kept in registers; beyond that (2-wave blocks: 19) hipcc indexes them from scratch
-    int d_row[PRE ? PT : 1];
-    unsigned int d_off[PRE ? PT : 1];
+    unsigned int d_pk[PRE ? PT : 1];          // (row + 1) << 20 | off: one register per instruction (off < 2^20: a qkv row is a few KiB)
     if (PRE) {
 #pragma unroll
-        for (int u = 0; u < PT; ++u) slot_of(u, d_row[PRE ? u : 0], d_off[PRE ? u : 0]);
-    }
-    const unsigned int ldsK0 = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) void*)&sK[0][0];
-    const unsigned int ldsV0 = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) void*)&sV[0][0];
-    const unsigned int row_bytes = (unsigned int)p.ld_qkv * 2u;
-    auto dma_tile = [&](int kv0, int buf) {
-#pragma unroll
         for (int u = 0; u < PT; ++u) {
-            int idx = wave + u * NW;                       // scalar: which 1 KiB slab of which image
-            idx = idx >= TOT ? idx - TOT : idx;
-            const bool isk = idx < NKI;
-            const unsigned int slab = isk ? ldsK0 + buf * (TILE * KP * 2) + idx * 1024 : ldsV0 + buf * (TILE * VP * 2) + (idx - NKI) * 1024;
             int row;
             unsigned int off;
-            if (PRE) { row = d_row[PRE ? u : 0]; off = d_off[PRE ? u : 0]; }
+            slot_of(u, row, off);
+            d_pk[PRE ? u : 0] = ((unsigned int)(row + 1) << 20) | off;
+        }
+    }
+    const unsigned int ldsKV0 = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) void*)&sKV[0][0];
+    const unsigned int row_bytes = (unsigned int)p.ld_qkv * 2u;
+    auto dma_tile = [&](int kv0, int buf) {
+        const unsigned int slab0 = ldsKV0 + buf * (BUFE * 2) + wave * (PT * 1024);
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            if (u % 8 == 0) glds_base(slab0 + u * 1024 + 4096);
+            int row;
+            unsigned int off;
+            if (PRE) { row = (int)(d_pk[PRE ? u : 0] >> 20) - 1; off = d_pk[PRE ? u : 0] & 0xFFFFFu; }
             else slot_of(u, row, off);
-            const int kg = min(kv0 + row, len - 1);
-            if (row >= 0) glds16((const char*)base + ((size_t)(unsigned int)kg * row_bytes + off), slab);
+            const int krow = min(kv0 + row, len - 1);
+            if (row >= 0) glds16_slab_j(u % 8, (const char*)base + ((size_t)(unsigned int)krow * row_bytes + off));
         }
     };
     auto wait_all_but = [&](int younger) {   // wave-uniform
@@ -239,6 +278,32 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
         constexpr int NG = decltype(ng_tag)::value;
         // S^T = K . Q^T ; one K fragment read feeds the MFMAs of all QB query blocks
         f32x16_t st[QB][NG];
+        // KSPL (one 32-key group per step, ~170 registers): all K fragments of the step requested before the first MFMA, and the V^T
+        // fragments before the softmax arithmetic -- left to itself hipcc reads two fragments, waits, issues two MFMAs, eight times over
+        // (one LDS round trip per pair), which at one or two waves per SIMD nothing covers
+        constexpr bool PREF = KSPL == 2;
+        u32x2_t vpre[PREF ? 2 : 1][PREF ? NDB : 1][2];
+        if constexpr (PREF) {
+            bf16x8_t kfa[NKK];
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) kfa[kk] = *(const bf16x8_t*)(&Kg[k_off + kk * 16]);
+            typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    const bf16_t* vb = Vg + (mm * 16) * VP + v_off + db * 32;
+                    vpre[mm][db][0] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)vb));
+                    vpre[mm][db][1] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + 8 * VP)));
+                }
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                st[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[kk], qf[0][kk], kk == 0 ? zero : st[0][0], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, NKK + 4 * NDB, 0);   // pinned: every LDS read of the step, then the MFMA chain
+            __builtin_amdgcn_sched_group_barrier(0x008, NKK, 0);
+        } else {
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
@@ -250,6 +315,7 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
                     st[qb][gi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][kk], kk == 0 ? zero : st[qb][gi], 0, 0, 0);
                 }
             }
+        }
         // online softmax per query block; P^T packed to bf16
         u32x4_t pf[QB][NG][2];
 #pragma unroll
@@ -270,9 +336,29 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
 #pragma unroll
                 for (int r = 0; r < 16; ++r) m_tile = fmaxf(m_tile, st[qb][gi][r]);
             m_tile = half_max(m_tile);
-            const float m_new = fmaxf(m_run[qb], m_tile);     // finite from the first step on: key 0 is visible to every query
-            const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
-            const float mc = m_new * c;
+            float alpha = 1.0f, mc;
+            if constexpr (LZ) {
+                // lazy reference maximum, as in the resident kernel below: m_run moves only when the step's maximum exceeds it by more
+                // than 2^8 in the exp2 domain (always at a wave's first step), and the rescale of l and the 64 O^T registers runs only
+                // when some row of the wave moved -- multiplied in place by asm, so the wave-uniform branch leaves hipcc nothing to copy
+                const bool move = m_tile * c > m_run[qb] * c + 8.0f;   // finite m_tile: every step a wave runs holds a key each of its rows sees
+                if (__builtin_amdgcn_ballot_w64(move) != 0) {
+                    const float m_new = move ? m_tile : m_run[qb];
+                    alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);   // 1 for the rows that stay
+                    l_run[qb] *= alpha;
+                    m_run[qb] = m_new;
+#pragma unroll
+                    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(o[qb][i][r]) : "v"(alpha));
+                }
+                mc = m_run[qb] * c;
+            } else {
+                const float m_new = fmaxf(m_run[qb], m_tile);     // finite from the first step on: key 0 is visible to every query
+                alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
+                mc = m_new * c;
+                m_run[qb] = m_new;
+            }
             float psum = 0.f;
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi)
@@ -285,14 +371,25 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
                         psum += p0 + p1;
                         pf[qb][gi][mm][t] = pack_bf16x2(p0, p1);
                     }
-            l_run[qb] = __builtin_fmaf(l_run[qb], alpha, psum);
-            m_run[qb] = m_new;
+            if constexpr (LZ) l_run[qb] += psum;
+            else {
+                l_run[qb] = __builtin_fmaf(l_run[qb], alpha, psum);
 #pragma unroll
-            for (int i = 0; i < NDB; ++i)
+                for (int i = 0; i < NDB; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[qb][i][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[qb][i][r] *= alpha;
+            }
         }
         // O^T += V^T . P^T : k steps of 16 keys; one V^T fragment (two transpose reads) feeds all QB query blocks
+        if constexpr (PREF) {
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    const u32x4_t av = {vpre[mm][db][0][0], vpre[mm][db][0][1], vpre[mm][db][1][0], vpre[mm][db][1][1]};
+                    o[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, pf[0][0][mm]), o[0][db], 0, 0, 0);
+                }
+        } else
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
@@ -318,14 +415,18 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
     // wave's key range, so the tiles are walked in three consecutive loops -- mask-free tiles, tiles with the mask, ring-only
     // tiles -- each with ONE call site of the step: with the masked and the unmasked step as the two arms of a branch inside one
     // loop, hipcc kept the O^T accumulators in different registers per arm and copied all of them (24-48 v_mov per step) ----
-    const int ntile_w = wave_live ? (kv_end_w + TILE - 1) / TILE : 0;
+    // (KSPL: the tiles in which this wave's half -- keys 64 j + 32 kg .. + 32 -- starts below the wave's last visible key)
+    const int ntile_w = !wave_live ? 0 : KSPL == 2 ? (kv_end_w > 32 * kg ? (kv_end_w - 32 * kg + TILE - 1) / TILE : 0) : (kv_end_w + TILE - 1) / TILE;
     constexpr int STEP = 32 * NGMAX;
     using NGfull = std::integral_constant<int, NGMAX>;
     using NGone = std::integral_constant<int, 1>;
     auto step_is_edge = [&](int ks0) { return (ks0 + STEP > len) || (p.causal && ks0 + STEP - 1 > q_w0); };
     auto steps_of = [&](int kv0) { return min(TILE / STEP, (kv_end_w - kv0 + STEP - 1) / STEP); };
     int j_plain = 0;   // leading tiles without a masked step
-    while (j_plain < ntile_w && !step_is_edge(j_plain * TILE + (steps_of(j_plain * TILE) - 1) * STEP)) ++j_plain;
+    if (KSPL == 2)
+        while (j_plain < ntile_w && !step_is_edge(j_plain * TILE + kg * 32)) ++j_plain;
+    else
+        while (j_plain < ntile_w && !step_is_edge(j_plain * TILE + (steps_of(j_plain * TILE) - 1) * STEP)) ++j_plain;
     auto ring = [&](int j) {
         // tile j + NBUF - 1 goes into the buffer tile j - 1 was read from (everybody passed the barrier that ended it)
         if (j + NBUF - 1 < ntile) dma_tile((j + NBUF - 1) * TILE, (j + NBUF - 1) % NBUF);
@@ -338,25 +439,54 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
     for (; j < j_plain; ++j) {
         ring(j);
         const int kv0 = j * TILE, buf = j % NBUF, nst = steps_of(kv0);
+        if (KSPL == 2) step(std::false_type{}, NGone{}, kv0 + kg * 32, sK(buf) + kg * 32 * KP, sV(buf) + kg * 32 * VP);
+        else
         for (int sidx = 0; sidx < nst; ++sidx)
-            step(std::false_type{}, NGfull{}, kv0 + sidx * STEP, &sK[buf][sidx * STEP * KP], &sV[buf][sidx * STEP * VP]);
+            step(std::false_type{}, NGfull{}, kv0 + sidx * STEP, sK(buf) + sidx * STEP * KP, sV(buf) + sidx * STEP * VP);
         tile_end(j);
     }
     for (; j < ntile_w; ++j) {
         ring(j);
         const int kv0 = j * TILE, buf = j % NBUF, nst = steps_of(kv0);
+        if (KSPL == 2) step(std::true_type{}, NGone{}, kv0 + kg * 32, sK(buf) + kg * 32 * KP, sV(buf) + kg * 32 * VP);
+        else
         for (int sidx = 0; sidx < nst; ++sidx) {
             const int ks0 = kv0 + sidx * STEP;
             if (NGMAX == 2 && kv_end_w - ks0 <= 32)   // a tail of <= 32 keys (DINOv2: 261 = 4 x 64 + 5; causal diagonal): half a step
-                step(std::true_type{}, NGone{}, ks0, &sK[buf][sidx * STEP * KP], &sV[buf][sidx * STEP * VP]);
+                step(std::true_type{}, NGone{}, ks0, sK(buf) + sidx * STEP * KP, sV(buf) + sidx * STEP * VP);
             else
-                step(std::true_type{}, NGfull{}, ks0, &sK[buf][sidx * STEP * KP], &sV[buf][sidx * STEP * VP]);
+                step(std::true_type{}, NGfull{}, ks0, sK(buf) + sidx * STEP * KP, sV(buf) + sidx * STEP * VP);
         }
         tile_end(j);
     }
     for (; j < ntile; ++j) {
         ring(j);
         tile_end(j);
+    }
+
+    // ---- KSPL: the two key groups of a query wave meet.  Group 1 leaves (O^T, m, l) in LDS -- the tile images are dead: the last
+    // tile_end was a barrier behind everybody's last read -- and group 0 folds it into its own state with the usual rescale.  A
+    // group-1 wave that saw no key at all (the first 32 queries of a sequence) hands over m = -inf, l = 0, O = 0: weight exp2(-inf) = 0 ----
+    if constexpr (KSPL == 2) {
+        float* mine = sM + (wq * MREG) * 64 + lane;
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[(i * 16 + r) * 64] = o[0][i][r];
+            mine[(16 * NDB) * 64] = m_run[0];
+            mine[(16 * NDB + 1) * 64] = l_run[0];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+        const float m1 = mine[(16 * NDB) * 64], l1 = mine[(16 * NDB + 1) * 64];
+        const float m = fmaxf(m_run[0], m1);
+        const float a0 = __builtin_amdgcn_exp2f((m_run[0] - m) * c), a1 = __builtin_amdgcn_exp2f((m1 - m) * c);
+        l_run[0] = l_run[0] * a0 + l1 * a1;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[0][i][r] = o[0][i][r] * a0 + mine[(i * 16 + r) * 64] * a1;
     }
 
     // ---- write O[q][d]: lane (ql, hi) holds d = 32 db + 8 a + 4 hi + (0..3) in o[db][4 a .. 4 a + 3] ----
@@ -760,7 +890,15 @@ int launch_attention(const AttnParams& p, int head_dim, hipStream_t stream) {
     switch (head_dim) {
         case 64: return three ? launch_attention_t<AttnCfg<64, 3, 1, 2, 4>>(p, stream) : launch_attention_t<AttnCfg<64, 4, 1, 2, 3>>(p, stream);
         case 72: return three ? launch_attention_t<AttnCfg<72, 3, 1, 2, 4>>(p, stream) : launch_attention_t<AttnCfg<72, 4, 1, 2, 3>>(p, stream);
-        case 128: return launch_attention_t<AttnCfg<128, 4, 1, 2, 2>>(p, stream);
+        case 128: {
+            // an under-filled causal launch (one frame's prefill: 6 chunks x 32 heads = 192 blocks) lasts as long as its heaviest block:
+            // two key groups per block halve that chain (AttnCfg::KSPL; tuning switch attn_ksplit: -1 = when the grid leaves at most one
+            // block per CU, 0 never, 1 every causal head_dim-128 launch).  Measured: profiles/r05_attn_ksplit_ab.txt
+            const int sw = emmax_tune().attn_ksplit;
+            const int blocks = 8 * cdiv(p.B * p.Hq, 8) * cdiv(p.max_seqlen, 128);
+            if (p.causal && (sw == 1 || (sw < 0 && blocks <= 256))) return launch_attention_t<AttnCfg<128, 8, 1, 2, 1, 2>>(p, stream);
+            return launch_attention_t<AttnCfg<128, 4, 1, 2, 2>>(p, stream);
+        }
         default: return -1;
     }
 }

@@ -83,7 +83,7 @@ int emmax_config_size(void);
  * environment variable EMMAX_<NAME> for each of them ONCE, the first time any value is needed; afterwards only emmax_tuning_set
  * changes them (no launcher reads the environment).  Every default is the product path; the other values are the A/B partners
  * DESIGN.md quotes.  Names: graph (1 = hipGraph replay of the decode step, BASELINE configs[4]), ks, ks_oproj, ks_oproj_grid, km,
- * km_down, km_roll, streamk, fp8_gemv, attn_nsplit, attn_direct, attn_nw, attn_deep, fold_embed, mfma_xbar, gemm_big (2 = the 128 x 256 x 32 lab tile), gemm_splitk,
+ * km_down, km_roll, streamk, fp8_gemv, attn_nsplit, attn_direct, attn_nw, attn_deep, attn_ksplit, fold_embed, mfma_xbar, gemm_big (2 = the 128 x 256 x 32 lab tile), gemm_splitk,
  * gemm_hybrid, gemm_normfuse, gemm_deep, gemm_lnfuse, attn_resident, resid32 (1 = fp32 residual stream in prefill and decode, 2 = decode only,
  * 0 = bf16 rows), kv_fp8 (1 = sessions created from now on keep an e4m3 KV cache).
  * Three switches are read when an object is BUILT and frozen in it: gemm_lnfuse at emmax_model_finalize (the LayerNorm fold rewrites the ViT
@@ -276,7 +276,6 @@ int emmax_op_decode_attention(const void* q_dev, const void* kcache_dev, const v
 int emmax_op_decode_attention_direct(const void* q_dev, const void* kcache_dev, const void* vcache_dev, const int32_t* page_table_dev,
                                      const int32_t* ctx_len_dev, const int32_t* done_dev, void* o_out_dev, int B, int Hq, int Hkv,
                                      int page, int max_pages, float scale, emmax_stream stream);
-/* Decode-path weight-streaming GEMV: y[b,n] = sum_k x[b,k] W[n,k]  (bf16 in, fp32 accumulate, bf16 out), B <= 8. */
 /* The same kernel over the opt-in fp8 KV cache (round 5, tuning switch kv_fp8 at emmax_session_create): K / V pages hold e4m3 rows
  * [pages][Hkv][page][128] with one power-of-two fp32 scale per row (the smallest with amax / scale <= 448), kscale / vscale fp32 [pages][Hkv][page].  The key of THIS step
  * (position ctx_len[b]) is NOT in the cache yet: it waits as bf16 in kv_stage [B][Hkv][2][128] (K row, V row), every block quantises
@@ -286,6 +285,7 @@ int emmax_op_decode_attention_kv8(const void* q_dev, void* kcache8_dev, void* vc
                                   const void* kv_stage_dev, const int32_t* page_table_dev, const int32_t* ctx_len_dev, const int32_t* done_dev,
                                   float* partials_out_dev, void* o_out_dev, int B, int Hq, int Hkv, int page, int max_pages, int nsplit,
                                   float scale, emmax_stream stream);
+/* Decode-path weight-streaming GEMV: y[b,n] = sum_k x[b,k] W[n,k]  (bf16 in, fp32 accumulate, bf16 out), B <= 8. */
 int emmax_op_gemv(const void* x_dev, const void* W_dev, void* y_dev, int B, int N, int K, emmax_stream stream);
 
 /* Pillow-exact antialiased bicubic resize of uint8 RGB frames [B,H,W,3] -> [B,OH,OW,3] on the device (the `resize-naive`

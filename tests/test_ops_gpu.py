@@ -404,6 +404,21 @@ def _attn_ref(qkv, cu, Hq, Hkv, hd, q_off, k_off, v_off, scale, causal):
     (128, 2, 2, [300], 1), (128, 4, 2, [70, 1, 129, 64], 1), (128, 2, 2, [768], 1), (128, 2, 1, [5, 200], 1),
 ])
 def test_attention(device, hd, Hq, Hkv, lens, causal):
+    _attention_case(device, hd, Hq, Hkv, lens, causal)
+
+
+@pytest.mark.parametrize("ksplit", [0, 1])
+@pytest.mark.parametrize("Hq,Hkv,lens", [(2, 2, [300]), (4, 2, [70, 1, 129, 64]), (2, 2, [768]), (2, 1, [5, 200]), (32, 32, [768]), (8, 8, [33, 1023])])
+def test_attention_causal_with_and_without_key_groups(device, Hq, Hkv, lens, ksplit):
+    """The causal head_dim-128 launch in both block forms (tuning switch attn_ksplit): four query waves per block, and eight waves as two
+    key groups over the same four query waves whose (m, l, O) states meet through LDS -- the form an under-filled launch (one frame's
+    prefill: 192 blocks) takes by default.  Includes the first 32 queries of a sequence, whose second key group sees no key at all."""
+    L, _ = _lib()
+    with L.tuning(attn_ksplit=ksplit):
+        _attention_case(device, 128, Hq, Hkv, lens, 1)
+
+
+def _attention_case(device, hd, Hq, Hkv, lens, causal):
     L, lib = _lib()
     g = torch.Generator().manual_seed(hd + sum(lens))
     total = sum(lens)
@@ -893,6 +908,12 @@ def test_attention_resident_form_many_short_sequences(device, hd, Hq, Hkv, top, 
 
 @pytest.mark.parametrize("seed", range(12))
 def test_attention_random_ragged_shapes(device, seed):
+    L, _ = _lib()
+    with L.tuning(attn_ksplit=seed // 3 % 2 if seed % 3 == 2 else -1):     # head_dim 128: both block forms
+        _attention_random_ragged(device, seed)
+
+
+def _attention_random_ragged(device, seed):
     """Seeded random ragged batches through the attention kernel (the LDS-DMA ring, the masked / 32-key tail steps, the
     3- and 4-wave block shapes and the XCD work map all depend on the lengths): 1..6 sequences of 1..900 tokens, each head
     size, causal for head_dim 128, against the fp32 reference."""
