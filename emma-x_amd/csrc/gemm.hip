@@ -1057,9 +1057,26 @@ static double cost_small(long tiles) {
 }
 
 // slices for launch_gemm_splitk, or 0 when splitting does not pay
-static int splitk_plan(const GemmParams& p) {
+static int splitk_plan(const GemmParams& p, int* big_out = nullptr) {
+    if (big_out) *big_out = 0;
     if (!p.ws || p.ln_stats || (p.act == 2 && p.out_f32)) return 0;
     const int nk = p.K / BK;
+    // 256 x 256 tiles with floor(256 / tiles) slices (round 5, tools/gemm_sk_sweep.py, profiles/r05_gemm_sk_sweep.txt): for a VERY long K
+    // (the down projection, 172 steps) and at most half a round of big tiles, one slice of a big tile per CU beats the small tiles --
+    // M = 768: 78.7 against 86.1 us (5 slices of 48 tiles), M = 1536: 138 against 151 us (2 slices of 96 tiles; that shape had no
+    // split-K plan at all: 384 small tiles); at K = 4096 (o-proj) the small tiles stay ahead (44 against 49 us), from 144 tiles on the
+    // plans are within noise of each other.  The fp32 partials of a slice cost the same per tile in both geometries; what the big tile
+    // buys is its K-step rate (section 6), what it costs is slices of uneven value: 240 of 256 CUs busy.
+    {
+        const long tb = (long)cdiv(p.M, GeomBig::BM) * cdiv(p.N, GeomBig::BN);
+        int ks = tb > 0 && tb <= 128 ? (int)(256 / tb) : 0;
+        if (ks > 8) ks = 8;
+        while (ks >= 2 && (long long)ks * p.M * p.N * 4 > p.ws_bytes) --ks;
+        if (nk >= 128 && ks >= 2 && nk / ks >= 16 && p.act != 2 && emmax_tune().gemm_sk_big != 0) {
+            if (big_out) *big_out = 1;
+            return ks;
+        }
+    }
     const long ts = (long)cdiv(p.M, GeomSmall::BM) * cdiv(p.N, GeomSmall::BN);
     if (nk < 32 || ts > 224) return 0;              // K >= 2048, at most ~1 block per CU without the split
     int ks = (int)(512 / ts);
@@ -1123,6 +1140,7 @@ int launch_gemm_splitk(const GemmParams& p, int ks, hipStream_t stream, int big)
     if (p.act == 2 && (p.out_f32 || (p.N & 31))) return -1;
     if ((long long)ks * p.M * p.N * 4 > p.ws_bytes) return -1;
     if (p.K / BK < ks) return -1;
+    if (emmax_tune().gemm_sk_big >= 0) big = emmax_tune().gemm_sk_big;   // (tools: the planned geometry overridden)
     GemmParams a = p;
     a.ksplit = ks;
     a.C = p.ws; a.ldc = p.N; a.N_store = p.N; a.out_f32 = 1; a.act = 0;
@@ -1181,7 +1199,7 @@ bool gemm_fuses_norm(const GemmParams& p) {
 
 // The launch plan of launch_gemm, as data (gemm_plan_describe prints it: the CPU tests pin the plans of the shapes of the hot path).
 //   GEOM    one geometry, forced by the tuning switch gemm_big
-//   SPLITK  the whole problem K-split on 128 x 128 tiles + reduce pass (ks slices)
+//   SPLITK  the whole problem K-split on 128 x 128 tiles (big: 256 x 256, for a very long K) + reduce pass (ks slices)
 //   HYBRID  columns [0, n1): rows plan m1 (big tile rows, the rest small); columns [n1, N): K-split (ks) + reduce pass
 //   COLS    columns [0, n1): rows plan m1; columns [n1, N): one all-small launch (half-empty last tile column)
 //   ROWS    m1 big tile rows, the remaining rows in small tiles (m1 = all: one big launch; 0: one small launch)
@@ -1192,7 +1210,8 @@ static GemmPlan plan_gemm(const GemmParams& p) {
     const int force = emmax_tune().gemm_big;   // 0 / 1: one geometry, no split
     if (force >= 0) { pl.kind = GemmPlan::GEOM; pl.big = force > 2 ? 1 : force; return pl; }   // 0 small, 1 big, 2 = 128 x 256 x 32
     const bool no_splitk = emmax_tune().gemm_splitk == 0;
-    if (const int ks = no_splitk ? 0 : splitk_plan(p)) { pl.kind = GemmPlan::SPLITK; pl.ks = ks; return pl; }
+    int sk_big = 0;
+    if (const int ks = no_splitk ? 0 : splitk_plan(p, &sk_big)) { pl.kind = GemmPlan::SPLITK; pl.ks = ks; pl.big = sk_big; return pl; }
     long m1 = 0;
     const double whole = plan_rows(p.M, p.N, &m1);
     if (!no_splitk && emmax_tune().gemm_hybrid != 0) {
@@ -1239,7 +1258,7 @@ int gemm_plan_describe(const GemmParams& p, char* buf, int len) {
     char r[96];
     switch (pl.kind) {
         case GemmPlan::GEOM: snprintf(buf, len, "forced %s", pl.big == 2 ? "k32" : pl.big ? "big" : "small"); break;
-        case GemmPlan::SPLITK: snprintf(buf, len, "splitk ks=%d%s", pl.ks, gemm_fuses_norm(p) ? " +norm" : ""); break;
+        case GemmPlan::SPLITK: snprintf(buf, len, "splitk%s ks=%d%s", pl.big ? " big" : "", pl.ks, gemm_fuses_norm(p) ? " +norm" : ""); break;
         case GemmPlan::HYBRID: rows(pl.m1, r, sizeof r); snprintf(buf, len, "hybrid cols 0..%d: %s | cols %d..%d: splitk ks=%d", pl.n1, r, pl.n1, p.N, pl.ks); break;
         case GemmPlan::COLS: rows(pl.m1, r, sizeof r); snprintf(buf, len, "cols 0..%d: %s | cols %d..%d: small", pl.n1, r, pl.n1, p.N); break;
         case GemmPlan::ROWS: rows(pl.m1, r, sizeof r); snprintf(buf, len, "%s", r); break;
@@ -1252,7 +1271,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.norm_out && !gemm_fuses_norm(p)) return -1;   // (the caller asks first)
     const GemmPlan pl = plan_gemm(p);
     if (pl.kind == GemmPlan::GEOM) return launch_gemm_geom(p, pl.big, stream);
-    if (pl.kind == GemmPlan::SPLITK) return launch_gemm_splitk(p, pl.ks, stream);
+    if (pl.kind == GemmPlan::SPLITK) return launch_gemm_splitk(p, pl.ks, stream, pl.big);
     if (pl.kind == GemmPlan::ROWS) return launch_planned_rows(p, pl.m1, stream);
     // column parts: a = columns [0, n1), b = columns [n1, N)
     const int n1 = pl.n1;

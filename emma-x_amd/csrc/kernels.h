@@ -139,6 +139,7 @@ struct EmmaxTune {
     int mfma_xbar;       // 1: decode_mfma.hip orders the activation requests ahead of the weight head with a block barrier
     int gemm_big;        // -1: planned tile geometry; 0 / 1: all small / all big tiles, no split-K
     int gemm_splitk;     // 1: split-K for under-filled long-K GEMMs
+    int gemm_sk_big;     // split-K tile geometry: -1 = planned (128 x 128, or 256 x 256 when the cost model prefers it), 0 / 1 = small / big forced (tools)
     int gemm_hybrid;     // 1: a column remainder behind whole rounds of big tiles goes through K-split small tiles when K is long (one-frame prefill gate/up)
     int gemm_normfuse;   // 1: the split-K reduce pass of the one-frame prefill o-proj / down also applies the RMSNorm that follows
     int gemm_deep;       // GEMM main loop: -1 = by geometry (256x256: staggered wave groups, 128x128: deep A ring), 0 = two stages + one barrier per step, 1 = third LDS stage for A, 3 = staggered wave groups (256x256 only)

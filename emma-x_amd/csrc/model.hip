@@ -57,6 +57,7 @@ const TuneEntry kTune[] = {
     {"attn_nsplit", &EmmaxTune::attn_nsplit, 0}, {"attn_direct", &EmmaxTune::attn_direct, 1},
     {"fold_embed", &EmmaxTune::fold_embed, 1}, {"mfma_xbar", &EmmaxTune::mfma_xbar, 1},
     {"gemm_big", &EmmaxTune::gemm_big, -1},    {"gemm_splitk", &EmmaxTune::gemm_splitk, 1},
+    {"gemm_sk_big", &EmmaxTune::gemm_sk_big, -1},
     {"gemm_deep", &EmmaxTune::gemm_deep, -1},       {"gemm_dbg", &EmmaxTune::gemm_dbg, 0},
     {"gemm_lnfuse", &EmmaxTune::gemm_lnfuse, 1}, {"attn_resident", &EmmaxTune::attn_resident, -1},
     {"gemm_hybrid", &EmmaxTune::gemm_hybrid, 1}, {"gemm_normfuse", &EmmaxTune::gemm_normfuse, 1},

@@ -81,7 +81,7 @@ def test_tuning_switches_are_a_table_with_a_setter(lib):
     L, so = lib
     names = ["graph", "ks", "ks_oproj", "ks_oproj_grid", "km", "km_down", "streamk", "fp8_gemv", "attn_nsplit", "attn_direct", "fold_embed",
              "mfma_xbar", "gemm_big", "gemm_splitk", "gemm_hybrid", "gemm_normfuse", "gemm_deep", "gemm_lnfuse", "attn_resident",
-             "resid32", "kv_fp8", "km_roll", "attn_nw", "attn_deep", "attn_ksplit"]   # (the last six: round 5)
+             "resid32", "kv_fp8", "km_roll", "attn_nw", "attn_deep", "attn_ksplit", "gemm_sk_big"]   # (the last seven: round 5)
     header = open(os.path.join(ROOT, "include", "emmax.h")).read()
     for n in names:
         assert re.search(r"\b%s\b" % n, header), n
@@ -171,11 +171,16 @@ def test_gemm_launch_plans_of_the_hot_path(lib):
     assert L.gemm_plan(768, 22016, 4096, act=2, ws_bytes=0) == "big rows 0..512 + small rows 512..768"      # no scratch: never split
     assert L.gemm_plan(768, 12288, 4096) == "big"
     assert L.gemm_plan(768, 4096, 4096, residual=True, norm=True) == "splitk ks=2 +norm"
-    assert L.gemm_plan(768, 4096, 11008, residual=True, norm=True) == "splitk ks=2 +norm"
-    assert L.gemm_plan(768, 4096, 11008, residual=True) == "splitk ks=2"
+    # (round 5: a VERY long K and at most half a round of 256x256 tiles -- one slice of a big tile per CU; tools/gemm_sk_sweep.py)
+    assert L.gemm_plan(768, 4096, 11008, residual=True, norm=True) == "splitk big ks=5 +norm"
+    assert L.gemm_plan(768, 4096, 11008, residual=True) == "splitk big ks=5"
+    assert L.gemm_plan(1536, 4096, 11008, residual=True, norm=True) == "splitk big ks=2 +norm"      # two frames: 96 big tiles
+    assert L.gemm_plan(1536, 4096, 4096, residual=True, norm=True) == L.gemm_plan(1536, 4096, 4096, residual=True)   # K = 4096: no split from 384 small tiles on
+    with L.tuning(gemm_sk_big=0):
+        assert L.gemm_plan(768, 4096, 11008, residual=True, norm=True) == "splitk ks=2 +norm"
     # round 5: the prefill's fp32 residual stream (fp32 residual in, fp32 C out) takes the same plans, the norm still in the reduce pass
     assert L.gemm_plan(768, 4096, 4096, out_f32=True, residual=2, norm=True) == "splitk ks=2 +norm"
-    assert L.gemm_plan(768, 4096, 11008, out_f32=True, residual=2, norm=True) == "splitk ks=2 +norm"
+    assert L.gemm_plan(768, 4096, 11008, out_f32=True, residual=2, norm=True) == "splitk big ks=5 +norm"
     assert L.gemm_plan(6144, 4096, 11008, out_f32=True, residual=2, norm=True) == "big rows 0..4096 + small rows 4096..6144"
     assert L.gemm_plan(768, 2048, 4096, residual=True, norm=True) == "splitk ks=5"                             # the fused norm is for 4096-wide rows
     assert L.gemm_plan(6144, 22016, 4096, act=2) == "hybrid cols 0..21760: big | cols 21760..22016: splitk ks=5"
