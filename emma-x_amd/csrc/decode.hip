@@ -853,7 +853,8 @@ __global__ __launch_bounds__(NW * 64) void emmax_decode_attn_kernel(DecodeAttnPa
             if constexpr (KV8) {
                 const int pg8 = s_pages[kk >> p.page_shift];
                 const size_t rowi = (((size_t)pg8 * p.Hkv + hk) << p.page_shift) + (kk & (p.page - 1));
-                const u32x2_t k8 = *(const u32x2_t*)(kc8 + rowi * HD + ch * 8), v8 = *(const u32x2_t*)(vc8 + rowi * HD + ch * 8);
+                const u32x2_t k8 = __builtin_nontemporal_load((const u32x2_t*)(kc8 + rowi * HD + ch * 8)),   // (non-temporal: see the bf16 path below)
+                              v8 = __builtin_nontemporal_load((const u32x2_t*)(vc8 + rowi * HD + ch * 8));
                 kv[u] = (u32x4_t){k8[0], k8[1], __float_as_uint(p.kscale[rowi]), (uint32_t)key};
                 vv[u] = (u32x4_t){v8[0], v8[1], __float_as_uint(p.vscale[rowi]), 0u};
                 continue;
@@ -863,8 +864,12 @@ __global__ __launch_bounds__(NW * 64) void emmax_decode_attn_kernel(DecodeAttnPa
             // every key's lookup waited for the previous key's rows
             const int pg = s_pages[kk >> p.page_shift];
             const size_t off = ((((size_t)pg * p.Hkv + hk) << p.page_shift) + (kk & (p.page - 1))) * HD + ch * 8;
-            kv[u] = *(const u32x4_t*)(kc + off);
-            vv[u] = *(const u32x4_t*)(vc + off);
+            // NON-TEMPORAL loads (round 5): a K / V row is read by ONE block, once per step -- as plain loads the rows were allocated in the
+            // XCD's L2 and in the MALL on their way through, displacing the lines every block of the NEXT launches re-reads (activation rows,
+            // norm weights, RoPE tables).  Measured, builds alternating on one box (profiles/r05_attn_kv_nt_ab.txt): this launch 5.63 ->
+            // 5.42 us at batch 1, 19.9 -> 18.3 at 8 rows, 69.0 -> 61.7 at 32; the whole step 2.593 -> 2.568 ms/token, 3.26 -> 3.19, 5.37 -> 5.11 ms
+            kv[u] = __builtin_nontemporal_load((const u32x4_t*)(kc + off));
+            vv[u] = __builtin_nontemporal_load((const u32x4_t*)(vc + off));
             if (coh && kk == L - 1) {   // the row appended by the qkv kernel of THIS step (one kernel back): agent-scope re-read
                 kv[u] = ld_act16((const u32x4_t*)(kc + off), true);
                 vv[u] = ld_act16((const u32x4_t*)(vc + off), true);

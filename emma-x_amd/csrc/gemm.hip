@@ -1065,11 +1065,11 @@ static int splitk_plan(const GemmParams& p, int* big_out = nullptr) {
     // (the down projection, 172 steps) and at most half a round of big tiles, one slice of a big tile per CU beats the small tiles --
     // M = 768: 78.7 against 86.1 us (5 slices of 48 tiles), M = 1536: 138 against 151 us (2 slices of 96 tiles; that shape had no
     // split-K plan at all: 384 small tiles); at K = 4096 (o-proj) the small tiles stay ahead (44 against 49 us), from 144 tiles on the
-    // plans are within noise of each other.  The fp32 partials of a slice cost the same per tile in both geometries; what the big tile
+    // plans are within noise of each other; 64 / 80 tiles (M = 1024 / 1280): 92 / 109 against 99 / 146 us.  The fp32 partials of a slice cost the same per tile in both geometries; what the big tile
     // buys is its K-step rate (section 6), what it costs is slices of uneven value: 240 of 256 CUs busy.
     {
         const long tb = (long)cdiv(p.M, GeomBig::BM) * cdiv(p.N, GeomBig::BN);
-        int ks = tb > 0 && tb <= 128 ? (int)(256 / tb) : 0;
+        int ks = tb >= 48 && tb <= 128 ? (int)(256 / tb) : 0;   // (below 48 big tiles the small ones win: 16 tiles 36 against 44 us, 32 tiles 51 against 55)
         if (ks > 8) ks = 8;
         while (ks >= 2 && (long long)ks * p.M * p.N * 4 > p.ws_bytes) --ks;
         if (nk >= 128 && ks >= 2 && nk / ks >= 16 && p.act != 2 && emmax_tune().gemm_sk_big != 0) {

@@ -130,6 +130,7 @@ struct EmmaxTune {
     int km_roll;         // 1: decode_km.hip refills a weight register as soon as its MFMA has issued (rolling ring); 0: a tile's sixteen refills together
     int attn_deep;       // bf16 decode attention: four chunks of keys in flight per wave instead of two (the fp8-cache form always has four): -1 = from 1024 blocks (batch 32), 0 never, 1 always
     int attn_ksplit;     // causal prefill attention (head_dim 128): two key groups per block (8 waves) -- -1 = when the launch leaves <= 1 block per CU (one frame), 0 never, 1 always
+    int attn_lazy;       // causal prefill attention (head_dim 128): 1 = lazy reference maximum (round 5), 0 = the running maximum of rounds 1-4 (bit-regression probes)
     int attn_nw;         // waves per decode-attention block: 0 = by shape (4; 8 for the one-split form when that leaves <= 256 blocks), 4 / 8 forced
     int streamk;         // 1: stream-K work split in decode_mfma.hip; 0: whole tasks per block
     int fp8_gemv;        // -1: default routing of the batch 1-2 fp8 projections; >= 0: bit mask (1 qkv, 2 o-proj, 4 gate/up, 8 down, 16 lm-head) on the row GEMV

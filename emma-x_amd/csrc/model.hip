@@ -53,6 +53,7 @@ const TuneEntry kTune[] = {
     {"km", &EmmaxTune::km, 1},                 {"km_down", &EmmaxTune::km_down, 1},
     {"km_roll", &EmmaxTune::km_roll, 0},       {"attn_nw", &EmmaxTune::attn_nw, 4},
     {"attn_deep", &EmmaxTune::attn_deep, -1},  {"attn_ksplit", &EmmaxTune::attn_ksplit, -1},
+    {"attn_lazy", &EmmaxTune::attn_lazy, 1},
     {"streamk", &EmmaxTune::streamk, 1},       {"fp8_gemv", &EmmaxTune::fp8_gemv, -1},
     {"attn_nsplit", &EmmaxTune::attn_nsplit, 0}, {"attn_direct", &EmmaxTune::attn_direct, 1},
     {"fold_embed", &EmmaxTune::fold_embed, 1}, {"mfma_xbar", &EmmaxTune::mfma_xbar, 1},

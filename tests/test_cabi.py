@@ -81,7 +81,7 @@ def test_tuning_switches_are_a_table_with_a_setter(lib):
     L, so = lib
     names = ["graph", "ks", "ks_oproj", "ks_oproj_grid", "km", "km_down", "streamk", "fp8_gemv", "attn_nsplit", "attn_direct", "fold_embed",
              "mfma_xbar", "gemm_big", "gemm_splitk", "gemm_hybrid", "gemm_normfuse", "gemm_deep", "gemm_lnfuse", "attn_resident",
-             "resid32", "kv_fp8", "km_roll", "attn_nw", "attn_deep", "attn_ksplit", "gemm_sk_big"]   # (the last seven: round 5)
+             "resid32", "kv_fp8", "km_roll", "attn_nw", "attn_deep", "attn_ksplit", "gemm_sk_big", "attn_lazy"]   # (the last eight: round 5)
     header = open(os.path.join(ROOT, "include", "emmax.h")).read()
     for n in names:
         assert re.search(r"\b%s\b" % n, header), n
@@ -176,6 +176,7 @@ def test_gemm_launch_plans_of_the_hot_path(lib):
     assert L.gemm_plan(768, 4096, 11008, residual=True) == "splitk big ks=5"
     assert L.gemm_plan(1536, 4096, 11008, residual=True, norm=True) == "splitk big ks=2 +norm"      # two frames: 96 big tiles
     assert L.gemm_plan(1536, 4096, 4096, residual=True, norm=True) == L.gemm_plan(1536, 4096, 4096, residual=True)   # K = 4096: no split from 384 small tiles on
+    assert L.gemm_plan(512, 4096, 8704, act=1) == "splitk ks=4"                                       # the projector's fc2 at two frames: 32 big tiles, small ones win
     with L.tuning(gemm_sk_big=0):
         assert L.gemm_plan(768, 4096, 11008, residual=True, norm=True) == "splitk ks=2 +norm"
     # round 5: the prefill's fp32 residual stream (fp32 residual in, fp32 C out) takes the same plans, the norm still in the reduce pass

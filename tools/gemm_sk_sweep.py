@@ -15,6 +15,8 @@ dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream
 ws = torch.empty(64 << 20, dtype=torch.float32, device=dev)   # 256 MB of scratch: every variant below fits
 SHAPES = [("o", 4096, 4096), ("down", 4096, 11008)]
+if os.environ.get("SK_SHAPES"):          # "name,N,K;..." e.g. the projector's fc2: "projfc2,4096,8704"
+    SHAPES = [(t.split(",")[0], int(t.split(",")[1]), int(t.split(",")[2])) for t in os.environ["SK_SHAPES"].split(";")]
 MS = [int(x) for x in os.environ.get("SK_MS", "768,1536,2304,3072").split(",")]
 for name, N, K in SHAPES:
     for M in MS:
@@ -22,7 +24,7 @@ for name, N, K in SHAPES:
         W = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
         C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         R = (torch.randn(M, N, device=dev) * 0.5).to(torch.bfloat16)
-        variants = [("plan", -1, 0)] + [("small", 0, ks) for ks in (2, 3, 4)] + [("big", 1, ks) for ks in (2, 3, 4, 5, 6, 8, 10)]
+        variants = [("plan", -1, 0)] + [("small", 0, ks) for ks in (2, 3, 4, 8)] + [("big", 1, ks) for ks in (2, 3, 4, 5, 6, 8, 10, 16)]
         variants = [v for v in variants if v[2] == 0 or v[2] * M * N * 4 <= ws.numel() * 4]
 
         def run(v):
