@@ -173,14 +173,16 @@ __global__ __launch_bounds__(256) void emmax_rope_kv_write_vec_kernel(bf16_t* __
         *(u32x4_t*)(x + d + half) = yhi;
         if (hh >= Hq && kcache) {   // (null: fp8 KV cache -- the quantising pass below appends the rows)
             bf16_t* kc = kcache + (((size_t)pg * Hkv + (hh - Hq)) * page + slot) * hd;
-            *(u32x4_t*)(kc + d) = ylo;
-            *(u32x4_t*)(kc + d + half) = yhi;
+            // (non-temporal: the cache rows are next read by the decode steps, a whole prefill later -- they need not displace the qkv rows the
+            // attention launch is about to read)
+            __builtin_nontemporal_store(ylo, (u32x4_t*)(kc + d));
+            __builtin_nontemporal_store(yhi, (u32x4_t*)(kc + d + half));
         }
     }
     for (int i = threadIdx.x; vcache && i < Hkv * hd / 8; i += blockDim.x) {
         const int hk = i / (hd / 8), ch = i - hk * (hd / 8);
         const u32x4_t v = *(const u32x4_t*)(r + v_off + hk * hd + ch * 8);
-        *(u32x4_t*)(vcache + (((size_t)pg * Hkv + hk) * page + slot) * hd + ch * 8) = v;
+        __builtin_nontemporal_store(v, (u32x4_t*)(vcache + (((size_t)pg * Hkv + hk) * page + slot) * hd + ch * 8));
     }
 }
 
