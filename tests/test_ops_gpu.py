@@ -180,6 +180,20 @@ def test_gemm_column_split_plan(device, variant):
 def test_gemm_splitk(device, M, N, K, ks, variant):
     """K slices per tile + reduce / epilogue pass (under-filled problems with a long K); incl. a slice count that does not
     divide the K steps and the in-place residual form the prefill uses (C == residual)."""
+    _gemm_splitk_case(device, M, N, K, ks, variant)
+
+
+@pytest.mark.parametrize("M,N,K,ks", [(768, 4096, 11008, 5), (1536, 4096, 11008, 2), (300, 384, 640, 3), (1000, 4096, 8704, 4)])
+@pytest.mark.parametrize("variant", ["plain", "scale_res_inplace", "f32"])
+def test_gemm_splitk_on_big_tiles(device, M, N, K, ks, variant):
+    """The same pass with the K slices taken from 256 x 256 tiles (tuning switch gemm_sk_big; what the launch plan picks for the down
+    projection of a one- / two-frame prefill: 5 / 2 slices), incl. ragged edge tiles and a slice count that does not divide the K steps."""
+    L, _ = _lib()
+    with L.tuning(gemm_sk_big=1):
+        _gemm_splitk_case(device, M, N, K, ks, variant)
+
+
+def _gemm_splitk_case(device, M, N, K, ks, variant):
     L, lib = _lib()
     g = torch.Generator().manual_seed(M + N + K + ks)
     A = bf(torch.randn(M, K, generator=g)).to(device)
