@@ -17,6 +17,13 @@ import os
 import sys
 import time
 
+# hipGraph replay (--graph): ROCm 7.2's default replay path ("graph packet capture") costs ~0.65 us per kernel node on the device -- 4 % of a
+# 163-node decode step; with the runtime switch below the replay runs at the eager rate (profiles/r05_graph_switches.txt: 2.5745 against 2.5749
+# ms/token eager and 2.69 default replay).  The runtime reads it once, at its first call: set before anything touches HIP (emmax/__init__.py does
+# the same when EMMAX_GRAPH=1 is exported)
+if "--graph" in sys.argv:
+    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "emma-x_amd")):
     if p not in sys.path:
