@@ -8,6 +8,7 @@ the hand-written gfx950 kernels behind the C ABI (include/emmax.h).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -50,6 +51,42 @@ class _Staged:
         self.event.synchronize()
 
 
+class _LabBuffer:
+    """Device bytes from hipExtMallocWithFlags (lab only: EMMAX_LAB_MALLOC_<ARENA|AUX|KV>=<flag>, 1 = fine-grained, 3 = uncached) with the two
+    members the engine uses of a torch tensor.  The product path allocates through torch (measured, no gain)."""
+
+    _hip = None
+
+    def __init__(self, nbytes: int, flag: int):
+        if _LabBuffer._hip is None:
+            _LabBuffer._hip = C.CDLL("libamdhip64.so")
+        self._n = int(nbytes)
+        self._p = C.c_void_p()
+        rc = _LabBuffer._hip.hipExtMallocWithFlags(C.byref(self._p), C.c_size_t(self._n), C.c_uint(flag))
+        if rc != 0 or not self._p.value:
+            raise _lib.EmmaxError(f"hipExtMallocWithFlags({nbytes}, {flag}) failed: {rc}")
+
+    def data_ptr(self) -> int:
+        return int(self._p.value)
+
+    def numel(self) -> int:
+        return self._n
+
+    def __del__(self):
+        try:
+            if self._p.value:
+                _LabBuffer._hip.hipFree(self._p)
+        except Exception:
+            pass
+
+
+def _device_bytes(nbytes: int, device, what: str):
+    flag = os.environ.get("EMMAX_LAB_MALLOC_" + what)
+    if flag:
+        return _LabBuffer(nbytes, int(flag))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
 class EmmaxEngine:
     """Model weights (re-laid-out into one device arena) + one session (workspace + paged KV cache)."""
 
@@ -79,7 +116,7 @@ class EmmaxEngine:
             if free_state_dict:
                 state_dict[key] = None  # drop the caller's copy as soon as ours exists
         nbytes = self.lib.emmax_model_arena_bytes(self._model)
-        self.arena = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.arena = _device_bytes(nbytes, self.device, "ARENA")
         stream = _lib.current_stream()
         import time
 
@@ -106,7 +143,7 @@ class EmmaxEngine:
         _lib.check(self.lib.emmax_session_bytes_ex(self._model, max_batch, max_prompt, max_ctx, int(stage_rows), C.byref(ws), C.byref(kv)),
                    "emmax_session_bytes_ex")
         self.workspace = torch.empty(ws.value, dtype=torch.uint8, device=self.device)
-        self.kv = torch.empty(kv.value, dtype=torch.uint8, device=self.device)
+        self.kv = _device_bytes(kv.value, self.device, "KV")
         _lib.check(self.lib.emmax_session_create_ex(self._model, max_batch, max_prompt, max_ctx, int(stage_rows), self.workspace.data_ptr(),
                                                     ws.value, self.kv.data_ptr(), kv.value, C.byref(self._session)),
                    "emmax_session_create_ex")
@@ -127,7 +164,7 @@ class EmmaxEngine:
         import time
 
         t0 = time.perf_counter()
-        self.aux_arena = torch.empty(max(n, 256), dtype=torch.uint8, device=self.device)
+        self.aux_arena = _device_bytes(max(n, 256), self.device, "AUX")
         _lib.check(self.lib.emmax_model_build_aux(self._model, self.aux_arena.data_ptr(), n, _lib.current_stream()), "emmax_model_build_aux")
         self.aux_build_s = time.perf_counter() - t0
 
