@@ -869,6 +869,7 @@ int launch_attention(const AttnParams& p, int head_dim, hipStream_t stream) {
     if (p.B <= 0 || p.max_seqlen <= 0) return 0;
     if (p.Hq % p.Hkv != 0) return -1;
     if ((p.ld_qkv % 8) || (p.q_off % 8) || (p.k_off % 8) || (p.v_off % 8) || (p.ld_out % 4)) return -1;
+    if (p.ld_qkv >= (1 << 19)) return -1;   // the ring kernel packs a lane's source byte offset inside a row into 20 bits (d_pk)
     const int force = emmax_tune().attn_resident;   // -1 default; 0 never; 2 = whenever it fits (tests)
     const bool no_resident = force == 0;
     // short non-causal sequences with enough (sequence, head) items to keep persistent blocks busy: the resident form (see
