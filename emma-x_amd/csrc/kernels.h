@@ -131,6 +131,7 @@ struct EmmaxTune {
     int attn_deep;       // bf16 decode attention: four chunks of keys in flight per wave instead of two (the fp8-cache form always has four): -1 = from 1024 blocks (batch 32), 0 never, 1 always
     int attn_ksplit;     // causal prefill attention (head_dim 128): two key groups per block (8 waves) -- -1 = when the launch leaves <= 1 block per CU (one frame), 0 never, 1 always
     int attn_lazy;       // causal prefill attention (head_dim 128): 1 = lazy reference maximum (round 5), 0 = the running maximum of rounds 1-4 (bit-regression probes)
+    int vis_streams;     // vision encode: 1 = the two towers side by side on two streams (default; batches up to 256 frames), 0 = one after the other on the caller's stream
     int attn_nw;         // waves per decode-attention block: 0 = by shape (4; 8 for the one-split form when that leaves <= 256 blocks), 4 / 8 forced
     int streamk;         // 1: stream-K work split in decode_mfma.hip; 0: whole tasks per block
     int fp8_gemv;        // -1: default routing of the batch 1-2 fp8 projections; >= 0: bit mask (1 qkv, 2 o-proj, 4 gate/up, 8 down, 16 lm-head) on the row GEMV

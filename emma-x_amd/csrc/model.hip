@@ -53,7 +53,7 @@ const TuneEntry kTune[] = {
     {"km", &EmmaxTune::km, 1},                 {"km_down", &EmmaxTune::km_down, 1},
     {"km_roll", &EmmaxTune::km_roll, 0},       {"attn_nw", &EmmaxTune::attn_nw, 4},
     {"attn_deep", &EmmaxTune::attn_deep, -1},  {"attn_ksplit", &EmmaxTune::attn_ksplit, -1},
-    {"attn_lazy", &EmmaxTune::attn_lazy, 1},
+    {"attn_lazy", &EmmaxTune::attn_lazy, 1},      {"vis_streams", &EmmaxTune::vis_streams, 1},
     {"streamk", &EmmaxTune::streamk, 1},       {"fp8_gemv", &EmmaxTune::fp8_gemv, -1},
     {"attn_nsplit", &EmmaxTune::attn_nsplit, 0}, {"attn_direct", &EmmaxTune::attn_direct, 1},
     {"fold_embed", &EmmaxTune::fold_embed, 1}, {"mfma_xbar", &EmmaxTune::mfma_xbar, 1},
@@ -317,6 +317,15 @@ struct emmax_session {
     bf16 *vA, *vpe, *vtok, *vln, *vqkv, *vatt, *vmlp, *feats, *pj1, *pj2, *patch_embeds;
     float* vstats;              // LayerNorm (mean, rstd) of every token row, f32 [rows][2]
     int32_t* cu_vit[2];
+    // a SECOND set of tower scratch for up to vis2_B frames (round 5): the two towers do not depend on each other, and at small batches each
+    // is a chain of under-filled, launch-latency-bound kernels (one frame: ~360 launches of ~14 us) -- tower 1 runs on the session's vision
+    // stream beside tower 0 (run_vision; tuning switch vis_streams)
+    bf16 *v2A, *v2pe, *v2tok, *v2ln, *v2qkv, *v2att, *v2mlp;
+    float *v2stats, *v2splitk_ws;
+    int64_t v2splitk_bytes;
+    int vis2_B = 0;
+    hipStream_t vis_stream = nullptr;
+    hipEvent_t ev_vfork = nullptr, ev_vjoin = nullptr;
     // prefill scratch
     bf16 *ph, *pxn, *pqkv, *patt, *pact;
     float* ph32;                // the prefill's residual stream in fp32 (tuning switch resid32 = 1), [max_rows][H]
@@ -398,6 +407,21 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->pj2 = (bf16*)b.take((int64_t)Bv * np * m->H * 2);
     s->patch_embeds = (bf16*)b.take((int64_t)Bv * np * m->H * 2);
     for (int t = 0; t < 2; ++t) s->cu_vit[t] = (int32_t*)b.take((Bv + 1) * 4);
+    {   // tower 1's own scratch for the two-stream form (sized for tower 1 alone, up to 256 frames: ~5 MB per frame)
+        const TowerW& T1 = m->tw[1];
+        s->vis2_B = std::min(Bv, 256);
+        const int64_t B2 = s->vis2_B, r2 = B2 * T1.N;
+        s->v2A = (bf16*)b.take(B2 * np * T1.Kpe * 2);
+        s->v2pe = (bf16*)b.take(B2 * np * T1.Dp * 2);
+        s->v2tok = (bf16*)b.take(r2 * T1.Dp * 2);
+        s->v2ln = (bf16*)b.take(r2 * T1.Dp * 2);
+        s->v2stats = (float*)b.take(r2 * 2 * 4);
+        s->v2qkv = (bf16*)b.take(r2 * T1.D3p * 2);
+        s->v2att = (bf16*)b.take(r2 * T1.Dp * 2);
+        s->v2mlp = (bf16*)b.take(r2 * T1.Mp * 2);
+        s->v2splitk_bytes = (int64_t)64 << 20;   // the same budget as the session's split-K scratch: the same plans, bit-identical towers
+        s->v2splitk_ws = (float*)b.take(s->v2splitk_bytes);
+    }
     const int64_t R = s->max_rows;
     s->ph = (bf16*)b.take(R * m->H * 2);
     s->ph32 = (float*)b.take(R * m->H * 4);
@@ -466,62 +490,105 @@ static GemmParams gps(emmax_session* s, const void* A, int lda, const void* W, i
     return p;
 }
 
-static int run_vision(emmax_session* s, bool from_u8, const void* src, int B, void* out, hipStream_t st) {
+// one tower's scratch (run_vision): set 0 = the session's shared buffers (either tower, any batch), set 1 = tower 1's own (two-stream form)
+struct VisScratch {
+    bf16 *vA, *vpe, *vtok, *vln, *vqkv, *vatt, *vmlp;
+    float *vstats, *ws;
+    int64_t ws_bytes;
+};
+
+static int run_tower(emmax_session* s, int t, const VisScratch& v, bool from_u8, const void* src, int B, int col_off, hipStream_t st) {
     emmax_model* m = s->m;
-    if (!m->finalized) return fail(EMMAX_ERR_STATE, "model not finalized");
-    if (B <= 0 || B > s->max_batch) return fail(EMMAX_ERR_INVALID, "vision batch %d outside 1..%d", B, s->max_batch);
     const int np = m->tw[0].n_patches;
-    int col_off = 0;
-    for (int t = 0; t < 2; ++t) {
+    auto gpv = [&](const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K) {
+        GemmParams p = gp(A, lda, W, ldw, C, ldc, M, N, K);
+        p.ws = v.ws;
+        p.ws_bytes = v.ws_bytes;
+        return p;
+    };
+    {
         const TowerW& T = m->tw[t];
         const emmax_tower_config& tc = m->cfg.tower[t];
-        KCHK(launch_patch_gather(from_u8, src, s->vA, B, tc.image_size, tc.patch, T.Kpe, 3 * t, tc.mean, tc.std, st));
-        GemmParams g = gps(s, s->vA, T.Kpe, T.patch_w, T.Kpe, s->vpe, T.Dp, B * np, T.Dp, T.Kpe);
+        KCHK(launch_patch_gather(from_u8, src, v.vA, B, tc.image_size, tc.patch, T.Kpe, 3 * t, tc.mean, tc.std, st));
+        GemmParams g = gpv(v.vA, T.Kpe, T.patch_w, T.Kpe, v.vpe, T.Dp, B * np, T.Dp, T.Kpe);
         g.bias = T.patch_b;
         KCHK(launch_gemm(g, st));
-        KCHK(launch_assemble_tokens(s->vpe, T.pos, T.cls, T.reg, s->vtok, B, np, T.n_prefix, tc.has_cls, T.D, T.Dp, st));
+        KCHK(launch_assemble_tokens(v.vpe, T.pos, T.cls, T.reg, v.vtok, B, np, T.n_prefix, tc.has_cls, T.D, T.Dp, st));
         const int rows = B * T.N;
         for (int i = 0; i < T.n_blocks; ++i) {
             const BlockW& k = T.blk[i];
             // LayerNorm folded into the projection: only the row statistics are computed here, the GEMM reads the raw rows and
             // its epilogue finishes the algebra (kernels.h) -- no normalised copy of the tokens is ever written or re-read
             if (m->ln_folded) {
-                KCHK(launch_row_stats(s->vtok, s->vstats, rows, T.D, T.Dp, tc.ln_eps, st));
-                g = gps(s, s->vtok, T.Dp, k.qkv_w, T.Dp, s->vqkv, T.D3p, rows, T.D3p, T.Dp);
-                g.ln_stats = s->vstats; g.ln_s = k.ln1_s; g.ln_c = k.ln1_c;
+                KCHK(launch_row_stats(v.vtok, v.vstats, rows, T.D, T.Dp, tc.ln_eps, st));
+                g = gpv(v.vtok, T.Dp, k.qkv_w, T.Dp, v.vqkv, T.D3p, rows, T.D3p, T.Dp);
+                g.ln_stats = v.vstats; g.ln_s = k.ln1_s; g.ln_c = k.ln1_c;
             } else {
-                KCHK(launch_layernorm(s->vtok, s->vln, k.n1w, k.n1b, rows, T.D, T.Dp, T.Dp, tc.ln_eps, st));
-                g = gps(s, s->vln, T.Dp, k.qkv_w, T.Dp, s->vqkv, T.D3p, rows, T.D3p, T.Dp);
+                KCHK(launch_layernorm(v.vtok, v.vln, k.n1w, k.n1b, rows, T.D, T.Dp, T.Dp, tc.ln_eps, st));
+                g = gpv(v.vln, T.Dp, k.qkv_w, T.Dp, v.vqkv, T.D3p, rows, T.D3p, T.Dp);
                 g.bias = k.qkv_b;
             }
             KCHK(launch_gemm(g, st));
             AttnParams a;
-            a.qkv = s->vqkv; a.out = s->vatt; a.cu_seqlens = s->cu_vit[t];
+            a.qkv = v.vqkv; a.out = v.vatt; a.cu_seqlens = s->cu_vit[t];
             a.ld_qkv = T.D3p; a.q_off = 0; a.k_off = T.D; a.v_off = 2 * T.D; a.ld_out = T.Dp;
             a.B = B; a.max_seqlen = T.N; a.Hq = tc.num_heads; a.Hkv = tc.num_heads;
             a.scale = 1.0f / sqrtf((float)T.hd); a.causal = 0;
             KCHK(launch_attention(a, T.hd, st));
-            g = gps(s, s->vatt, T.Dp, k.proj_w, T.Dp, s->vtok, T.Dp, rows, T.Dp, T.Dp);
-            g.bias = k.proj_b; g.scale = tc.layerscale ? k.ls1 : nullptr; g.residual = s->vtok; g.ldr = T.Dp;
+            g = gpv(v.vatt, T.Dp, k.proj_w, T.Dp, v.vtok, T.Dp, rows, T.Dp, T.Dp);
+            g.bias = k.proj_b; g.scale = tc.layerscale ? k.ls1 : nullptr; g.residual = v.vtok; g.ldr = T.Dp;
             KCHK(launch_gemm(g, st));
             if (m->ln_folded) {
-                KCHK(launch_row_stats(s->vtok, s->vstats, rows, T.D, T.Dp, tc.ln_eps, st));
-                g = gps(s, s->vtok, T.Dp, k.fc1_w, T.Dp, s->vmlp, T.Mp, rows, T.Mp, T.Dp);
-                g.ln_stats = s->vstats; g.ln_s = k.ln2_s; g.ln_c = k.ln2_c;
+                KCHK(launch_row_stats(v.vtok, v.vstats, rows, T.D, T.Dp, tc.ln_eps, st));
+                g = gpv(v.vtok, T.Dp, k.fc1_w, T.Dp, v.vmlp, T.Mp, rows, T.Mp, T.Dp);
+                g.ln_stats = v.vstats; g.ln_s = k.ln2_s; g.ln_c = k.ln2_c;
             } else {
-                KCHK(launch_layernorm(s->vtok, s->vln, k.n2w, k.n2b, rows, T.D, T.Dp, T.Dp, tc.ln_eps, st));
-                g = gps(s, s->vln, T.Dp, k.fc1_w, T.Dp, s->vmlp, T.Mp, rows, T.Mp, T.Dp);
+                KCHK(launch_layernorm(v.vtok, v.vln, k.n2w, k.n2b, rows, T.D, T.Dp, T.Dp, tc.ln_eps, st));
+                g = gpv(v.vln, T.Dp, k.fc1_w, T.Dp, v.vmlp, T.Mp, rows, T.Mp, T.Dp);
                 g.bias = k.fc1_b;
             }
             g.act = 1;
             KCHK(launch_gemm(g, st));
-            g = gps(s, s->vmlp, T.Mp, k.fc2_w, T.Mp, s->vtok, T.Dp, rows, T.Dp, T.Mp);
-            g.bias = k.fc2_b; g.scale = tc.layerscale ? k.ls2 : nullptr; g.residual = s->vtok; g.ldr = T.Dp;
+            g = gpv(v.vmlp, T.Mp, k.fc2_w, T.Mp, v.vtok, T.Dp, rows, T.Dp, T.Mp);
+            g.bias = k.fc2_b; g.scale = tc.layerscale ? k.ls2 : nullptr; g.residual = v.vtok; g.ldr = T.Dp;
             KCHK(launch_gemm(g, st));
         }
         // drop prefix tokens, no final norm, concat along the feature axis (modeling_prismatic.py:120-123)
-        KCHK(launch_copy_rows(s->vtok, T.Dp, s->feats, B, T.N, T.n_prefix, np, T.D, m->Vp, col_off, st));
-        col_off += T.D;
+        KCHK(launch_copy_rows(v.vtok, T.Dp, s->feats, B, T.N, T.n_prefix, np, T.D, m->Vp, col_off, st));
+    }
+    return 0;
+}
+
+static int run_vision(emmax_session* s, bool from_u8, const void* src, int B, void* out, hipStream_t st) {
+    emmax_model* m = s->m;
+    if (!m->finalized) return fail(EMMAX_ERR_STATE, "model not finalized");
+    if (B <= 0 || B > s->max_batch) return fail(EMMAX_ERR_INVALID, "vision batch %d outside 1..%d", B, s->max_batch);
+    const int np = m->tw[0].n_patches;
+    const VisScratch v0 = {s->vA, s->vpe, s->vtok, s->vln, s->vqkv, s->vatt, s->vmlp, s->vstats, s->splitk_ws, s->splitk_bytes};
+    // Two streams (round 5; tuning switch vis_streams: 1 = on, the default; 0 = one stream): the towers share nothing but the frames and write
+    // disjoint columns of `feats`; at one frame each is a chain of ~180 under-filled, launch-latency-bound kernels, and side by side they take
+    // the time of the longer chain -- 5.01 -> 3.14 ms at one frame, 7.03 -> 5.36 at 8, 16.6 -> 13.9 at 32, 54.4 -> 52.5 at 128, 106.0 -> 104.8
+    // at 256 (one tower's tile tails and launch ramps under the other's kernels; profiles/r05_vision_two_streams.txt).  Identical results:
+    // same kernels, same plans (tower 1 has a split-K scratch of the session's size).
+    const int vsw = emmax_tune().vis_streams;
+    const bool two = s->vis_stream && B <= s->vis2_B && vsw != 0;
+    if (two) {
+        const VisScratch v1 = {s->v2A, s->v2pe, s->v2tok, s->v2ln, s->v2qkv, s->v2att, s->v2mlp, s->v2stats, s->v2splitk_ws, s->v2splitk_bytes};
+        HIPCHK(hipEventRecord(s->ev_vfork, st));
+        HIPCHK(hipStreamWaitEvent(s->vis_stream, s->ev_vfork, 0));
+        int r = run_tower(s, 1, v1, from_u8, src, B, m->tw[0].D, s->vis_stream);
+        if (r == 0) r = run_tower(s, 0, v0, from_u8, src, B, 0, st);
+        // (joined even on an error: the caller's stream must not run ahead of work queued on ours)
+        HIPCHK(hipEventRecord(s->ev_vjoin, s->vis_stream));
+        HIPCHK(hipStreamWaitEvent(st, s->ev_vjoin, 0));
+        if (r) return r;
+    } else {
+        int col_off = 0;
+        for (int t = 0; t < 2; ++t) {
+            const int r = run_tower(s, t, v0, from_u8, src, B, col_off, st);
+            if (r) return r;
+            col_off += m->tw[t].D;
+        }
     }
     GemmParams g = gps(s, s->feats, m->Vp, m->pj1_w, m->Vp, s->pj1, m->P1p, B * np, m->P1p, m->Vp);
     g.bias = m->pj1_b; g.act = 1;
@@ -1202,6 +1269,9 @@ int emmax_session_create_ex(emmax_model* m, int max_batch, int max_prompt, int m
     HIPCHK(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&s->vis_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_vfork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_vjoin, hipEventDisableTiming));
     // static page assignment: row b owns pages [b*max_pages, (b+1)*max_pages)
     {
         std::vector<int32_t> pt((size_t)s->rows_total * s->max_pages);
@@ -1238,6 +1308,9 @@ void emmax_session_destroy(emmax_session* s) {
     if (s->ev_in) (void)hipEventDestroy(s->ev_in);
     if (s->ev_out) (void)hipEventDestroy(s->ev_out);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
+    if (s->vis_stream) (void)hipStreamDestroy(s->vis_stream);
+    if (s->ev_vfork) (void)hipEventDestroy(s->ev_vfork);
+    if (s->ev_vjoin) (void)hipEventDestroy(s->ev_vjoin);
     delete s;
 }
 

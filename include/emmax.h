@@ -83,7 +83,7 @@ int emmax_config_size(void);
  * environment variable EMMAX_<NAME> for each of them ONCE, the first time any value is needed; afterwards only emmax_tuning_set
  * changes them (no launcher reads the environment).  Every default is the product path; the other values are the A/B partners
  * DESIGN.md quotes.  Names: graph (1 = hipGraph replay of the decode step, BASELINE configs[4]), ks, ks_oproj, ks_oproj_grid, km,
- * km_down, km_roll, streamk, fp8_gemv, attn_nsplit, attn_direct, attn_nw, attn_deep, attn_ksplit, attn_lazy, fold_embed, mfma_xbar, gemm_big (2 = the 128 x 256 x 32 lab tile), gemm_splitk, gemm_sk_big,
+ * km_down, km_roll, streamk, fp8_gemv, attn_nsplit, attn_direct, attn_nw, attn_deep, attn_ksplit, attn_lazy, vis_streams, fold_embed, mfma_xbar, gemm_big (2 = the 128 x 256 x 32 lab tile), gemm_splitk, gemm_sk_big,
  * gemm_hybrid, gemm_normfuse, gemm_deep, gemm_lnfuse, attn_resident, resid32 (1 = fp32 residual stream in prefill and decode, 2 = decode only,
  * 0 = bf16 rows), kv_fp8 (1 = sessions created from now on keep an e4m3 KV cache).
  * Three switches are read when an object is BUILT and frozen in it: gemm_lnfuse at emmax_model_finalize (the LayerNorm fold rewrites the ViT

@@ -81,7 +81,7 @@ def test_tuning_switches_are_a_table_with_a_setter(lib):
     L, so = lib
     names = ["graph", "ks", "ks_oproj", "ks_oproj_grid", "km", "km_down", "streamk", "fp8_gemv", "attn_nsplit", "attn_direct", "fold_embed",
              "mfma_xbar", "gemm_big", "gemm_splitk", "gemm_hybrid", "gemm_normfuse", "gemm_deep", "gemm_lnfuse", "attn_resident",
-             "resid32", "kv_fp8", "km_roll", "attn_nw", "attn_deep", "attn_ksplit", "gemm_sk_big", "attn_lazy"]   # (the last eight: round 5)
+             "resid32", "kv_fp8", "km_roll", "attn_nw", "attn_deep", "attn_ksplit", "gemm_sk_big", "attn_lazy", "vis_streams"]   # (the last nine: round 5)
     header = open(os.path.join(ROOT, "include", "emmax.h")).read()
     for n in names:
         assert re.search(r"\b%s\b" % n, header), n

@@ -86,6 +86,25 @@ def test_vision_features_and_projector(device, tiny_random):
     assert rel(got2, got_proj.float().cpu()) < 1e-6 or rel(got2, ref_proj) < FEAT_TOL
 
 
+def test_vision_towers_on_two_streams_equal_one_stream(device, tiny_random):
+    """The two towers side by side on two streams (tuning switch vis_streams, the default) against one after the other on the caller's
+    stream: the same kernels and plans over separate scratch -- bit-identical features and patch embeddings, call after call (a missing
+    fork / join dependency would race with the previous call's scratch)."""
+    from emmax import _lib as L
+
+    cfg, model, _ = tiny_random
+    eng = model.engine
+    rng = np.random.default_rng(11)
+    for B in (1, 2, 4):
+        frames = torch.from_numpy(rng.integers(0, 256, size=(B, 224, 224, 3), dtype=np.uint8)).to(device)
+        with L.tuning(vis_streams=0):
+            one = eng.vision_encode(frames).clone()
+            feats_one = eng.vision_features(B).clone()
+        for _ in range(3):
+            two = eng.vision_encode(frames)
+            assert torch.equal(two, one) and torch.equal(eng.vision_features(B), feats_one), B
+
+
 def test_prefill_logits_all_positions(device, tiny_random):
     from oracle import emmax_oracle as orc
 
