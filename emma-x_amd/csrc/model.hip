@@ -497,7 +497,9 @@ struct VisScratch {
     int64_t ws_bytes;
 };
 
-static int run_tower(emmax_session* s, int t, const VisScratch& v, bool from_u8, const void* src, int B, int col_off, hipStream_t st) {
+// blocks [i0, i1) of tower t; i0 == 0: the patch embedding in front of them, i1 == n_blocks: the feature copy behind them
+static int run_tower(emmax_session* s, int t, const VisScratch& v, bool from_u8, const void* src, int B, int col_off, hipStream_t st, int i0 = 0,
+                     int i1 = 1 << 30) {
     emmax_model* m = s->m;
     const int np = m->tw[0].n_patches;
     auto gpv = [&](const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K) {
@@ -509,13 +511,17 @@ static int run_tower(emmax_session* s, int t, const VisScratch& v, bool from_u8,
     {
         const TowerW& T = m->tw[t];
         const emmax_tower_config& tc = m->cfg.tower[t];
-        KCHK(launch_patch_gather(from_u8, src, v.vA, B, tc.image_size, tc.patch, T.Kpe, 3 * t, tc.mean, tc.std, st));
-        GemmParams g = gpv(v.vA, T.Kpe, T.patch_w, T.Kpe, v.vpe, T.Dp, B * np, T.Dp, T.Kpe);
-        g.bias = T.patch_b;
-        KCHK(launch_gemm(g, st));
-        KCHK(launch_assemble_tokens(v.vpe, T.pos, T.cls, T.reg, v.vtok, B, np, T.n_prefix, tc.has_cls, T.D, T.Dp, st));
+        GemmParams g;
+        i1 = std::min(i1, T.n_blocks);
+        if (i0 == 0) {
+            KCHK(launch_patch_gather(from_u8, src, v.vA, B, tc.image_size, tc.patch, T.Kpe, 3 * t, tc.mean, tc.std, st));
+            g = gpv(v.vA, T.Kpe, T.patch_w, T.Kpe, v.vpe, T.Dp, B * np, T.Dp, T.Kpe);
+            g.bias = T.patch_b;
+            KCHK(launch_gemm(g, st));
+            KCHK(launch_assemble_tokens(v.vpe, T.pos, T.cls, T.reg, v.vtok, B, np, T.n_prefix, tc.has_cls, T.D, T.Dp, st));
+        }
         const int rows = B * T.N;
-        for (int i = 0; i < T.n_blocks; ++i) {
+        for (int i = i0; i < i1; ++i) {
             const BlockW& k = T.blk[i];
             // LayerNorm folded into the projection: only the row statistics are computed here, the GEMM reads the raw rows and
             // its epilogue finishes the algebra (kernels.h) -- no normalised copy of the tokens is ever written or re-read
@@ -554,7 +560,7 @@ static int run_tower(emmax_session* s, int t, const VisScratch& v, bool from_u8,
             KCHK(launch_gemm(g, st));
         }
         // drop prefix tokens, no final norm, concat along the feature axis (modeling_prismatic.py:120-123)
-        KCHK(launch_copy_rows(v.vtok, T.Dp, s->feats, B, T.N, T.n_prefix, np, T.D, m->Vp, col_off, st));
+        if (i1 == T.n_blocks) KCHK(launch_copy_rows(v.vtok, T.Dp, s->feats, B, T.N, T.n_prefix, np, T.D, m->Vp, col_off, st));
     }
     return 0;
 }
@@ -576,8 +582,14 @@ static int run_vision(emmax_session* s, bool from_u8, const void* src, int B, vo
         const VisScratch v1 = {s->v2A, s->v2pe, s->v2tok, s->v2ln, s->v2qkv, s->v2att, s->v2mlp, s->v2stats, s->v2splitk_ws, s->v2splitk_bytes};
         HIPCHK(hipEventRecord(s->ev_vfork, st));
         HIPCHK(hipStreamWaitEvent(s->vis_stream, s->ev_vfork, 0));
-        int r = run_tower(s, 1, v1, from_u8, src, B, m->tw[0].D, s->vis_stream);
-        if (r == 0) r = run_tower(s, 0, v0, from_u8, src, B, 0, st);
+        // the launches of the two chains ENQUEUED alternately, block by block: one host thread feeds both streams, and with tower 1's ~180
+        // launches enqueued first tower 0 started ~0.6 ms late at one frame
+        int r = 0;
+        const int nb = std::max(m->tw[0].n_blocks, m->tw[1].n_blocks);
+        for (int i = 0; i < nb && r == 0; ++i) {
+            if (i < m->tw[1].n_blocks) r = run_tower(s, 1, v1, from_u8, src, B, m->tw[0].D, s->vis_stream, i, i + 1);
+            if (r == 0 && i < m->tw[0].n_blocks) r = run_tower(s, 0, v0, from_u8, src, B, 0, st, i, i + 1);
+        }
         // (joined even on an error: the caller's stream must not run ahead of work queued on ours)
         HIPCHK(hipEventRecord(s->ev_vjoin, s->vis_stream));
         HIPCHK(hipStreamWaitEvent(st, s->ev_vjoin, 0));
