@@ -51,39 +51,9 @@ class _Staged:
         self.event.synchronize()
 
 
-class _LabBuffer:
-    """Device bytes from hipExtMallocWithFlags (lab only: EMMAX_LAB_MALLOC_<ARENA|AUX|KV>=<flag>, 1 = fine-grained, 3 = uncached) with the two
-    members the engine uses of a torch tensor.  The product path allocates through torch (measured, no gain)."""
-
-    _hip = None
-
-    def __init__(self, nbytes: int, flag: int):
-        if _LabBuffer._hip is None:
-            _LabBuffer._hip = C.CDLL("libamdhip64.so")
-        self._n = int(nbytes)
-        self._p = C.c_void_p()
-        rc = _LabBuffer._hip.hipExtMallocWithFlags(C.byref(self._p), C.c_size_t(self._n), C.c_uint(flag))
-        if rc != 0 or not self._p.value:
-            raise _lib.EmmaxError(f"hipExtMallocWithFlags({nbytes}, {flag}) failed: {rc}")
-
-    def data_ptr(self) -> int:
-        return int(self._p.value)
-
-    def numel(self) -> int:
-        return self._n
-
-    def __del__(self):
-        try:
-            if self._p.value:
-                _LabBuffer._hip.hipFree(self._p)
-        except Exception:
-            pass
-
-
 def _device_bytes(nbytes: int, device, what: str):
-    flag = os.environ.get("EMMAX_LAB_MALLOC_" + what)
-    if flag:
-        return _LabBuffer(nbytes, int(flag))
+    """The weight arenas ("ARENA", "AUX") and the paged KV region ("KV") come from torch's allocator (tools/malloc_flags_probe.py replaces
+    this function to measure uncached / fine-grained device memory: no difference, profiles/r05_malloc_flags_ab.txt)."""
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
