@@ -83,19 +83,6 @@ __device__ __forceinline__ void glds16_group4(unsigned int lds_base, unsigned in
                  : "m0", "memory");
 }
 
-// the same with the non-temporal hint (lab, gemm_dbg 64 / 128: the A / the W requests of the main kernel -- the operand that only streams
-// through an XCD's L2 marked evict-first so that the re-read panels of the other operand stay)
-__device__ __forceinline__ void glds16_group4_nt(unsigned int lds_base, unsigned int v0, unsigned int v1, unsigned int v2, unsigned int v3,
-                                                 unsigned long long sbase) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %5 offset:0 nt\n\t"
-                 "global_load_lds_dwordx4 %2, %5 offset:1024 nt\n\t"
-                 "global_load_lds_dwordx4 %3, %5 offset:2048 nt\n\t"
-                 "global_load_lds_dwordx4 %4, %5 offset:3072 nt"
-                 ::"s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase)
-                 : "m0", "memory");
-}
-
 // bf16 epilogue through LDS: a wave parks 64 rows of its result (64 columns; SwiGLU: 32) in its private 8 KiB window
 // (16-byte chunks XOR-swizzled with the row, so both the 8-byte writes in accumulator layout and the 16-byte reads in row
 // layout are conflict-free) and stores them back as whole rows.
@@ -422,17 +409,15 @@ __global__ __launch_bounds__(G::NW * 64, 2) void emmax_gemm_bf16_kernel(GemmPara
         }
     };
     static_assert(G::SA == 4 && G::SB == 4, "a wave's slabs of one operand share one M0 (immediates 0 .. 3072)");
-    const bool ntA = (p.dbg & 64) != 0, ntW = (p.dbg & 128) != 0;   // (uniform)
+    // (round 5: the non-temporal hint on these requests -- `global_load_lds_dwordx4 ... nt` on the A or on the W operand -- was measured and
+    // not kept: ViT shapes +-1 %, LLaMA shapes -3 .. -16 %; the panels ARE shared through the XCD's L2.  profiles/r05_gemm_nt_ab.txt,
+    // commit 8203bcd has the switch)
     auto issueA = [&](int kt, int slot) {   // K step kt of the current tile into A slot `slot`
-        if (ntA) glds16_group4_nt(lds0 + a_slot(slot) + wave * G::SA * 1024, offA_l[0], offA_l[1], offA_l[2], offA_l[3],
-                                  baseA + (unsigned long long)(kbeg + kt) * (BK * 2));
-        else glds16_group4(lds0 + a_slot(slot) + wave * G::SA * 1024, offA_l[0], offA_l[1], offA_l[2], offA_l[3],
+        glds16_group4(lds0 + a_slot(slot) + wave * G::SA * 1024, offA_l[0], offA_l[1], offA_l[2], offA_l[3],
                       baseA + (unsigned long long)(kbeg + kt) * (BK * 2));
     };
     auto issueW = [&](int kt, int slot) {
-        if (ntW) glds16_group4_nt(lds0 + w_slot(slot) + wave * G::SB * 1024, offB_l[0], offB_l[1], offB_l[2], offB_l[3],
-                                  baseB + (unsigned long long)(kbeg + kt) * (BK * 2));
-        else glds16_group4(lds0 + w_slot(slot) + wave * G::SB * 1024, offB_l[0], offB_l[1], offB_l[2], offB_l[3],
+        glds16_group4(lds0 + w_slot(slot) + wave * G::SB * 1024, offB_l[0], offB_l[1], offB_l[2], offB_l[3],
                       baseB + (unsigned long long)(kbeg + kt) * (BK * 2));
     };
 
