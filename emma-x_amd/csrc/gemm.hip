@@ -411,7 +411,7 @@ __global__ __launch_bounds__(G::NW * 64, 2) void emmax_gemm_bf16_kernel(GemmPara
     static_assert(G::SA == 4 && G::SB == 4, "a wave's slabs of one operand share one M0 (immediates 0 .. 3072)");
     // (round 5: the non-temporal hint on these requests -- `global_load_lds_dwordx4 ... nt` on the A or on the W operand -- was measured and
     // not kept: ViT shapes +-1 %, LLaMA shapes -3 .. -16 %; the panels ARE shared through the XCD's L2.  profiles/r05_gemm_nt_ab.txt,
-    // commit 8203bcd has the switch)
+    // commit 62b3d01 has the switch)
     auto issueA = [&](int kt, int slot) {   // K step kt of the current tile into A slot `slot`
         glds16_group4(lds0 + a_slot(slot) + wave * G::SA * 1024, offA_l[0], offA_l[1], offA_l[2], offA_l[3],
                       baseA + (unsigned long long)(kbeg + kt) * (BK * 2));
