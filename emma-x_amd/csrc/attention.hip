@@ -278,32 +278,8 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
         constexpr int NG = decltype(ng_tag)::value;
         // S^T = K . Q^T ; one K fragment read feeds the MFMAs of all QB query blocks
         f32x16_t st[QB][NG];
-        // KSPL (one 32-key group per step, ~170 registers): all K fragments of the step requested before the first MFMA, and the V^T
-        // fragments before the softmax arithmetic -- left to itself hipcc reads two fragments, waits, issues two MFMAs, eight times over
-        // (one LDS round trip per pair), which at one or two waves per SIMD nothing covers
-        constexpr bool PREF = KSPL == 2;
-        u32x2_t vpre[PREF ? 2 : 1][PREF ? NDB : 1][2];
-        if constexpr (PREF) {
-            bf16x8_t kfa[NKK];
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) kfa[kk] = *(const bf16x8_t*)(&Kg[k_off + kk * 16]);
-            typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
-#pragma unroll
-            for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-                for (int db = 0; db < NDB; ++db) {
-                    const bf16_t* vb = Vg + (mm * 16) * VP + v_off + db * 32;
-                    vpre[mm][db][0] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)vb));
-                    vpre[mm][db][1] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + 8 * VP)));
-                }
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                st[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[kk], qf[0][kk], kk == 0 ? zero : st[0][0], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, NKK + 4 * NDB, 0);   // pinned: every LDS read of the step, then the MFMA chain
-            __builtin_amdgcn_sched_group_barrier(0x008, NKK, 0);
-        } else {
+        // (round 5, KSPL form: requesting all K and V^T fragments of a step ahead of its MFMA chain -- pinned with sched_group_barrier, 212
+        // registers -- was measured and not kept: 20.4 against 20.1 us; with two waves per SIMD the partner wave covers the LDS round trips)
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
@@ -315,7 +291,6 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
                     st[qb][gi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][kk], kk == 0 ? zero : st[qb][gi], 0, 0, 0);
                 }
             }
-        }
         // online softmax per query block; P^T packed to bf16
         u32x4_t pf[QB][NG][2];
 #pragma unroll
@@ -381,15 +356,6 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
             }
         }
         // O^T += V^T . P^T : k steps of 16 keys; one V^T fragment (two transpose reads) feeds all QB query blocks
-        if constexpr (PREF) {
-#pragma unroll
-            for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-                for (int db = 0; db < NDB; ++db) {
-                    const u32x4_t av = {vpre[mm][db][0][0], vpre[mm][db][0][1], vpre[mm][db][1][0], vpre[mm][db][1][1]};
-                    o[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, pf[0][0][mm]), o[0][db], 0, 0, 0);
-                }
-        } else
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
