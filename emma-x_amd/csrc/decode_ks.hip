@@ -22,6 +22,9 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifndef KS_W_AUX
+#define KS_W_AUX 2   // cache policy of the weight stream (lab: -DKS_W_AUX=n; 2 = nt, the product)
+#endif
 namespace {
 
 constexpr int KS_WAVES = 8;
@@ -154,7 +157,7 @@ __device__ __forceinline__ void ks_issue(const GemvParams& p, int g_lo, int nrow
         const unsigned so = (unsigned)r * (unsigned)p.ldw * 2u;
 #pragma unroll
         for (int j = 0; j < CPL; ++j)
-            wr[jj * CPL + j] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff[j], so, 2));   // aux 2 = nt
+            wr[jj * CPL + j] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff[j], so, KS_W_AUX));   // aux 2 = nt
     }
 }
 
