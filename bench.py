@@ -319,7 +319,7 @@ def main():
         dom = "gateup_gemv"
         achieved = stage_bytes[dom] / (stage_us[dom] * 1e-6) / 1e9
         # HBM traffic of the same kernel from PMC counters (separate rocprofv3 --pmc passes over tools/pmc_probe.py with the same
-        # batch; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md): collected offline by tools/gpucmd_profile_r05.sh on
+        # batch; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md): collected offline by tools/profile_round.sh on
         # the kernels this line names, not during this run -- null when no pass exists for this (batch, weight format), and on every
         # N > 1 line (it carries no number that was not measured in its own run)
         traffic = None
