@@ -204,6 +204,8 @@ def _workload(args, world, B, P, T):
         head = "BASELINE configs[1] extended to %d frame(s)/GPU" % B
     if getattr(args, "kv_fp8", False):
         head += " [opt-in fp8-e4m3 KV cache: NOT the bf16 headline numerics]"
+    if getattr(args, "exact", False):
+        head += " [EXACT NUMERICS: fp32 activations, two-term bf16 MFMA / dot2 operands, fp32 attention over an fp32 KV cache -- the reference's fp32 CPU arithmetic]"
     return head + (": Emma-X-7B bf16, %d frame(s)/GPU 224x224, %d-token prompt, greedy, %d new tokens (EOS disabled), random-init weights; "
                    "uint8 frames and prompt ids are resident in HBM when the timed region starts; the 7-vector is de-tokenised from the "
                    "generated ids by the ids-level stand-in `actions_from_ids` (no LLaMA tokenizer offline: decode -> Solver text parse is "
@@ -224,6 +226,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the decode step as a hipGraph (EMMAX_GRAPH=1) instead of eager launch-ahead")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5: fp8-e4m3 decode weights (NOT the bf16 headline)")
     ap.add_argument("--kv-fp8", action="store_true", help="opt-in fp8-e4m3 KV cache, one scale per (token, head) row (NOT the bf16 headline)")
+    ap.add_argument("--exact", action="store_true", help="exact numerics (tuning switch exact): fp32 activations, two-term bf16 operands, fp32 KV cache -- "
+                                                         "the reference's fp32 CPU arithmetic; batch 1-2 (a conformance mode: the line says so)")
     ap.add_argument("--scale-baseline", type=float, default=None,
                     help="N > 1 only: actions/s of ONE GPU on the same per-GPU workload, measured elsewhere; default: rank 0 measures it "
                          "live (alone on its GPU, the other ranks parked at a barrier) before the group run")
@@ -231,6 +235,8 @@ def main():
     args = ap.parse_args()
     if args.kv_fp8:
         os.environ["EMMAX_KV_FP8"] = "1"   # (as EMMAX_GRAPH: read once at library start-up, inherited by self-launched ranks)
+    if args.exact:
+        os.environ["EMMAX_EXACT"] = "1"
     if args.graph:
         os.environ["EMMAX_GRAPH"] = "1"   # read once by the library at start-up (include/emmax.h: tuning switches); inherited by self-launched ranks
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -310,7 +316,7 @@ def main():
         ctx = cfg.n_patches + P
         stage_bytes = {
             "qkv_gemv": (qd + 2 * kvd) * L.hidden_size * wbytes,
-            "paged_attn": B * 2 * ctx * kvd * (1 if args.kv_fp8 else 2) + (B * 2 * ctx * L.num_kv_heads * 4 if args.kv_fp8 else 0),
+            "paged_attn": B * 2 * ctx * kvd * (1 if args.kv_fp8 else 4 if args.exact else 2) + (B * 2 * ctx * L.num_kv_heads * 4 if args.kv_fp8 else 0),
             "oproj_gemv": L.hidden_size * qd * wbytes,
             "gateup_gemv": 2 * inter_p * L.hidden_size * wbytes,
             "down_gemv": L.hidden_size * inter_p * wbytes,
@@ -323,7 +329,7 @@ def main():
         # the kernels this line names, not during this run -- null when no pass exists for this (batch, weight format), and on every
         # N > 1 line (it carries no number that was not measured in its own run)
         traffic = None
-        pmc_name = "r05_pmc_traffic_b%d.json" % B if (world == 1 and not args.fp8 and not args.kv_fp8) else None
+        pmc_name = "r05_pmc_traffic_b%d.json" % B if (world == 1 and not args.fp8 and not args.kv_fp8 and not args.exact) else None
         pmc_file = os.path.join(ROOT, "profiles", pmc_name or "none")
         if not args.tiny and pmc_name and os.path.isfile(pmc_file):
             with open(pmc_file) as f:
@@ -336,17 +342,17 @@ def main():
         step_ms = (time.perf_counter() - t_s) / nsteps * 1e3
         w_llm = (L.num_layers * ((qd + 2 * kvd) * L.hidden_size + L.hidden_size * qd + 3 * L.intermediate_size * L.hidden_size
                                  + 2 * L.hidden_size) + L.hidden_size + L.vocab_size * L.hidden_size) * wbytes
-        kv_bytes = L.num_layers * B * 2 * (ctx + nsteps // 2) * (kvd * (1 if args.kv_fp8 else 2) + (L.num_kv_heads * 4 if args.kv_fp8 else 0))
+        kv_bytes = L.num_layers * B * 2 * (ctx + nsteps // 2) * (kvd * (1 if args.kv_fp8 else 4 if args.exact else 2) + (L.num_kv_heads * 4 if args.kv_fp8 else 0))
         step_gbs = (w_llm + kv_bytes) / (step_ms * 1e-3) / 1e9
         out = {
             "metric": "actions/sec", "value": round(actions_per_s, 4), "unit": "actions/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not args.fp8 else "bf16 activations / fp8-e4m3 decode weights", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": ("bf16 weights x two-term bf16 activations (fp32-equivalent), fp32 accumulate" if args.exact else "bf16") if not args.fp8 else "bf16 activations / fp8-e4m3 decode weights", "data": "synthetic",
             "cmd": "python bench.py --gpus %d --steps %d --warmup %d --batch-per-gpu %d --prompt-tokens %d --new-tokens %d%s%s%s"
-                   % (world, args.steps, args.warmup, B, P, T, " --fp8" if args.fp8 else "", (" --graph" if args.graph else "") + (" --kv-fp8" if args.kv_fp8 else ""), " --tiny" if args.tiny else ""),
+                   % (world, args.steps, args.warmup, B, P, T, " --fp8" if args.fp8 else "", (" --graph" if args.graph else "") + (" --kv-fp8" if args.kv_fp8 else "") + (" --exact" if args.exact else ""), " --tiny" if args.tiny else ""),
             "config": {"workload": _workload(args, world, B, P, T),
                        "batch_per_gpu": B, "global_batch": B * world, "prompt_tokens": P, "new_tokens": T, "context": ctx + T,
-                       "parallelism": f"dp{world}", "hipgraph": eng.graph_active()},
+                       "parallelism": f"dp{world}", "hipgraph": eng.graph_active(), "exact_numerics": bool(eng.exact)},
             "value_per_gpu": round(actions_per_s / world, 4), "single_gpu_same_workload": alone,
             "scaling_efficiency": round(actions_per_s / (world * alone["value"]), 4) if alone else None,
             "rccl_ranks": rccl_ranks, "dist_backend": edist.backend_name(),
@@ -358,7 +364,7 @@ def main():
                         "finalize_s": round(eng.finalize_s, 3), "aux_build_s": round(eng.aux_build_s, 3)},
             "stage_us": {k: round(v, 2) for k, v in stage_us.items()},
             "stage_gbs": {k: round(stage_bytes[k] / (stage_us[k] * 1e-6) / 1e9, 1) for k in stage_names},
-            "roofline": {"kernel": ("emmax_decode_ks_kernel<B=%d,GATEUP,NORM,CPL=1>" % B if B <= 2 and not args.fp8 else ("emmax_decode_kmp_kernel<GATEUP,NORM,TMAX=6> (B=%d)" % B if B > 16 else "emmax_decode_km_kernel<GATEUP,NORM%s> (B=%d)" % (",FP8" if args.fp8 else "", B))) + " (gate/up projection + SiLU*mul)", "bound": "hbm",
+            "roofline": {"kernel": ("emmax_decode_ks_kernel<B=%d,GATEUP,NORM,CPL=1%s>" % (B, ",EX" if args.exact else "") if B <= 2 and not args.fp8 else ("emmax_decode_kmp_kernel<GATEUP,NORM,TMAX=6> (B=%d)" % B if B > 16 else "emmax_decode_km_kernel<GATEUP,NORM%s> (B=%d)" % (",FP8" if args.fp8 else "", B))) + " (gate/up projection + SiLU*mul)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "bytes_per_launch": stage_bytes[dom], "us_per_launch": round(stage_us[dom], 2), "traffic": traffic,
                          "traffic_source": "profiles/%s (rocprofv3 --pmc, offline)" % pmc_name if traffic else None},

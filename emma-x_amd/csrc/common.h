@@ -172,6 +172,17 @@ __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
 // sequence (two v_div_scale, rcp, five fma, v_div_fmas, v_div_fixup): 13 instructions per element of a SwiGLU epilogue for a last-bit
 // difference that the bf16 rounding of the product erases (v_rcp_f32: 1 ulp).
 __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+// the exact-numerics path (round 6): the IEEE quotient (the product is NOT rounded to bf16 afterwards there)
+__device__ __forceinline__ float silu_precise(float x) { return x / (1.0f + __expf(-x)); }
+
+// ---- exact numerics (round 6): an activation as two bf16 terms, x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits ----
+struct hl2_t { uint32_t hi, lo; };
+__device__ __forceinline__ hl2_t split_hl2(float a, float b) {
+    const uint32_t hi = pack_bf16x2(a, b);
+    return {hi, pack_bf16x2(a - bf_lo(hi), b - bf_hi(hi))};
+}
+// position of element c of a row inside its HL image (per 64 elements: 64 hi, then 64 lo)
+__host__ __device__ __forceinline__ int hl_col(int c) { return ((c >> 6) << 7) + (c & 63); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Activation accesses with a block-uniform `coh` switch: plain under ordinary stream ordering; agent-scope (sc1: past the
@@ -228,7 +239,7 @@ __device__ __forceinline__ void st_sc1_f32x4(float* p, f32x4_t v) {
 // ---------------------------------------------------------------------------------------------------------------------
 #define EMMAX_PSTRIDE 132
 template <int NS, int GMAX = 4>   // GMAX: vector loads (pairs) in flight per group -- the register budget of the caller
-__device__ __forceinline__ u32x4_t attn_merge_chunk(const float* __restrict__ pp, int d0) {
+__device__ __forceinline__ u32x4_t attn_merge_chunk(const float* __restrict__ pp, int d0, float* out32 = nullptr) {
     float ms[NS], dn[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -262,6 +273,10 @@ __device__ __forceinline__ u32x4_t attn_merge_chunk(const float* __restrict__ pp
         }
     }
     const float inv = den > 0.f ? 1.0f / den : 0.f;
+    if (out32) {   // exact numerics: the merged head chunk in fp32
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out32[j] = a8[j] * inv;
+    }
     u32x4_t v;
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = pack_bf16x2(a8[2 * j] * inv, a8[2 * j + 1] * inv);
@@ -269,7 +284,7 @@ __device__ __forceinline__ u32x4_t attn_merge_chunk(const float* __restrict__ pp
 }
 // generic split count, small register footprint (the dot2 GEMV keeps its 16-load weight ring live across the prologue
 // and must stay under 128 VGPRs)
-__device__ __forceinline__ u32x4_t attn_merge_chunk_loop(const float* __restrict__ pp, int d0, int nsplit, bool coh = false) {
+__device__ __forceinline__ u32x4_t attn_merge_chunk_loop(const float* __restrict__ pp, int d0, int nsplit, bool coh = false, float* out32 = nullptr) {
     float M = -INFINITY;
     for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ld_act_f32(pp + s * EMMAX_PSTRIDE + 128, coh));
     float den = 0.f, a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -286,6 +301,10 @@ __device__ __forceinline__ u32x4_t attn_merge_chunk_loop(const float* __restrict
         }
     }
     const float inv = den > 0.f ? 1.0f / den : 0.f;
+    if (out32) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out32[j] = a8[j] * inv;
+    }
     u32x4_t v;
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = pack_bf16x2(a8[2 * j] * inv, a8[2 * j + 1] * inv);

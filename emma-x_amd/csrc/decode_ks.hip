@@ -182,7 +182,9 @@ __device__ __forceinline__ void ks_chunks(int K, int wave, int lane, int (&coff)
 // (Round 3 chained four of these in one persistent launch with in-kernel mailbox hand-offs: bit-identical and 18 % slower --
 // DESIGN.md section 6; that variant lives in the history, commit 61d5036, not in the product source.)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int B, int MODE, bool NORM, int XS, int CPL, bool R32>
+//   EX: exact numerics (GemvParams::exact): the activation slice as two bf16 terms hi + lo of the fp32 value -- twice the dot2 issues per
+//       weight register against the same accumulator (the stream stays HBM-bound: ~3.6 x VALU headroom per CU at batch 1), fp32 hand-offs
+template <int B, int MODE, bool NORM, int XS, int CPL, bool R32, bool EX = false>
 __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsRegs<B>::N], float* part, float* sumsq, int rows_cap,
                                           int trace_op = -1) {
     constexpr int RB = KsShape<B, CPL>::RB;
@@ -231,7 +233,26 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
 
     // ---- activations: the wave's slice, straight into registers ----
     u32x4_t xr[B][CPL];
-    if constexpr (XS == XS_ATTN) {
+    u32x4_t xl[EX ? B : 1][EX ? CPL : 1];   // EX: the lo terms
+    if constexpr (EX && XS == XS_GLOBAL && !NORM) {
+        // exact numerics, down projection: the SwiGLU product arrives as fp32 rows
+        f32x8_t xq[B][CPL];
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) xq[b][j] = ld_f32x8((const float*)p.x + (size_t)b * p.ldx + (size_t)coff[j] * 8);
+        ks_issue<B, MODE, CPL>(p, g_lo, nrows, 0, voff, wr);
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const hl2_t t = split_hl2(cok[j] ? f32x8_at(xq[b][j], 2 * e) : 0.f, cok[j] ? f32x8_at(xq[b][j], 2 * e + 1) : 0.f);
+                    xr[b][j][e] = t.hi;
+                    xl[b][j][e] = t.lo;
+                }
+    } else if constexpr (XS == XS_ATTN) {
         // chunk cg of the merged attention output = head (cg >> 4), elements (cg & 15) * 8 .. + 8 of the split partials; each
         // lane merges the chunks it will multiply with, every load of a chunk in flight at once
 #pragma unroll
@@ -240,9 +261,20 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
             for (int j = 0; j < CPL; ++j) {
                 const int cg = coff[j];
                 const float* pp = p.attn_part + (size_t)(b * p.Hq + (cg >> 4)) * p.nsplit * PSTRIDE;
-                const u32x4_t v = p.nsplit == 8 ? attn_merge_chunk<8, 4>(pp, (cg & 15) * 8) : attn_merge_chunk_loop(pp, (cg & 15) * 8, p.nsplit);
+                if constexpr (EX) {
+                    float m8[8];
+                    (void)(p.nsplit == 8 ? attn_merge_chunk<8, 4>(pp, (cg & 15) * 8, m8) : attn_merge_chunk_loop(pp, (cg & 15) * 8, p.nsplit, false, m8));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xr[b][j][e] = cok[j] ? v[e] : 0u;
+                    for (int e = 0; e < 4; ++e) {
+                        const hl2_t t = split_hl2(cok[j] ? m8[2 * e] : 0.f, cok[j] ? m8[2 * e + 1] : 0.f);
+                        xr[b][j][e] = t.hi;
+                        xl[b][j][e] = t.lo;
+                    }
+                } else {
+                    const u32x4_t v = p.nsplit == 8 ? attn_merge_chunk<8, 4>(pp, (cg & 15) * 8) : attn_merge_chunk_loop(pp, (cg & 15) * 8, p.nsplit);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xr[b][j][e] = cok[j] ? v[e] : 0u;
+                }
             }
         __builtin_amdgcn_sched_barrier(0);
         ks_issue<B, MODE, CPL>(p, g_lo, nrows, 0, voff, wr);
@@ -270,7 +302,13 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
                     for (int e = 0; e < 4; ++e) {
                         const float a = cok[j] ? f32x8_at(xq[b][j], 2 * e) : 0.f, c = cok[j] ? f32x8_at(xq[b][j], 2 * e + 1) : 0.f;
                         ss[b] += a * a + c * c;
-                        xr[b][j][e] = pack_bf16x2(a * bf_lo(nw[j][e]), c * bf_hi(nw[j][e]));
+                        if constexpr (EX) {
+                            const hl2_t t = split_hl2(a * bf_lo(nw[j][e]), c * bf_hi(nw[j][e]));
+                            xr[b][j][e] = t.hi;
+                            xl[b][j][e] = t.lo;
+                        } else {
+                            xr[b][j][e] = pack_bf16x2(a * bf_lo(nw[j][e]), c * bf_hi(nw[j][e]));
+                        }
                     }
             }
         } else {
@@ -309,7 +347,13 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
                         if constexpr (NORM) {
                             const float a = bf_lo(v), c = bf_hi(v);
                             ss[b] += a * a + c * c;
-                            v = pack_bf16x2(a * bf_lo(nw[j][e]), c * bf_hi(nw[j][e]));
+                            if constexpr (EX) {   // (the embedding row of layer 0: exact bf16 values, x g in fp32, two terms)
+                                const hl2_t t = split_hl2(a * bf_lo(nw[j][e]), c * bf_hi(nw[j][e]));
+                                v = t.hi;
+                                xl[b][j][e] = t.lo;
+                            } else {
+                                v = pack_bf16x2(a * bf_lo(nw[j][e]), c * bf_hi(nw[j][e]));
+                            }
                         }
                         xr[b][j][e] = v;
                     }
@@ -340,6 +384,12 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
                     a = dot2_bf16(wr[jj * CPL + j][1], xr[b][j][1], a);
                     a = dot2_bf16(wr[jj * CPL + j][2], xr[b][j][2], a);
                     a = dot2_bf16(wr[jj * CPL + j][3], xr[b][j][3], a);
+                    if constexpr (EX) {
+                        a = dot2_bf16(wr[jj * CPL + j][0], xl[b][j][0], a);
+                        a = dot2_bf16(wr[jj * CPL + j][1], xl[b][j][1], a);
+                        a = dot2_bf16(wr[jj * CPL + j][2], xl[b][j][2], a);
+                        a = dot2_bf16(wr[jj * CPL + j][3], xl[b][j][3], a);
+                    }
                 }
                 acc[b][jj] = a;
             }
@@ -396,8 +446,27 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
             if (has1) hp[er1] = (bf16_t)(hv >> 16);
         }
     } else if (MODE == GEMV_GATEUP) {
-        const float a = silu(red0) * red1;
-        if (epi) ((bf16_t*)p.y)[(size_t)eb * p.ldy + epair] = f2bf(a);
+        if constexpr (EX) {
+            if (epi) ((float*)p.y)[(size_t)eb * p.ldy + epair] = silu_precise(red0) * red1;
+        } else {
+            const float a = silu(red0) * red1;
+            if (epi) ((bf16_t*)p.y)[(size_t)eb * p.ldy + epair] = f2bf(a);
+        }
+    } else if (MODE == GEMV_QKV && EX) {
+        if (epi) {   // exact numerics: nothing is rounded to bf16 -- fp32 RoPE (every product rounded on its own, as torch does), fp32 q, fp32 cache rows
+            const int hd = p.head_dim, half = hd >> 1;
+            const int hb = epair >> p.ks_shift, d = epair - hb * half;
+            if (hb < p.Hq + p.Hkv) {
+                const float y0 = __fadd_rn(__fmul_rn(red0, pre_a), -__fmul_rn(red1, pre_b)), y1 = __fadd_rn(__fmul_rn(red1, pre_a), __fmul_rn(red0, pre_b));
+                float* dst = hb < p.Hq ? (float*)p.y + (size_t)eb * p.ldy + hb * hd : gemv_kv_row32(p, false, pre_pg, pre_pos, hb - p.Hq);
+                dst[d] = y0;
+                dst[d + half] = y1;
+            } else {
+                float* vc = gemv_kv_row32(p, true, pre_pg, pre_pos, hb - p.Hq - p.Hkv);
+                vc[d] = red0;
+                vc[d + half] = red1;
+            }
+        }
     } else if (MODE == GEMV_QKV) {
         if (epi) {
             const int hd = p.head_dim, half = hd >> 1;
@@ -451,7 +520,7 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
 // work on pairs: (d, d + hd/2) of a head for QKV, (gate_i, up_i) for GATEUP, two consecutive rows otherwise).
 // Dynamic LDS: float part[8 waves][B][rows_cap] + float sumsq[8][B].
 // ---------------------------------------------------------------------------------------------------------------------
-template <int B, int MODE, bool NORM, int XS, int CPL, bool R32>
+template <int B, int MODE, bool NORM, int XS, int CPL, bool R32, bool EX = false>
 __global__ __launch_bounds__(KS_NT, 4) void emmax_decode_ks_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -459,10 +528,10 @@ __global__ __launch_bounds__(KS_NT, 4) void emmax_decode_ks_kernel(GemvParams p)
     float* part = (float*)ks_smem;          // [KS_WAVES][B][rows_cap]
     float* sumsq = part + KS_WAVES * B * rows_cap;   // [KS_WAVES][B]
     u32x4_t wr[KsRegs<B>::N];
-    ks_run_op<B, MODE, NORM, XS, CPL, R32>(p, wr, part, sumsq, rows_cap, 0);
+    ks_run_op<B, MODE, NORM, XS, CPL, R32, EX>(p, wr, part, sumsq, rows_cap, 0);
 }
 
-template <int B, int MODE, bool NORM, int XS, int CPL, bool R32>
+template <int B, int MODE, bool NORM, int XS, int CPL, bool R32, bool EX = false>
 int ks_launch_r(GemvParams p, hipStream_t stream, int* grid_out) {
     constexpr int RB = KsShape<B, CPL>::RB;
     int grid = min(512, p.n_groups);
@@ -474,13 +543,24 @@ int ks_launch_r(GemvParams p, hipStream_t stream, int* grid_out) {
     p.kc = cdiv(2 * pairs_max, RB) * RB;
     const size_t smem = (size_t)(KS_WAVES * B * p.kc + KS_WAVES * B) * sizeof(float);
     if (grid_out) *grid_out = grid;
-    hipLaunchKernelGGL((emmax_decode_ks_kernel<B, MODE, NORM, XS, CPL, R32>), dim3(grid), dim3(KS_NT), smem, stream, p);
+    hipLaunchKernelGGL((emmax_decode_ks_kernel<B, MODE, NORM, XS, CPL, R32, EX>), dim3(grid), dim3(KS_NT), smem, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 // the fp32 residual stream concerns the modes that read (NORM) or update (RESID) the hidden rows; the embedding gather exists for qkv only
 template <int B, int MODE, bool NORM, bool XATTN, int CPL>
 int ks_launch_t(const GemvParams& p, hipStream_t stream, int* grid_out) {
     constexpr bool touches_h = NORM || MODE == GEMV_RESID;
+    if (p.exact) {   // exact numerics: the projections of a decode step only, always on the fp32 stream
+        if constexpr (MODE == GEMV_PLAIN) return -2;
+        else {
+            if (!p.h32) return -2;
+            if constexpr (MODE == GEMV_QKV) {
+                if (p.x_tok) return ks_launch_r<B, MODE, NORM, XS_EMBED, CPL, true, true>(p, stream, grid_out);
+            }
+            if (p.x_tok) return -2;
+            return ks_launch_r<B, MODE, NORM, XATTN ? XS_ATTN : XS_GLOBAL, CPL, true, true>(p, stream, grid_out);
+        }
+    }
     if constexpr (MODE == GEMV_QKV) {
         if (p.x_tok) return p.h32 ? ks_launch_r<B, MODE, NORM, XS_EMBED, CPL, true>(p, stream, grid_out) : ks_launch_r<B, MODE, NORM, XS_EMBED, CPL, false>(p, stream, grid_out);
     } else if (p.x_tok) return -2;

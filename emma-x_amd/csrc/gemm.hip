@@ -250,7 +250,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4_t
                 if (row < p.M && col < p.N) {
                     float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = silu(acc[i][j][r]) * acc[i][j + 1][r];
+                    for (int r = 0; r < 4; ++r) v[r] = (OUT_F32 ? silu_precise(acc[i][j][r]) : silu(acc[i][j][r])) * acc[i][j + 1][r];
+                    if (OUT_F32) {   // exact numerics: the product stays fp32 (split into two bf16 terms by the consumer's pass)
+                        float* d32 = (float*)p.C + (size_t)row * p.ldc + ocol;
+                        if (vec) *(f32x4_t*)d32 = (f32x4_t){v[0], v[1], v[2], v[3]};
+                        else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) d32[r] = v[r];
+                        }
+                        continue;
+                    }
                     bf16_t* dst = (bf16_t*)p.C + (size_t)row * p.ldc + ocol;
                     if (vec) {
                         *(u32x2_t*)dst = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -286,7 +295,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4_t
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[r] = (acc[i][j][r] - st[0] * cs[r]) * st[1] + bv[r];
-                if (ACT == 1) v[r] = gelu_erf(v[r]);
+                if (ACT == 1) v[r] = gelu_erf(v[r]);   // (2.8e-7 absolute: also what the exact-numerics path uses)
                 v[r] *= sv[r];
             }
             if (OUT_F32 && res && p.res_f32) {   // fp32 residual stream (C may alias it)
@@ -416,9 +425,11 @@ __global__ __launch_bounds__(G::NW * 64, 2) void emmax_gemm_bf16_kernel(GemmPara
         glds16_group4(lds0 + a_slot(slot) + wave * G::SA * 1024, offA_l[0], offA_l[1], offA_l[2], offA_l[3],
                       baseA + (unsigned long long)(kbeg + kt) * (BK * 2));
     };
+    // a_hl (exact numerics, GemmParams): K steps 2 j and 2 j + 1 of A hold the hi and the lo bf16 term of the SAME 64 activations -- both
+    // meet W's K step j (a scalar shift; the weights are exact bf16 and are fetched into LDS once per term from the XCD's L2)
     auto issueW = [&](int kt, int slot) {
         glds16_group4(lds0 + w_slot(slot) + wave * G::SB * 1024, offB_l[0], offB_l[1], offB_l[2], offB_l[3],
-                      baseB + (unsigned long long)(kbeg + kt) * (BK * 2));
+                      baseB + (unsigned long long)((kbeg + kt) >> p.a_hl) * (BK * 2));
     };
 
     // ---- fragment read offsets: row base + swizzled chunk; (row >> 1) & 7 == (li >> 1) & 7 for every 16-row tile ----
@@ -1018,10 +1029,7 @@ int launch_t(const GemmParams& p, hipStream_t stream) {
 
 template <class G>
 int launch_geom(const GemmParams& p, hipStream_t stream) {
-    if (p.act == 2) {
-        if (p.out_f32) return -1;
-        return launch_t<G, 2, false>(p, stream);
-    }
+    if (p.act == 2) return p.out_f32 ? launch_t<G, 2, true>(p, stream) : launch_t<G, 2, false>(p, stream);
     if (p.ln_stats && !p.out_f32)   // LayerNorm folded in: the staged epilogue's LN form (an unaligned C falls to the direct epilogue, which reads p.ln_*)
         return p.act == 1 ? launch_t<G, 1, false, true>(p, stream) : launch_t<G, 0, false, true>(p, stream);
     if (p.act == 1) return p.out_f32 ? launch_t<G, 1, true>(p, stream) : launch_t<G, 1, false>(p, stream);
@@ -1039,6 +1047,7 @@ int launch_gemm_geom(const GemmParams& p, int big, hipStream_t stream) {
     if ((p.lda % 8) || (p.ldw % 8)) return -1;
     if (p.ln_stats && (!p.ln_s || !p.ln_c || p.bias || p.scale || p.residual || p.act == 2 || p.ksplit > 1)) return -1;
     if (p.res_f32 && (!p.out_f32 || !p.residual || p.act == 2)) return -1;   // the fp32 residual stream yields an fp32 result
+    if (p.a_hl && (p.a_hl != 1 || p.K % (2 * BK) || p.ln_stats || big == 2)) return -1;   // (hi, lo) pairs of K steps; no folded LayerNorm, no 32-deep tile
     if (big == 2) return launch_k32(p, stream);   // 128 x 256 x 32, two blocks per CU
     return big ? launch_geom<GeomBig>(p, stream) : launch_geom<GeomSmall>(p, stream);
 }

@@ -42,6 +42,12 @@ struct GemmParams {
     void* norm_out;
     int ld_norm;
     float norm_eps;
+    // exact numerics (round 6, tuning switch `exact`): A holds every activation as TWO bf16 terms x = hi + lo (16 mantissa bits), laid out
+    // per 64 elements as [64 x hi][64 x lo] ("HL rows": K steps 2 j / 2 j + 1 of A are the two terms of W's K step j).  The caller passes
+    // K = 2 x the real K and lda = the HL row pitch; W keeps its real K columns.  Both terms go through the SAME bf16 MFMAs into the same
+    // fp32 accumulators: weights are exact bf16, products are exact in fp32, so the result carries the fp32 reference's arithmetic to
+    // ~2^-17 relative per operand instead of the 2^-9 of one bf16 term.
+    int a_hl;
     int dbg;               // tools only: 1 = skip the operand DMA after K step 1 (LDS + MFMA time alone), 2 = skip the stores
     long long* trace;      // tools only (tools/gemm_trace.hip): block 0 writes wall_clock64() stamps per tile phase; null in the product
 };
@@ -75,6 +81,23 @@ struct AttnParams {
     int causal;
 };
 int launch_attention(const AttnParams& p, int head_dim, hipStream_t stream);
+int launch_x_attention(const AttnParams& p, int head_dim, hipStream_t stream);   // exact.hip: fp32 q / k / v rows in, HL rows out, fp32 MFMA
+
+// ---- exact.hip: the exact-numerics mode (tuning switch `exact`; GemmParams::a_hl) ----
+// "HL rows": bf16 rows holding every element as two terms, per 64 elements [64 x hi][64 x lo]; pitch >= 2 x the padded width
+int launch_x_split_rows(const float* x, void* y_hl, int rows, int D, int Dp, int ldx, int ldy, hipStream_t stream);
+int launch_x_rmsnorm(const float* x, void* y_hl, const void* w, int rows, int D, int ldx, int ldy, float eps, hipStream_t stream);
+int launch_x_layernorm(const float* x, void* y_hl, const void* w, const void* b, int rows, int D, int Dp, int ldx, int ldy, float eps, hipStream_t stream);
+int launch_x_join_rows(const void* x_hl, float* y, int rows, int D, int ldx, int ldy, hipStream_t stream);   // y = hi + lo (tests)
+int launch_x_to_bf16(const float* x, int ldx, void* y, int ldy, int rows, int D, hipStream_t stream);
+int launch_x_patch_gather(bool from_u8, const void* src, void* out_hl, int B, int img, int patch, int kpad, int chan0, const float* mean, const float* std,
+                          hipStream_t stream);
+int launch_x_assemble_tokens(const float* pe, const void* pos, const void* cls, const void* reg, float* tokens, int B, int n_patches, int n_prefix, int has_cls,
+                             int D, int ld, hipStream_t stream);
+int launch_x_embed_splice(const int32_t* ids, int P_max, const int32_t* cu, const void* E, const float* patches32, const void* patches_bf, float* h32, int B,
+                          int max_seqlen, int n_patches, int hidden, int vocab, hipStream_t stream);
+int launch_x_rope_kv_write(float* qkv, int ld, int q_off, int k_off, int v_off, const int32_t* cu, int B, int total_rows, const float* cos_t, const float* sin_t,
+                           float* kcache, float* vcache, const int32_t* page_table, int max_pages, int Hq, int Hkv, int hd, int page, hipStream_t stream);
 
 // ---- misc.hip ----
 int launch_patch_gather(bool from_u8, const void* src, void* out, int B, int img, int patch, int kpad, int chan0,
@@ -150,6 +173,10 @@ struct EmmaxTune {
     int attn_resident;   // -1: resident ViT attention kernel where measured faster; 0: never; 2: whenever it fits (tests)
     int kv_fp8;          // 1: sessions created from now on keep the paged KV cache as e4m3 rows + one fp32 scale per (token, head) row (opt-in: half the attention bytes of a decode step, its own error line in the tests); 0: bf16
     int resid32;         // 1: prefill and decode step keep the residual stream in fp32 (GemmParams::res_f32, GemvParams::h32); 2: the decode step only; 0: bf16 rows (rounds 1-4)
+    int exact;           // 1: EXACT NUMERICS (round 6) -- models finalized and sessions created from now on carry fp32 activations end to end, every bf16
+                         //    MFMA / dot2 activation operand as two bf16 terms (hi + lo), fp32 attention (fp32 MFMA) over an fp32 KV cache: the
+                         //    reference's fp32 CPU arithmetic to ~1e-5 of max|logit| instead of 2.4e-2.  Batch 1-2 sessions on bf16 weights; the model
+                         //    keeps the ViT LayerNorms unfolded.  0: the bf16-operand product path (default)
     int epoch;           // bumped by every emmax_tuning_set: sessions drop captured graphs when it moves
 };
 const EmmaxTune& emmax_tune();
@@ -204,11 +231,19 @@ struct GemvParams {
     // the stream is no longer rounded after each of the 64 additions of a token: the mirror is re-derived from fp32 every time.
     float* h32;
     int ldh;
+    // exact numerics (round 6, tuning switch `exact`; decode_ks.hip, batch 1-2): every activation operand enters the dot products as TWO bf16
+    // terms (hi + lo of the fp32 value; the fp32 stream h32 must be set), and what the projections hand on stays fp32 -- QKV: p.y = f32 q rows
+    // [B, ldy], the K / V rows go to an fp32 paged cache (kcache / vcache as float); GATEUP: p.y = f32 [B, ldy]; RESID over the SwiGLU
+    // product: p.x = f32 [B, ldx]; RESID over the attention partials: the merge stays fp32 until it is split.
+    int exact;
 };
 // where the QKV epilogues put element block (head hk, K or V) of batch row b: the paged bf16 cache, or the staging rows of the fp8 KV cache
 __device__ __forceinline__ bf16_t* gemv_kv_row(const GemvParams& p, bool is_v, int b, int pg, int pos, int hk) {
     if (p.kv_stage) return (bf16_t*)p.kv_stage + (((size_t)b * p.Hkv + hk) * 2 + (is_v ? 1 : 0)) * p.head_dim;
     return (bf16_t*)(is_v ? p.vcache : p.kcache) + (((size_t)pg * p.Hkv + hk) * p.page + pos % p.page) * p.head_dim;
+}
+__device__ __forceinline__ float* gemv_kv_row32(const GemvParams& p, bool is_v, int pg, int pos, int hk) {   // exact numerics: the fp32 paged cache
+    return (float*)(is_v ? p.vcache : p.kcache) + (((size_t)pg * p.Hkv + hk) * p.page + pos % p.page) * p.head_dim;
 }
 int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
 // decode_ks.hip: the batch 1-2 bf16 projections with K split across the waves of a block (activation slice in registers, no
@@ -239,6 +274,7 @@ struct DecodeAttnParams {
 };
 int decode_attn_nsplit(int B, int Hkv);
 int launch_decode_attn(const DecodeAttnParams& p, int B, int Hq, int head_dim, int nsplit, hipStream_t stream);
+int launch_x_decode_attn(const DecodeAttnParams& p, int B, int Hq, int head_dim, int nsplit, hipStream_t stream);   // exact.hip: fp32 q, fp32 cache
 
 struct FinishParams {
     const float* part_val;

@@ -63,6 +63,7 @@ const TuneEntry kTune[] = {
     {"gemm_lnfuse", &EmmaxTune::gemm_lnfuse, 1}, {"attn_resident", &EmmaxTune::attn_resident, -1},
     {"gemm_hybrid", &EmmaxTune::gemm_hybrid, 1}, {"gemm_normfuse", &EmmaxTune::gemm_normfuse, 1},
     {"resid32", &EmmaxTune::resid32, 1},       {"kv_fp8", &EmmaxTune::kv_fp8, 0},
+    {"exact", &EmmaxTune::exact, 0},
 };
 EmmaxTune g_tune;
 std::once_flag g_tune_once;
@@ -326,6 +327,7 @@ struct emmax_session {
     int vis2_B = 0;
     hipStream_t vis_stream = nullptr;
     hipEvent_t ev_vfork = nullptr, ev_vjoin = nullptr;
+    const void* last_vis_out = nullptr;   // exact numerics: the caller's bf16 `out` of the last vision encode (handed back to emmax_prefill = "use the fp32 result")
     // prefill scratch
     bf16 *ph, *pxn, *pqkv, *patt, *pact;
     float* ph32;                // the prefill's residual stream in fp32 (tuning switch resid32 = 1), [max_rows][H]
@@ -337,6 +339,13 @@ struct emmax_session {
     float *part, *part_val, *logits, *part_val2 /* lm-head argmax partials of a staged prefill */;
     int32_t *part_idx2;
     int32_t *part_idx, *cur_tok, *ctx_len, *done, *n_out, *out_ids, *max_new_d /* [max_batch] */, *page_table;
+    // EXACT NUMERICS (round 6; tuning switch `exact` at emmax_session_create): fp32 activations end to end.  x32a: the fp32 result of the GEMM
+    // in flight (qkv rows, SwiGLU product, fc1 output ...); xhla / xhlb: the two-term bf16 ("HL") A operands, ping-pong; xtok32: the ViT's fp32
+    // token rows; xfeats32 / xpe32: fp32 tower features / projected patch embeddings; dq32 / dact32: the decode step's fp32 q rows and SwiGLU
+    // product.  The paged KV region holds fp32 rows (twice the bytes of the bf16 cache).
+    bool exact = false;
+    float *x32a = nullptr, *xtok32 = nullptr, *xfeats32 = nullptr, *xpe32 = nullptr, *dq32 = nullptr, *dact32 = nullptr;
+    bf16 *xhla = nullptr, *xhlb = nullptr;
     float* splitk_ws;           // fp32 partial tiles of split-K GEMMs (gemm.hip)
     int64_t splitk_bytes;
     unsigned long long* sk_ws = nullptr;     // device: stream-K granules of the MFMA decode projections (decode_mfma.hip), all zero between launches
@@ -461,15 +470,32 @@ static void plan_session(emmax_session* s, SBump& b) {
     s->splitk_ws = (float*)b.take(s->splitk_bytes);
     s->cos_t = (float*)b.take((int64_t)s->max_ctx * (m->cfg.head_dim / 2) * 4);
     s->sin_t = (float*)b.take((int64_t)s->max_ctx * (m->cfg.head_dim / 2) * 4);
+    if (s->exact) {
+        const int64_t npr = (int64_t)Bv * np;
+        auto mx = [](int64_t a, int64_t b2) { return a > b2 ? a : b2; };
+        const int64_t n32 = mx(mx(vr * mx(maxD3p, maxMp), npr * mx(mx(m->P1p, m->H), maxDp)), R * mx(m->qkv_dim, m->inter_p));
+        const int64_t nhla = mx(mx(npr * maxK, vr * maxDp), mx(npr * mx(m->Vp, m->H), R * m->H));
+        const int64_t nhlb = mx(mx(vr * mx(maxDp, maxMp), npr * m->P1p), R * mx(m->q_dim, m->inter_p));
+        s->x32a = (float*)b.take(n32 * 4);
+        s->xhla = (bf16*)b.take(nhla * 4);   // two bf16 terms per element
+        s->xhlb = (bf16*)b.take(nhlb * 4);
+        s->xtok32 = (float*)b.take(vr * maxDp * 4);
+        s->xfeats32 = (float*)b.take(npr * m->Vp * 4);
+        s->xpe32 = (float*)b.take(npr * m->H * 4);
+        s->dq32 = (float*)b.take((int64_t)Bd * m->q_dim * 4);
+        s->dact32 = (float*)b.take((int64_t)Bd * m->inter_p * 4);
+    }
 }
 
 // paged KV region: per layer K and V, rows x pages x kv heads x 64 tokens x head_dim elements -- bf16, or (kv8) e4m3 bytes + a 4-byte scale per row
 static int64_t kv_rows_per_layer(const emmax_model* m, int rows, int max_pages) { return (int64_t)rows * max_pages * m->cfg.n_kv_heads * PAGE; }
-static int64_t kv_layer_bytes(const emmax_model* m, int rows, int max_pages, bool kv8) {
-    return 2 * kv_rows_per_layer(m, rows, max_pages) * (kv8 ? m->cfg.head_dim + 4 : m->cfg.head_dim * 2);
+enum { KV_BF16 = 0, KV_FP8 = 1, KV_F32 = 2 };   // format of the paged cache: bf16 rows; e4m3 rows + a scale (kv_fp8); fp32 rows (exact numerics)
+static int kv_format_now() { return emmax_tune().exact ? KV_F32 : (emmax_tune().kv_fp8 ? KV_FP8 : KV_BF16); }
+static int64_t kv_layer_bytes(const emmax_model* m, int rows, int max_pages, int fmt) {
+    return 2 * kv_rows_per_layer(m, rows, max_pages) * (fmt == KV_FP8 ? m->cfg.head_dim + 4 : fmt == KV_F32 ? m->cfg.head_dim * 4 : m->cfg.head_dim * 2);
 }
-static int64_t kv_bytes_for(const emmax_model* m, int max_batch, int max_pages, bool kv8) {
-    return (int64_t)m->cfg.n_layers * kv_layer_bytes(m, max_batch, max_pages, kv8);
+static int64_t kv_bytes_for(const emmax_model* m, int max_batch, int max_pages, int fmt) {
+    return (int64_t)m->cfg.n_layers * kv_layer_bytes(m, max_batch, max_pages, fmt);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -565,10 +591,95 @@ static int run_tower(emmax_session* s, int t, const VisScratch& v, bool from_u8,
     return 0;
 }
 
+// ---- exact numerics (tuning switch exact; exact.hip): the same stages on fp32 activations --------------------------------------------
+// C[M, N] f32 = A (HL rows, K real columns padded to Kp) . W^T: both bf16 terms of A through the bf16 MFMAs (GemmParams::a_hl)
+static GemmParams gpx(emmax_session* s, const void* A_hl, int Kp, const void* W, int ldw, float* C, int ldc, int M, int N) {
+    GemmParams p = gps(s, A_hl, 2 * Kp, W, ldw, C, ldc, M, N, 2 * Kp);
+    p.a_hl = 1;
+    p.out_f32 = 1;
+    return p;
+}
+
+static int run_tower_x(emmax_session* s, int t, bool from_u8, const void* src, int B, int col_off, hipStream_t st) {
+    emmax_model* m = s->m;
+    const TowerW& T = m->tw[t];
+    const emmax_tower_config& tc = m->cfg.tower[t];
+    const int np = m->tw[0].n_patches, rows = B * T.N;
+    KCHK(launch_x_patch_gather(from_u8, src, s->xhla, B, tc.image_size, tc.patch, T.Kpe, 3 * t, tc.mean, tc.std, st));
+    GemmParams g = gpx(s, s->xhla, T.Kpe, T.patch_w, T.Kpe, s->x32a, T.Dp, B * np, T.Dp);
+    g.bias = T.patch_b;
+    KCHK(launch_gemm(g, st));
+    KCHK(launch_x_assemble_tokens(s->x32a, T.pos, T.cls, T.reg, s->xtok32, B, np, T.n_prefix, tc.has_cls, T.D, T.Dp, st));
+    if (T.Dp != T.D) HIPCHK(hipMemsetAsync(s->xhlb, 0, (size_t)rows * 2 * T.Dp * 2, st));   // the attention writes the real columns only
+    auto into_tokens = [&](GemmParams& q, const void* bias, const void* ls) {   // tokens += LayerScale . (A W^T + bias), fp32 rows
+        q.C = s->xtok32; q.ldc = T.Dp; q.bias = bias; q.scale = tc.layerscale ? ls : nullptr;
+        q.residual = s->xtok32; q.res_f32 = 1; q.ldr = T.Dp;
+    };
+    for (int i = 0; i < T.n_blocks; ++i) {
+        const BlockW& k = T.blk[i];
+        KCHK(launch_x_layernorm(s->xtok32, s->xhla, k.n1w, k.n1b, rows, T.D, T.Dp, T.Dp, 2 * T.Dp, tc.ln_eps, st));
+        g = gpx(s, s->xhla, T.Dp, k.qkv_w, T.Dp, s->x32a, T.D3p, rows, T.D3p);
+        g.bias = k.qkv_b;
+        KCHK(launch_gemm(g, st));
+        AttnParams a;
+        a.qkv = s->x32a; a.out = s->xhlb; a.cu_seqlens = s->cu_vit[t];
+        a.ld_qkv = T.D3p; a.q_off = 0; a.k_off = T.D; a.v_off = 2 * T.D; a.ld_out = 2 * T.Dp;
+        a.B = B; a.max_seqlen = T.N; a.Hq = tc.num_heads; a.Hkv = tc.num_heads;
+        a.scale = 1.0f / sqrtf((float)T.hd); a.causal = 0;
+        KCHK(launch_x_attention(a, T.hd, st));
+        g = gpx(s, s->xhlb, T.Dp, k.proj_w, T.Dp, nullptr, 0, rows, T.Dp);
+        into_tokens(g, k.proj_b, k.ls1);
+        KCHK(launch_gemm(g, st));
+        KCHK(launch_x_layernorm(s->xtok32, s->xhla, k.n2w, k.n2b, rows, T.D, T.Dp, T.Dp, 2 * T.Dp, tc.ln_eps, st));
+        g = gpx(s, s->xhla, T.Dp, k.fc1_w, T.Dp, s->x32a, T.Mp, rows, T.Mp);
+        g.bias = k.fc1_b; g.act = 1;
+        KCHK(launch_gemm(g, st));
+        KCHK(launch_x_split_rows(s->x32a, s->xhlb, rows, T.Mp, T.Mp, T.Mp, 2 * T.Mp, st));
+        g = gpx(s, s->xhlb, T.Mp, k.fc2_w, T.Mp, nullptr, 0, rows, T.Dp);
+        into_tokens(g, k.fc2_b, k.ls2);
+        KCHK(launch_gemm(g, st));
+    }
+    // drop prefix tokens, no final norm, concat along the feature axis (modeling_prismatic.py:120-123): fp32 rows
+    for (int b = 0; b < B; ++b)
+        HIPCHK(hipMemcpy2DAsync(s->xfeats32 + (size_t)b * np * m->Vp + col_off, (size_t)m->Vp * 4, s->xtok32 + ((size_t)b * T.N + T.n_prefix) * T.Dp,
+                                (size_t)T.Dp * 4, (size_t)T.D * 4, np, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+static int run_vision_x(emmax_session* s, bool from_u8, const void* src, int B, void* out, hipStream_t st) {
+    emmax_model* m = s->m;
+    const int np = m->tw[0].n_patches, R = B * np;
+    if (m->ln_folded) return fail(EMMAX_ERR_STATE, "exact numerics: the model was finalized with folded LayerNorms (set exact = 1 before emmax_model_finalize)");
+    int col_off = 0;
+    for (int t = 0; t < 2; ++t) {
+        const int r = run_tower_x(s, t, from_u8, src, B, col_off, st);
+        if (r) return r;
+        col_off += m->tw[t].D;
+    }
+    KCHK(launch_x_split_rows(s->xfeats32, s->xhla, R, m->Vp, m->Vp, m->Vp, 2 * m->Vp, st));
+    GemmParams g = gpx(s, s->xhla, m->Vp, m->pj1_w, m->Vp, s->x32a, m->P1p, R, m->P1p);
+    g.bias = m->pj1_b; g.act = 1;
+    KCHK(launch_gemm(g, st));
+    KCHK(launch_x_split_rows(s->x32a, s->xhlb, R, m->P1p, m->P1p, m->P1p, 2 * m->P1p, st));
+    g = gpx(s, s->xhlb, m->P1p, m->pj2_w, m->P1p, s->x32a, m->H, R, m->H);
+    g.bias = m->pj2_b; g.act = 1;
+    KCHK(launch_gemm(g, st));
+    KCHK(launch_x_split_rows(s->x32a, s->xhla, R, m->H, m->H, m->H, 2 * m->H, st));
+    g = gpx(s, s->xhla, m->H, m->pj3_w, m->H, s->xpe32, m->H, R, m->H);
+    g.bias = m->pj3_b;
+    KCHK(launch_gemm(g, st));
+    // the C ABI hands out bf16 patch embeddings: a rounded copy for the caller; the prefill reads the fp32 rows (run_prefill_x)
+    KCHK(launch_x_to_bf16(s->xpe32, m->H, out ? out : (void*)s->patch_embeds, m->H, R, m->H, st));
+    s->last_vis_out = out;
+    s->vision_B = B;
+    return 0;
+}
+
 static int run_vision(emmax_session* s, bool from_u8, const void* src, int B, void* out, hipStream_t st) {
     emmax_model* m = s->m;
     if (!m->finalized) return fail(EMMAX_ERR_STATE, "model not finalized");
     if (B <= 0 || B > s->max_batch) return fail(EMMAX_ERR_INVALID, "vision batch %d outside 1..%d", B, s->max_batch);
+    if (s->exact) return run_vision_x(s, from_u8, src, B, out, st);
     const int np = m->tw[0].n_patches;
     const VisScratch v0 = {s->vA, s->vpe, s->vtok, s->vln, s->vqkv, s->vatt, s->vmlp, s->vstats, s->splitk_ws, s->splitk_bytes};
     // Two streams (round 5; tuning switch vis_streams: 1 = on, the default; 0 = one stream): the towers share nothing but the frames and write
@@ -639,6 +750,11 @@ static int fp8_gemv_mask(int B) {
 static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_fm, int B, hipStream_t st, int* grid_out = nullptr,
                        const float* w_scale = nullptr, const void* w_r8 = nullptr, int f8bit = 0, const void* w_km = nullptr,
                        const float* km_scale = nullptr) {
+    if (p.exact) {   // exact numerics: decode_ks.hip's two-term form or nothing
+        p.W = w_rm;
+        const int r = B < EMMAX_MFMA_MIN_BATCH && !w_scale ? launch_decode_ks(mode, p, B, st, grid_out) : -2;
+        return r == -2 ? fail(EMMAX_ERR_INVALID, "exact numerics: no two-term kernel for this projection (batch %d, K %d)", B, p.K) : r;
+    }
     if (B < EMMAX_MFMA_MIN_BATCH && w_scale && w_r8 && (fp8_gemv_mask(B) & f8bit) && decode_gemv_fp8_fits(B, p.K)) {
         p.W = w_r8;
         p.wscale = w_scale;
@@ -683,11 +799,12 @@ static int model_max_decode_batch(const emmax_model* m) {
     return p_ok ? EMMAX_MAX_DECODE_BATCH : 16;
 }
 
+static int run_prefill_x(emmax_session* s, const int32_t* ids, int B, int P_max, const void* patches, int np, int total, int maxS, int r0, hipStream_t st);
 static char* kv_layer(emmax_session* s, int layer) { return (char*)s->kv + (size_t)layer * s->kv_layer_stride; }
 static int64_t kv_rows(emmax_session* s) { return kv_rows_per_layer(s->m, s->rows_total, s->max_pages); }
 static bf16* kcache_of(emmax_session* s, int layer) { return (bf16*)kv_layer(s, layer); }
 static bf16* vcache_of(emmax_session* s, int layer) {
-    return (bf16*)(kv_layer(s, layer) + kv_rows(s) * (s->kv8 ? s->m->cfg.head_dim : s->m->cfg.head_dim * 2));
+    return (bf16*)(kv_layer(s, layer) + kv_rows(s) * (s->kv8 ? s->m->cfg.head_dim : s->exact ? s->m->cfg.head_dim * 4 : s->m->cfg.head_dim * 2));
 }
 static float* kscale_of(emmax_session* s, int layer) { return (float*)(kv_layer(s, layer) + 2 * kv_rows(s) * s->m->cfg.head_dim); }   // kv8 only
 static float* vscale_of(emmax_session* s, int layer) { return kscale_of(s, layer) + kv_rows(s); }
@@ -769,6 +886,7 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
     KCHK(launch_prefill_state(ps, s->cu, s->ctx_len + r0, s->done + r0, s->n_out + r0, s->max_new_d + r0, s->stop_m + r0, s->stop_after + r0, st));
     if (!slot_mode) { s->cur_B = B; s->dec_steps = 0; }
     s->total_rows = total; s->max_seqlen = maxS;
+    if (s->exact) return run_prefill_x(s, ids, B, P_max, patches, np, total, maxS, r0, st);
 
     // fp32 residual stream (tuning switch resid32 = 1; 2 = the decode step only): o-proj and down add into fp32 rows -- through the
     // split-K reduce passes of a one-frame prefill, through the direct fp32 epilogue of the big GEMMs otherwise -- and the RMSNorms read
@@ -833,11 +951,54 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
     return 0;
 }
 
+// the prefill in exact numerics: fp32 residual rows (ph32), every GEMM over two-term A operands with fp32 results, fp32 RoPE, fp32 K / V
+// into the fp32 cache, fp32-MFMA causal attention; semantics as run_prefill (modeling_prismatic.py:362-415, HF LlamaDecoderLayer)
+static int run_prefill_x(emmax_session* s, const int32_t* ids, int B, int P_max, const void* patches, int np, int total, int maxS, int r0, hipStream_t st) {
+    emmax_model* m = s->m;
+    const auto& c = m->cfg;
+    // patch rows: the session's own fp32 result when the caller hands back what emmax_vision_encode gave it (or nothing); else the caller's bf16 rows, widened
+    const bool internal = np > 0 && s->vision_B == B && (patches == (const void*)s->patch_embeds || patches == s->last_vis_out);
+    KCHK(launch_x_embed_splice(ids, P_max, s->cu, m->embed, internal ? s->xpe32 : nullptr, internal ? nullptr : patches, s->ph32, B, maxS, np, m->H, m->vocab, st));
+    s->p32 = true;
+    auto into_stream = [&](GemmParams& g) { g.C = s->ph32; g.ldc = m->H; g.residual = s->ph32; g.res_f32 = 1; g.ldr = m->H; };
+    for (int li = 0; li < c.n_layers; ++li) {
+        const LayerW& L = m->layers[li];
+        KCHK(launch_x_rmsnorm(s->ph32, s->xhla, L.ln1, total, m->H, m->H, 2 * m->H, c.rms_eps, st));
+        GemmParams g = gpx(s, s->xhla, m->H, L.wqkv, m->H, s->x32a, m->qkv_dim, total, m->qkv_dim);
+        KCHK(launch_gemm(g, st));
+        KCHK(launch_x_rope_kv_write(s->x32a, m->qkv_dim, 0, m->q_dim, m->q_dim + m->kv_dim, s->cu, B, total, s->cos_t, s->sin_t, (float*)kcache_of(s, li),
+                                    (float*)vcache_of(s, li), s->page_table + (size_t)r0 * s->max_pages, s->max_pages, c.n_heads, c.n_kv_heads, c.head_dim, PAGE, st));
+        AttnParams a;
+        a.qkv = s->x32a; a.out = s->xhlb; a.cu_seqlens = s->cu;
+        a.ld_qkv = m->qkv_dim; a.q_off = 0; a.k_off = m->q_dim; a.v_off = m->q_dim + m->kv_dim; a.ld_out = 2 * m->q_dim;
+        a.B = B; a.max_seqlen = maxS; a.Hq = c.n_heads; a.Hkv = c.n_kv_heads;
+        a.scale = 1.0f / sqrtf((float)c.head_dim); a.causal = 1;
+        KCHK(launch_x_attention(a, c.head_dim, st));
+        g = gpx(s, s->xhlb, m->q_dim, L.wo, m->q_dim, nullptr, 0, total, m->H);
+        into_stream(g);
+        KCHK(launch_gemm(g, st));
+        KCHK(launch_x_rmsnorm(s->ph32, s->xhla, L.ln2, total, m->H, m->H, 2 * m->H, c.rms_eps, st));
+        g = gpx(s, s->xhla, m->H, L.wgu, m->H, s->x32a, m->inter_p, total, 2 * m->inter_p);
+        g.act = 2;
+        KCHK(launch_gemm(g, st));
+        KCHK(launch_x_split_rows(s->x32a, s->xhlb, total, m->inter_p, m->inter_p, m->inter_p, 2 * m->inter_p, st));
+        g = gpx(s, s->xhlb, m->inter_p, L.wdown, m->inter_p, nullptr, 0, total, m->H);
+        into_stream(g);
+        KCHK(launch_gemm(g, st));
+    }
+    KCHK(launch_gather_last_rows(s->ph, s->dh + (size_t)r0 * m->H, s->cu, B, m->H, st, s->dh32 + (size_t)r0 * m->H, s->ph32));
+    int r = run_lm_head_step(s, B, true, nullptr, true, st, r0);
+    if (r) return r;
+    s->prefilled = true;
+    return 0;
+}
+
 enum { STAGE_QKV = 0, STAGE_ATTN = 1, STAGE_OPROJ = 2, STAGE_GATEUP = 3, STAGE_DOWN = 4, STAGE_LMHEAD = 5 };
 
 // one KV split per (row, head) (batch >= 5 at 32 heads): nothing to merge -- the attention launch normalises and writes the bf16 row
 // itself and the o-proj is a plain projection; otherwise the o-proj prologue merges the split partials.
 static bool attn_direct_on(const emmax_session* s, int B) {
+    if (s->exact) return false;   // the split partials stay fp32 until the o-proj splits them into two terms
     return decode_attn_nsplit(B, s->m->cfg.n_kv_heads) == 1 && emmax_tune().attn_direct != 0;
 }
 
@@ -849,6 +1010,7 @@ static void stage_params(emmax_session* s, int B, int li, int stage, GemvParams&
     memset(&p, 0, sizeof(p));
     p.sk_ws = streamk_on() ? s->sk_ws : nullptr;
     if (stage != STAGE_ATTN) { p.h32 = h32_of(s); p.ldh = m->H; }   // qkv / gate-up read the hidden rows, o-proj / down add into them
+    if (s->exact) { p.exact = 1; p.h32 = s->dh32; p.ldh = m->H; }
     switch (stage) {
         case STAGE_QKV:
             p.x = s->dh; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln1; p.eps = c.rms_eps;
@@ -857,6 +1019,7 @@ static void stage_params(emmax_session* s, int B, int li, int stage, GemvParams&
             p.ctx_len = s->ctx_len; p.page_table = s->page_table; p.cos_t = s->cos_t; p.sin_t = s->sin_t;
             p.kcache = kcache_of(s, li); p.vcache = vcache_of(s, li);
             p.kv_stage = s->kv8 ? s->kv_stage : nullptr;   // fp8 KV cache: the new rows wait as bf16 for the attention launch
+            if (s->exact) p.y = s->dq32;                    // fp32 q rows; kcache / vcache are the fp32 cache
             break;
         case STAGE_OPROJ:
             p.x = s->datt; p.ldx = m->q_dim; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
@@ -867,9 +1030,11 @@ static void stage_params(emmax_session* s, int B, int li, int stage, GemvParams&
         case STAGE_GATEUP:
             p.x = s->dh; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = L.ln2; p.eps = c.rms_eps;
             p.y = s->dact; p.ldy = m->inter_p; p.n_rows = 2 * m->inter_p;
+            if (s->exact) p.y = s->dact32;
             break;
         case STAGE_DOWN:
             p.x = s->dact; p.ldx = m->inter_p; p.ldw = m->inter_p; p.K = m->inter_p; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
+            if (s->exact) p.x = s->dact32;
             break;
         default: break;
     }
@@ -880,6 +1045,7 @@ static void lmhead_params(emmax_session* s, int slot0, float* logits_out, GemvPa
     p.sk_ws = streamk_on() ? (slot0 >= s->stg0 ? s->sk_ws2 : s->sk_ws) : nullptr;
     p.x = s->dh + (size_t)slot0 * m->H; p.ldx = m->H; p.ldw = m->H; p.K = m->H; p.norm_w = m->final_norm; p.eps = m->cfg.rms_eps;
     p.h32 = h32_of(s, slot0); p.ldh = m->H;
+    if (s->exact) { p.exact = 1; p.h32 = s->dh32 + (size_t)slot0 * m->H; }
     const bool stg = slot0 >= s->stg0;
     p.n_rows = m->vocab; p.max_parts = s->n_lm_blocks; p.part_val = stg ? s->part_val2 : s->part_val; p.part_idx = stg ? s->part_idx2 : s->part_idx;
     p.logits_out = logits_out;
@@ -906,6 +1072,11 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             a.max_pages = s->max_pages; a.scale = 1.0f / sqrtf((float)c.head_dim);
             a.o_out = attn_direct_on(s, B) ? s->datt : nullptr;
             const int ns = decode_attn_nsplit(B, c.n_kv_heads);
+            if (s->exact) {
+                a.q = s->dq32;
+                KCHK(launch_x_decode_attn(a, B, c.n_heads, c.head_dim, ns, st));
+                return 0;
+            }
             KCHK(launch_decode_attn(a, B, c.n_heads, c.head_dim, ns, st));
             return 0;
         }
@@ -936,7 +1107,7 @@ static int run_qkv0_with_embed(emmax_session* s, int B, hipStream_t st) {
     p.x = m->embed; p.x_tok = s->cur_tok; p.x_copy = s->dh; p.x_vocab = m->vocab;
     int r = launch_decode_ks(GEMV_QKV, p, B, st, nullptr);
     if (r == -2) {
-        KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st, h32_of(s)));
+        KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st, s->exact ? s->dh32 : h32_of(s)));
         return run_decode_stage(s, B, 0, STAGE_QKV, st);
     }
     return r ? fail(EMMAX_ERR_HIP, "qkv launch of layer 0 failed (code %d)", r) : 0;
@@ -947,7 +1118,7 @@ static int run_decode_step(emmax_session* s, int B, hipStream_t st) {
     // batch 1-2 on bf16 weights: the embedding row is read by layer 0's qkv launch itself (K-split kernel) -- one launch fewer
     const bool fold_embed = B < EMMAX_MFMA_MIN_BATCH && !m->fp8 && decode_ks_enabled() && m->H % 64 == 0 && m->H <= 12288 &&
                             emmax_tune().fold_embed != 0;
-    if (!fold_embed) KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st, h32_of(s)));
+    if (!fold_embed) KCHK(launch_decode_embed(s->cur_tok, m->embed, s->dh, B, m->H, m->vocab, st, s->exact ? s->dh32 : h32_of(s)));
     for (int li = 0; li < m->cfg.n_layers; ++li)
         for (int stage = STAGE_QKV; stage <= STAGE_DOWN; ++stage) {
             int r = (li == 0 && stage == STAGE_QKV && fold_embed) ? run_qkv0_with_embed(s, B, st) : run_decode_stage(s, B, li, stage, st);
@@ -1081,7 +1252,7 @@ int emmax_model_finalize(emmax_model* m, void* arena, int64_t arena_bytes, emmax
     plan_arena(m, b);
     HIPCHK(hipMemsetAsync(arena, 0, need, st));   // all padding is zero
     const char* pre[2] = {"vision_backbone.featurizer.", "vision_backbone.fused_featurizer."};
-    const bool fold_ln = emmax_tune().gemm_lnfuse != 0;
+    const bool fold_ln = emmax_tune().gemm_lnfuse != 0 && emmax_tune().exact == 0;   // exact numerics multiplies by the checkpoint's weights, not by bf16(W .* gamma)
     int r;
 #define PUT2(key, rows, cols, dst, ld, row0) if ((r = put2d(m, key, rows, cols, dst, ld, row0, st))) return r
 #define PUT1(key, n, dst) if ((r = put1d(m, key, n, dst, st))) return r
@@ -1224,6 +1395,16 @@ static int check_stage_rows(int max_batch, int stage_rows) {
         return fail(EMMAX_ERR_INVALID, "stage_rows %d outside 0..min(max_batch=%d, %d)", stage_rows, max_batch, EMMAX_MAX_DECODE_BATCH);
     return 0;
 }
+// what an exact-numerics session needs of its model and its shape
+static int check_exact(const emmax_model* m, int max_batch, int stage_rows) {
+    if (m->fp8) return fail(EMMAX_ERR_INVALID, "exact numerics (tuning switch exact) runs on bf16 weights: this model streams fp8 decode weights");
+    if (m->finalized && m->ln_folded)
+        return fail(EMMAX_ERR_STATE, "exact numerics needs the ViT LayerNorms unfolded: set the tuning switch exact = 1 BEFORE emmax_model_finalize");
+    if (max_batch > 2) return fail(EMMAX_ERR_INVALID, "exact numerics serves batches of 1-2 rows (decode_ks.hip); max_batch %d", max_batch);
+    if (stage_rows) return fail(EMMAX_ERR_INVALID, "exact numerics sessions hold no staging rows (no slot serving)");
+    if (m->H % 64 || m->q_dim % 64) return fail(EMMAX_ERR_INVALID, "exact numerics needs hidden and q widths in multiples of 64");
+    return 0;
+}
 int emmax_session_bytes(const emmax_model* m, int max_batch, int max_prompt, int max_ctx, int64_t* ws, int64_t* kv) {
     return emmax_session_bytes_ex(m, max_batch, max_prompt, max_ctx, 0, ws, kv);
 }
@@ -1236,10 +1417,12 @@ int emmax_session_bytes_ex(const emmax_model* m, int max_batch, int max_prompt, 
     tmp.max_batch = max_batch; tmp.max_prompt = max_prompt; tmp.max_ctx = max_ctx; tmp.max_pages = mp; tmp.max_rows = mr;
     tmp.max_out = max_ctx;
     tmp.n_stg = stage_rows; tmp.stg0 = max_batch; tmp.rows_total = max_batch + tmp.n_stg;
+    tmp.exact = emmax_tune().exact != 0;
+    if (tmp.exact && (r = check_exact(m, max_batch, stage_rows))) return r;
     SBump b{nullptr};
     plan_session(&tmp, b);
     if (ws) *ws = b.off + 256;
-    if (kv) *kv = kv_bytes_for(m, tmp.rows_total, mp, emmax_tune().kv_fp8 != 0);
+    if (kv) *kv = kv_bytes_for(m, tmp.rows_total, mp, kv_format_now());
     return 0;
 }
 
@@ -1248,6 +1431,7 @@ int emmax_session_create(emmax_model* m, int max_batch, int max_prompt, int max_
     return emmax_session_create_ex(m, max_batch, max_prompt, max_ctx, 0, ws, ws_bytes, kv, kvb, out);
 }
 int emmax_session_stage_rows(const emmax_session* s) { return s ? s->n_stg : -1; }
+int emmax_session_exact(const emmax_session* s) { return s ? (s->exact ? 1 : 0) : -1; }
 int emmax_session_create_ex(emmax_model* m, int max_batch, int max_prompt, int max_ctx, int stage_rows, void* ws, int64_t ws_bytes, void* kv,
                             int64_t kvb, emmax_session** out) {
     if (!m || !ws || !kv || !out) return fail(EMMAX_ERR_INVALID, "null argument");
@@ -1267,11 +1451,12 @@ int emmax_session_create_ex(emmax_model* m, int max_batch, int max_prompt, int m
     session_dims(m, max_batch, max_prompt, max_ctx, &s->max_pages, &s->max_rows);
     s->max_out = max_ctx;
     s->n_stg = stage_rows; s->stg0 = max_batch; s->rows_total = max_batch + s->n_stg;
+    s->exact = emmax_tune().exact != 0;
     SBump b{(char*)ws};
     plan_session(s, b);
     s->kv = (bf16*)kv;
-    s->kv8 = emmax_tune().kv_fp8 != 0;
-    s->kv_layer_stride = kv_layer_bytes(m, s->rows_total, s->max_pages, s->kv8);
+    s->kv8 = !s->exact && emmax_tune().kv_fp8 != 0;
+    s->kv_layer_stride = kv_layer_bytes(m, s->rows_total, s->max_pages, kv_format_now());
     HIPCHK(hipMemset(ws, 0, need_ws));   // padding columns of every activation buffer stay zero forever
     HIPCHK(hipMemset(kv, 0, need_kv));
     HIPCHK(hipDeviceSynchronize());
@@ -1338,6 +1523,10 @@ int emmax_vision_features(emmax_session* s, int B, void* out, emmax_stream st) {
     if (!s || !out) return fail(EMMAX_ERR_INVALID, "null argument");
     if (B != s->vision_B) return fail(EMMAX_ERR_STATE, "no vision result for batch %d", B);
     emmax_model* m = s->m;
+    if (s->exact) {   // the fp32 features, rounded for the caller
+        KCHK(launch_x_to_bf16(s->xfeats32, m->Vp, out, m->V, B * m->tw[0].n_patches, m->V, (hipStream_t)st));
+        return 0;
+    }
     HIPCHK(hipMemcpy2DAsync(out, (size_t)m->V * 2, s->feats, (size_t)m->Vp * 2, (size_t)m->V * 2, (size_t)B * m->tw[0].n_patches,
                             hipMemcpyDeviceToDevice, (hipStream_t)st));
     return 0;
@@ -1360,6 +1549,13 @@ int emmax_prefill_logits(emmax_session* s, float* out, emmax_stream stream) {
     if (!s->prefilled) return fail(EMMAX_ERR_STATE, "prefill has not run");
     emmax_model* m = s->m;
     hipStream_t st = (hipStream_t)stream;
+    if (s->exact) {
+        KCHK(launch_x_rmsnorm(s->ph32, s->xhla, m->final_norm, s->total_rows, m->H, m->H, 2 * m->H, m->cfg.rms_eps, st));
+        GemmParams gx = gpx(s, s->xhla, m->H, m->lm_head, m->H, out, m->vocab, s->total_rows, m->vocab_p);
+        gx.N_store = m->vocab;
+        KCHK(launch_gemm(gx, st));
+        return 0;
+    }
     if (s->p32) KCHK(launch_rmsnorm_f32(s->ph32, s->pxn, m->final_norm, s->total_rows, m->H, m->H, m->H, m->cfg.rms_eps, st));
     else KCHK(launch_rmsnorm(s->ph, s->pxn, m->final_norm, s->total_rows, m->H, m->H, m->H, m->cfg.rms_eps, st));
     GemmParams g = gps(s, s->pxn, m->H, m->lm_head, m->H, out, m->vocab, s->total_rows, m->vocab_p, m->H);
@@ -1502,6 +1698,7 @@ int emmax_slots_open(emmax_session* s, int n_slots, emmax_stream stream) {
         return fail(EMMAX_ERR_INVALID, "%d slots outside 1..min(max_batch=%d, %d)", n_slots, s->max_batch, model_max_decode_batch(s->m));
     if (n_slots >= EMMAX_MFMA_MIN_BATCH && !s->m->aux_built)
         return fail(EMMAX_ERR_STATE, "%d slots decode on the fragment-major weight copies: call emmax_model_build_aux first", n_slots);
+    if (s->exact) return fail(EMMAX_ERR_STATE, "slot serving is not available in an exact-numerics session");
     hipStream_t user = (hipStream_t)stream, st;
     int r = slot_enter(s, user, &st);
     if (r) return r;
@@ -1792,6 +1989,64 @@ int emmax_op_decode_attention_kv8(const void* q, void* kcache8, void* vcache8, f
     if (ns > 16) return fail(EMMAX_ERR_INVALID, "emmax_op_decode_attention_kv8: nsplit %d > 16", ns);
     int r = launch_decode_attn(a, B, Hq, 128, ns, (hipStream_t)st);
     if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_decode_attention_kv8: unsupported (GQA group in {1,2,4,8}, page = 2^k, max_pages <= 512, nsplit = 2^k)");
+    return 0;
+}
+// ---- exact numerics: single-kernel entry points (fp32 in, fp32 out; hl_ws: caller scratch for the two-term image of the operand) ----
+int emmax_op_x_gemm(const float* A32, int lda, const void* W, int ldw, float* C32, int ldc, int M, int N, int K, const void* bias, int act,
+                    const float* residual32, int ldr, void* hl_ws, void* ws, int64_t ws_bytes, emmax_stream stream) {
+    if (!A32 || !W || !C32 || !hl_ws) return fail(EMMAX_ERR_INVALID, "emmax_op_x_gemm: null argument");
+    if (K % 64 || N % 128) return fail(EMMAX_ERR_INVALID, "emmax_op_x_gemm: K %% 64, N %% 128 required");
+    hipStream_t st = (hipStream_t)stream;
+    KCHK(launch_x_split_rows(A32, hl_ws, M, K, K, lda, 2 * K, st));
+    GemmParams p = gp(hl_ws, 2 * K, W, ldw, C32, ldc, M, N, 2 * K);
+    p.a_hl = 1; p.out_f32 = 1; p.bias = bias; p.act = act;
+    if (act == 2) p.N_store = N;
+    if (residual32) { p.residual = residual32; p.res_f32 = 1; p.ldr = ldr; }
+    if (ws) { p.ws = (float*)ws; p.ws_bytes = ws_bytes; }
+    int r = launch_gemm(p, st);
+    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_x_gemm: unsupported shape or launch failure");
+    return 0;
+}
+int emmax_op_x_rownorm(int mode, const float* x, float* y32, const void* w, const void* b, int rows, int D, float eps, void* hl_ws, emmax_stream stream) {
+    if (!x || !y32 || !hl_ws || (mode != 0 && !w) || (mode == 2 && !b)) return fail(EMMAX_ERR_INVALID, "emmax_op_x_rownorm: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int Dp = pad_to(D, 64);
+    int r = mode == 0 ? launch_x_split_rows(x, hl_ws, rows, D, Dp, D, 2 * Dp, st)
+          : mode == 1 ? (D % 64 ? -1 : launch_x_rmsnorm(x, hl_ws, w, rows, D, D, 2 * Dp, eps, st))
+                      : launch_x_layernorm(x, hl_ws, w, b, rows, D, Dp, D, 2 * Dp, eps, st);
+    if (r) return fail(EMMAX_ERR_INVALID, "emmax_op_x_rownorm: unsupported shape (D %% 8; RMSNorm: D %% 64)");
+    KCHK(launch_x_join_rows(hl_ws, y32, rows, D, 2 * Dp, D, st));
+    return 0;
+}
+int emmax_op_x_attention(const float* qkv32, int ld_qkv, int q_off, int k_off, int v_off, const int32_t* cu, int B,
+                         int max_seqlen, int Hq, int Hkv, int head_dim, float scale, int causal, void* hl_ws, emmax_stream stream) {
+    if (!qkv32 || !cu || !hl_ws) return fail(EMMAX_ERR_INVALID, "emmax_op_x_attention: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int Dq = Hq * head_dim, Dp = pad_to(Dq, 64);
+    AttnParams a;
+    a.qkv = qkv32; a.out = hl_ws; a.cu_seqlens = cu; a.ld_qkv = ld_qkv; a.q_off = q_off; a.k_off = k_off; a.v_off = v_off;
+    a.ld_out = 2 * Dp; a.B = B; a.max_seqlen = max_seqlen; a.Hq = Hq; a.Hkv = Hkv; a.scale = scale; a.causal = causal;
+    int r = launch_x_attention(a, head_dim, st);
+    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_x_attention: unsupported head_dim (64, 72, 128) / strides");
+    return 0;   // the result stays in hl_ws as HL rows of pitch 2 * pad64(Hq * head_dim): emmax_op_x_join widens them
+}
+int emmax_op_x_join(const void* hl, float* out32, int rows, int D, emmax_stream stream) {
+    if (!hl || !out32) return fail(EMMAX_ERR_INVALID, "emmax_op_x_join: null argument");
+    const int Dp = pad_to(D, 64);
+    KCHK(launch_x_join_rows(hl, out32, rows, D, 2 * Dp, D, (hipStream_t)stream));
+    return 0;
+}
+int emmax_op_x_decode_attention(const float* q32, const float* kcache32, const float* vcache32, const int32_t* page_table, const int32_t* ctx_len,
+                                const int32_t* done, float* part_out, int B, int Hq, int Hkv, int page, int max_pages, int nsplit, float scale,
+                                emmax_stream st) {
+    if (!q32 || !kcache32 || !vcache32 || !page_table || !ctx_len || !part_out) return fail(EMMAX_ERR_INVALID, "emmax_op_x_decode_attention: null argument");
+    if (B < 1 || B > EMMAX_MAX_DECODE_BATCH || Hkv < 1 || Hq % Hkv) return fail(EMMAX_ERR_INVALID, "emmax_op_x_decode_attention: bad B / heads");
+    DecodeAttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.q = q32; a.ldq = Hq * 128; a.kcache = kcache32; a.vcache = vcache32; a.page_table = page_table; a.ctx_len = ctx_len; a.done = done;
+    a.part = part_out; a.Hkv = Hkv; a.page = page; a.max_pages = max_pages; a.scale = scale;
+    int r = launch_x_decode_attn(a, B, Hq, 128, nsplit, (hipStream_t)st);
+    if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_x_decode_attention: unsupported (GQA group in {1,2,4,8}, page = 2^k, max_pages <= 512, nsplit = 2^k)");
     return 0;
 }
 int emmax_op_gemv(const void* x, const void* W, void* y, int B, int N, int K, emmax_stream st) {

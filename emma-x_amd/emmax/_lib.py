@@ -43,7 +43,7 @@ class ConfigC(C.Structure):
     ]
 
 
-ABI_VERSION = 4   # EMMAX_ABI_VERSION of include/emmax.h this binding was written against
+ABI_VERSION = 5   # EMMAX_ABI_VERSION of include/emmax.h this binding was written against
 
 # name -> (restype, argtypes): exactly the entry points of include/emmax.h
 SIGNATURES = {
@@ -114,6 +114,12 @@ SIGNATURES = {
     "emmax_op_gemm_small": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "emmax_op_repack_km": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "emmax_op_gemm_small_km": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "emmax_session_exact": (C.c_int, [_vp]),
+    "emmax_op_x_gemm": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int64, _vp]),
+    "emmax_op_x_rownorm": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp]),
+    "emmax_op_x_attention": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp]),
+    "emmax_op_x_join": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
+    "emmax_op_x_decode_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

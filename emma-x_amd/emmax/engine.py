@@ -61,8 +61,12 @@ class EmmaxEngine:
     """Model weights (re-laid-out into one device arena) + one session (workspace + paged KV cache)."""
 
     def __init__(self, cfg: EmmaXConfig, state_dict: Dict[str, torch.Tensor], device: str = "cuda:0",
-                 max_batch: int = 1, max_prompt: int = 512, max_ctx: Optional[int] = None, free_state_dict: bool = False):
+                 max_batch: int = 1, max_prompt: int = 512, max_ctx: Optional[int] = None, free_state_dict: bool = False,
+                 exact: Optional[bool] = None):
         self.lib = _lib.load()
+        # EXACT NUMERICS (include/emmax.h, tuning switch `exact`): the fp32 CPU arithmetic of the reference instead of bf16 operands.  Frozen into
+        # the model at finalize (ViT LayerNorms unfolded) and into every session of this engine; None = what the library's switch says (EMMAX_EXACT)
+        self.exact = bool(_lib.tuning_get("exact")) if exact is None else bool(exact)
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -91,7 +95,8 @@ class EmmaxEngine:
         import time
 
         t0 = time.perf_counter()
-        _lib.check(self.lib.emmax_model_finalize(self._model, self.arena.data_ptr(), nbytes, stream), "emmax_model_finalize")
+        with _lib.tuning(exact=int(self.exact)):
+            _lib.check(self.lib.emmax_model_finalize(self._model, self.arena.data_ptr(), nbytes, stream), "emmax_model_finalize")
         self.finalize_s = time.perf_counter() - t0     # re-layout of the bound tensors into the arena (synchronous)
         self.aux_build_s = 0.0
         del keep
@@ -110,13 +115,15 @@ class EmmaxEngine:
         if max_ctx is None:
             max_ctx = np_ + max_prompt + 512 + 1
         ws, kv = C.c_int64(), C.c_int64()
-        _lib.check(self.lib.emmax_session_bytes_ex(self._model, max_batch, max_prompt, max_ctx, int(stage_rows), C.byref(ws), C.byref(kv)),
-                   "emmax_session_bytes_ex")
-        self.workspace = torch.empty(ws.value, dtype=torch.uint8, device=self.device)
-        self.kv = _device_bytes(kv.value, self.device, "KV")
-        _lib.check(self.lib.emmax_session_create_ex(self._model, max_batch, max_prompt, max_ctx, int(stage_rows), self.workspace.data_ptr(),
-                                                    ws.value, self.kv.data_ptr(), kv.value, C.byref(self._session)),
-                   "emmax_session_create_ex")
+        with _lib.tuning(exact=int(self.exact)):   # the session kind (and the KV format) is read when the session is sized and created
+            _lib.check(self.lib.emmax_session_bytes_ex(self._model, max_batch, max_prompt, max_ctx, int(stage_rows), C.byref(ws), C.byref(kv)),
+                       "emmax_session_bytes_ex")
+            self.workspace = torch.empty(ws.value, dtype=torch.uint8, device=self.device)
+            self.kv = _device_bytes(kv.value, self.device, "KV")
+            _lib.check(self.lib.emmax_session_create_ex(self._model, max_batch, max_prompt, max_ctx, int(stage_rows), self.workspace.data_ptr(),
+                                                        ws.value, self.kv.data_ptr(), kv.value, C.byref(self._session)),
+                       "emmax_session_create_ex")
+        assert bool(self.lib.emmax_session_exact(self._session)) == self.exact
         self.max_batch, self.max_prompt, self.max_ctx, self.stage_rows = max_batch, max_prompt, max_ctx, int(stage_rows)
 
     def ensure_stage_rows(self, n: int) -> None:

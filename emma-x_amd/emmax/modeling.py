@@ -139,7 +139,9 @@ class EmmaXForActionPrediction:
         return m.to(device, **engine_kw)
 
     def to(self, device: Union[str, torch.device], max_batch: int = 1, max_prompt: int = 512,
-           max_ctx: Optional[int] = None) -> "EmmaXForActionPrediction":
+           max_ctx: Optional[int] = None, exact: Optional[bool] = None) -> "EmmaXForActionPrediction":
+        """`exact=True`: exact numerics -- the reference's fp32 CPU arithmetic (prismatic.py:659-663 on CPU) instead of bf16 operands
+        (include/emmax.h, tuning switch `exact`; batches of 1-2 rows; None = the library's switch, EMMAX_EXACT)."""
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("EmmaXForActionPrediction runs on MI355X (cuda:N) only; there is no CPU execution path")
@@ -147,7 +149,7 @@ class EmmaXForActionPrediction:
             if self._state_dict is None:
                 raise RuntimeError("no weights to load")
             self.engine = EmmaxEngine(self.config, self._state_dict, device=str(device), max_batch=max_batch,
-                                      max_prompt=max_prompt, max_ctx=max_ctx, free_state_dict=True)
+                                      max_prompt=max_prompt, max_ctx=max_ctx, free_state_dict=True, exact=exact)
             self._state_dict = None
         elif device != self.device:
             raise RuntimeError("moving an already-materialised engine between devices is not supported")

@@ -36,7 +36,7 @@ extern "C" {
  *   1: rounds 1-2;  2: emmax_config grew `decode_fp8` (round 2, not bumped then);  3: round 4 -- emmax_config_size / emmax_tuning_*
  *   added, the lab-only entry points (persistent layer chain, in-attention split merge) removed;  4: round 5 -- emmax_session_*_ex (staging rows
  *   are asked for, the plain calls give none), decode batches / slot counts up to 32 (emmax_model_max_decode_batch). */
-#define EMMAX_ABI_VERSION 4
+#define EMMAX_ABI_VERSION 5
 
 typedef enum emmax_status {
     EMMAX_OK = 0,
@@ -89,6 +89,12 @@ int emmax_config_size(void);
  * Three switches are read when an object is BUILT and frozen in it: gemm_lnfuse at emmax_model_finalize (the LayerNorm fold rewrites the ViT
  * qkv / fc1 weights in place: setting it afterwards does not change a finalized model), km at emmax_model_build_aux (which copies exist),
  * kv_fp8 at emmax_session_create (the cache format).
+ * exact (round 6; 0 = off, the default): EXACT NUMERICS -- the reference's fp32 CPU arithmetic (prismatic/models/vlms/prismatic.py:659-663 under
+ * BASELINE configs[0]) instead of bf16 operands: fp32 activations end to end, every activation operand of a bf16 MFMA / dot2 as TWO bf16 terms
+ * hi + lo (the checkpoint's weights are exact bf16), attention on the fp32 MFMA over an fp32 KV cache.  Read at emmax_model_finalize (the ViT
+ * LayerNorms stay unfolded: the fold rounds W .* gamma) and at emmax_session_create (fp32 scratch, fp32 cache = twice the KV bytes).  Exact
+ * sessions run batches of 1-2 rows on bf16 weights, without slot serving; emmax_session_exact() tells which kind a session is.  Logits sit
+ * ~1e-5 of max|logit| from the fp32 restatement at full depth (default path: 2.4e-2) -- measured cost in DESIGN.md section 6.
  * Not thread-safe against concurrent launches; a session re-captures its decode graph after a change. */
 int emmax_tuning_set(const char* name, int value);
 int emmax_tuning_get(const char* name, int* value_out);
@@ -130,6 +136,8 @@ int emmax_session_create_ex(emmax_model* m, int max_batch, int max_prompt, int m
                             void* workspace_dev, int64_t workspace_bytes, void* kv_dev, int64_t kv_bytes,
                             emmax_session** out);
 int emmax_session_stage_rows(const emmax_session* s);
+/* 1: the session was created under the tuning switch exact = 1 (fp32 activations / fp32 KV cache, see above), 0: bf16-operand path */
+int emmax_session_exact(const emmax_session* s);
 void emmax_session_destroy(emmax_session* s);
 
 /* frames_u8_dev: uint8 [B,224,224,3] RGB (normalisation fused into the patch gather);  out: bf16 [B,256,hidden]. */
@@ -319,6 +327,26 @@ int emmax_op_gemv_fp8(const void* x_dev, const void* W8_rows_dev, const float* s
  * emmax_op_repack_fm produces from a row-major [N,ld] matrix (N % 16 == 0, K % 32 == 0); 1 <= B <= 8. */
 int emmax_op_repack_fm(const void* W_dev, int ld, void* W_fm_out_dev, int N, int K, emmax_stream stream);
 int emmax_op_gemm_small(const void* x_dev, const void* W_fm_dev, void* y_dev, int B, int N, int K, emmax_stream stream);
+
+/* ---- exact numerics (tuning switch exact), kernel by kernel: fp32 operands in, fp32 results out (tests/test_exact_gpu.py).
+ * hl_ws: device scratch for the two-term bf16 image of the activation operand, 4 bytes per (padded) element.
+ *   emmax_op_x_gemm       C32[M, N] = act(A32[M, K] W[N, K]^T + bias) (+ residual32): A split into hi + lo, both through the bf16 MFMAs
+ *                         (replaces F.linear on fp32 activations; act 0 / 1 GELU / 2 SwiGLU over 16-column (gate, up) groups, C32 [M, N / 2])
+ *   emmax_op_x_rownorm    mode 0: y = hi + lo of x (the split alone); 1: HF LlamaRMSNorm in fp32; 2: F.layer_norm in fp32 -- y32 = the two
+ *                         terms the consumer GEMM would read, joined
+ *   emmax_op_x_attention  softmax(q k^T scale [causal]) v on the fp32 MFMA over packed fp32 qkv rows -> HL rows in hl_ws (pitch 2 * pad64(Hq *
+ *                         head_dim)); emmax_op_x_join widens HL rows to fp32 (timm Attention / HF SDPA: modeling_prismatic.py:114-123,404-415)
+ *   emmax_op_x_decode_attention  emmax_op_decode_attention over fp32 q rows and an fp32 paged cache (same partial layout) */
+int emmax_op_x_gemm(const float* A32_dev, int lda, const void* W_dev, int ldw, float* C32_dev, int ldc, int M, int N, int K, const void* bias_dev, int act,
+                    const float* residual32_dev, int ldr, void* hl_ws_dev, void* ws_dev, int64_t ws_bytes, emmax_stream stream);
+int emmax_op_x_rownorm(int mode, const float* x_dev, float* y32_dev, const void* w_dev, const void* b_dev, int rows, int D, float eps, void* hl_ws_dev,
+                       emmax_stream stream);
+int emmax_op_x_attention(const float* qkv32_dev, int ld_qkv, int q_off, int k_off, int v_off, const int32_t* cu_seqlens_dev, int B, int max_seqlen, int Hq,
+                         int Hkv, int head_dim, float scale, int causal, void* hl_ws_dev, emmax_stream stream);
+int emmax_op_x_join(const void* hl_dev, float* out32_dev, int rows, int D, emmax_stream stream);
+int emmax_op_x_decode_attention(const float* q32_dev, const float* kcache32_dev, const float* vcache32_dev, const int32_t* page_table_dev,
+                                const int32_t* ctx_len_dev, const int32_t* done_dev, float* part_out_dev, int B, int Hq, int Hkv, int page, int max_pages,
+                                int nsplit, float scale, emmax_stream stream);
 
 #ifdef __cplusplus
 }

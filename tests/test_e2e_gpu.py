@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ID_BUDGET_SHALLOW, above_id_line
 
 pytestmark = pytest.mark.gpu
 
@@ -137,14 +137,13 @@ def test_teacher_forced_decode_margin_aware(device, tiny_random):
         err = (got - ref).abs().max().item()
         worst = max(worst, err / ref.abs().max().item())
         print(f"step {t}: rel err {err / ref.abs().max().item():.4f} argmax got {int(got.argmax())} ref {gen[t]}")
-        top2 = torch.topk(ref, 2).values
-        if (top2[0] - top2[1]).item() > 2 * err:   # a flip needs |d top1| + |d top2| >= margin
+        if above_id_line(ref, ID_BUDGET_SHALLOW):   # the a-priori id line (conftest.py): NOT derived from this run's error
             checked += 1
             agree += int(int(got.argmax()) == gen[t])
         eng.set_current_tokens([gen[t]])   # teacher forcing: feed the oracle's token
         eng.decode_step()
     assert worst < FEAT_TOL, worst
-    assert checked >= T // 4, "margin filter rejected too many steps to be meaningful"
+    assert checked >= T // 6, "the id line rejected too many steps to be meaningful"
     assert agree == checked, f"argmax differs from the oracle on {checked - agree}/{checked} unambiguous steps"
 
 
