@@ -1152,7 +1152,8 @@ int launch_gemm_splitk(const GemmParams& p, int ks, hipStream_t stream, int big)
     if (p.act == 2 && (p.out_f32 || (p.N & 31))) return -1;
     if ((long long)ks * p.M * p.N * 4 > p.ws_bytes) return -1;
     if (p.K / BK < ks) return -1;
-    if (emmax_tune().gemm_sk_big >= 0) big = emmax_tune().gemm_sk_big;   // (tools: the planned geometry overridden)
+    // (the tools' geometry override gemm_sk_big is applied where the plan is made -- plan_gemm, kind SPLITK -- not here: the HYBRID column
+    // remainder is planned for small tiles and its slice count was chosen for them)
     GemmParams a = p;
     a.ksplit = ks;
     a.C = p.ws; a.ldc = p.N; a.N_store = p.N; a.out_f32 = 1; a.act = 0;
@@ -1223,7 +1224,11 @@ static GemmPlan plan_gemm(const GemmParams& p) {
     if (force >= 0) { pl.kind = GemmPlan::GEOM; pl.big = force > 2 ? 1 : force; return pl; }   // 0 small, 1 big, 2 = 128 x 256 x 32
     const bool no_splitk = emmax_tune().gemm_splitk == 0;
     int sk_big = 0;
-    if (const int ks = no_splitk ? 0 : splitk_plan(p, &sk_big)) { pl.kind = GemmPlan::SPLITK; pl.ks = ks; pl.big = sk_big; return pl; }
+    if (const int ks = no_splitk ? 0 : splitk_plan(p, &sk_big)) {
+        pl.kind = GemmPlan::SPLITK; pl.ks = ks; pl.big = sk_big;
+        if (emmax_tune().gemm_sk_big >= 0 && (emmax_tune().gemm_sk_big == 0 || p.K / BK / ks >= 16)) pl.big = emmax_tune().gemm_sk_big;   // tools: geometry forced (big: >= 16 K steps per slice)
+        return pl;
+    }
     long m1 = 0;
     const double whole = plan_rows(p.M, p.N, &m1);
     if (!no_splitk && emmax_tune().gemm_hybrid != 0) {

@@ -132,7 +132,7 @@ int launch_rope_kv_write(void* qkv, int ld, int q_off, int k_off, int v_off, con
                          const float* cos_t, const float* sin_t, void* kcache, void* vcache, const int32_t* page_table,
                          int max_pages, int Hq, int Hkv, int hd, int page, hipStream_t stream);
 // fp8 KV cache: quantise the prefill's K / V rows (K rotated in place by launch_rope_kv_write with null cache pointers) into e4m3 pages + row scales
-int launch_kv_quant_rows(const void* qkv, int ld, int k_off, int v_off, const int32_t* cu, int B, int total_rows, void* k8, void* v8, float* kscale,
+int launch_kv_quant_rows(void* qkv /* rows written back as bf16(e4m3 x scale): the prefill attention sees what the cache holds */, int ld, int k_off, int v_off, const int32_t* cu, int B, int total_rows, void* k8, void* v8, float* kscale,
                          float* vscale, const int32_t* page_table, int max_pages, int Hkv, int hd, int page, hipStream_t stream);
 int launch_resize_bicubic_u8(const uint8_t* src, int B, int H, int W, uint8_t* dst, int OH, int OW, uint8_t* tmp, const int32_t* bounds_h,
                              const int32_t* kk_h, int ksize_h, const int32_t* bounds_v, const int32_t* kk_v, int ksize_v, hipStream_t stream);

@@ -188,7 +188,9 @@ __global__ __launch_bounds__(256) void emmax_rope_kv_write_vec_kernel(bf16_t* __
 
 // fp8 KV cache (round 5, opt-in): the prefill's K (already rotated in place by the pass above) and V rows of every packed token as e4m3 bytes
 // with one power-of-two fp32 scale per (token, kv head) row (common.h: e4m3_row_scale).  One block per token, a 16-lane group per 128-element row (head_dim 128).
-__global__ __launch_bounds__(256) void emmax_kv_quant_rows_kernel(const bf16_t* __restrict__ qkv, int ld, int k_off, int v_off,
+// The rows are written BACK into the qkv buffer as bf16(e4m3 x scale) (round 6): the prefill attention that follows then attends
+// over exactly the values every later decode step reads from the cache, as the decode step's own new key already does.
+__global__ __launch_bounds__(256) void emmax_kv_quant_rows_kernel(bf16_t* __restrict__ qkv, int ld, int k_off, int v_off,
                                                                  const int32_t* __restrict__ cu, int B, uint8_t* __restrict__ k8,
                                                                  uint8_t* __restrict__ v8, float* __restrict__ kscale, float* __restrict__ vscale,
                                                                  const int32_t* __restrict__ page_table, int max_pages, int Hkv, int page) {
@@ -198,19 +200,22 @@ __global__ __launch_bounds__(256) void emmax_kv_quant_rows_kernel(const bf16_t* 
     while (b + 1 < B && row >= cu[b + 1]) ++b;
     const int pos = row - cu[b];
     const int pg = page_table[(size_t)b * max_pages + pos / page], slot = pos % page;
-    const bf16_t* r = qkv + (size_t)row * ld;
+    bf16_t* r = qkv + (size_t)row * ld;
     const int grp = threadIdx.x >> 4, ch = threadIdx.x & 15;
     for (int i = grp; i < 2 * Hkv; i += 16) {   // (a 16-lane group = one DPP row: the reduction never mixes an idle group in)
         const bool is_v = i >= Hkv;
         const int hk = is_v ? i - Hkv : i;
-        const u32x4_t v = *(const u32x4_t*)(r + (is_v ? v_off : k_off) + hk * HD + ch * 8);
+        bf16_t* src = r + (is_v ? v_off : k_off) + hk * HD + ch * 8;
+        const u32x4_t v = *(const u32x4_t*)src;
         float am = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) am = fmaxf(am, fmaxf(fabsf(bf_lo(v[j])), fabsf(bf_hi(v[j]))));
         am = row16_max(am);
         const float sc = e4m3_row_scale(am);
         const size_t rowi = ((size_t)pg * Hkv + hk) * page + slot;
-        *(u32x2_t*)((is_v ? v8 : k8) + rowi * HD + ch * 8) = quant8_e4m3(v, 1.0f / sc);
+        const u32x2_t q8 = quant8_e4m3(v, 1.0f / sc);
+        *(u32x2_t*)((is_v ? v8 : k8) + rowi * HD + ch * 8) = q8;
+        *(u32x4_t*)src = dequant8_e4m3(q8, sc);
         if (ch == 0) (is_v ? vscale : kscale)[rowi] = sc;
     }
 }
@@ -436,10 +441,10 @@ int launch_rope_kv_write(void* qkv, int ld, int q_off, int k_off, int v_off, con
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-int launch_kv_quant_rows(const void* qkv, int ld, int k_off, int v_off, const int32_t* cu, int B, int total_rows, void* k8, void* v8, float* kscale,
+int launch_kv_quant_rows(void* qkv, int ld, int k_off, int v_off, const int32_t* cu, int B, int total_rows, void* k8, void* v8, float* kscale,
                          float* vscale, const int32_t* page_table, int max_pages, int Hkv, int hd, int page, hipStream_t stream) {
     if (hd != 128 || (ld | k_off | v_off) % 8) return -1;
-    hipLaunchKernelGGL(emmax_kv_quant_rows_kernel, dim3(total_rows), dim3(256), 0, stream, (const bf16_t*)qkv, ld, k_off, v_off, cu, B, (uint8_t*)k8,
+    hipLaunchKernelGGL(emmax_kv_quant_rows_kernel, dim3(total_rows), dim3(256), 0, stream, (bf16_t*)qkv, ld, k_off, v_off, cu, B, (uint8_t*)k8,
                        (uint8_t*)v8, kscale, vscale, page_table, max_pages, Hkv, page);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }

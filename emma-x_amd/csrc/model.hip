@@ -82,6 +82,14 @@ const EmmaxTune& emmax_tune() {
     return g_tune;
 }
 
+// hipGraph replay of the decode step (tuning switch graph): ROCm 7.2's default replay path ("graph packet capture") adds ~0.65 us per kernel
+// node on the device (2.69 against 2.57 ms/token at B = 1); with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 the replay runs at the rate of eager launches
+// (profiles/r05_graph_switches.txt).  The HIP runtime reads the variable ONCE, at its first call -- so it is exported when THIS LIBRARY IS
+// LOADED (a constructor; never overriding a value the host set), which makes the replay fast however graph mode is switched on later
+// (EMMAX_GRAPH=1 or emmax_tuning_set("graph", 1)), provided the host loads libemmax_hip.so before its first HIP call -- the Python package
+// does (emmax/__init__.py sets the same variable at import).  VERDICT r05 next #6.
+__attribute__((constructor)) static void emmax_export_runtime_switches() { setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0", 0); }
+
 static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 static const int PAGE = 64;   // KV page: 64 tokens x head_dim bf16 per kv head
 
@@ -796,6 +804,9 @@ static int model_max_decode_batch(const emmax_model* m) {
     // 17-32 rows: decode_kmp.hip -- the down projection within eleven phases of 128 elements per wave (K in whole load steps of 32
     // elements, 64 with fp8 tiles; the widest wave share <= 1408 elements: K <= 11264), one tile per block there (H <= 4096)
     const bool p_ok = ((m->inter_p / kd + 7) / 8) * kd <= 11 * 128 && m->H <= 4096 && m->H / 16 <= 256;
+    // batches of 9-32 rows exist in the ONE-split direct attention form only: with split partials (tuning switches attn_direct = 0 or a
+    // forced attn_nsplit > 1) the o-proj would carry p.attn_part, which the bf16 decode_km / decode_kmp kernels do not take
+    if (emmax_tune().attn_direct == 0 || decode_attn_nsplit(9, c.n_kv_heads) != 1) return 8;
     return p_ok ? EMMAX_MAX_DECODE_BATCH : 16;
 }
 
@@ -1745,6 +1756,8 @@ int emmax_slots_prefill_staged(emmax_session* s, int n, const int32_t* ids, int 
                                const int32_t* max_new_host, emmax_stream stream) {
     if (!s || !ids || !lens_host || !max_new_host) return fail(EMMAX_ERR_INVALID, "null argument");
     if (!s->slots_open) return fail(EMMAX_ERR_STATE, "emmax_slots_prefill_staged before emmax_slots_open");
+    if (s->n_stg == 0)
+        return fail(EMMAX_ERR_INVALID, "session created without staging rows: use emmax_session_create_ex(..., stage_rows > 0) (a plain emmax_session_create gives none since ABI 4)");
     if (n < 1 || n > s->n_stg)
         return fail(EMMAX_ERR_INVALID, "%d staged requests outside 1..%d (the session's staging rows: emmax_session_create_ex)", n, s->n_stg);
     if ((uintptr_t)stream <= 2) return fail(EMMAX_ERR_INVALID, "a staged prefill needs its own (non-default) stream: it runs beside the decode steps");
@@ -1892,7 +1905,7 @@ int emmax_op_gemm_splitk(const void* A, int lda, const void* W, int ldw, void* C
     p.bias = bias; p.act = act; p.scale = scale; p.residual = residual; p.ldr = ldr; p.out_f32 = out_f32;
     p.ws = (float*)ws; p.ws_bytes = ws_bytes;
     // ksplit = 0: the launch plan of a session stage with this scratch (whole tiles, split-K, or a column remainder through split-K)
-    int r = ksplit == 0 ? launch_gemm(p, (hipStream_t)st) : launch_gemm_splitk(p, ksplit, (hipStream_t)st);
+    int r = ksplit == 0 ? launch_gemm(p, (hipStream_t)st) : launch_gemm_splitk(p, ksplit, (hipStream_t)st, emmax_tune().gemm_sk_big > 0 ? 1 : 0);   // (tools: explicit slices, geometry by switch)
     if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID,
                        "emmax_op_gemm_splitk: unsupported (ksplit = 0 or 2 <= ksplit <= K/64, ws >= ksplit*M*N*4 bytes, K%%64, N%%128; SwiGLU: bf16 output)");
     return 0;

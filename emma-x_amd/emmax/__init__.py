@@ -2,12 +2,12 @@
 
 import os as _os
 
-# hipGraph replay of the decode step (EMMAX_GRAPH=1): ROCm 7.2's default replay path ("graph packet capture") adds ~0.65 us per kernel node on
-# the device; with it off the replay runs at the rate of eager launches (profiles/r05_graph_switches.txt).  The runtime reads the variable once,
-# at its first HIP call -- so it is set here, at import, and only when the host asked for graph replay through the environment; a host that
-# switches replay on later (emmax_tuning_set("graph", 1)) exports it itself before its first HIP call.
-if _os.environ.get("EMMAX_GRAPH") == "1":
-    _os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+# hipGraph replay of the decode step: ROCm 7.2's default replay path ("graph packet capture") adds ~0.65 us per kernel node on the device;
+# with it off the replay runs at the rate of eager launches (profiles/r05_graph_switches.txt).  The runtime reads the variable once, at its
+# first HIP call -- so it is set here, at import, UNCONDITIONALLY since round 6 (never overriding the host's own value): replay is then fast
+# however graph mode is switched on later (EMMAX_GRAPH=1 or emmax_tuning_set("graph", 1)).  libemmax_hip.so exports the same variable from a
+# load-time constructor for hosts that bind the C ABI directly.
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 from .config import EmmaXConfig, LlmConfig, TowerConfig  # noqa: F401,E402
 

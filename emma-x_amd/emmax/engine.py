@@ -130,7 +130,8 @@ class EmmaxEngine:
         """Slot serving with overlapped admission stages up to `n` requests at a time: re-create the session with that many staging
         rows if it has fewer (drops any state of the current session -- call before slots_open)."""
         if n > getattr(self, "stage_rows", 0):
-            self.new_session(self.max_batch, self.max_prompt, self.max_ctx, stage_rows=int(n))
+            # staging rows are bounded by the decode batch: grow that first, so that n_slots > max_batch surfaces as what it is (ADVICE r05)
+            self.new_session(max(self.max_batch, int(n)), self.max_prompt, self.max_ctx, stage_rows=int(n))
 
     def ensure_decode_batch(self, batch: int) -> None:
         """Decode batches >= 3 read MFMA-fragment-major weight copies that live in a second arena (include/emmax.h:

@@ -9,6 +9,8 @@ for p in (ROOT, os.path.join(ROOT, "emma-x_amd")):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# before any test makes the process's first HIP call (torch.cuda.is_available() in the `device` fixture): what `import emmax` sets
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 
 def pytest_configure(config):

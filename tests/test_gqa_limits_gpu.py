@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import ID_BUDGET_SHALLOW, above_id_line
+
 pytestmark = pytest.mark.gpu
 
 FEAT_TOL = 3e-2
@@ -64,14 +66,13 @@ def test_gqa_prefill_logits_and_teacher_forced_decode(device, gqa_random):
         got = eng.last_logits()[0].float().cpu()
         err = (got - trace[t]).abs().max().item()
         worst = max(worst, err / trace[t].abs().max().item())
-        top2 = torch.topk(trace[t], 2).values
-        if (top2[0] - top2[1]).item() > 2 * err:
+        if above_id_line(trace[t], ID_BUDGET_SHALLOW):   # the a-priori id line (conftest.py)
             checked += 1
             agree += int(int(got.argmax()) == gen[t])
         eng.set_current_tokens([gen[t]])
         eng.decode_step()
     assert worst < FEAT_TOL, worst
-    assert checked >= T // 4 and agree == checked
+    assert checked >= T // 8 and agree == checked
 
 
 def test_gqa_planted_ids_and_batch_rows(device):

@@ -19,6 +19,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import ID_BUDGET_SHALLOW, above_id_line
+
 pytestmark = pytest.mark.gpu
 
 TOL = 3e-2
@@ -115,7 +117,9 @@ def model_fp8(device, setup):
     return _model(cfg, sd_bf, device, True)
 
 
-def _teacher_forced(model, frames, rows, gens, traces, sel, T, device):
+def _teacher_forced(model, frames, rows, gens, traces, sel, T, device, budget=ID_BUDGET_SHALLOW):
+    """worst per-step error, and the ids: `checked` = (row, step) pairs whose fp32 margin clears the A-PRIORI id line (2 x budget x
+    max|logit|, conftest.py -- fixed before the run, not derived from the measured error), `agree` = those whose argmax equals the oracle's."""
     eng = model.engine
     model._prefill([rows[i] for i in sel], None, torch.from_numpy(frames[sel]).to(device), max_new=T + 1)
     worst, checked, agree = 0.0, 0, 0
@@ -125,8 +129,7 @@ def _teacher_forced(model, frames, rows, gens, traces, sel, T, device):
             ref = traces[i][t]
             err = (got[j] - ref).abs().max().item()
             worst = max(worst, err / ref.abs().max().item())
-            top2 = torch.topk(ref, 2).values
-            if (top2[0] - top2[1]).item() > 2 * err:
+            if above_id_line(ref, budget):
                 checked += 1
                 agree += int(int(got[j].argmax()) == gens[i][t])
         eng.set_current_tokens([gens[i][t] for i in sel])
@@ -143,7 +146,7 @@ def test_bf16_decode_at_context_768_matches_oracle(device, setup, oracle_bf16, m
     worst, checked, agree = _teacher_forced(model_bf16, frames, rows, gens, traces, sel, T8, device)
     assert model_bf16.engine.graph_active() == graph
     assert worst < TOL, worst
-    assert checked >= len(sel) * T8 // 8 and agree == checked, (agree, checked)
+    assert checked >= max(1, len(sel) * T8 // 16) and agree == checked, (agree, checked)
 
 
 @pytest.mark.parametrize("switches", [dict(resid32=0), dict(ks=0, km_down=0), dict(resid32=0, ks=0, km_down=0)],
@@ -217,7 +220,7 @@ def test_fp8_decode_at_context_768_matches_dequantised_oracle(device, setup, ora
     worst, checked, agree = _teacher_forced(model_fp8, frames, rows, gens, traces, sel, 40, device)
     assert model_fp8.engine.graph_active() == graph
     assert worst < TOL, worst
-    assert checked >= len(sel) * 40 // 8 and agree == checked, (agree, checked)
+    assert checked >= max(1, len(sel) * 40 // 16) and agree == checked, (agree, checked)
 
 
 def test_bf16_prefill_512_every_logit_row(device, setup, model_bf16):
@@ -319,10 +322,10 @@ def test_slot_served_rows_against_their_bs1_runs_at_7b_dims(device, setup, oracl
            "logit_err_rel": err, "rows_identical": 8 - len(report) - len(unrated), "divergences": report, "unrated": unrated}
     print("\nslot-served vs bs=1:", json.dumps(out))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r05_slot_vs_bs1.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r06_slot_vs_bs1.json"), "w") as f:
         json.dump(out, f, indent=1)
-    for d in report:
-        assert d["margin"] <= 2 * err, d
+    for d in report:   # a divergence is only legitimate below the a-priori id line (relative margins; conftest.py)
+        assert d["margin"] <= 2 * ID_BUDGET_SHALLOW, d
     eng.new_session(8, 512, 256 + 512 + 96)
 
 
@@ -332,7 +335,7 @@ def test_bf16_decode_over_the_fp8_kv_cache(device, setup, oracle_bf16, tune, sel
     to e4m3 with one scale per (token, head) row, every decode step appends its own key that way and attends over the de-quantised
     rows.  Same oracle trace as the bf16 cache (the fp32 restatement knows nothing of the cache format): the logit error is REPORTED
     next to the bf16 cache's on the same steps, bounded by 2.5 x TOL, and the argmax must hold wherever the oracle's top-2 margin
-    exceeds twice the measured error."""
+    clears the a-priori id line (2.5 x the bf16 cache's budget for the e4m3 cache)."""
     from emmax.modeling import EmmaXForActionPrediction
 
     cfg, sd_bf, _, frames, rows = setup
@@ -341,7 +344,7 @@ def test_bf16_decode_over_the_fp8_kv_cache(device, setup, oracle_bf16, tune, sel
     for kv8 in (0, 1):
         tune(kv_fp8=kv8)
         model = EmmaXForActionPrediction(copy.deepcopy(cfg), dict(sd_bf)).to(device, max_batch=8, max_prompt=512, max_ctx=256 + 512 + 96)
-        worst, checked, agree = _teacher_forced(model, frames, rows, gens, traces, sel, 40, device)
+        worst, checked, agree = _teacher_forced(model, frames, rows, gens, traces, sel, 40, device, budget=2.5 * ID_BUDGET_SHALLOW if kv8 else ID_BUDGET_SHALLOW)
         out[kv8] = worst
         assert agree == checked and checked >= len(sel), (kv8, agree, checked)
         del model
@@ -413,10 +416,10 @@ def test_thirty_two_slots_with_overlapped_admissions_at_7b_dims(device, setup, t
            "overlapped_admissions": sch.overlapped_admissions}
     print("\n32 slots vs bs=1:", json.dumps(out))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r05_slots32.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r06_slots32.json"), "w") as f:
         json.dump(out, f, indent=1)
     assert same >= n_req // 2
     for d in report:
-        assert d["margin"] <= 2 * err, d
+        assert d["margin"] <= 2 * ID_BUDGET_SHALLOW, d
     del model
     torch.cuda.empty_cache()
