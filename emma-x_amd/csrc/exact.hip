@@ -428,7 +428,10 @@ __global__ __launch_bounds__(256) void emmax_x_attention_kernel(AttnParams p) {
 // ---------------------------------------------------------------------------------------------------------------------
 template <int G>
 __global__ __launch_bounds__(256) void emmax_x_decode_attn_kernel(DecodeAttnParams p) {
-    constexpr int HD = 128, NW = 4, NT = 256, KU = 2, SP = 512, PSTRIDE = EMMAX_PSTRIDE, CHK = 4 * NW * KU;
+    // KU keys per lane group and chunk, two chunks in flight: 32 KiB of K / V per wave at KU = 4 -- a batch-1 launch is one block per CU (one wave
+    // per SIMD: registers are no constraint) and a latency chain of L / (nsplit 16 KU) round trips: KU = 2 took 8.6 us per launch, twice the
+    // bf16 kernel's trips for twice its bytes
+    constexpr int HD = 128, NW = 4, NT = 256, KU = G <= 2 ? 4 : 2, SP = 512, PSTRIDE = EMMAX_PSTRIDE, CHK = 4 * NW * KU;
     __shared__ int s_pages[SP];
     __shared__ float red_o[NW][G][HD];
     __shared__ float red_ml[NW][G][2];

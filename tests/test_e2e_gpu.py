@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, ID_BUDGET_SHALLOW, above_id_line
+from conftest import GOLDEN, ID_BUDGET_TINY, above_id_line
 
 pytestmark = pytest.mark.gpu
 
@@ -137,7 +137,7 @@ def test_teacher_forced_decode_margin_aware(device, tiny_random):
         err = (got - ref).abs().max().item()
         worst = max(worst, err / ref.abs().max().item())
         print(f"step {t}: rel err {err / ref.abs().max().item():.4f} argmax got {int(got.argmax())} ref {gen[t]}")
-        if above_id_line(ref, ID_BUDGET_SHALLOW):   # the a-priori id line (conftest.py): NOT derived from this run's error
+        if above_id_line(ref, ID_BUDGET_TINY):   # the a-priori id line (conftest.py): NOT derived from this run's error
             checked += 1
             agree += int(int(got.argmax()) == gen[t])
         eng.set_current_tokens([gen[t]])   # teacher forcing: feed the oracle's token
