@@ -205,7 +205,7 @@ def _workload(args, world, B, P, T):
     if getattr(args, "kv_fp8", False):
         head += " [opt-in fp8-e4m3 KV cache: NOT the bf16 headline numerics]"
     if getattr(args, "exact", False):
-        head += " [EXACT NUMERICS: fp32 activations, two-term bf16 MFMA / dot2 operands, fp32 attention over an fp32 KV cache -- the reference's fp32 CPU arithmetic]"
+        head += " [EXACT NUMERICS: fp32 activations, two-term bf16 MFMA / dot2 operands, fp32 attention over a %s KV cache -- the reference's fp32 CPU arithmetic]" % ("fp32" if getattr(args, "exact_fp32kv", False) else "24-bit") + ""
     return head + (": Emma-X-7B bf16, %d frame(s)/GPU 224x224, %d-token prompt, greedy, %d new tokens (EOS disabled), random-init weights; "
                    "uint8 frames and prompt ids are resident in HBM when the timed region starts; the 7-vector is de-tokenised from the "
                    "generated ids by the ids-level stand-in `actions_from_ids` (no LLaMA tokenizer offline: decode -> Solver text parse is "
@@ -228,6 +228,7 @@ def main():
     ap.add_argument("--kv-fp8", action="store_true", help="opt-in fp8-e4m3 KV cache, one scale per (token, head) row (NOT the bf16 headline)")
     ap.add_argument("--exact", action="store_true", help="exact numerics (tuning switch exact): fp32 activations, two-term bf16 operands, fp32 KV cache -- "
                                                          "the reference's fp32 CPU arithmetic; batch 1-2 (a conformance mode: the line says so)")
+    ap.add_argument("--exact-fp32kv", action="store_true", help="--exact with an fp32 K / V cache (tuning switch exact = 2) instead of the 24-bit one: the A/B partner")
     ap.add_argument("--scale-baseline", type=float, default=None,
                     help="N > 1 only: actions/s of ONE GPU on the same per-GPU workload, measured elsewhere; default: rank 0 measures it "
                          "live (alone on its GPU, the other ranks parked at a barrier) before the group run")
@@ -235,8 +236,10 @@ def main():
     args = ap.parse_args()
     if args.kv_fp8:
         os.environ["EMMAX_KV_FP8"] = "1"   # (as EMMAX_GRAPH: read once at library start-up, inherited by self-launched ranks)
+    if args.exact_fp32kv:
+        args.exact = True
     if args.exact:
-        os.environ["EMMAX_EXACT"] = "1"
+        os.environ["EMMAX_EXACT"] = "2" if args.exact_fp32kv else "1"
     if args.graph:
         os.environ["EMMAX_GRAPH"] = "1"   # read once by the library at start-up (include/emmax.h: tuning switches); inherited by self-launched ranks
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -316,7 +319,7 @@ def main():
         ctx = cfg.n_patches + P
         stage_bytes = {
             "qkv_gemv": (qd + 2 * kvd) * L.hidden_size * wbytes,
-            "paged_attn": B * 2 * ctx * kvd * (1 if args.kv_fp8 else 4 if args.exact else 2) + (B * 2 * ctx * L.num_kv_heads * 4 if args.kv_fp8 else 0),
+            "paged_attn": B * 2 * ctx * kvd * (1 if args.kv_fp8 else (4 if args.exact_fp32kv else 3) if args.exact else 2) + (B * 2 * ctx * L.num_kv_heads * 4 if args.kv_fp8 else 0),
             "oproj_gemv": L.hidden_size * qd * wbytes,
             "gateup_gemv": 2 * inter_p * L.hidden_size * wbytes,
             "down_gemv": L.hidden_size * inter_p * wbytes,
@@ -342,14 +345,14 @@ def main():
         step_ms = (time.perf_counter() - t_s) / nsteps * 1e3
         w_llm = (L.num_layers * ((qd + 2 * kvd) * L.hidden_size + L.hidden_size * qd + 3 * L.intermediate_size * L.hidden_size
                                  + 2 * L.hidden_size) + L.hidden_size + L.vocab_size * L.hidden_size) * wbytes
-        kv_bytes = L.num_layers * B * 2 * (ctx + nsteps // 2) * (kvd * (1 if args.kv_fp8 else 4 if args.exact else 2) + (L.num_kv_heads * 4 if args.kv_fp8 else 0))
+        kv_bytes = L.num_layers * B * 2 * (ctx + nsteps // 2) * (kvd * (1 if args.kv_fp8 else (4 if args.exact_fp32kv else 3) if args.exact else 2) + (L.num_kv_heads * 4 if args.kv_fp8 else 0))
         step_gbs = (w_llm + kv_bytes) / (step_ms * 1e-3) / 1e9
         out = {
             "metric": "actions/sec", "value": round(actions_per_s, 4), "unit": "actions/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": ("bf16 weights x two-term bf16 activations (fp32-equivalent), fp32 accumulate" if args.exact else "bf16") if not args.fp8 else "bf16 activations / fp8-e4m3 decode weights", "data": "synthetic",
             "cmd": "python bench.py --gpus %d --steps %d --warmup %d --batch-per-gpu %d --prompt-tokens %d --new-tokens %d%s%s%s"
-                   % (world, args.steps, args.warmup, B, P, T, " --fp8" if args.fp8 else "", (" --graph" if args.graph else "") + (" --kv-fp8" if args.kv_fp8 else "") + (" --exact" if args.exact else ""), " --tiny" if args.tiny else ""),
+                   % (world, args.steps, args.warmup, B, P, T, " --fp8" if args.fp8 else "", (" --graph" if args.graph else "") + (" --kv-fp8" if args.kv_fp8 else "") + (" --exact-fp32kv" if args.exact_fp32kv else " --exact" if args.exact else ""), " --tiny" if args.tiny else ""),
             "config": {"workload": _workload(args, world, B, P, T),
                        "batch_per_gpu": B, "global_batch": B * world, "prompt_tokens": P, "new_tokens": T, "context": ctx + T,
                        "parallelism": f"dp{world}", "hipgraph": eng.graph_active(), "exact_numerics": bool(eng.exact)},

@@ -334,18 +334,22 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
                 mc = m_new * c;
                 m_run[qb] = m_new;
             }
-            float psum = 0.f;
+            // (round 6: the exp2 arguments and the row-sum adds as 2-vectors -- v_pk_fma_f32 / v_pk_add_f32, two scores per issue slot; VALU and
+            // MFMA clocks of a SIMD add up, and of the ~70 VALU instructions of a 32-key group these were 32)
+            f32x2_t ps2 = {0.f, 0.f};
+            const f32x2_t c2 = {c, c}, nmc2 = {-mc, -mc};
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qb][gi][8 * mm + 2 * t], c, -mc));
-                        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qb][gi][8 * mm + 2 * t + 1], c, -mc));
-                        psum += p0 + p1;
-                        pf[qb][gi][mm][t] = pack_bf16x2(p0, p1);
+                        const f32x2_t a2 = __builtin_elementwise_fma((f32x2_t){st[qb][gi][8 * mm + 2 * t], st[qb][gi][8 * mm + 2 * t + 1]}, c2, nmc2);
+                        const f32x2_t p2 = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+                        ps2 += p2;
+                        pf[qb][gi][mm][t] = pack_bf16x2(p2[0], p2[1]);
                     }
+            const float psum = ps2[0] + ps2[1];
             if constexpr (LZ) l_run[qb] += psum;
             else {
                 l_run[qb] = __builtin_fmaf(l_run[qb], alpha, psum);
@@ -733,18 +737,19 @@ __global__ __launch_bounds__(RC::NT, RC::MINW) void emmax_attention_resident_ker
                     }
                 }
                 const float mc = m_run * c;
-                float psum = 0.f;
+                f32x2_t ps2 = {0.f, 0.f};                       // (round 6: 2-vectors -> v_pk_fma_f32 / v_pk_add_f32, see the ring kernel)
+                const f32x2_t c2 = {c, c}, nmc2 = {-mc, -mc};
                 u32x4_t pf[2];
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[8 * mm + 2 * t], c, -mc));
-                        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[8 * mm + 2 * t + 1], c, -mc));
-                        psum += p0 + p1;
-                        pf[mm][t] = pack_bf16x2(p0, p1);
+                        const f32x2_t a2 = __builtin_elementwise_fma((f32x2_t){st[8 * mm + 2 * t], st[8 * mm + 2 * t + 1]}, c2, nmc2);
+                        const f32x2_t p2 = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+                        ps2 += p2;
+                        pf[mm][t] = pack_bf16x2(p2[0], p2[1]);
                     }
-                l_run += psum;
+                l_run += ps2[0] + ps2[1];
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm) {
                     if (mm >= VPRE) read_v(mm);

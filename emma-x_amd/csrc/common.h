@@ -181,6 +181,17 @@ __device__ __forceinline__ hl2_t split_hl2(float a, float b) {
     const uint32_t hi = pack_bf16x2(a, b);
     return {hi, pack_bf16x2(a - bf_lo(hi), b - bf_hi(hi))};
 }
+// ---- exact numerics, the 24-bit K / V cache ("x24"): the top 24 bits of the fp32 value (sign, exponent, 15 mantissa bits, rounded to nearest) as a bf16
+// plane (the top 16 bits) + an 8-bit extension plane: 2^-16 relative per element at 1.5 x the bytes of the bf16 cache (fp32: 2 x) ----
+__device__ __forceinline__ uint32_t x24_bits(float x) { return __float_as_uint(x) + 0x80u; }            // (hi = bits >> 16, ext = (bits >> 8) & 0xff)
+// 8 elements: hi = 8 x 16 bits (u32x4), ext = 8 x 8 bits (u32x2) -> 8 floats; v_perm_b32 assembles {hi.b1, hi.b0, ext.b, 0x00} per element
+__device__ __forceinline__ void x24_unpack8(const u32x4_t& hi, const u32x2_t& ext, float (&f)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t sel = ((e & 1) ? 0x07060000u : 0x05040000u) | ((uint32_t)(e & 3) << 8) | 0x0cu;
+        f[e] = __uint_as_float(__builtin_amdgcn_perm(hi[e >> 1], ext[e >> 2], sel));
+    }
+}
 // position of element c of a row inside its HL image (per 64 elements: 64 hi, then 64 lo)
 __host__ __device__ __forceinline__ int hl_col(int c) { return ((c >> 6) << 7) + (c & 63); }
 

@@ -458,13 +458,17 @@ __device__ __forceinline__ void ks_run_op(const GemvParams& p, u32x4_t (&wr)[KsR
             const int hb = epair >> p.ks_shift, d = epair - hb * half;
             if (hb < p.Hq + p.Hkv) {
                 const float y0 = __fadd_rn(__fmul_rn(red0, pre_a), -__fmul_rn(red1, pre_b)), y1 = __fadd_rn(__fmul_rn(red1, pre_a), __fmul_rn(red0, pre_b));
-                float* dst = hb < p.Hq ? (float*)p.y + (size_t)eb * p.ldy + hb * hd : gemv_kv_row32(p, false, pre_pg, pre_pos, hb - p.Hq);
-                dst[d] = y0;
-                dst[d + half] = y1;
+                if (hb < p.Hq) {
+                    float* dst = (float*)p.y + (size_t)eb * p.ldy + hb * hd;
+                    dst[d] = y0;
+                    dst[d + half] = y1;
+                } else {
+                    gemv_kv_store_x(p, false, pre_pg, pre_pos, hb - p.Hq, d, y0);
+                    gemv_kv_store_x(p, false, pre_pg, pre_pos, hb - p.Hq, d + half, y1);
+                }
             } else {
-                float* vc = gemv_kv_row32(p, true, pre_pg, pre_pos, hb - p.Hq - p.Hkv);
-                vc[d] = red0;
-                vc[d + half] = red1;
+                gemv_kv_store_x(p, true, pre_pg, pre_pos, hb - p.Hq - p.Hkv, d, red0);
+                gemv_kv_store_x(p, true, pre_pg, pre_pos, hb - p.Hq - p.Hkv, d + half, red1);
             }
         }
     } else if (MODE == GEMV_QKV) {

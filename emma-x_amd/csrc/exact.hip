@@ -203,11 +203,11 @@ __global__ __launch_bounds__(256) void emmax_x_embed_splice_kernel(const int32_t
     }
 }
 
-// Prefill RoPE (rotate-half) on the fp32 q / k of every packed row, in place, + fp32 K / V append.  One block per row.
+// Prefill RoPE (rotate-half) on the fp32 q / k of every packed row, in place, + K / V append to the fp32 or 24-bit (kv24 > 0) cache.  One block per row.
 __global__ __launch_bounds__(256) void emmax_x_rope_kv_write_kernel(float* __restrict__ qkv, int ld, int q_off, int k_off, int v_off, const int32_t* __restrict__ cu,
                                                                    int B, const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                                                   float* __restrict__ kcache, float* __restrict__ vcache, const int32_t* __restrict__ page_table,
-                                                                   int max_pages, int Hq, int Hkv, int hd, int page) {
+                                                                   void* __restrict__ kcache, void* __restrict__ vcache, long long kv24,
+                                                                   const int32_t* __restrict__ page_table, int max_pages, int Hq, int Hkv, int hd, int page) {
     const int row = blockIdx.x;
     int b = 0;
     while (b + 1 < B && row >= cu[b + 1]) ++b;
@@ -217,6 +217,15 @@ __global__ __launch_bounds__(256) void emmax_x_rope_kv_write_kernel(float* __res
     const float* cs = cos_t + (size_t)pos * half;
     const float* sn = sin_t + (size_t)pos * half;
     const int pg = page_table[(size_t)b * max_pages + pos / page], slot = pos % page;
+    auto put = [&](void* base, size_t idx, float v) {
+        if (kv24 > 0) {
+            const uint32_t u = x24_bits(v);
+            ((bf16_t*)base)[idx] = (bf16_t)(u >> 16);
+            ((uint8_t*)base + (size_t)kv24 * 2)[idx] = (uint8_t)(u >> 8);
+        } else {
+            ((float*)base)[idx] = v;
+        }
+    };
     for (int i = threadIdx.x; i < (Hq + Hkv) * half; i += blockDim.x) {
         const int hh = i / half, d = i - hh * half;
         float* x = (hh < Hq) ? (r + q_off + hh * hd) : (r + k_off + (hh - Hq) * hd);
@@ -227,14 +236,14 @@ __global__ __launch_bounds__(256) void emmax_x_rope_kv_write_kernel(float* __res
         x[d] = y0;
         x[d + half] = y1;
         if (hh >= Hq) {
-            float* kc = kcache + (((size_t)pg * Hkv + (hh - Hq)) * page + slot) * hd;
-            kc[d] = y0;
-            kc[d + half] = y1;
+            const size_t kc = (((size_t)pg * Hkv + (hh - Hq)) * page + slot) * hd;
+            put(kcache, kc + d, y0);
+            put(kcache, kc + d + half, y1);
         }
     }
-    for (int i = threadIdx.x; i < Hkv * hd / 4; i += blockDim.x) {
-        const int hk = i / (hd / 4), ch = i - hk * (hd / 4);
-        *(f32x4_t*)(vcache + (((size_t)pg * Hkv + hk) * page + slot) * hd + ch * 4) = *(const f32x4_t*)(r + v_off + hk * hd + ch * 4);
+    for (int i = threadIdx.x; i < Hkv * hd; i += blockDim.x) {
+        const int hk = i / hd, d = i - hk * hd;
+        put(vcache, (((size_t)pg * Hkv + hk) * page + slot) * hd + d, r[v_off + hk * hd + d]);
     }
 }
 
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(256) void emmax_x_attention_kernel(AttnParams p) {
 // merged by the o-proj's prologue) with fp32 q (8 elements per lane), fp32 K / V rows (two 16-byte loads per lane, key and operand) and
 // fma dot products -- the arithmetic of HF's eager attention on an fp32 cache.  grid (nsplit, Hkv, B), 256 threads.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int G>
+template <int G, bool X24>
 __global__ __launch_bounds__(256) void emmax_x_decode_attn_kernel(DecodeAttnParams p) {
     // KU keys per lane group and chunk, two chunks in flight: 32 KiB of K / V per wave at KU = 4 -- a batch-1 launch is one block per CU (one wave
     // per SIMD: registers are no constraint) and a latency chain of L / (nsplit 16 KU) round trips: KU = 2 took 8.6 us per launch, twice the
@@ -466,6 +475,8 @@ __global__ __launch_bounds__(256) void emmax_x_decode_attn_kernel(DecodeAttnPara
     }
     const float* kc = (const float*)p.kcache;
     const float* vc = (const float*)p.vcache;
+    const bf16_t *kh = (const bf16_t*)p.kcache, *vh = (const bf16_t*)p.vcache;                 // X24: the bf16 planes ...
+    const uint8_t *ke = (const uint8_t*)p.kcache + (size_t)p.kv24 * 2, *ve = (const uint8_t*)p.vcache + (size_t)p.kv24 * 2;   // ... and the extension planes
     __syncthreads();
     float m[G], l[G], o[G][8];
 #pragma unroll
@@ -483,11 +494,28 @@ __global__ __launch_bounds__(256) void emmax_x_decode_attn_kernel(DecodeAttnPara
             const int kk = ok[u] ? key : k0;
             const int pg = s_pages[kk >> p.page_shift];
             const size_t off = ((((size_t)pg * p.Hkv + hk) << p.page_shift) + (kk & (p.page - 1))) * HD + ch * 8;
-            kv[u] = {__builtin_nontemporal_load((const f32x4_t*)(kc + off)), __builtin_nontemporal_load((const f32x4_t*)(kc + off + 4))};
-            vv[u] = {__builtin_nontemporal_load((const f32x4_t*)(vc + off)), __builtin_nontemporal_load((const f32x4_t*)(vc + off + 4))};
+            if constexpr (X24) {   // 16 + 8 bytes per lane, key and operand; carried as raw bits until consume_chunk widens them
+                const u32x4_t k16 = __builtin_nontemporal_load((const u32x4_t*)(kh + off)), v16 = __builtin_nontemporal_load((const u32x4_t*)(vh + off));
+                const u32x2_t k8 = __builtin_nontemporal_load((const u32x2_t*)(ke + off)), v8 = __builtin_nontemporal_load((const u32x2_t*)(ve + off));
+                kv[u] = {__builtin_bit_cast(f32x4_t, k16), (f32x4_t){__uint_as_float(k8[0]), __uint_as_float(k8[1]), 0.f, 0.f}};
+                vv[u] = {__builtin_bit_cast(f32x4_t, v16), (f32x4_t){__uint_as_float(v8[0]), __uint_as_float(v8[1]), 0.f, 0.f}};
+            } else {
+                kv[u] = {__builtin_nontemporal_load((const f32x4_t*)(kc + off)), __builtin_nontemporal_load((const f32x4_t*)(kc + off + 4))};
+                vv[u] = {__builtin_nontemporal_load((const f32x4_t*)(vc + off)), __builtin_nontemporal_load((const f32x4_t*)(vc + off + 4))};
+            }
         }
     };
-    auto consume_chunk = [&](const f32x8_t (&kv)[KU], const f32x8_t (&vv)[KU], const bool (&ok)[KU]) {
+    auto consume_chunk = [&](f32x8_t (&kv)[KU], f32x8_t (&vv)[KU], const bool (&ok)[KU]) {
+        if constexpr (X24) {
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                float kf[8], vf[8];
+                x24_unpack8(__builtin_bit_cast(u32x4_t, kv[u].lo), (u32x2_t){__float_as_uint(kv[u].hi[0]), __float_as_uint(kv[u].hi[1])}, kf);
+                x24_unpack8(__builtin_bit_cast(u32x4_t, vv[u].lo), (u32x2_t){__float_as_uint(vv[u].hi[0]), __float_as_uint(vv[u].hi[1])}, vf);
+                kv[u] = {(f32x4_t){kf[0], kf[1], kf[2], kf[3]}, (f32x4_t){kf[4], kf[5], kf[6], kf[7]}};
+                vv[u] = {(f32x4_t){vf[0], vf[1], vf[2], vf[3]}, (f32x4_t){vf[4], vf[5], vf[6], vf[7]}};
+            }
+        }
 #pragma unroll
         for (int gq = 0; gq < G; ++gq) {
             float sc[KU];
@@ -649,10 +677,10 @@ int launch_x_embed_splice(const int32_t* ids, int P_max, const int32_t* cu, cons
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 int launch_x_rope_kv_write(float* qkv, int ld, int q_off, int k_off, int v_off, const int32_t* cu, int B, int total_rows, const float* cos_t, const float* sin_t,
-                           float* kcache, float* vcache, const int32_t* page_table, int max_pages, int Hq, int Hkv, int hd, int page, hipStream_t stream) {
+                           void* kcache, void* vcache, long long kv24, const int32_t* page_table, int max_pages, int Hq, int Hkv, int hd, int page, hipStream_t stream) {
     if (total_rows <= 0) return 0;
     if (hd % 4 || ld % 4 || q_off % 4 || k_off % 4 || v_off % 4) return -1;
-    hipLaunchKernelGGL(emmax_x_rope_kv_write_kernel, dim3(total_rows), dim3(256), 0, stream, qkv, ld, q_off, k_off, v_off, cu, B, cos_t, sin_t, kcache, vcache,
+    hipLaunchKernelGGL(emmax_x_rope_kv_write_kernel, dim3(total_rows), dim3(256), 0, stream, qkv, ld, q_off, k_off, v_off, cu, B, cos_t, sin_t, kcache, vcache, kv24,
                        page_table, max_pages, Hq, Hkv, hd, page);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
@@ -675,13 +703,16 @@ int launch_x_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_d
     p.page_shift = 0;
     while ((1 << p.page_shift) < p.page) ++p.page_shift;
     dim3 grid(nsplit, p.Hkv, B), block(256);
+#define XDA(GG) do { if (p.kv24 > 0) hipLaunchKernelGGL((emmax_x_decode_attn_kernel<GG, true>), grid, block, 0, stream, p); \
+                     else hipLaunchKernelGGL((emmax_x_decode_attn_kernel<GG, false>), grid, block, 0, stream, p); } while (0)
     switch (Hq / p.Hkv) {
-        case 1: hipLaunchKernelGGL((emmax_x_decode_attn_kernel<1>), grid, block, 0, stream, p); break;
-        case 2: hipLaunchKernelGGL((emmax_x_decode_attn_kernel<2>), grid, block, 0, stream, p); break;
-        case 4: hipLaunchKernelGGL((emmax_x_decode_attn_kernel<4>), grid, block, 0, stream, p); break;
-        case 8: hipLaunchKernelGGL((emmax_x_decode_attn_kernel<8>), grid, block, 0, stream, p); break;
+        case 1: XDA(1); break;
+        case 2: XDA(2); break;
+        case 4: XDA(4); break;
+        case 8: XDA(8); break;
         default: return -1;
     }
+#undef XDA
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

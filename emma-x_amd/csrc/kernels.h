@@ -97,7 +97,7 @@ int launch_x_assemble_tokens(const float* pe, const void* pos, const void* cls, 
 int launch_x_embed_splice(const int32_t* ids, int P_max, const int32_t* cu, const void* E, const float* patches32, const void* patches_bf, float* h32, int B,
                           int max_seqlen, int n_patches, int hidden, int vocab, hipStream_t stream);
 int launch_x_rope_kv_write(float* qkv, int ld, int q_off, int k_off, int v_off, const int32_t* cu, int B, int total_rows, const float* cos_t, const float* sin_t,
-                           float* kcache, float* vcache, const int32_t* page_table, int max_pages, int Hq, int Hkv, int hd, int page, hipStream_t stream);
+                           void* kcache, void* vcache, long long kv24, const int32_t* page_table, int max_pages, int Hq, int Hkv, int hd, int page, hipStream_t stream);
 
 // ---- misc.hip ----
 int launch_patch_gather(bool from_u8, const void* src, void* out, int B, int img, int patch, int kpad, int chan0,
@@ -236,14 +236,25 @@ struct GemvParams {
     // [B, ldy], the K / V rows go to an fp32 paged cache (kcache / vcache as float); GATEUP: p.y = f32 [B, ldy]; RESID over the SwiGLU
     // product: p.x = f32 [B, ldx]; RESID over the attention partials: the merge stays fp32 until it is split.
     int exact;
+    long long kv24;         // exact numerics: > 0 = the K / V caches are 24-bit (common.h: x24) -- kcache / vcache point at the bf16 plane of kv24 elements,
+                            //   the 8-bit extension plane follows it; 0 = fp32 rows
 };
 // where the QKV epilogues put element block (head hk, K or V) of batch row b: the paged bf16 cache, or the staging rows of the fp8 KV cache
 __device__ __forceinline__ bf16_t* gemv_kv_row(const GemvParams& p, bool is_v, int b, int pg, int pos, int hk) {
     if (p.kv_stage) return (bf16_t*)p.kv_stage + (((size_t)b * p.Hkv + hk) * 2 + (is_v ? 1 : 0)) * p.head_dim;
     return (bf16_t*)(is_v ? p.vcache : p.kcache) + (((size_t)pg * p.Hkv + hk) * p.page + pos % p.page) * p.head_dim;
 }
-__device__ __forceinline__ float* gemv_kv_row32(const GemvParams& p, bool is_v, int pg, int pos, int hk) {   // exact numerics: the fp32 paged cache
-    return (float*)(is_v ? p.vcache : p.kcache) + (((size_t)pg * p.Hkv + hk) * p.page + pos % p.page) * p.head_dim;
+// exact numerics: element d of the (page, kv head, position) row of the fp32 / 24-bit paged cache
+__device__ __forceinline__ void gemv_kv_store_x(const GemvParams& p, bool is_v, int pg, int pos, int hk, int d, float v) {
+    const size_t idx = (((size_t)pg * p.Hkv + hk) * p.page + pos % p.page) * p.head_dim + d;
+    void* base = is_v ? p.vcache : p.kcache;
+    if (p.kv24 > 0) {
+        const uint32_t u = x24_bits(v);
+        ((bf16_t*)base)[idx] = (bf16_t)(u >> 16);
+        ((uint8_t*)base + (size_t)p.kv24 * 2)[idx] = (uint8_t)(u >> 8);
+    } else {
+        ((float*)base)[idx] = v;
+    }
 }
 int launch_decode_gemv(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out = nullptr);
 // decode_ks.hip: the batch 1-2 bf16 projections with K split across the waves of a block (activation slice in registers, no
@@ -271,6 +282,7 @@ struct DecodeAttnParams {
     int ldq, Hkv, page, max_pages;
     int page_shift;         // log2(page), set by the launcher
     float scale;
+    long long kv24;         // exact numerics (launch_x_decode_attn): > 0 = 24-bit caches (GemvParams::kv24), 0 = fp32 rows
 };
 int decode_attn_nsplit(int B, int Hkv);
 int launch_decode_attn(const DecodeAttnParams& p, int B, int Hq, int head_dim, int nsplit, hipStream_t stream);

@@ -352,6 +352,8 @@ struct emmax_session {
     // token rows; xfeats32 / xpe32: fp32 tower features / projected patch embeddings; dq32 / dact32: the decode step's fp32 q rows and SwiGLU
     // product.  The paged KV region holds fp32 rows (twice the bytes of the bf16 cache).
     bool exact = false;
+    int kv_fmt = 0;             // KV_BF16 / KV_FP8 / KV_F32 / KV_X24 (kv_format_now() at emmax_session_create)
+    long long kv24 = 0;         // KV_X24: elements of one operand's plane of a layer (GemvParams::kv24), else 0
     float *x32a = nullptr, *xtok32 = nullptr, *xfeats32 = nullptr, *xpe32 = nullptr, *dq32 = nullptr, *dact32 = nullptr;
     bf16 *xhla = nullptr, *xhlb = nullptr;
     float* splitk_ws;           // fp32 partial tiles of split-K GEMMs (gemm.hip)
@@ -497,10 +499,13 @@ static void plan_session(emmax_session* s, SBump& b) {
 
 // paged KV region: per layer K and V, rows x pages x kv heads x 64 tokens x head_dim elements -- bf16, or (kv8) e4m3 bytes + a 4-byte scale per row
 static int64_t kv_rows_per_layer(const emmax_model* m, int rows, int max_pages) { return (int64_t)rows * max_pages * m->cfg.n_kv_heads * PAGE; }
-enum { KV_BF16 = 0, KV_FP8 = 1, KV_F32 = 2 };   // format of the paged cache: bf16 rows; e4m3 rows + a scale (kv_fp8); fp32 rows (exact numerics)
-static int kv_format_now() { return emmax_tune().exact ? KV_F32 : (emmax_tune().kv_fp8 ? KV_FP8 : KV_BF16); }
+// format of the paged cache: bf16 rows; e4m3 rows + a scale (kv_fp8); exact numerics: 24-bit rows (exact = 1: a bf16 plane + an 8-bit extension plane per
+// operand = the top 24 bits of the fp32 value, 2^-16 relative, 1.5 x the bf16 bytes) or fp32 rows (exact = 2: 2 x the bytes -- the A/B partner)
+enum { KV_BF16 = 0, KV_FP8 = 1, KV_F32 = 2, KV_X24 = 3 };
+static int kv_format_now() { return emmax_tune().exact >= 2 ? KV_F32 : emmax_tune().exact == 1 ? KV_X24 : (emmax_tune().kv_fp8 ? KV_FP8 : KV_BF16); }
+static int kv_elem_bytes(const emmax_model* m, int fmt) { return fmt == KV_F32 ? 4 : fmt == KV_X24 ? 3 : fmt == KV_FP8 ? 1 : 2; }
 static int64_t kv_layer_bytes(const emmax_model* m, int rows, int max_pages, int fmt) {
-    return 2 * kv_rows_per_layer(m, rows, max_pages) * (fmt == KV_FP8 ? m->cfg.head_dim + 4 : fmt == KV_F32 ? m->cfg.head_dim * 4 : m->cfg.head_dim * 2);
+    return 2 * kv_rows_per_layer(m, rows, max_pages) * (m->cfg.head_dim * kv_elem_bytes(m, fmt) + (fmt == KV_FP8 ? 4 : 0));
 }
 static int64_t kv_bytes_for(const emmax_model* m, int max_batch, int max_pages, int fmt) {
     return (int64_t)m->cfg.n_layers * kv_layer_bytes(m, max_batch, max_pages, fmt);
@@ -815,7 +820,7 @@ static char* kv_layer(emmax_session* s, int layer) { return (char*)s->kv + (size
 static int64_t kv_rows(emmax_session* s) { return kv_rows_per_layer(s->m, s->rows_total, s->max_pages); }
 static bf16* kcache_of(emmax_session* s, int layer) { return (bf16*)kv_layer(s, layer); }
 static bf16* vcache_of(emmax_session* s, int layer) {
-    return (bf16*)(kv_layer(s, layer) + kv_rows(s) * (s->kv8 ? s->m->cfg.head_dim : s->exact ? s->m->cfg.head_dim * 4 : s->m->cfg.head_dim * 2));
+    return (bf16*)(kv_layer(s, layer) + kv_rows(s) * s->m->cfg.head_dim * kv_elem_bytes(s->m, s->kv_fmt));
 }
 static float* kscale_of(emmax_session* s, int layer) { return (float*)(kv_layer(s, layer) + 2 * kv_rows(s) * s->m->cfg.head_dim); }   // kv8 only
 static float* vscale_of(emmax_session* s, int layer) { return kscale_of(s, layer) + kv_rows(s); }
@@ -977,8 +982,8 @@ static int run_prefill_x(emmax_session* s, const int32_t* ids, int B, int P_max,
         KCHK(launch_x_rmsnorm(s->ph32, s->xhla, L.ln1, total, m->H, m->H, 2 * m->H, c.rms_eps, st));
         GemmParams g = gpx(s, s->xhla, m->H, L.wqkv, m->H, s->x32a, m->qkv_dim, total, m->qkv_dim);
         KCHK(launch_gemm(g, st));
-        KCHK(launch_x_rope_kv_write(s->x32a, m->qkv_dim, 0, m->q_dim, m->q_dim + m->kv_dim, s->cu, B, total, s->cos_t, s->sin_t, (float*)kcache_of(s, li),
-                                    (float*)vcache_of(s, li), s->page_table + (size_t)r0 * s->max_pages, s->max_pages, c.n_heads, c.n_kv_heads, c.head_dim, PAGE, st));
+        KCHK(launch_x_rope_kv_write(s->x32a, m->qkv_dim, 0, m->q_dim, m->q_dim + m->kv_dim, s->cu, B, total, s->cos_t, s->sin_t, kcache_of(s, li),
+                                    vcache_of(s, li), s->kv24, s->page_table + (size_t)r0 * s->max_pages, s->max_pages, c.n_heads, c.n_kv_heads, c.head_dim, PAGE, st));
         AttnParams a;
         a.qkv = s->x32a; a.out = s->xhlb; a.cu_seqlens = s->cu;
         a.ld_qkv = m->qkv_dim; a.q_off = 0; a.k_off = m->q_dim; a.v_off = m->q_dim + m->kv_dim; a.ld_out = 2 * m->q_dim;
@@ -1030,7 +1035,7 @@ static void stage_params(emmax_session* s, int B, int li, int stage, GemvParams&
             p.ctx_len = s->ctx_len; p.page_table = s->page_table; p.cos_t = s->cos_t; p.sin_t = s->sin_t;
             p.kcache = kcache_of(s, li); p.vcache = vcache_of(s, li);
             p.kv_stage = s->kv8 ? s->kv_stage : nullptr;   // fp8 KV cache: the new rows wait as bf16 for the attention launch
-            if (s->exact) p.y = s->dq32;                    // fp32 q rows; kcache / vcache are the fp32 cache
+            if (s->exact) { p.y = s->dq32; p.kv24 = s->kv24; }   // fp32 q rows; kcache / vcache are the 24-bit (or fp32) cache
             break;
         case STAGE_OPROJ:
             p.x = s->datt; p.ldx = m->q_dim; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
@@ -1084,7 +1089,7 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             a.o_out = attn_direct_on(s, B) ? s->datt : nullptr;
             const int ns = decode_attn_nsplit(B, c.n_kv_heads);
             if (s->exact) {
-                a.q = s->dq32;
+                a.q = s->dq32; a.kv24 = s->kv24;
                 KCHK(launch_x_decode_attn(a, B, c.n_heads, c.head_dim, ns, st));
                 return 0;
             }
@@ -1467,7 +1472,9 @@ int emmax_session_create_ex(emmax_model* m, int max_batch, int max_prompt, int m
     plan_session(s, b);
     s->kv = (bf16*)kv;
     s->kv8 = !s->exact && emmax_tune().kv_fp8 != 0;
-    s->kv_layer_stride = kv_layer_bytes(m, s->rows_total, s->max_pages, kv_format_now());
+    s->kv_fmt = kv_format_now();
+    s->kv_layer_stride = kv_layer_bytes(m, s->rows_total, s->max_pages, s->kv_fmt);
+    s->kv24 = s->kv_fmt == KV_X24 ? (long long)kv_rows_per_layer(m, s->rows_total, s->max_pages) * m->cfg.head_dim : 0;
     HIPCHK(hipMemset(ws, 0, need_ws));   // padding columns of every activation buffer stay zero forever
     HIPCHK(hipMemset(kv, 0, need_kv));
     HIPCHK(hipDeviceSynchronize());
@@ -2049,15 +2056,15 @@ int emmax_op_x_join(const void* hl, float* out32, int rows, int D, emmax_stream 
     KCHK(launch_x_join_rows(hl, out32, rows, D, 2 * Dp, D, (hipStream_t)stream));
     return 0;
 }
-int emmax_op_x_decode_attention(const float* q32, const float* kcache32, const float* vcache32, const int32_t* page_table, const int32_t* ctx_len,
-                                const int32_t* done, float* part_out, int B, int Hq, int Hkv, int page, int max_pages, int nsplit, float scale,
-                                emmax_stream st) {
+int emmax_op_x_decode_attention(const float* q32, const void* kcache32, const void* vcache32, int64_t kv24_elems, const int32_t* page_table,
+                                const int32_t* ctx_len, const int32_t* done, float* part_out, int B, int Hq, int Hkv, int page, int max_pages, int nsplit,
+                                float scale, emmax_stream st) {
     if (!q32 || !kcache32 || !vcache32 || !page_table || !ctx_len || !part_out) return fail(EMMAX_ERR_INVALID, "emmax_op_x_decode_attention: null argument");
     if (B < 1 || B > EMMAX_MAX_DECODE_BATCH || Hkv < 1 || Hq % Hkv) return fail(EMMAX_ERR_INVALID, "emmax_op_x_decode_attention: bad B / heads");
     DecodeAttnParams a;
     memset(&a, 0, sizeof(a));
     a.q = q32; a.ldq = Hq * 128; a.kcache = kcache32; a.vcache = vcache32; a.page_table = page_table; a.ctx_len = ctx_len; a.done = done;
-    a.part = part_out; a.Hkv = Hkv; a.page = page; a.max_pages = max_pages; a.scale = scale;
+    a.part = part_out; a.Hkv = Hkv; a.page = page; a.max_pages = max_pages; a.scale = scale; a.kv24 = kv24_elems;
     int r = launch_x_decode_attn(a, B, Hq, 128, nsplit, (hipStream_t)st);
     if (r) return fail(r == -4 ? EMMAX_ERR_HIP : EMMAX_ERR_INVALID, "emmax_op_x_decode_attention: unsupported (GQA group in {1,2,4,8}, page = 2^k, max_pages <= 512, nsplit = 2^k)");
     return 0;

@@ -119,7 +119,7 @@ SIGNATURES = {
     "emmax_op_x_rownorm": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp]),
     "emmax_op_x_attention": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp]),
     "emmax_op_x_join": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
-    "emmax_op_x_decode_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
+    "emmax_op_x_decode_attention": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

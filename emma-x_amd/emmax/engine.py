@@ -66,7 +66,8 @@ class EmmaxEngine:
         self.lib = _lib.load()
         # EXACT NUMERICS (include/emmax.h, tuning switch `exact`): the fp32 CPU arithmetic of the reference instead of bf16 operands.  Frozen into
         # the model at finalize (ViT LayerNorms unfolded) and into every session of this engine; None = what the library's switch says (EMMAX_EXACT)
-        self.exact = bool(_lib.tuning_get("exact")) if exact is None else bool(exact)
+        # (1 / True: 24-bit K / V cache, the default exact format; 2: fp32 cache, its A/B partner)
+        self.exact = int(_lib.tuning_get("exact")) if exact is None else int(exact)
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -123,7 +124,7 @@ class EmmaxEngine:
             _lib.check(self.lib.emmax_session_create_ex(self._model, max_batch, max_prompt, max_ctx, int(stage_rows), self.workspace.data_ptr(),
                                                         ws.value, self.kv.data_ptr(), kv.value, C.byref(self._session)),
                        "emmax_session_create_ex")
-        assert bool(self.lib.emmax_session_exact(self._session)) == self.exact
+        assert bool(self.lib.emmax_session_exact(self._session)) == bool(self.exact)
         self.max_batch, self.max_prompt, self.max_ctx, self.stage_rows = max_batch, max_prompt, max_ctx, int(stage_rows)
 
     def ensure_stage_rows(self, n: int) -> None:

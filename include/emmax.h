@@ -336,7 +336,9 @@ int emmax_op_gemm_small(const void* x_dev, const void* W_fm_dev, void* y_dev, in
  *                         terms the consumer GEMM would read, joined
  *   emmax_op_x_attention  softmax(q k^T scale [causal]) v on the fp32 MFMA over packed fp32 qkv rows -> HL rows in hl_ws (pitch 2 * pad64(Hq *
  *                         head_dim)); emmax_op_x_join widens HL rows to fp32 (timm Attention / HF SDPA: modeling_prismatic.py:114-123,404-415)
- *   emmax_op_x_decode_attention  emmax_op_decode_attention over fp32 q rows and an fp32 paged cache (same partial layout) */
+ *   emmax_op_x_decode_attention  emmax_op_decode_attention over fp32 q rows and the exact-numerics paged cache (same partial layout): kv24_elems = 0:
+ *                         fp32 rows [pages][Hkv][page][128] (tuning switch exact = 2); > 0: the 24-bit cache of exact = 1 -- per operand a bf16 plane of
+ *                         kv24_elems elements (the top 16 bits of the fp32 value rounded to 24 bits) followed by an 8-bit extension plane */
 int emmax_op_x_gemm(const float* A32_dev, int lda, const void* W_dev, int ldw, float* C32_dev, int ldc, int M, int N, int K, const void* bias_dev, int act,
                     const float* residual32_dev, int ldr, void* hl_ws_dev, void* ws_dev, int64_t ws_bytes, emmax_stream stream);
 int emmax_op_x_rownorm(int mode, const float* x_dev, float* y32_dev, const void* w_dev, const void* b_dev, int rows, int D, float eps, void* hl_ws_dev,
@@ -344,7 +346,7 @@ int emmax_op_x_rownorm(int mode, const float* x_dev, float* y32_dev, const void*
 int emmax_op_x_attention(const float* qkv32_dev, int ld_qkv, int q_off, int k_off, int v_off, const int32_t* cu_seqlens_dev, int B, int max_seqlen, int Hq,
                          int Hkv, int head_dim, float scale, int causal, void* hl_ws_dev, emmax_stream stream);
 int emmax_op_x_join(const void* hl_dev, float* out32_dev, int rows, int D, emmax_stream stream);
-int emmax_op_x_decode_attention(const float* q32_dev, const float* kcache32_dev, const float* vcache32_dev, const int32_t* page_table_dev,
+int emmax_op_x_decode_attention(const float* q32_dev, const void* kcache_dev, const void* vcache_dev, int64_t kv24_elems, const int32_t* page_table_dev,
                                 const int32_t* ctx_len_dev, const int32_t* done_dev, float* part_out_dev, int B, int Hq, int Hkv, int page, int max_pages,
                                 int nsplit, float scale, emmax_stream stream);
 

@@ -59,3 +59,9 @@ def test_model_section_on_the_hip_path(device, tmp_path):
     rep = json.load(open(out))["model"]
     assert rep["status"] == "PASS" and len(rep["prompts"]) == 3
     assert all(r["ids_equal"] and r["action_err"] <= 1e-3 for r in rep["prompts"])
+    assert all(r["logit_rel_err_max"] < 3e-2 and r["teacher_forced_flips"] == 0 for r in rep["prompts"])   # planted margins: no flip in either mode
+    # the same command with the HIP side in exact numerics (round 6): the margin statistic drops to fp32 level
+    assert vc.main([d, "--device", device, "--prompts", "2", "--exact", "--json", out]) == 0
+    rep = json.load(open(out))["model"]
+    assert rep["status"] == "PASS" and rep["hip_numerics"].startswith("exact")
+    assert all(r["ids_equal"] and r["logit_rel_err_max"] < 1e-4 and r["teacher_forced_flips"] == 0 for r in rep["prompts"])

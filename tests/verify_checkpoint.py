@@ -3,7 +3,7 @@ verify_checkpoint.py -- one-command closure of the three "parity unpinned" gaps 
 (the protocol of /root/reference/vla-scripts/extern/verify_openvla.py:71-85 with an oracle beside it).
 
     python tests/verify_checkpoint.py <hf_checkpoint_dir> [--device cuda:0] [--prompts 5] [--new-tokens 7]
-                                      [--oracle-dtype fp32|bf16] [--skip-model] [--json out.json]
+                                      [--oracle-dtype fp32|bf16] [--exact] [--skip-model] [--json out.json]
 
 It lives under tests/ because it drives the CPU oracle (oracle/ is test infrastructure; the product never imports it).
 Sections -- each prints PASS / FAIL / SKIPPED (reason) and lands in the JSON summary; exit code 1 if any section FAILS:
@@ -17,7 +17,10 @@ Sections -- each prints PASS / FAIL / SKIPPED (reason) and lands in the JSON sum
              1e-4) and, with a GPU, against emmax_vision_features (3e-2): closes "ViT pinned to HF, not to timm"
   model      (needs a GPU) verify_openvla.py-style: N random 256x256 images + the OpenVLA prompt -> `predict_action` on the
              HIP path vs the CPU oracle (fp32 = the reference's CPU path, or bf16 = per-op-rounded emulation of its accelerator
-             path): generated ids identical, action within 1e-3, per-step top-2 margins reported
+             path): generated ids identical, action within 1e-3, per-step top-2 margins reported, and (round 6) the margin statistic
+             of DESIGN.md section 2a on THIS checkpoint: the HIP path teacher-forced with the oracle's ids, per step |logit error| /
+             max|logit| (median / max) and the steps whose argmax differs.  `--exact` runs the HIP side in exact numerics (tuning
+             switch exact: the reference's fp32 CPU arithmetic) -- there the ids are REQUIRED to equal the fp32 oracle's
 On the synthetic checkpoint of tools/make_synthetic_checkpoint.py the tokenizer / timm sections report SKIPPED.
 """
 
@@ -144,7 +147,7 @@ def section_timm(cfg, sd, device, report):
     report["timm"] = out
 
 
-def section_model(path, cfg, sd, tok, device, n_prompts, new_tokens, oracle_dtype, report):
+def section_model(path, cfg, sd, tok, device, n_prompts, new_tokens, oracle_dtype, report, exact=False):
     from emmax.modeling import EmmaXForActionPrediction
     from emmax.processing import EmmaXProcessor
     from oracle import emmax_oracle as orc
@@ -161,7 +164,7 @@ def section_model(path, cfg, sd, tok, device, n_prompts, new_tokens, oracle_dtyp
         proc = EmmaXProcessor.from_synthetic(cfg)
         tok_kind = "StubTokenizer (no tokenizer files in the directory: ids-level check only)"
     unnorm_key = "bridge_orig" if "bridge_orig" in cfg.norm_stats else next(iter(cfg.norm_stats))
-    vla = EmmaXForActionPrediction(cfg, {k: v.to(torch.bfloat16) for k, v in sd.items()}).to(device, max_batch=1, max_prompt=128)
+    vla = EmmaXForActionPrediction(cfg, {k: v.to(torch.bfloat16) for k, v in sd.items()}).to(device, max_batch=1, max_prompt=128, exact=exact)
     dt = torch.float32 if oracle_dtype == "fp32" else torch.bfloat16
     sd_ref = {k: (v.to(torch.bfloat16).float() if dt == torch.float32 else v.to(torch.bfloat16)) for k, v in sd.items()}
     rng = np.random.default_rng(7)
@@ -186,9 +189,21 @@ def section_model(path, cfg, sd, tok, device, n_prompts, new_tokens, oracle_dtyp
         same = got_ids == ref_ids[0, len(ids):].tolist()
         err = float(np.abs(action - want).max())
         ok = ok and same and err <= 1e-3
-        rows.append({"prompt": i, "ids_equal": same, "action_err": err, "min_margin": min(margins), "hip_seconds": round(dt_hip, 4)})
+        # the margin statistic on this checkpoint: teacher-forced with the oracle's ids, every step's logits against the oracle's
+        want_ids = ref_ids[0, len(ids):].tolist()
+        vla._prefill([ids], None, inputs["frames_u8"], max_new=len(want_ids) + 1)
+        rel, flips = [], 0
+        for t, tr in enumerate(trace):
+            got = vla.engine.last_logits().float().cpu()[0]
+            rel.append(float((got - tr.float()).abs().max() / tr.float().abs().max()))
+            flips += int(int(got.argmax()) != want_ids[t])
+            if t + 1 < len(trace):
+                vla.engine.set_current_tokens([want_ids[t]])
+                vla.engine.decode_step()
+        rows.append({"prompt": i, "ids_equal": same, "action_err": err, "min_margin": min(margins), "hip_seconds": round(dt_hip, 4),
+                     "logit_rel_err_median": float(np.median(rel)), "logit_rel_err_max": float(np.max(rel)), "teacher_forced_flips": flips})
     report["model"] = {"status": "PASS" if ok else "FAIL", "oracle_dtype": oracle_dtype, "unnorm_key": unnorm_key, "tokenizer": tok_kind,
-                       "prompts": rows}
+                       "hip_numerics": "exact (fp32 activations, two-term bf16 operands)" if exact else "default (bf16 operands)", "prompts": rows}
 
 
 def main(argv=None) -> int:
@@ -198,6 +213,7 @@ def main(argv=None) -> int:
     ap.add_argument("--prompts", type=int, default=5)
     ap.add_argument("--new-tokens", type=int, default=7)
     ap.add_argument("--oracle-dtype", choices=("fp32", "bf16"), default="fp32")
+    ap.add_argument("--exact", action="store_true", help="run the HIP side in exact numerics (tuning switch exact)")
     ap.add_argument("--skip-model", action="store_true")
     ap.add_argument("--json", default=None)
     a = ap.parse_args(argv)
@@ -208,7 +224,7 @@ def main(argv=None) -> int:
         gpu = torch.cuda.is_available() and not a.skip_model
         section_timm(cfg, sd, a.device if gpu else None, report)
         if gpu:
-            section_model(a.path, cfg, sd, tok, a.device, a.prompts, a.new_tokens, a.oracle_dtype, report)
+            section_model(a.path, cfg, sd, tok, a.device, a.prompts, a.new_tokens, a.oracle_dtype, report, exact=a.exact)
         else:
             report["model"] = {"status": "SKIPPED", "why": "no HIP device (or --skip-model)"}
     for k, v in report.items():
