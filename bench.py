@@ -332,7 +332,7 @@ def main():
         # the kernels this line names, not during this run -- null when no pass exists for this (batch, weight format), and on every
         # N > 1 line (it carries no number that was not measured in its own run)
         traffic = None
-        pmc_name = "r05_pmc_traffic_b%d.json" % B if (world == 1 and not args.fp8 and not args.kv_fp8 and not args.exact) else None
+        pmc_name = "r06_pmc_traffic_b%d.json" % B if (world == 1 and not args.fp8 and not args.kv_fp8 and not args.exact) else None
         pmc_file = os.path.join(ROOT, "profiles", pmc_name or "none")
         if not args.tiny and pmc_name and os.path.isfile(pmc_file):
             with open(pmc_file) as f:

@@ -325,7 +325,14 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
 #pragma unroll
                     for (int i = 0; i < NDB; ++i)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(o[qb][i][r]) : "v"(alpha));
+                        for (int r = 0; r < 16; ++r) {
+                            // the FIRST multiply carries its own hazard guard: alpha comes from v_exp_f32, and hipcc's hazard recogniser does not look
+                            // inside an asm statement (cdna_hip_programming.md 5.7) -- scheduled right behind the transcendental (round 6, once the
+                            // packed softmax arithmetic had removed what used to sit between them) it read the register one wait state early: NaN in
+                            // accumulator register 0 of some rows.  s_nop 1 = the two wait states of the trans-use hazard
+                            if (i == 0 && r == 0) asm volatile("s_nop 1\n\tv_mul_f32 %0, %0, %1" : "+v"(o[qb][i][r]) : "v"(alpha));
+                            else asm volatile("v_mul_f32 %0, %0, %1" : "+v"(o[qb][i][r]) : "v"(alpha));
+                        }
                 }
                 mc = m_run[qb] * c;
             } else {
@@ -334,22 +341,21 @@ __global__ __launch_bounds__(DM::NT, DM::MINW) void emmax_attention_kernel(AttnP
                 mc = m_new * c;
                 m_run[qb] = m_new;
             }
-            // (round 6: the exp2 arguments and the row-sum adds as 2-vectors -- v_pk_fma_f32 / v_pk_add_f32, two scores per issue slot; VALU and
-            // MFMA clocks of a SIMD add up, and of the ~70 VALU instructions of a 32-key group these were 32)
-            f32x2_t ps2 = {0.f, 0.f};
-            const f32x2_t c2 = {c, c}, nmc2 = {-mc, -mc};
+            // (round 6: the exp2 arguments and the row-sum adds as 2-vectors -- v_pk_fma_f32 / v_pk_add_f32, two scores per issue slot -- were built and
+            // measured: the VALU count of a 32-key group drops from ~70 to ~54, the launches do not get faster (ViT B = 256 103.3 against 103.8 ms,
+            // prefill equal; profiles/r06_attn_packed_ab.txt): the step is bound by its 16 quarter-rate v_exp_f32 and the MFMAs, not by issue slots)
+            float psum = 0.f;
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const f32x2_t a2 = __builtin_elementwise_fma((f32x2_t){st[qb][gi][8 * mm + 2 * t], st[qb][gi][8 * mm + 2 * t + 1]}, c2, nmc2);
-                        const f32x2_t p2 = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
-                        ps2 += p2;
-                        pf[qb][gi][mm][t] = pack_bf16x2(p2[0], p2[1]);
+                        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qb][gi][8 * mm + 2 * t], c, -mc));
+                        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qb][gi][8 * mm + 2 * t + 1], c, -mc));
+                        psum += p0 + p1;
+                        pf[qb][gi][mm][t] = pack_bf16x2(p0, p1);
                     }
-            const float psum = ps2[0] + ps2[1];
             if constexpr (LZ) l_run[qb] += psum;
             else {
                 l_run[qb] = __builtin_fmaf(l_run[qb], alpha, psum);
@@ -728,7 +734,10 @@ __global__ __launch_bounds__(RC::NT, RC::MINW) void emmax_attention_resident_ker
 #pragma unroll
                         for (int i = 0; i < NDB; ++i)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(o[i][r]) : "v"(alpha));
+                            for (int r = 0; r < 16; ++r) {
+                                if (i == 0 && r == 0) asm volatile("s_nop 1\n\tv_mul_f32 %0, %0, %1" : "+v"(o[i][r]) : "v"(alpha));   // trans-use hazard guard, see the ring kernel
+                                else asm volatile("v_mul_f32 %0, %0, %1" : "+v"(o[i][r]) : "v"(alpha));
+                            }
                     } else {
 #pragma unroll
                         for (int i = 0; i < NDB; ++i)
@@ -737,19 +746,18 @@ __global__ __launch_bounds__(RC::NT, RC::MINW) void emmax_attention_resident_ker
                     }
                 }
                 const float mc = m_run * c;
-                f32x2_t ps2 = {0.f, 0.f};                       // (round 6: 2-vectors -> v_pk_fma_f32 / v_pk_add_f32, see the ring kernel)
-                const f32x2_t c2 = {c, c}, nmc2 = {-mc, -mc};
+                float psum = 0.f;
                 u32x4_t pf[2];
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const f32x2_t a2 = __builtin_elementwise_fma((f32x2_t){st[8 * mm + 2 * t], st[8 * mm + 2 * t + 1]}, c2, nmc2);
-                        const f32x2_t p2 = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
-                        ps2 += p2;
-                        pf[mm][t] = pack_bf16x2(p2[0], p2[1]);
+                        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[8 * mm + 2 * t], c, -mc));
+                        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[8 * mm + 2 * t + 1], c, -mc));
+                        psum += p0 + p1;
+                        pf[mm][t] = pack_bf16x2(p0, p1);
                     }
-                l_run += ps2[0] + ps2[1];
+                l_run += psum;
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm) {
                     if (mm >= VPRE) read_v(mm);

