@@ -81,12 +81,13 @@ def test_tuning_switches_are_a_table_with_a_setter(lib):
     L, so = lib
     names = ["graph", "ks", "ks_oproj", "ks_oproj_grid", "km", "km_down", "streamk", "fp8_gemv", "attn_nsplit", "attn_direct", "fold_embed",
              "mfma_xbar", "gemm_big", "gemm_splitk", "gemm_hybrid", "gemm_normfuse", "gemm_deep", "gemm_lnfuse", "attn_resident",
-             "resid32", "kv_fp8", "km_roll", "attn_nw", "attn_deep", "attn_ksplit", "gemm_sk_big", "attn_lazy", "vis_streams"]   # (the last nine: round 5)
+             "resid32", "kv_fp8", "km_roll", "attn_nw", "attn_deep", "attn_ksplit", "gemm_sk_big", "attn_lazy", "vis_streams", "exact"]   # (round 5: nine before the last; round 6: exact)
     header = open(os.path.join(ROOT, "include", "emmax.h")).read()
     for n in names:
         assert re.search(r"\b%s\b" % n, header), n
         L.tuning_get(n)
     assert L.tuning_get("graph") == int(os.environ.get("EMMAX_GRAPH", "0")) and L.tuning_get("ks") == int(os.environ.get("EMMAX_KS", "1"))
+    assert L.tuning_get("exact") == int(os.environ.get("EMMAX_EXACT", "0"))   # exact numerics is opt-in: the headline path is the bf16-operand one
     # the product defaults of round 5: fp32 residual stream on, bf16 KV cache
     assert L.tuning_get("resid32") == int(os.environ.get("EMMAX_RESID32", "1")) and L.tuning_get("kv_fp8") == int(os.environ.get("EMMAX_KV_FP8", "0"))
     with L.tuning(graph=1, attn_nsplit=4):
@@ -144,6 +145,18 @@ def test_config_validation_and_sizing(lib):
     assert so.emmax_session_bytes_ex(h, 16, 512, 1281, 16, C.byref(ws2), C.byref(kv2)) == 0     # decode batches up to 16 (round 5)
     assert so.emmax_session_bytes(h, 8, 512, 700, C.byref(ws), C.byref(kv)) != 0
     assert b"max_ctx" in so.emmax_last_error()
+    # exact numerics (round 6): batches of 1-2 rows; the paged cache holds 24-bit rows (a bf16 plane + an 8-bit extension plane: 1.5 x the bf16
+    # bytes), fp32 rows under exact = 2; more workspace (fp32 activations + their two-term images)
+    ws1, kv1 = C.c_int64(), C.c_int64()
+    assert so.emmax_session_bytes(h, 2, 512, 1281, C.byref(ws1), C.byref(kv1)) == 0
+    with L.tuning(exact=1):
+        assert so.emmax_session_bytes(h, 2, 512, 1281, C.byref(ws2), C.byref(kv2)) == 0
+        assert kv2.value == 32 * 2 * 2 * 21 * 32 * 64 * 128 * 3 and 2 * kv2.value == 3 * kv1.value and ws2.value > ws1.value
+        assert so.emmax_session_bytes(h, 3, 512, 1281, C.byref(ws2), C.byref(kv2)) != 0 and b"1-2 rows" in so.emmax_last_error()
+        assert so.emmax_session_bytes_ex(h, 2, 512, 1281, 1, C.byref(ws2), C.byref(kv2)) != 0 and b"staging" in so.emmax_last_error()
+    with L.tuning(exact=2):
+        assert so.emmax_session_bytes(h, 2, 512, 1281, C.byref(ws2), C.byref(kv2)) == 0 and kv2.value == 2 * kv1.value
+    assert L.tuning_get("exact") == 0
     so.emmax_model_destroy(h)
     bad = EmmaXConfig.tiny()
     bad.llm.head_dim = 64

@@ -20,7 +20,8 @@ for t in cfg.towers:
 B = int(os.environ.get("PROBE_BATCH", "1"))
 if os.environ.get("PROBE_FP8"):   # e4m3 decode weights (BASELINE configs[4])
     cfg.decode_weight_dtype = "fp8"
-model = EmmaXForActionPrediction.from_synthetic(cfg, seed=0, device="cuda:0", max_batch=B, max_prompt=512, max_ctx=1281)
+EXACT = int(os.environ.get("PROBE_EXACT", "0"))   # 1: exact numerics (24-bit K / V cache), 2: with fp32 K / V rows
+model = EmmaXForActionPrediction.from_synthetic(cfg, seed=0, device="cuda:0", max_batch=B, max_prompt=512, max_ctx=1281, exact=EXACT)
 rng = np.random.default_rng(0)
 frames = torch.from_numpy(rng.integers(0, 256, size=(B, 224, 224, 3), dtype=np.uint8)).cuda()
 prompts = [[1] + [int(x) for x in rng.integers(3, 31744, size=511)] for _ in range(B)]

@@ -16,7 +16,7 @@ STAGE_OF = [  # (substring of the kernel name, stage)
     ("emmax_decode_ks_kernel<1, 2,", "gateup_gemv"), ("emmax_decode_ks_kernel<1, 1, false, 0,", "down_gemv"),
     ("emmax_decode_ks_kernel<1, 1, false, true,", "oproj_gemv"), ("emmax_decode_ks_kernel<1, 1, false, false,", "down_gemv"),   # rounds 3-4
     ("emmax_decode_ks_kernel<1, 3,", "lmhead_argmax"),
-    ("emmax_decode_gemv_kernel<1, 0,", "qkv_gemv"), ("emmax_decode_attn_kernel", "paged_attn"),
+    ("emmax_decode_gemv_kernel<1, 0,", "qkv_gemv"), ("emmax_decode_attn_kernel", "paged_attn"), ("emmax_x_decode_attn_kernel", "paged_attn"),   # (x: exact numerics, round 6)
     ("emmax_decode_gemv_kernel<1, 1, false, true,", "oproj_gemv"), ("emmax_decode_gemv_kernel<1, 2,", "gateup_gemv"),
     ("emmax_decode_gemv_kernel<1, 1, false, false,", "down_gemv"), ("emmax_decode_gemv_kernel<1, 3,", "lmhead_argmax"),
     # batch >= 3 (PROBE_BATCH=8), round 3: the K-split MFMA kernels of decode_km.hip <MODE, NORM, XATTN, FP8, F8N> / the two-phase down kernel

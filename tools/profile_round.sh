@@ -3,7 +3,7 @@
 # git-ignored tools/bin/): bench line with 50 timed calls, rocprofv3 kernel stats of the same command, bench variants (graph,
 # B = 8 / 16 / 32, fp8 weights, fp8 KV cache, exact numerics), decode-kernel HBM traffic (PMC: B = 1, 8, 16, 32), GEMM MFMA-pipe
 # counters, stage / serve benches.
-#   usage: ROUND=r06 tools/profile_round.sh [part...]     parts: bench rocprof variants stage serve gemm pmc pmcgemm pmcattn (default: all)
+#   usage: ROUND=r06 tools/profile_round.sh [part...]     parts: bench rocprof variants stage serve gemm pmc pmcgemm pmcattn (default: all) + pmcexact (the exact-numerics decode step)
 # Outputs: gpurun_out/prof_$ROUND/ (the summaries are copied into profiles/${ROUND}_* by hand)
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 ROUND=${ROUND:-r06}
@@ -38,6 +38,11 @@ for part in $parts; do
                 done
                 python tools/pmc_summarize.py $(find $O/pmc_b${B}_FETCH_SIZE -name "*counter_collection.csv") $(find $O/pmc_b${B}_WRITE_SIZE -name "*counter_collection.csv") $O/pmc_traffic_b$B.json $B 2>&1 | tail -1
               done ;;
+    pmcexact) for c in FETCH_SIZE WRITE_SIZE; do
+                PROBE_EXACT=1 timeout 600 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "emmax_(x_)?decode" --output-format csv -d $O/pmc_exact_$c -o pmc -- python tools/pmc_probe.py > $O/pmc_exact_$c.log 2>&1
+                rm -f $O/pmc_exact_$c/*/*kernel_trace.csv
+              done
+              python tools/pmc_summarize.py $(find $O/pmc_exact_FETCH_SIZE -name "*counter_collection.csv") $(find $O/pmc_exact_WRITE_SIZE -name "*counter_collection.csv") $O/pmc_traffic_exact_b1.json 1 2>&1 | tail -1 ;;
     pmcattn)  A=$O/attn_pmc; mkdir -p $A
               python tools/attn_probe.py > $A/attn_probe.txt 2>&1
               ATTN_REPS=2 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU --kernel-trace --kernel-include-regex emmax_attention --output-format csv -d $A/pmc1 -o pmc -- python tools/attn_probe.py > $A/pmc1.log 2>&1
