@@ -93,8 +93,13 @@ __device__ __forceinline__ void km_merge_rows(const float* __restrict__ attn_par
 // the block's only barrier) -- then sumsq[8][16]: 8 x 16.25 KiB at NB = 16, where window + partial tiles side by side would not fit.
 // ROLL (tuning switch km_roll): a weight register is refilled with its step of the tile two ahead as soon as its MFMA has issued (32 KiB
 // per wave in flight at all times) instead of all sixteen once the tile is done (16-32 KiB)
-template <int MODE, bool NORM, bool XATTN, bool FP8, bool R32, int NB, bool ROLL>
+// EX (exact numerics, round 6, batch 3-8; NB = 16): the activations arrive as fp32 rows and enter the MFMA as two bf16 terms -- the hi terms of row b in
+// batch column b, the lo terms in column b + 8: the eight columns a batch <= 8 leaves empty carry the second term, so the weight stream, the
+// MFMA count and the register budget are those of the plain kernel; the epilogue adds columns b and b + 8 and hands fp32 results on (fp32 q rows,
+// fp32 RoPE with torch's per-product rounding, the 24-bit / fp32 cache, the SwiGLU product in fp32) as decode_ks.hip's EX form does at batch 1-2.
+template <int MODE, bool NORM, bool XATTN, bool FP8, bool R32, int NB, bool ROLL, bool EX = false>
 __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p) {
+    static_assert(!EX || (NB == 16 && !FP8 && !ROLL), "exact numerics: sixteen window rows = eight batch rows x two terms, bf16 weights");
     extern __shared__ __attribute__((aligned(16))) unsigned char km_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g4 = lane >> 4, c16 = lane & 15;
@@ -109,7 +114,8 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
     const int wreg = XATTN ? tiles_cap * 1024 : max(NB * XPITCH, tiles_cap * 1024);
     auto part_of = [&](int w) { return (float*)(km_smem + (size_t)w * wreg); };   // [tiles_cap][64][4]
     float* sumsq = (float*)(km_smem + (size_t)KM_WAVES * wreg);      // [KM_WAVES][16]
-    unsigned char* xlds = (unsigned char*)(sumsq + KM_WAVES * 16);   // XATTN: the merged rows [B][K] bf16
+    unsigned char* xlds = (unsigned char*)(sumsq + KM_WAVES * 16);   // XATTN: the merged rows [B][K] bf16 (EX: [16][K], rows b / b + 8 = the two terms)
+    auto col_live = [&](int c) { return EX ? (c & 7) < B : c < B; };   // batch column c of the MFMA carries a row
 
     const int G = gridDim.x, bid = blockIdx.x;
     const int n_tiles = p.n_groups;
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
     // thread (tl = tid >> 6, l = tid & 63) finalises tile tl of the block: rows 4 (l >> 4) + j, batch column l & 15
     const int e_tl = tid >> 6, e_l = lane, e_c = e_l & 15, e_rq = e_l >> 4;
     const bool e_pairs = MODE == GEMV_QKV || MODE == GEMV_GATEUP;          // rows r, r + 8 of a tile belong together
-    const bool e_on = e_tl < ntb && e_c < B && (!e_pairs || e_rq < 2);
+    const bool e_on = e_tl < ntb && e_c < B && (!EX || e_c < 8) && (!e_pairs || e_rq < 2);
     const int e_tile = t_lo + min(e_tl, max(ntb - 1, 0));
     float pre_a[4] = {0.f, 0.f, 0.f, 0.f}, pre_b[4] = {0.f, 0.f, 0.f, 0.f};
     int pre_pos = 0, pre_pg = 0;
@@ -178,6 +184,22 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
         const int nch = K >> 3;
         for (int c = tid; c < nch; c += KM_NT) {
             unsigned char* dst = xlds + (size_t)c * 16;
+            if constexpr (EX) {   // the merged chunk in fp32, split into its two terms: rows b and b + 8
+                for (int b = 0; b < B; ++b) {
+                    float m8[8];
+                    (void)attn_merge_chunk_loop(p.attn_part + (size_t)(b * p.Hq + (c >> 4)) * p.nsplit * PSTRIDE, (c & 15) * 8, p.nsplit, false, m8);
+                    u32x4_t hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const hl2_t t = split_hl2(m8[2 * e], m8[2 * e + 1]);
+                        hi[e] = t.hi;
+                        lo[e] = t.lo;
+                    }
+                    *(u32x4_t*)(dst + (size_t)b * K * 2) = hi;
+                    *(u32x4_t*)(dst + (size_t)(b + 8) * K * 2) = lo;
+                }
+                continue;
+            }
             switch (p.nsplit) {
                 case 1: km_merge_rows<1>(p.attn_part, dst, K * 2, B, p.Hq, c); break;
                 case 2: km_merge_rows<2>(p.attn_part, dst, K * 2, B, p.Hq, c); break;
@@ -193,13 +215,52 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
 #pragma unroll
         for (int s = 0; s < KM_STEPS; ++s) {
             const int k0 = (wave * ksl + s) * 32 + g4 * 8;
-            const u32x4_t v = (s < ksl && c16 < B) ? *(const u32x4_t*)(xlds + ((size_t)c16 * K + k0) * 2) : (u32x4_t){0u, 0u, 0u, 0u};
+            const u32x4_t v = (s < ksl && col_live(c16)) ? *(const u32x4_t*)(xlds + ((size_t)c16 * K + k0) * 2) : (u32x4_t){0u, 0u, 0u, 0u};
             xf[s] = __builtin_bit_cast(bf16x8_t, v);
         }
     } else {
         unsigned char* xw = km_smem + (size_t)wave * wreg;                           // this wave's window: [NB rows][XPITCH]
         const bool mine = lane < ksl * 4;                                            // 16-byte chunks of the slice
         const int ch = min(lane, ksl * 4 - 1);
+        if constexpr (EX) {
+            // fp32 rows (NORM: the residual stream h32; else the fp32 operand p.x): lane l holds elements [8 l, 8 l + 8) of the wave's slice of every
+            // batch row; statistics and x g in fp32, then the two terms into window rows b (hi) and b + 8 (lo)
+            const float* src = NORM ? (const float*)p.h32 : (const float*)p.x;
+            const size_t ld = NORM ? (size_t)p.ldh : (size_t)p.ldx;
+            f32x4_t xq[8][2];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const float* rp = src + (size_t)min(b, B - 1) * ld + (size_t)wave * ksl * 32 + (size_t)ch * 8;
+                xq[b][0] = *(const f32x4_t*)rp;
+                xq[b][1] = *(const f32x4_t*)(rp + 4);
+            }
+            u32x4_t nwv = {0u, 0u, 0u, 0u};
+            if constexpr (NORM) nwv = *((const u32x4_t*)((const bf16_t*)p.norm_w + wave * ksl * 32) + ch);
+            issue(wa, 0);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                float ss = 0.f;
+                u32x4_t hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = (mine && b < B) ? xq[b][e >> 1][2 * (e & 1)] : 0.f, c = (mine && b < B) ? xq[b][e >> 1][2 * (e & 1) + 1] : 0.f;
+                    if constexpr (NORM) {
+                        ss += a * a + c * c;
+                        a *= bf_lo(nwv[e]);
+                        c *= bf_hi(nwv[e]);
+                    }
+                    const hl2_t t = split_hl2(a, c);
+                    hi[e] = t.hi;
+                    lo[e] = t.lo;
+                }
+                if constexpr (NORM) {
+                    const float t = wave_sum(ss);
+                    if (lane == 0) sumsq[wave * 16 + b] = t;
+                }
+                *(u32x4_t*)(xw + (size_t)b * XPITCH + (size_t)lane * 16) = hi;
+                *(u32x4_t*)(xw + (size_t)(b + 8) * XPITCH + (size_t)lane * 16) = lo;
+            }
+        } else {
         u32x4_t xr[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) xr[b] = *((const u32x4_t*)((const bf16_t*)p.x + (size_t)min(b, B - 1) * p.ldx + wave * ksl * 32) + ch);
@@ -225,10 +286,11 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
             }
             *(u32x4_t*)(xw + (size_t)b * XPITCH + (size_t)lane * 16) = xr[b];   // lanes past the slice write zeros (never read)
         }
+        }
         // wave-private: the reads below only need this wave's own LDS writes to have landed (hipcc's lgkmcnt), no barrier
 #pragma unroll
         for (int s = 0; s < KM_STEPS; ++s) {
-            const u32x4_t v = (s < ksl && c16 < B) ? *(const u32x4_t*)(xw + (size_t)c16 * XPITCH + (size_t)(s * 4 + g4) * 16) : (u32x4_t){0u, 0u, 0u, 0u};
+            const u32x4_t v = (s < ksl && col_live(c16)) ? *(const u32x4_t*)(xw + (size_t)c16 * XPITCH + (size_t)(s * 4 + g4) * 16) : (u32x4_t){0u, 0u, 0u, 0u};
             xf[s] = __builtin_bit_cast(bf16x8_t, v);
         }
     }
@@ -274,6 +336,22 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
                 for (int j = 0; j < 4; ++j) u[j] += b2[j];
             }
         }
+        if constexpr (EX) {   // the lo terms' products: batch column e_c + 8 of the same rows
+            float vl[4] = {0.f, 0.f, 0.f, 0.f}, ul[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < KM_WAVES; ++w) {
+                const f32x4_t a = *(const f32x4_t*)(part_of(w) + ((size_t)e_tl * 64 + e_l + 8) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vl[j] += a[j];
+                if (e_pairs) {
+                    const f32x4_t b2 = *(const f32x4_t*)(part_of(w) + ((size_t)e_tl * 64 + e_l + 40) * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ul[j] += b2[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] += vl[j]; u[j] += ul[j]; }
+        }
         float sc = 1.f;
         if constexpr (NORM) {
             float t = 0.f;
@@ -306,10 +384,37 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_km_kernel(GemvParams p)
             bf16_t* hp = (bf16_t*)p.y + (size_t)e_c * p.ldy + row0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) hp[j] = f2bf(pre_a[j] + v[j]);
+        } else if (MODE == GEMV_GATEUP && EX) {
+            float* yp = (float*)p.y + (size_t)e_c * p.ldy + 8 * e_tile + 4 * e_rq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) yp[j] = silu_precise(v[j]) * u[j];
         } else if (MODE == GEMV_GATEUP) {
             bf16_t* yp = (bf16_t*)p.y + (size_t)e_c * p.ldy + 8 * e_tile + 4 * e_rq;
 #pragma unroll
             for (int j = 0; j < 4; ++j) yp[j] = f2bf(silu(v[j]) * u[j]);
+        } else if (MODE == GEMV_QKV && EX) {
+            // nothing is rounded to bf16: fp32 RoPE (every product rounded on its own, as torch does), fp32 q rows, 24-bit / fp32 cache rows
+            const int hd = p.head_dim, half = hd >> 1, tph = hd / 16;
+            const int hb = e_tile / tph, d0 = 8 * (e_tile - hb * tph) + 4 * e_rq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = d0 + j;
+                if (hb < p.Hq + p.Hkv) {
+                    const float y0 = __fadd_rn(__fmul_rn(v[j], pre_a[j]), -__fmul_rn(u[j], pre_b[j]));
+                    const float y1 = __fadd_rn(__fmul_rn(u[j], pre_a[j]), __fmul_rn(v[j], pre_b[j]));
+                    if (hb < p.Hq) {
+                        float* q = (float*)p.y + (size_t)e_c * p.ldy + hb * hd;
+                        q[d] = y0;
+                        q[d + half] = y1;
+                    } else {
+                        gemv_kv_store_x(p, false, pre_pg, pre_pos, hb - p.Hq, d, y0);
+                        gemv_kv_store_x(p, false, pre_pg, pre_pos, hb - p.Hq, d + half, y1);
+                    }
+                } else {
+                    gemv_kv_store_x(p, true, pre_pg, pre_pos, hb - p.Hq - p.Hkv, d, v[j]);
+                    gemv_kv_store_x(p, true, pre_pg, pre_pos, hb - p.Hq - p.Hkv, d + half, u[j]);
+                }
+            }
         } else if (MODE == GEMV_QKV) {
             const int hd = p.head_dim, half = hd >> 1, tph = hd / 16;
             const int hb = e_tile / tph, d0 = 8 * (e_tile - hb * tph) + 4 * e_rq;
@@ -385,8 +490,11 @@ template <int NB> struct KdShape {
     static constexpr int XP = FR * 64 + 16;           // bytes per staged row slice
     static constexpr int CH = (FR * 4 + 63) / 64;     // 16-byte chunks per lane and row of a phase
 };
-template <bool FP8, bool R32, int NB>
+// EX (exact numerics, batch 3-8; NB = 16): p.x holds the fp32 SwiGLU product; window rows b / b + 8 = the two bf16 terms of batch row b (see
+// emmax_decode_km_kernel); the row registers hold the fp32 chunk as two quads (r[2 b], r[2 b + 1]).
+template <bool FP8, bool R32, int NB, bool EX = false>
 __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_kmd_kernel(GemvParams p) {
+    static_assert(!EX || (NB == 16 && !FP8 && R32), "exact numerics: eight batch rows x two terms, bf16 weights, fp32 residual stream");
     extern __shared__ __attribute__((aligned(16))) unsigned char km_smem[];
     using S = KdShape<NB>;
     constexpr int FR = S::FR, NPH = S::NPH, XP = S::XP, CH = S::CH;
@@ -403,7 +511,7 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_kmd_kernel(GemvParams p
     const int tile = blockIdx.x;
 
     // epilogue operands of thread (lane l of wave 0): rows 4 (l >> 4) + j, batch column l & 15
-    const bool e_on = tid < 64 && c16 < B;
+    const bool e_on = tid < 64 && c16 < B && (!EX || c16 < 8);
     float pre[4] = {0.f, 0.f, 0.f, 0.f};
     if (e_on) {
         if constexpr (R32) {
@@ -421,6 +529,17 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_kmd_kernel(GemvParams p
     auto phase_steps = [&](int ph) { return max(0, min(NST, k_n - ph * NST)); };
     auto load_rows = [&](int ph, u32x4_t (&r)[NB][CH]) {
         const int nch = phase_steps(ph) * (KS / 8);             // 16-byte chunks in the slice
+        if constexpr (EX) {
+            static_assert(!EX || CH == 1, "one chunk per lane and row");
+            const float* b32 = (const float*)p.x + (size_t)(k_lo + ph * NST) * KS + (size_t)min(lane, max(nch - 1, 0)) * 8;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const float* rp = b32 + (size_t)min(b, B - 1) * p.ldx;
+                r[2 * b][0] = *(const u32x4_t*)rp;
+                r[2 * b + 1][0] = *(const u32x4_t*)(rp + 4);
+            }
+            return;
+        }
         const bf16_t* base = (const bf16_t*)p.x + (size_t)(k_lo + ph * NST) * KS;
 #pragma unroll
         for (int b = 0; b < NB; ++b)
@@ -432,6 +551,25 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_kmd_kernel(GemvParams p
     };
     auto store_rows = [&](int ph, const u32x4_t (&r)[NB][CH]) {
         const int nch = phase_steps(ph) * (KS / 8);
+        if constexpr (EX) {
+            if (lane < FR * 4) {
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const bool live = lane < nch && b < B;
+                    u32x4_t hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const u32x4_t& q = r[2 * b + (e >> 1)][0];
+                        const hl2_t t = split_hl2(live ? __uint_as_float(q[2 * (e & 1)]) : 0.f, live ? __uint_as_float(q[2 * (e & 1) + 1]) : 0.f);
+                        hi[e] = t.hi;
+                        lo[e] = t.lo;
+                    }
+                    *(u32x4_t*)(xw + (size_t)b * XP + (size_t)lane * 16) = hi;
+                    *(u32x4_t*)(xw + (size_t)(b + 8) * XP + (size_t)lane * 16) = lo;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -466,7 +604,7 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_kmd_kernel(GemvParams p
     const unsigned char* xcol = xw + (size_t)min(c16, NB - 1) * XP + (size_t)g4 * 16;
     auto frag = [&](int f) {
         const u32x4_t v = *(const u32x4_t*)(xcol + (size_t)f * 64);
-        return __builtin_bit_cast(bf16x8_t, c16 < B ? v : (u32x4_t){0u, 0u, 0u, 0u});
+        return __builtin_bit_cast(bf16x8_t, (EX ? (c16 & 7) < B : c16 < B) ? v : (u32x4_t){0u, 0u, 0u, 0u});
     };
     auto mfma_step = [&](int s) {
         if constexpr (FP8) {
@@ -499,6 +637,17 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_kmd_kernel(GemvParams p
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += a[j];
         }
+        if constexpr (EX) {   // the lo terms' products: batch column c16 + 8
+            float vl[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int wv = 0; wv < KM_WAVES; ++wv) {
+                const f32x4_t a = *(const f32x4_t*)(part + ((size_t)wv * 64 + lane + 8) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vl[j] += a[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += vl[j];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if constexpr (FP8) v[j] *= p.wscale[tile * 16 + 4 * g4 + j];
@@ -511,7 +660,7 @@ __global__ __launch_bounds__(KM_NT, 2) void emmax_decode_kmd_kernel(GemvParams p
     }
 }
 
-template <bool FP8, int NB>
+template <bool FP8, int NB, bool EX = false>
 int kmd_launch(GemvParams p, int B, hipStream_t stream) {
     using S = KdShape<NB>;
     constexpr int KS = FP8 ? 64 : 32, FPS = FP8 ? 2 : 1;
@@ -521,12 +670,17 @@ int kmd_launch(GemvParams p, int B, hipStream_t stream) {
     if (cdiv(p.K / KS, KM_WAVES) > S::NPH * (S::FR / FPS)) return -2;   // NPH phases of FR fragments per wave
     if (p.K / KS < KM_WAVES) return -2;
     const size_t smem = (size_t)KM_WAVES * 1024 + (size_t)KM_WAVES * NB * S::XP;
-    if (p.h32) hipLaunchKernelGGL((emmax_decode_kmd_kernel<FP8, true, NB>), dim3(p.n_groups), dim3(KM_NT), smem, stream, p);
-    else hipLaunchKernelGGL((emmax_decode_kmd_kernel<FP8, false, NB>), dim3(p.n_groups), dim3(KM_NT), smem, stream, p);
+    if constexpr (EX) {
+        if (!p.h32 || B > 8) return -2;
+        hipLaunchKernelGGL((emmax_decode_kmd_kernel<false, true, 16, true>), dim3(p.n_groups), dim3(KM_NT), smem, stream, p);
+    } else {
+        if (p.h32) hipLaunchKernelGGL((emmax_decode_kmd_kernel<FP8, true, NB>), dim3(p.n_groups), dim3(KM_NT), smem, stream, p);
+        else hipLaunchKernelGGL((emmax_decode_kmd_kernel<FP8, false, NB>), dim3(p.n_groups), dim3(KM_NT), smem, stream, p);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-template <int MODE, bool NORM, bool XATTN, bool FP8, int NB, bool ROLL>
+template <int MODE, bool NORM, bool XATTN, bool FP8, int NB, bool ROLL, bool EX = false>
 int km_launch_nb(GemvParams p, int B, hipStream_t stream, int* grid_out) {
     constexpr int KS = FP8 ? 64 : 32;
     if (p.K % (KM_WAVES * KS) || p.K > KM_WAVES * KM_STEPS * 32 || p.n_rows % 16) return -2;
@@ -541,9 +695,14 @@ int km_launch_nb(GemvParams p, int B, hipStream_t stream, int* grid_out) {
     if (p.kc & 1) p.kc += 1;   // the loop runs tiles in pairs
     // one region per wave (kernel: window [NB][XPITCH] overlaid by the partial tiles) + sumsq (+ XATTN: the merged rows)
     const size_t wreg = XATTN ? (size_t)p.kc * 1024 : std::max((size_t)NB * (KM_STEPS * 64 + 16), (size_t)p.kc * 1024);
-    const size_t smem = (size_t)KM_WAVES * wreg + KM_WAVES * 16 * 4 + (XATTN ? (size_t)B * p.K * 2 : 0);
+    const size_t smem = (size_t)KM_WAVES * wreg + KM_WAVES * 16 * 4 + (XATTN ? (size_t)(EX ? 16 : B) * p.K * 2 : 0);
     if (smem > 150 * 1024) return -2;
     if (grid_out) *grid_out = grid;
+    if constexpr (EX) {   // exact numerics: fp32 rows in (h32 / p.x / the split partials), two terms per batch row, batch <= 8
+        if (B > 8 || !p.h32) return -2;
+        hipLaunchKernelGGL((emmax_decode_km_kernel<MODE, NORM, XATTN, false, MODE == GEMV_RESID, 16, false, true>), dim3(grid), dim3(KM_NT), smem, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : -4;
+    }
     if constexpr (MODE == GEMV_RESID) {   // (NORM modes read the bf16 mirror: h32 is ignored there)
         if (p.h32) {
             hipLaunchKernelGGL((emmax_decode_km_kernel<MODE, NORM, XATTN, FP8, true, NB, ROLL>), dim3(grid), dim3(KM_NT), smem, stream, p);
@@ -558,6 +717,20 @@ int km_launch_t(const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
     if (emmax_tune().km_roll)
         return B <= 8 ? km_launch_nb<MODE, NORM, XATTN, FP8, 8, true>(p, B, stream, grid_out) : km_launch_nb<MODE, NORM, XATTN, FP8, 16, true>(p, B, stream, grid_out);
     return B <= 8 ? km_launch_nb<MODE, NORM, XATTN, FP8, 8, false>(p, B, stream, grid_out) : km_launch_nb<MODE, NORM, XATTN, FP8, 16, false>(p, B, stream, grid_out);
+}
+
+// exact numerics (GemvParams::exact), batch 3-8: the EX forms
+int km_launch_mode_x(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
+    switch (mode) {
+        case GEMV_QKV: return km_launch_nb<GEMV_QKV, true, false, false, 16, false, true>(p, B, stream, grid_out);
+        case GEMV_RESID:
+            if (p.attn_part && p.K != p.Hq * 128) return -2;
+            return p.attn_part ? km_launch_nb<GEMV_RESID, false, true, false, 16, false, true>(p, B, stream, grid_out)
+                               : km_launch_nb<GEMV_RESID, false, false, false, 16, false, true>(p, B, stream, grid_out);
+        case GEMV_GATEUP: return km_launch_nb<GEMV_GATEUP, true, false, false, 16, false, true>(p, B, stream, grid_out);
+        case GEMV_LMHEAD: return km_launch_nb<GEMV_LMHEAD, true, false, false, 16, false, true>(p, B, stream, grid_out);
+        default: return -2;
+    }
 }
 
 template <bool FP8>
@@ -607,6 +780,11 @@ int decode_km_init() {
     KD_SET(false, false, 8); KD_SET(true, false, 8); KD_SET(false, true, 8); KD_SET(true, true, 8);
     KD_SET(false, false, 16); KD_SET(true, false, 16); KD_SET(false, true, 16); KD_SET(true, true, 16);
 #undef KD_SET
+#define KX_SET(M, N_, X) \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_km_kernel<M, N_, X, false, M == GEMV_RESID, 16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
+    KX_SET(GEMV_QKV, true, false); KX_SET(GEMV_RESID, false, true); KX_SET(GEMV_RESID, false, false); KX_SET(GEMV_GATEUP, true, false); KX_SET(GEMV_LMHEAD, true, false);
+#undef KX_SET
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)emmax_decode_kmd_kernel<false, true, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     done = (e == hipSuccess) ? 0 : -4;
     return done;
 }
@@ -629,6 +807,12 @@ int launch_decode_km(int mode, const GemvParams& p, int B, hipStream_t stream, i
     if (B < 1 || B > EMMAX_MAX_DECODE_BATCH) return -2;
     if (B > 16) return launch_decode_kmp(mode, p, B, stream, grid_out);   // two batch tiles: decode_kmp.hip
     if (decode_km_init() != 0) return -4;
+    if (p.exact) {   // exact numerics: batch <= 8 (two terms per batch row in the sixteen MFMA columns), bf16 weights
+        if (B > 8 || p.wscale) return -2;
+        // the down projection (the one RESID launch without split partials) on the phased kernel whatever its K
+        if (mode == GEMV_RESID && !p.attn_part) return kmd_launch<false, 16, true>(p, B, stream);
+        return km_launch_mode_x(mode, p, B, stream, grid_out);
+    }
     if (mode == GEMV_RESID && !p.attn_part && p.K > KM_WAVES * KM_STEPS * 32) {   // the down projection: two K phases (natural row order copy)
         if (!emmax_tune().km_down) return -2;   // A/B partner: decode_mfma.hip
         if (B <= 8) return p.wscale ? kmd_launch<true, 8>(p, B, stream) : kmd_launch<false, 8>(p, B, stream);

@@ -763,9 +763,16 @@ static int fp8_gemv_mask(int B) {
 static int launch_proj(int mode, GemvParams& p, const void* w_rm, const void* w_fm, int B, hipStream_t st, int* grid_out = nullptr,
                        const float* w_scale = nullptr, const void* w_r8 = nullptr, int f8bit = 0, const void* w_km = nullptr,
                        const float* km_scale = nullptr) {
-    if (p.exact) {   // exact numerics: decode_ks.hip's two-term form or nothing
-        p.W = w_rm;
-        const int r = B < EMMAX_MFMA_MIN_BATCH && !w_scale ? launch_decode_ks(mode, p, B, st, grid_out) : -2;
+    if (p.exact) {   // exact numerics: the two-term forms or nothing -- decode_ks.hip at batch 1-2, decode_km.hip's EX kernels at batch 3-8
+        int r = -2;
+        if (!w_scale && B < EMMAX_MFMA_MIN_BATCH) {
+            p.W = w_rm;
+            r = launch_decode_ks(mode, p, B, st, grid_out);
+        } else if (!w_scale && w_km) {
+            GemvParams q = p;
+            q.W = w_km;
+            r = launch_decode_km(mode, q, B, st, grid_out);
+        }
         return r == -2 ? fail(EMMAX_ERR_INVALID, "exact numerics: no two-term kernel for this projection (batch %d, K %d)", B, p.K) : r;
     }
     if (B < EMMAX_MFMA_MIN_BATCH && w_scale && w_r8 && (fp8_gemv_mask(B) & f8bit) && decode_gemv_fp8_fits(B, p.K)) {
@@ -1416,7 +1423,17 @@ static int check_exact(const emmax_model* m, int max_batch, int stage_rows) {
     if (m->fp8) return fail(EMMAX_ERR_INVALID, "exact numerics (tuning switch exact) runs on bf16 weights: this model streams fp8 decode weights");
     if (m->finalized && m->ln_folded)
         return fail(EMMAX_ERR_STATE, "exact numerics needs the ViT LayerNorms unfolded: set the tuning switch exact = 1 BEFORE emmax_model_finalize");
-    if (max_batch > 2) return fail(EMMAX_ERR_INVALID, "exact numerics serves batches of 1-2 rows (decode_ks.hip); max_batch %d", max_batch);
+    // batch 1-2: decode_ks.hip's two-term dot products; batch 3-8: decode_km.hip's EX kernels (the two terms of a row in the MFMA's sixteen batch
+    // columns), which need the shapes that file takes: K a multiple of 256 and <= 4096 for qkv / o-proj / gate-up / lm-head, at most 8 tiles per block,
+    // the down projection within four phases of 12 fragments per wave
+    if (max_batch > 8) return fail(EMMAX_ERR_INVALID, "exact numerics serves batches of 1-8 rows; max_batch %d", max_batch);
+    if (max_batch > 2) {
+        const bool k_ok = m->H % 256 == 0 && m->H <= 4096 && m->q_dim % 256 == 0 && m->q_dim <= 4096 && m->q_dim == m->cfg.n_heads * 128;
+        const bool n_ok = m->qkv_dim % 16 == 0 && m->qkv_dim <= 32768 && 2 * m->inter_p <= 32768 && m->vocab_p <= 32768 && m->H % 16 == 0 && m->cfg.head_dim % 16 == 0;
+        const bool d_ok = m->inter_p % 32 == 0 && m->inter_p / 32 >= 8 && (m->inter_p / 32 + 7) / 8 <= 48;
+        if (!(k_ok && n_ok && d_ok && decode_km_enabled()))
+            return fail(EMMAX_ERR_INVALID, "exact numerics at batch 3-8 needs the shapes decode_km.hip takes (hidden / q widths in multiples of 256 up to 4096, head_dim 128); max_batch %d", max_batch);
+    }
     if (stage_rows) return fail(EMMAX_ERR_INVALID, "exact numerics sessions hold no staging rows (no slot serving)");
     if (m->H % 64 || m->q_dim % 64) return fail(EMMAX_ERR_INVALID, "exact numerics needs hidden and q widths in multiples of 64");
     return 0;
