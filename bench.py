@@ -262,6 +262,9 @@ def main():
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
     cfg = EmmaXConfig.tiny() if args.tiny else EmmaXConfig.emma_x_7b()
+    # EOS disabled: no token id equals -1, so no row can end early on these random weights and every one of the T decode steps does its full work
+    # (a finished row would skip its K / V reads); checked after the timed loop -- every row must have emitted all T tokens
+    cfg.eos_token_id = -1
     if args.fp8:
         cfg.decode_weight_dtype = "fp8"
     wbytes = 1 if args.fp8 else 2   # bytes per decode weight
@@ -276,8 +279,11 @@ def main():
     alone = _alone_baseline(args, model, frames, prompts, T, rank, world, B)
     gather_s = []
 
+    last_lens = []
+
     def step():
         acts, ids, lens = model.generate_actions_batch(frames, prompts, max_new_tokens=T, stop_on_eos=False)
+        last_lens[:] = [lens]
         a = torch.from_numpy(acts).to(dev)
         torch.cuda.synchronize()
         g0 = time.perf_counter()
@@ -305,6 +311,8 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     actions_per_s = world * B * args.steps / elapsed
     gather_ms = edist.max_over_ranks(float(np.mean(gather_s)) * 1e3 if gather_s else 0.0, dev)
+    if last_lens and int(last_lens[0].min()) != T:
+        raise SystemExit("bench: a row stopped after %d of %d tokens -- the timed steps did not do the full work" % (int(last_lens[0].min()), T))
 
     # ---- stage breakdown + roofline of the dominant kernel (rank 0) ----
     out = None
@@ -367,7 +375,7 @@ def main():
                         "finalize_s": round(eng.finalize_s, 3), "aux_build_s": round(eng.aux_build_s, 3)},
             "stage_us": {k: round(v, 2) for k, v in stage_us.items()},
             "stage_gbs": {k: round(stage_bytes[k] / (stage_us[k] * 1e-6) / 1e9, 1) for k in stage_names},
-            "roofline": {"kernel": ("emmax_decode_ks_kernel<B=%d,GATEUP,NORM,CPL=1%s>" % (B, ",EX" if args.exact else "") if B <= 2 and not args.fp8 else ("emmax_decode_kmp_kernel<GATEUP,NORM,TMAX=6> (B=%d)" % B if B > 16 else "emmax_decode_km_kernel<GATEUP,NORM%s> (B=%d)" % (",FP8" if args.fp8 else "", B))) + " (gate/up projection + SiLU*mul)", "bound": "hbm",
+            "roofline": {"kernel": ("emmax_decode_ks_kernel<B=%d,GATEUP,NORM,CPL=1%s>" % (B, ",EX" if args.exact else "") if B <= 2 and not args.fp8 else ("emmax_decode_kmp_kernel<GATEUP,NORM,TMAX=6> (B=%d)" % B if B > 16 else "emmax_decode_km_kernel<GATEUP,NORM%s> (B=%d)" % (",FP8" if args.fp8 else ",EX" if args.exact else "", B))) + " (gate/up projection + SiLU*mul)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "bytes_per_launch": stage_bytes[dom], "us_per_launch": round(stage_us[dom], 2), "traffic": traffic,
                          "traffic_source": "profiles/%s (rocprofv3 --pmc, offline)" % pmc_name if traffic else None},
