@@ -93,7 +93,8 @@ int emmax_config_size(void);
  * BASELINE configs[0]) instead of bf16 operands: fp32 activations end to end, every activation operand of a bf16 MFMA / dot2 as TWO bf16 terms
  * hi + lo (the checkpoint's weights are exact bf16), attention on the fp32 MFMA over an fp32 KV cache.  Read at emmax_model_finalize (the ViT
  * LayerNorms stay unfolded: the fold rounds W .* gamma) and at emmax_session_create (fp32 scratch, fp32 cache = twice the KV bytes).  Exact
- * sessions run batches of 1-2 rows on bf16 weights, without slot serving; emmax_session_exact() tells which kind a session is.  Logits sit
+ * sessions run batches of 1-8 rows (1-2: decode_ks.hip's two-term dot products; 3-8: decode_km.hip with the two terms of a row in the MFMA's sixteen
+ * batch columns) on bf16 weights, without slot serving; emmax_session_exact() tells which kind a session is.  Logits sit
  * ~1e-5 of max|logit| from the fp32 restatement at full depth (default path: 2.4e-2) -- measured cost in DESIGN.md section 6.
  * Not thread-safe against concurrent launches; a session re-captures its decode graph after a change. */
 int emmax_tuning_set(const char* name, int value);
