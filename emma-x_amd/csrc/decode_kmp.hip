@@ -31,6 +31,9 @@ constexpr int KP_PH = 4;                    // k-steps (32 elements) per phase
 constexpr int KP_ROWS = 32;                 // staged batch rows = two MFMA batch tiles
 constexpr int KP_XP = KP_PH * 64 + 16;      // window pitch in bytes (+16: the rows of a fragment read start on different bank slots)
 constexpr int KP_RPL = KP_ROWS * KP_PH * 4 / 64;   // 16-byte chunks per lane and phase: rows (lane >> 4) + 4 j, chunk lane & 15
+#ifndef KP_XD_LONG
+#define KP_XD_LONG 2
+#endif
 
 // phases of weights in flight (fp8 tiles carry 64 k per KiB: twice the phases for the same bytes)
 template <int TMAX, bool FP8> struct KpLook { static constexpr int L = (TMAX >= 4 ? 1 : TMAX >= 2 ? 2 : 4) * (FP8 ? 2 : 1); };
@@ -44,6 +47,9 @@ __device__ __forceinline__ bf16x8_t kp_fp8x8(uint32_t lo, uint32_t hi) {
     const u32x4_t v = {kp_fp8x2<false>(lo), kp_fp8x2<true>(lo), kp_fp8x2<false>(hi), kp_fp8x2<true>(hi)};
     return __builtin_bit_cast(bf16x8_t, v);
 }
+
+// activation row sets in flight (registers): the eleven-phase down projection keeps two
+template <int TMAX, int NPH> struct KpRowSets { static constexpr int N = NPH > 4 ? KP_XD_LONG : 1; };
 
 template <int MODE, bool NORM, bool R32, int TMAX, int NPH, bool FP8>
 __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvParams p) {
@@ -125,7 +131,12 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
 
     // ---- activations of a phase: lane l holds chunk l & 15 (8 elements) of rows (l >> 4) + 4 j of the phase's 128-element slice ----
     const int r0 = lane >> 4;
-    u32x4_t xr[KP_RPL], nwv = {0u, 0u, 0u, 0u};
+    // XD row sets: the rows of phase ph wait in set ph % XD and were requested XD phases before they enter the window (the down projection's eleven
+    // short phases -- one tile, 8 MFMAs each -- stalled on every phase's rows at XD = 1: an L2 round trip per phase)
+    constexpr int XD = KpRowSets<TMAX, NPH>::N;
+    u32x4_t xr[XD][KP_RPL], nwv[XD];
+#pragma unroll
+    for (int d = 0; d < XD; ++d) nwv[d] = (u32x4_t){0u, 0u, 0u, 0u};
     float ssl[KP_RPL];   // NORM: this lane's running sum of squares of rows r0 + 4 j
 #pragma unroll
     for (int j = 0; j < KP_RPL; ++j) ssl[j] = 0.f;
@@ -138,24 +149,26 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
     unsigned xvoff[KP_RPL];
 #pragma unroll
     for (int j = 0; j < KP_RPL; ++j) xvoff[j] = (unsigned)min(r0 + 4 * j, B - 1) * (unsigned)p.ldx * 2u + (unsigned)c16 * 16u;
-    auto load_rows = [&](int ph) {
+    auto load_rows = [&](int ph, auto SET) {
+        constexpr int st = decltype(SET)::value;
         const unsigned so = (unsigned)(k_lo * KS + ph * KP_PH * 32) * 2u;   // first byte of the phase inside a row
 #pragma unroll
-        for (int j = 0; j < KP_RPL; ++j) xr[j] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xvoff[j], so, 0));
-        if constexpr (NORM) nwv = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(nrsrc, (unsigned)c16 * 16u, so, 0));
+        for (int j = 0; j < KP_RPL; ++j) xr[st][j] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xvoff[j], so, 0));
+        if constexpr (NORM) nwv[st] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(nrsrc, (unsigned)c16 * 16u, so, 0));
     };
-    auto store_rows = [&](int ph) {   // (NORM: x .* g rounded to bf16, squares added to the lane's row sums)
+    auto store_rows = [&](int ph, auto SET) {   // (NORM: x .* g rounded to bf16, squares added to the lane's row sums)
+        constexpr int st = decltype(SET)::value;
         const bool live = phase_live(ph);
 #pragma unroll
         for (int j = 0; j < KP_RPL; ++j) {
             u32x4_t o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                uint32_t v = (live && r0 + 4 * j < B) ? xr[j][e] : 0u;
+                uint32_t v = (live && r0 + 4 * j < B) ? xr[st][j][e] : 0u;
                 if constexpr (NORM) {
                     const float a = bf_lo(v), c = bf_hi(v);
                     ssl[j] += a * a + c * c;
-                    v = pack_bf16x2(a * bf_lo(nwv[e]), c * bf_hi(nwv[e]));
+                    v = pack_bf16x2(a * bf_lo(nwv[st][e]), c * bf_hi(nwv[st][e]));
                 }
                 o[e] = v;
             }
@@ -166,7 +179,11 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
         }
     };
 
-    load_rows(0);
+#define KP_SET(PHV) std::integral_constant<int, (PHV) % XD>{}
+    load_rows(0, KP_SET(0));
+    if constexpr (XD > 1 && 1 < KP_NPH) load_rows(1, KP_SET(1));
+    if constexpr (XD > 2 && 2 < KP_NPH) load_rows(2, KP_SET(2));
+    static_assert(XD <= 3, "row sets are spelled out");
     // the first LOOK phases of weights, behind the activation requests (those are waited for by count)
 #pragma unroll
     for (int ph = 0; ph < LOOK; ++ph)
@@ -175,9 +192,9 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
 #pragma unroll
             for (int s = 0; s < PHS; ++s) issue_w(ph, tl, s);
     __builtin_amdgcn_sched_barrier(0);
-    store_rows(0);
+    store_rows(0, KP_SET(0));
     __builtin_amdgcn_sched_barrier(0);
-    load_rows(1);
+    if constexpr (XD < KP_NPH) load_rows(XD, KP_SET(XD));   // set 0 is free again
     __builtin_amdgcn_sched_barrier(0);
 
     f32x4_t acc[TMAX][2];
@@ -200,9 +217,9 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
            are requested (pinned: left alone, the scheduler gathers the row requests of every phase at the top: 128 registers) */ \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
         if constexpr (ph + 1 < KP_NPH) {                                                                                \
-            store_rows(ph + 1);                                                                                         \
+            store_rows(ph + 1, KP_SET(ph + 1));                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
-            if constexpr (ph + 2 < KP_NPH) load_rows(ph + 2);                                                           \
+            if constexpr (ph + 1 + XD < KP_NPH) load_rows(ph + 1 + XD, KP_SET(ph + 1 + XD));                            \
         }                                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
         _Pragma("unroll") for (int tl = 0; tl < TMAX; ++tl) {                                                           \
@@ -232,6 +249,7 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
     KP_PHASE_IF(6) KP_PHASE_IF(7) KP_PHASE_IF(8) KP_PHASE_IF(9) KP_PHASE_IF(10)
 #undef KP_PHASE_IF
 #undef KP_RUN_PHASE
+#undef KP_SET
     static_assert(KP_NPH <= 11, "phases are spelled out");
 
     // ---- the wave's partial tiles into its region (the window is dead), row sums of squares, one barrier ----
