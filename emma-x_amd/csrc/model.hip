@@ -335,7 +335,6 @@ struct emmax_session {
     int vis2_B = 0;
     hipStream_t vis_stream = nullptr;
     hipEvent_t ev_vfork = nullptr, ev_vjoin = nullptr;
-    const void* last_vis_out = nullptr;   // exact numerics: the caller's bf16 `out` of the last vision encode (handed back to emmax_prefill = "use the fp32 result")
     // prefill scratch
     bf16 *ph, *pxn, *pqkv, *patt, *pact;
     float* ph32;                // the prefill's residual stream in fp32 (tuning switch resid32 = 1), [max_rows][H]
@@ -681,9 +680,8 @@ static int run_vision_x(emmax_session* s, bool from_u8, const void* src, int B, 
     g = gpx(s, s->xhla, m->H, m->pj3_w, m->H, s->xpe32, m->H, R, m->H);
     g.bias = m->pj3_b;
     KCHK(launch_gemm(g, st));
-    // the C ABI hands out bf16 patch embeddings: a rounded copy for the caller; the prefill reads the fp32 rows (run_prefill_x)
-    KCHK(launch_x_to_bf16(s->xpe32, m->H, out ? out : (void*)s->patch_embeds, m->H, R, m->H, st));
-    s->last_vis_out = out;
+    // an exact session exchanges patch embeddings as FP32 rows [B, n_patches, hidden] (include/emmax.h): the caller's copy, if it wants one
+    if (out && out != (void*)s->xpe32) HIPCHK(hipMemcpyAsync(out, s->xpe32, (size_t)R * m->H * 4, hipMemcpyDeviceToDevice, st));
     s->vision_B = B;
     return 0;
 }
@@ -979,9 +977,8 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
 static int run_prefill_x(emmax_session* s, const int32_t* ids, int B, int P_max, const void* patches, int np, int total, int maxS, int r0, hipStream_t st) {
     emmax_model* m = s->m;
     const auto& c = m->cfg;
-    // patch rows: the session's own fp32 result when the caller hands back what emmax_vision_encode gave it (or nothing); else the caller's bf16 rows, widened
-    const bool internal = np > 0 && s->vision_B == B && (patches == (const void*)s->patch_embeds || patches == s->last_vis_out);
-    KCHK(launch_x_embed_splice(ids, P_max, s->cu, m->embed, internal ? s->xpe32 : nullptr, internal ? nullptr : patches, s->ph32, B, maxS, np, m->H, m->vocab, st));
+    // patch rows: fp32 [B, n_patches, hidden] -- what emmax_vision_encode* hands out in an exact session (the session's own copy when the caller passes none)
+    KCHK(launch_x_embed_splice(ids, P_max, s->cu, m->embed, (const float*)patches, nullptr, s->ph32, B, maxS, np, m->H, m->vocab, st));
     s->p32 = true;
     auto into_stream = [&](GemmParams& g) { g.C = s->ph32; g.ldc = m->H; g.residual = s->ph32; g.res_f32 = 1; g.ldr = m->H; };
     for (int li = 0; li < c.n_layers; ++li) {
@@ -1434,7 +1431,6 @@ static int check_exact(const emmax_model* m, int max_batch, int stage_rows) {
         if (!(k_ok && n_ok && d_ok && decode_km_enabled()))
             return fail(EMMAX_ERR_INVALID, "exact numerics at batch 3-8 needs the shapes decode_km.hip takes (hidden / q widths in multiples of 256 up to 4096, head_dim 128); max_batch %d", max_batch);
     }
-    if (stage_rows) return fail(EMMAX_ERR_INVALID, "exact numerics sessions hold no staging rows (no slot serving)");
     if (m->H % 64 || m->q_dim % 64) return fail(EMMAX_ERR_INVALID, "exact numerics needs hidden and q widths in multiples of 64");
     return 0;
 }
@@ -1569,7 +1565,7 @@ int emmax_vision_features(emmax_session* s, int B, void* out, emmax_stream st) {
 
 int emmax_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens, int B, int P_max, const void* patches, emmax_stream st) {
     if (!s || !ids || !lens) return fail(EMMAX_ERR_INVALID, "null argument");
-    const void* pe = patches ? patches : s->patch_embeds;
+    const void* pe = patches ? patches : (s->exact ? (const void*)s->xpe32 : (const void*)s->patch_embeds);
     if (!patches && s->vision_B != B) return fail(EMMAX_ERR_STATE, "no patch embeddings for batch %d (call emmax_vision_encode first)", B);
     return run_prefill(s, ids, lens, B, P_max, pe, (hipStream_t)st);
 }
@@ -1733,7 +1729,6 @@ int emmax_slots_open(emmax_session* s, int n_slots, emmax_stream stream) {
         return fail(EMMAX_ERR_INVALID, "%d slots outside 1..min(max_batch=%d, %d)", n_slots, s->max_batch, model_max_decode_batch(s->m));
     if (n_slots >= EMMAX_MFMA_MIN_BATCH && !s->m->aux_built)
         return fail(EMMAX_ERR_STATE, "%d slots decode on the fragment-major weight copies: call emmax_model_build_aux first", n_slots);
-    if (s->exact) return fail(EMMAX_ERR_STATE, "slot serving is not available in an exact-numerics session");
     hipStream_t user = (hipStream_t)stream, st;
     int r = slot_enter(s, user, &st);
     if (r) return r;

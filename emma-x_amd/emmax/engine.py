@@ -147,6 +147,11 @@ class EmmaxEngine:
         _lib.check(self.lib.emmax_model_build_aux(self._model, self.aux_arena.data_ptr(), n, _lib.current_stream()), "emmax_model_build_aux")
         self.aux_build_s = time.perf_counter() - t0
 
+    @property
+    def patch_dtype(self) -> torch.dtype:
+        """Element type of the patch embeddings the session hands out and takes back: bf16, fp32 in exact numerics (include/emmax.h)."""
+        return torch.float32 if self.exact else torch.bfloat16
+
     def max_decode_batch(self) -> int:
         """Rows of one decode batch this model can run (16 for LLaMA-2-7B shapes, 8 for shapes outside decode_km.hip)."""
         n = int(self.lib.emmax_model_max_decode_batch(self._model))
@@ -177,11 +182,11 @@ class EmmaxEngine:
 
     # ------------------------------------------------------------------------------------------------------------------
     def vision_encode(self, frames_u8: torch.Tensor) -> torch.Tensor:
-        """uint8 [B,224,224,3] on device -> bf16 [B,256,hidden] projected patch embeddings."""
+        """uint8 [B,224,224,3] on device -> [B,256,hidden] projected patch embeddings (bf16; fp32 in an exact-numerics session: `patch_dtype`)."""
         assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.is_contiguous()
         frames_u8 = self.resize_frames(frames_u8)   # no-op at the native 224x224
         B = frames_u8.shape[0]
-        out = torch.empty(B, self.cfg.n_patches, self.cfg.llm.hidden_size, dtype=torch.bfloat16, device=self.device)
+        out = torch.empty(B, self.cfg.n_patches, self.cfg.llm.hidden_size, dtype=self.patch_dtype, device=self.device)
         _lib.check(self.lib.emmax_vision_encode(self._session, frames_u8.data_ptr(), B, out.data_ptr(), _lib.current_stream()),
                    "emmax_vision_encode")
         return out
@@ -214,7 +219,7 @@ class EmmaxEngine:
         """bf16 [B,6,224,224] (PrismaticProcessor layout) -> bf16 [B,256,hidden]."""
         pv = pixel_values.to(device=self.device, dtype=torch.bfloat16).contiguous()
         B = pv.shape[0]
-        out = torch.empty(B, self.cfg.n_patches, self.cfg.llm.hidden_size, dtype=torch.bfloat16, device=self.device)
+        out = torch.empty(B, self.cfg.n_patches, self.cfg.llm.hidden_size, dtype=self.patch_dtype, device=self.device)
         _lib.check(self.lib.emmax_vision_encode_pixels(self._session, pv.data_ptr(), B, out.data_ptr(), _lib.current_stream()),
                    "emmax_vision_encode_pixels")
         return out
@@ -242,7 +247,7 @@ class EmmaxEngine:
             self._last_B = B
             return self._last_S
         pe = patch_embeds.contiguous()
-        assert pe.dtype == torch.bfloat16 and pe.shape[0] == B
+        assert pe.dtype == self.patch_dtype and pe.shape[0] == B
         _lib.check(self.lib.emmax_prefill(self._session, ids_d.data_ptr(), lens_c, B, P_max, pe.data_ptr(), _lib.current_stream()),
                    "emmax_prefill")
         self._last_S = [self.cfg.n_patches + n for n in lens]
@@ -298,7 +303,7 @@ class EmmaxEngine:
         pe = None
         if patch_embeds is not None:
             pe = patch_embeds.contiguous()
-            assert pe.dtype == torch.bfloat16 and pe.numel() == self.cfg.n_patches * self.cfg.llm.hidden_size
+            assert pe.dtype == self.patch_dtype and pe.numel() == self.cfg.n_patches * self.cfg.llm.hidden_size
         _lib.check(self.lib.emmax_slot_prefill(self._session, int(slot), ids_d.data_ptr(), len(input_ids), _lib.ptr(pe),
                                                int(max_new_tokens), _lib.current_stream()), "emmax_slot_prefill")
         torch.cuda.current_stream().synchronize()   # `ids_d` must outlive the embedding gather
@@ -320,7 +325,7 @@ class EmmaxEngine:
             if len(patch_embeds) != n:
                 raise ValueError("slots_prefill: one patch-embedding tensor per prompt")
             pe = torch.stack([t.reshape(self.cfg.n_patches, self.cfg.llm.hidden_size) for t in patch_embeds]).contiguous()
-            assert pe.dtype == torch.bfloat16
+            assert pe.dtype == self.patch_dtype
         lens_c = (C.c_int32 * n)(*lens)
         budget_c = (C.c_int32 * n)(*[int(v) for v in max_new_tokens])
         _lib.check(self.lib.emmax_slots_prefill(self._session, int(slot0), n, ids_d.data_ptr(), P, lens_c, _lib.ptr(pe), budget_c,
@@ -356,7 +361,7 @@ class EmmaxEngine:
             if len(patch_embeds) != n:
                 raise ValueError("slots_prefill_staged: one patch-embedding tensor per prompt")
             pe = torch.stack([t.reshape(self.cfg.n_patches, self.cfg.llm.hidden_size) for t in patch_embeds]).contiguous()
-            assert pe.dtype == torch.bfloat16
+            assert pe.dtype == self.patch_dtype
         lens_c = (C.c_int32 * n)(*lens)
         budget_c = (C.c_int32 * n)(*[int(v) for v in max_new_tokens])
         _lib.check(self.lib.emmax_slots_prefill_staged(self._session, n, ids_d.data_ptr(), P, lens_c, _lib.ptr(pe), budget_c,

@@ -94,7 +94,7 @@ int emmax_config_size(void);
  * hi + lo (the checkpoint's weights are exact bf16), attention on the fp32 MFMA over an fp32 KV cache.  Read at emmax_model_finalize (the ViT
  * LayerNorms stay unfolded: the fold rounds W .* gamma) and at emmax_session_create (fp32 scratch, fp32 cache = twice the KV bytes).  Exact
  * sessions run batches of 1-8 rows (1-2: decode_ks.hip's two-term dot products; 3-8: decode_km.hip with the two terms of a row in the MFMA's sixteen
- * batch columns) on bf16 weights, without slot serving; emmax_session_exact() tells which kind a session is.  Logits sit
+ * batch columns) on bf16 weights, slot serving included (up to 8 slots); emmax_session_exact() tells which kind a session is.  Logits sit
  * ~1e-5 of max|logit| from the fp32 restatement at full depth (default path: 2.4e-2) -- measured cost in DESIGN.md section 6.
  * Not thread-safe against concurrent launches; a session re-captures its decode graph after a change. */
 int emmax_tuning_set(const char* name, int value);
@@ -141,7 +141,9 @@ int emmax_session_stage_rows(const emmax_session* s);
 int emmax_session_exact(const emmax_session* s);
 void emmax_session_destroy(emmax_session* s);
 
-/* frames_u8_dev: uint8 [B,224,224,3] RGB (normalisation fused into the patch gather);  out: bf16 [B,256,hidden]. */
+/* frames_u8_dev: uint8 [B,224,224,3] RGB (normalisation fused into the patch gather);  out: bf16 [B,256,hidden].
+ * EXACT-NUMERICS sessions exchange patch embeddings as FP32 rows: `patch_embeds_out_dev` here and every `patch_embeds*` argument of the
+ * prefill / slot entry points below then hold float [B,256,hidden] (bf16 rows would put 2^-9 back into the input of the fp32 arithmetic). */
 int emmax_vision_encode(emmax_session* s, const uint8_t* frames_u8_dev, int B, void* patch_embeds_out_dev,
                         emmax_stream stream);
 /* pixel_values_dev: bf16 [B,6,224,224] as PrismaticProcessor emits (already normalised per tower). */

@@ -154,7 +154,7 @@ def test_config_validation_and_sizing(lib):
         assert kv2.value == 32 * 2 * 2 * 21 * 32 * 64 * 128 * 3 and 2 * kv2.value == 3 * kv1.value and ws2.value > ws1.value
         assert so.emmax_session_bytes(h, 8, 512, 1281, C.byref(ws2), C.byref(kv2)) == 0 and kv2.value == 32 * 2 * 8 * 21 * 32 * 64 * 128 * 3
         assert so.emmax_session_bytes(h, 9, 512, 1281, C.byref(ws2), C.byref(kv2)) != 0 and b"1-8 rows" in so.emmax_last_error()
-        assert so.emmax_session_bytes_ex(h, 2, 512, 1281, 1, C.byref(ws2), C.byref(kv2)) != 0 and b"staging" in so.emmax_last_error()
+        assert so.emmax_session_bytes_ex(h, 4, 512, 1281, 2, C.byref(ws2), C.byref(kv2)) == 0 and kv2.value == 32 * 2 * (4 + 2) * 21 * 32 * 64 * 128 * 3   # staging rows: slot serving
     with L.tuning(exact=2):
         assert so.emmax_session_bytes(h, 2, 512, 1281, C.byref(ws2), C.byref(kv2)) == 0 and kv2.value == 2 * kv1.value
     assert L.tuning_get("exact") == 0
