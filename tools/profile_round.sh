@@ -19,7 +19,7 @@ for part in $parts; do
               timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_b32 -o bench -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch-per-gpu 32 > $O/rocprof_bench_b32.log 2>&1
               rm -f $O/rocprof_b32/*/*kernel_trace.csv $O/rocprof_b32/*kernel_trace.csv ;;
     variants) : > $O/bench_variants.jsonl
-              for v in "--exact" "--exact-fp32kv" "--exact --graph" "--exact --batch-per-gpu 2" "--graph" "--batch-per-gpu 8" "--batch-per-gpu 16" "--batch-per-gpu 32" "--fp8" "--fp8 --batch-per-gpu 8" "--fp8 --batch-per-gpu 8 --graph" "--fp8 --batch-per-gpu 16" \
+              for v in "--exact" "--exact-fp32kv" "--exact --graph" "--exact --batch-per-gpu 2" "--exact --batch-per-gpu 8" "--graph" "--batch-per-gpu 8" "--batch-per-gpu 16" "--batch-per-gpu 32" "--fp8" "--fp8 --batch-per-gpu 8" "--fp8 --batch-per-gpu 8 --graph" "--fp8 --batch-per-gpu 16" \
                        "--batch-per-gpu 8 --kv-fp8" "--batch-per-gpu 16 --kv-fp8" "--batch-per-gpu 32 --kv-fp8" "--fp8 --batch-per-gpu 8 --kv-fp8" "--fp8 --batch-per-gpu 16 --kv-fp8"; do
                 timeout 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline $v 2>/dev/null | tail -1 >> $O/bench_variants.jsonl
               done
