@@ -809,8 +809,9 @@ int launch_decode_km(int mode, const GemvParams& p, int B, hipStream_t stream, i
     if (decode_km_init() != 0) return -4;
     if (p.exact) {   // exact numerics: batch <= 8 (two terms per batch row in the sixteen MFMA columns), bf16 weights
         if (B > 8 || p.wscale) return -2;
-        // the down projection (the one RESID launch without split partials) on the phased kernel whatever its K
-        if (mode == GEMV_RESID && !p.attn_part) return kmd_launch<false, 16, true>(p, B, stream);
+        // RESID launches without split partials (fp32 rows in p.x): the o-proj behind a one-split attention launch on the K-split kernel when its K fits,
+        // the down projection (and any other K) on the phased kernel
+        if (mode == GEMV_RESID && !p.attn_part && (p.K % (KM_WAVES * 32) || p.K > KM_WAVES * KM_STEPS * 32)) return kmd_launch<false, 16, true>(p, B, stream);
         return km_launch_mode_x(mode, p, B, stream, grid_out);
     }
     if (mode == GEMV_RESID && !p.attn_part && p.K > KM_WAVES * KM_STEPS * 32) {   // the down projection: two K phases (natural row order copy)

@@ -466,7 +466,15 @@ __global__ __launch_bounds__(256) void emmax_x_decode_attn_kernel(DecodeAttnPara
     const int k1 = min(L, k0 + kps);
     const int Hq = p.Hkv * G;
     float* part = p.part + ((size_t)(b * Hq + hk * G) * nsplit + split) * PSTRIDE;
+    // one split (p.o_out, batch >= 5 at 32 heads): the block owns the heads of its row, normalises them and writes the fp32 attention row itself -- in
+    // place over the row's q values (read into registers above by every thread of the block; other blocks own other columns)
+    float* orow = p.o_out ? (float*)p.o_out + (size_t)b * p.ldq + (size_t)hk * G * HD : nullptr;
     if (k0 >= L || row_done) {
+        if (orow) {
+            __syncthreads();   // (every thread holds its q values)
+            for (int i = tid; i < G * HD; i += NT) orow[i] = 0.f;
+            return;
+        }
         for (int i = tid; i < G * PSTRIDE; i += NT) {
             const int gq = i / PSTRIDE, j = i - gq * PSTRIDE;
             part[(size_t)gq * nsplit * PSTRIDE + j] = (j == HD) ? -INFINITY : 0.f;
@@ -576,6 +584,24 @@ __global__ __launch_bounds__(256) void emmax_x_decode_attn_kernel(DecodeAttnPara
         }
     }
     __syncthreads();
+    if (orow) {   // out = (sum_w o_w e^(m_w - M)) * (1 / sum_w l_w e^(m_w - M)): the arithmetic of the o-proj's one-split merge (attn_merge_chunk)
+        for (int i = tid; i < G * HD; i += NT) {
+            const int gq = i / HD, j = i - gq * HD;
+            float M = red_ml[0][gq][0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) M = fmaxf(M, red_ml[w][gq][0]);
+            const float msafe = (M == -INFINITY) ? 0.f : M;
+            float v = 0.f, den = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float f = __expf(red_ml[w][gq][0] - msafe);
+                v += red_o[w][gq][j] * f;
+                den += red_ml[w][gq][1] * f;
+            }
+            orow[i] = v * (den > 0.f ? 1.0f / den : 0.f);
+        }
+        return;
+    }
     for (int i = tid; i < G * PSTRIDE; i += NT) {
         const int gq = i / PSTRIDE, j = i - gq * PSTRIDE;
         float M = red_ml[0][gq][0];
@@ -699,7 +725,7 @@ int launch_x_decode_attn(const DecodeAttnParams& p_in, int B, int Hq, int head_d
     if (head_dim != 128) return -1;
     DecodeAttnParams p = p_in;
     if (p.max_pages < 1 || p.max_pages > 512 || p.page < 1 || (p.page & (p.page - 1))) return -1;
-    if (nsplit < 1 || (nsplit & (nsplit - 1)) || p.o_out || p.kv_stage) return -1;   // split partials only (the o-proj merges them in fp32)
+    if (nsplit < 1 || (nsplit & (nsplit - 1)) || p.kv_stage || (p.o_out && nsplit != 1)) return -1;   // o_out (one split only): the fp32 row, else split partials for the o-proj's merge
     p.page_shift = 0;
     while ((1 << p.page_shift) < p.page) ++p.page_shift;
     dim3 grid(nsplit, p.Hkv, B), block(256);

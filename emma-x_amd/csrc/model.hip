@@ -1018,7 +1018,8 @@ enum { STAGE_QKV = 0, STAGE_ATTN = 1, STAGE_OPROJ = 2, STAGE_GATEUP = 3, STAGE_D
 // one KV split per (row, head) (batch >= 5 at 32 heads): nothing to merge -- the attention launch normalises and writes the bf16 row
 // itself and the o-proj is a plain projection; otherwise the o-proj prologue merges the split partials.
 static bool attn_direct_on(const emmax_session* s, int B) {
-    if (s->exact) return false;   // the split partials stay fp32 until the o-proj splits them into two terms
+    // exact numerics: the fp32 row in place over the q rows, at batch >= 3 (decode_km.hip's EX o-proj takes fp32 rows; decode_ks.hip's merges the partials)
+    if (s->exact && B < EMMAX_MFMA_MIN_BATCH) return false;
     return decode_attn_nsplit(B, s->m->cfg.n_kv_heads) == 1 && emmax_tune().attn_direct != 0;
 }
 
@@ -1045,6 +1046,8 @@ static void stage_params(emmax_session* s, int B, int li, int stage, GemvParams&
             p.x = s->datt; p.ldx = m->q_dim; p.ldw = m->q_dim; p.K = m->q_dim; p.y = s->dh; p.ldy = m->H; p.n_rows = m->H;
             if (!attn_direct_on(s, B)) {   // split merge fused into the staging
                 p.attn_part = s->part; p.nsplit = decode_attn_nsplit(B, c.n_kv_heads); p.Hq = c.n_heads;
+            } else if (s->exact) {
+                p.x = s->dq32;             // the attention launch left the normalised fp32 rows in place of the q rows
             }
             break;
         case STAGE_GATEUP:
@@ -1094,6 +1097,7 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             const int ns = decode_attn_nsplit(B, c.n_kv_heads);
             if (s->exact) {
                 a.q = s->dq32; a.kv24 = s->kv24;
+                a.o_out = attn_direct_on(s, B) ? (void*)s->dq32 : nullptr;
                 KCHK(launch_x_decode_attn(a, B, c.n_heads, c.head_dim, ns, st));
                 return 0;
             }

@@ -467,17 +467,20 @@ def test_exact_batch_8_rows_at_full_depth_equal_the_oracle_and_their_bs1_runs(de
 
     for b in range(8):
         equal += int(compare(ids8[b, :T].cpu().tolist(), b, "batch 8"))
+    # four rows (two KV splits per head: the o-proj merges the fp32 partials; eight rows: one split, the attention launch writes the fp32 row itself)
+    ids4, _ = model8.generate_ids(rows[1:5], None, fr[1:5], max_new_tokens=T, stop_on_eos=False)
+    four = sum(int(compare(ids4[j, :T].cpu().tolist(), b, "batch 4")) for j, b in enumerate(range(1, 5)))
     alone = 0
     for b in (0, 3, 6):
         ids1, _ = model8.generate_ids([rows[b]], None, fr[b:b + 1], max_new_tokens=T, stop_on_eos=False)
         alone += int(compare(ids1[0, :T].cpu().tolist(), b, "bs 1"))
     out = {"what": "Emma-X-7B shape, 32 layers, random weights (seed 33), exact numerics: FREE-RUNNING ragged batch-8 generation (prompts of 17..512 tokens, %d new tokens) "
                    "against the fp32 restatement's bs = 1 greedy run of every row; three rows re-run alone" % T,
-           "rows_equal_in_the_batch": equal, "rows_equal_alone": alone, "runs": recs}
+           "rows_equal_in_the_batch": equal, "rows_equal_in_a_batch_of_four": four, "rows_equal_alone": alone, "runs": recs}
     print("\nexact batch-8 rows:", json.dumps(out))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "r06_exact_batch8_rows.json"), "w") as f:
         json.dump(out, f, indent=1)
     del model8
     torch.cuda.empty_cache()
-    assert equal >= 7 and alone >= 2, out
+    assert equal >= 7 and four >= 3 and alone >= 2, out
