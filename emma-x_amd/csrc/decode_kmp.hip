@@ -49,10 +49,15 @@ __device__ __forceinline__ bf16x8_t kp_fp8x8(uint32_t lo, uint32_t hi) {
 }
 
 // activation row sets in flight (registers): the eleven-phase down projection keeps two
-template <int TMAX, int NPH> struct KpRowSets { static constexpr int N = NPH > 4 ? KP_XD_LONG : 1; };
+template <int TMAX, int NPH> struct KpRowSets { static constexpr int N = (NPH > 4 && TMAX == 1) ? KP_XD_LONG : 1; };
 
-template <int MODE, bool NORM, bool R32, int TMAX, int NPH, bool FP8>
+// NH = 2 (round 6, batches of 33-64 rows): the block's eight waves are two HALVES of four -- half h stages rows 32 h .. 32 h + 31 and owns their two batch
+// tiles, its four waves split K four ways (twice the phases per wave); both halves stream the block's weight tiles (the second request is an L2 hit: HBM
+// reads them once), so the registers of a wave are those of the 32-row kernel.  Epilogue slots (tile, half) are dealt to the eight waves in passes.
+template <int MODE, bool NORM, bool R32, int TMAX, int NPH, bool FP8, int NH = 1>
 __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvParams p) {
+    static_assert(NH == 1 || (NH == 2 && MODE != GEMV_LMHEAD), "halves: 1 or 2; the lm-head of 33-64 rows runs as two launches");
+    constexpr int KW = KP_WAVES / NH;          // K slices = waves of a half
     constexpr int KP_NPH = NPH;
     extern __shared__ __attribute__((aligned(16))) unsigned char kp_smem[];
     constexpr int LOOK = KpLook<TMAX, FP8>::L;
@@ -61,11 +66,12 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
     constexpr int RING = TMAX * PHS * LOOK;            // weight registers (16-byte loads of 1 KiB tiles) of a wave
     constexpr int WREG = TMAX * 2048 > KP_ROWS * KP_XP ? TMAX * 2048 : KP_ROWS * KP_XP;   // a wave's LDS region: window, later its partial tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave % KW, half = wave / KW, row0 = 32 * half;   // K slice, half, first batch row of the half
     const int g4 = lane >> 4, c16 = lane & 15;
     const int B = p.batch, K = p.K;
     const int KT = K / KS;                             // load steps of a row
-    const int kq = KT / KP_WAVES, kr = KT % KP_WAVES;
-    const int k_lo = wave * kq + min(wave, kr), k_n = kq + (wave < kr ? 1 : 0);   // this wave's load steps (launcher: k_n <= NPH PHS)
+    const int kq = KT / KW, kr = KT % KW;
+    const int k_lo = wk * kq + min(wk, kr), k_n = kq + (wk < kr ? 1 : 0);   // this wave's load steps (launcher: k_n <= NPH PHS)
     unsigned char* xw = kp_smem + (size_t)wave * WREG;                     // this wave's window [32][KP_XP]
     auto part_of = [&](int w) { return (float*)(kp_smem + (size_t)w * WREG); };   // [TMAX][2][64][4]
     float* sumsq = (float*)(kp_smem + (size_t)KP_WAVES * WREG);            // [KP_WAVES][32]
@@ -77,7 +83,12 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
 
     // ---- epilogue operands of this thread's slots, requested before anything else: thread (tl = tid >> 6, lane) finalises tile tl of
     // the block, rows 4 (lane >> 4) + j, batch columns (lane & 15) and 16 + (lane & 15) ----
-    const int e_tl = tid >> 6, e_rq = lane >> 4;
+    // epilogue slots: slot s = (tile s / NH, half s % NH) of the block; wave w serves slots w, w + 8, ... (NPASS passes; the modes with operands to
+    // prefetch -- the residual rows, the RoPE tables -- fit one pass)
+    constexpr int NPASS = (TMAX * NH + KP_WAVES - 1) / KP_WAVES;
+    static_assert(NPASS == 1 || (MODE != GEMV_RESID && MODE != GEMV_QKV), "two epilogue passes: no prefetched operands");
+    const int e_slot = tid >> 6, e_rq = lane >> 4;
+    const int e_tl = e_slot / NH, e_hf = e_slot % NH;
     constexpr bool e_pairs = MODE == GEMV_QKV || MODE == GEMV_GATEUP;      // rows r, r + 8 of a tile belong together
     const int e_tile = t_lo + min(e_tl, max(ntb - 1, 0));
     bool e_on[2];
@@ -85,7 +96,7 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
     int pre_pos[2] = {0, 0}, pre_pg[2] = {0, 0};
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const int e_c = nt * 16 + c16;
+        const int e_c = 32 * e_hf + nt * 16 + c16;
         e_on[nt] = e_tl < ntb && e_tl < TMAX && e_c < B && (!e_pairs || e_rq < 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) pre_a[nt][j] = pre_b[nt][j] = 0.f;
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
     const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.norm_w, 0, NORM ? K * 2 : 0, 0x00020000);
     unsigned xvoff[KP_RPL];
 #pragma unroll
-    for (int j = 0; j < KP_RPL; ++j) xvoff[j] = (unsigned)min(r0 + 4 * j, B - 1) * (unsigned)p.ldx * 2u + (unsigned)c16 * 16u;
+    for (int j = 0; j < KP_RPL; ++j) xvoff[j] = (unsigned)min(row0 + r0 + 4 * j, B - 1) * (unsigned)p.ldx * 2u + (unsigned)c16 * 16u;
     auto load_rows = [&](int ph, auto SET) {
         constexpr int st = decltype(SET)::value;
         const unsigned so = (unsigned)(k_lo * KS + ph * KP_PH * 32) * 2u;   // first byte of the phase inside a row
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
             u32x4_t o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                uint32_t v = (live && r0 + 4 * j < B) ? xr[st][j][e] : 0u;
+                uint32_t v = (live && row0 + r0 + 4 * j < B) ? xr[st][j][e] : 0u;
                 if constexpr (NORM) {
                     const float a = bf_lo(v), c = bf_hi(v);
                     ssl[j] += a * a + c * c;
@@ -272,84 +283,93 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
     float best[2] = {-INFINITY, -INFINITY};
     int besti[2] = {0x7fffffff, 0x7fffffff};
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int e_c = nt * 16 + c16;
-        float v[4] = {0.f, 0.f, 0.f, 0.f}, u[4] = {0.f, 0.f, 0.f, 0.f};   // u: the partner rows r + 8 (qkv, gate/up)
-        if (!e_on[nt]) continue;
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int q_slot = e_slot + KP_WAVES * ps, q_tl = q_slot / NH, q_hf = q_slot % NH;
+        const int q_tile = t_lo + min(q_tl, max(ntb - 1, 0));
+        bool q_on[2];
 #pragma unroll
-        for (int wv = 0; wv < KP_WAVES; ++wv) {
-            const f32x4_t a = *(const f32x4_t*)(part_of(wv) + ((size_t)(e_tl * 2 + nt) * 64 + lane) * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += a[j];
-            if (e_pairs) {
-                const f32x4_t b2 = *(const f32x4_t*)(part_of(wv) + ((size_t)(e_tl * 2 + nt) * 64 + lane + 32) * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) u[j] += b2[j];
-            }
-        }
-        if constexpr (NORM) {
-            float t = 0.f;
-#pragma unroll
-            for (int wv = 0; wv < KP_WAVES; ++wv) t += sumsq[wv * 32 + e_c];
-            const float sc = rsqrtf(t / (float)K + p.eps);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] *= sc; u[j] *= sc; }
-        }
-        if constexpr (FP8) {   // per-row weight scales (km row order)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] *= p.wscale[e_tile * 16 + 4 * e_rq + j];
-                if (e_pairs) u[j] *= p.wscale[e_tile * 16 + 8 + 4 * e_rq + j];
-            }
-        }
-        const int row0 = e_tile * 16 + 4 * e_rq;   // natural-order matrices
-        if (MODE == GEMV_PLAIN) {
-            bf16_t* yp = (bf16_t*)p.y + (size_t)e_c * p.ldy + row0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) yp[j] = f2bf(v[j]);
-        } else if (MODE == GEMV_RESID) {
-            if constexpr (R32)
-                *(f32x4_t*)(p.h32 + (size_t)e_c * p.ldh + row0) = (f32x4_t){pre_a[nt][0] + v[0], pre_a[nt][1] + v[1], pre_a[nt][2] + v[2], pre_a[nt][3] + v[3]};
-            bf16_t* hp = (bf16_t*)p.y + (size_t)e_c * p.ldy + row0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) hp[j] = f2bf(pre_a[nt][j] + v[j]);
-        } else if (MODE == GEMV_GATEUP) {
-            bf16_t* yp = (bf16_t*)p.y + (size_t)e_c * p.ldy + 8 * e_tile + 4 * e_rq;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) yp[j] = f2bf(silu(v[j]) * u[j]);
-        } else if (MODE == GEMV_QKV) {
-            const int hd = p.head_dim, half = hd >> 1, tph = hd / 16;
-            const int hb = e_tile / tph, d0 = 8 * (e_tile - hb * tph) + 4 * e_rq;
-            const int pos = pre_pos[nt], pg = pre_pg[nt];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int d = d0 + j;
-                // linear outputs are bf16 activations in the reference; RoPE acts on those
-                const float x0 = bf2f(f2bf(v[j])), x1 = bf2f(f2bf(u[j]));
-                if (hb < p.Hq + p.Hkv) {
-                    const bf16_t y0 = f2bf(x0 * pre_a[nt][j] - x1 * pre_b[nt][j]), y1 = f2bf(x1 * pre_a[nt][j] + x0 * pre_b[nt][j]);
-                    if (hb < p.Hq) {
-                        bf16_t* q = (bf16_t*)p.y + (size_t)e_c * p.ldy + hb * hd;
-                        q[d] = y0;
-                        q[d + half] = y1;
-                    } else {
-                        bf16_t* kc = gemv_kv_row(p, false, e_c, pg, pos, hb - p.Hq);
-                        kc[d] = y0;
-                        kc[d + half] = y1;
-                    }
-                } else {
-                    bf16_t* vc = gemv_kv_row(p, true, e_c, pg, pos, hb - p.Hq - p.Hkv);
-                    vc[d] = f2bf(x0);
-                    vc[d + half] = f2bf(x1);
+        for (int nt = 0; nt < 2; ++nt)
+            q_on[nt] = ps == 0 ? e_on[nt] : (q_tl < ntb && q_tl < TMAX && 32 * q_hf + nt * 16 + c16 < B && (!e_pairs || e_rq < 2));
+    #pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int e_c = 32 * q_hf + nt * 16 + c16, e_cl = nt * 16 + c16;   // batch row; column inside the half
+            float v[4] = {0.f, 0.f, 0.f, 0.f}, u[4] = {0.f, 0.f, 0.f, 0.f};   // u: the partner rows r + 8 (qkv, gate/up)
+            if (!q_on[nt]) continue;
+    #pragma unroll
+            for (int wv = 0; wv < KW; ++wv) {
+                const f32x4_t a = *(const f32x4_t*)(part_of(q_hf * KW + wv) + ((size_t)(q_tl * 2 + nt) * 64 + lane) * 4);
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += a[j];
+                if (e_pairs) {
+                    const f32x4_t b2 = *(const f32x4_t*)(part_of(q_hf * KW + wv) + ((size_t)(q_tl * 2 + nt) * 64 + lane + 32) * 4);
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) u[j] += b2[j];
                 }
             }
-        } else if (MODE == GEMV_LMHEAD) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = row0 + j;
-                if (row < p.n_rows) {
-                    if (v[j] > best[nt]) { best[nt] = v[j]; besti[nt] = row; }   // rows ascend: the first index wins ties
-                    if (p.logits_out) p.logits_out[(size_t)e_c * p.n_rows + row] = v[j];
+            if constexpr (NORM) {
+                float t = 0.f;
+    #pragma unroll
+                for (int wv = 0; wv < KW; ++wv) t += sumsq[(q_hf * KW + wv) * 32 + e_cl];
+                const float sc = rsqrtf(t / (float)K + p.eps);
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] *= sc; u[j] *= sc; }
+            }
+            if constexpr (FP8) {   // per-row weight scales (km row order)
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] *= p.wscale[q_tile * 16 + 4 * e_rq + j];
+                    if (e_pairs) u[j] *= p.wscale[q_tile * 16 + 8 + 4 * e_rq + j];
+                }
+            }
+            const int row0 = q_tile * 16 + 4 * e_rq;   // natural-order matrices
+            if (MODE == GEMV_PLAIN) {
+                bf16_t* yp = (bf16_t*)p.y + (size_t)e_c * p.ldy + row0;
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) yp[j] = f2bf(v[j]);
+            } else if (MODE == GEMV_RESID) {
+                if constexpr (R32)
+                    *(f32x4_t*)(p.h32 + (size_t)e_c * p.ldh + row0) = (f32x4_t){pre_a[nt][0] + v[0], pre_a[nt][1] + v[1], pre_a[nt][2] + v[2], pre_a[nt][3] + v[3]};
+                bf16_t* hp = (bf16_t*)p.y + (size_t)e_c * p.ldy + row0;
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) hp[j] = f2bf(pre_a[nt][j] + v[j]);
+            } else if (MODE == GEMV_GATEUP) {
+                bf16_t* yp = (bf16_t*)p.y + (size_t)e_c * p.ldy + 8 * q_tile + 4 * e_rq;
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) yp[j] = f2bf(silu(v[j]) * u[j]);
+            } else if (MODE == GEMV_QKV) {
+                const int hd = p.head_dim, half = hd >> 1, tph = hd / 16;
+                const int hb = q_tile / tph, d0 = 8 * (q_tile - hb * tph) + 4 * e_rq;
+                const int pos = pre_pos[nt], pg = pre_pg[nt];
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d = d0 + j;
+                    // linear outputs are bf16 activations in the reference; RoPE acts on those
+                    const float x0 = bf2f(f2bf(v[j])), x1 = bf2f(f2bf(u[j]));
+                    if (hb < p.Hq + p.Hkv) {
+                        const bf16_t y0 = f2bf(x0 * pre_a[nt][j] - x1 * pre_b[nt][j]), y1 = f2bf(x1 * pre_a[nt][j] + x0 * pre_b[nt][j]);
+                        if (hb < p.Hq) {
+                            bf16_t* q = (bf16_t*)p.y + (size_t)e_c * p.ldy + hb * hd;
+                            q[d] = y0;
+                            q[d + half] = y1;
+                        } else {
+                            bf16_t* kc = gemv_kv_row(p, false, e_c, pg, pos, hb - p.Hq);
+                            kc[d] = y0;
+                            kc[d + half] = y1;
+                        }
+                    } else {
+                        bf16_t* vc = gemv_kv_row(p, true, e_c, pg, pos, hb - p.Hq - p.Hkv);
+                        vc[d] = f2bf(x0);
+                        vc[d + half] = f2bf(x1);
+                    }
+                }
+            } else if (MODE == GEMV_LMHEAD) {
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = row0 + j;
+                    if (row < p.n_rows) {
+                        if (v[j] > best[nt]) { best[nt] = v[j]; besti[nt] = row; }   // rows ascend: the first index wins ties
+                        if (p.logits_out) p.logits_out[(size_t)e_c * p.n_rows + row] = v[j];
+                    }
                 }
             }
         }
@@ -386,9 +406,9 @@ template <int TMAX> constexpr size_t kp_smem_bytes() {
     return (size_t)KP_WAVES * (TMAX * 2048 > KP_ROWS * KP_XP ? TMAX * 2048 : KP_ROWS * KP_XP) + KP_WAVES * 32 * 4;
 }
 
-template <int MODE, bool NORM, bool R32, int TMAX, int NPH, bool FP8>
+template <int MODE, bool NORM, bool R32, int TMAX, int NPH, bool FP8, int NH = 1>
 int kp_launch_r(const GemvParams& p, int grid, hipStream_t stream) {
-    auto kern = emmax_decode_kmp_kernel<MODE, NORM, R32, TMAX, NPH, FP8>;
+    auto kern = emmax_decode_kmp_kernel<MODE, NORM, R32, TMAX, NPH, FP8, NH>;
     static bool attr_done = false;   // per instantiation (first call: outside graph capture -- decode_kmp_init)
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kp_smem_bytes<TMAX>()) != hipSuccess) return -4;
@@ -398,23 +418,23 @@ int kp_launch_r(const GemvParams& p, int grid, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-template <int MODE, bool NORM, int TMAX, int NPH, bool FP8>
+template <int MODE, bool NORM, int TMAX, int NPH, bool FP8, int NH = 1>
 int kp_launch_tf(const GemvParams& p, int grid, bool r32, bool init_only, hipStream_t stream) {
     if constexpr (MODE == GEMV_RESID) {   // (NORM modes read the bf16 mirror of the fp32 residual stream, as in decode_km.hip)
         if (init_only || r32) {
-            const int r = kp_launch_r<MODE, NORM, true, TMAX, NPH, FP8>(p, init_only ? 0 : grid, stream);
+            const int r = kp_launch_r<MODE, NORM, true, TMAX, NPH, FP8, NH>(p, init_only ? 0 : grid, stream);
             if (r || !init_only) return r;
         }
     }
-    return kp_launch_r<MODE, NORM, false, TMAX, NPH, FP8>(p, init_only ? 0 : grid, stream);
+    return kp_launch_r<MODE, NORM, false, TMAX, NPH, FP8, NH>(p, init_only ? 0 : grid, stream);
 }
-template <int MODE, bool NORM, int TMAX, int NPH = 4>
+template <int MODE, bool NORM, int TMAX, int NPH = 4, int NH = 1>
 int kp_launch_tm(const GemvParams& p, int grid, bool r32, bool init_only, hipStream_t stream) {
     if (init_only || p.wscale) {
-        const int r = kp_launch_tf<MODE, NORM, TMAX, NPH, true>(p, grid, r32, init_only, stream);
+        const int r = kp_launch_tf<MODE, NORM, TMAX, NPH, true, NH>(p, grid, r32, init_only, stream);
         if (r || !init_only) return r;
     }
-    return kp_launch_tf<MODE, NORM, TMAX, NPH, false>(p, grid, r32, init_only, stream);
+    return kp_launch_tf<MODE, NORM, TMAX, NPH, false, NH>(p, grid, r32, init_only, stream);
 }
 
 template <int MODE, bool NORM>
@@ -426,7 +446,28 @@ int kp_launch_t(GemvParams p, int B, hipStream_t stream, int* grid_out, bool ini
         if constexpr (MODE == GEMV_RESID || MODE == GEMV_PLAIN) {
             if (!r) r = kp_launch_tm<MODE, NORM, 1, 11>(p, 0, false, true, stream);
         }
+        // 33-64 rows: two halves of four waves, eight phases (K <= 4096)
+        if constexpr (MODE == GEMV_QKV) { if (!r) r = kp_launch_tm<MODE, NORM, 3, 8, 2>(p, 0, false, true, stream); }
+        if constexpr (MODE == GEMV_RESID) { if (!r) r = kp_launch_tm<MODE, NORM, 1, 8, 2>(p, 0, false, true, stream); }
+        if constexpr (MODE == GEMV_GATEUP) { if (!r) r = kp_launch_tm<MODE, NORM, 6, 8, 2>(p, 0, false, true, stream); }
         return r;
+    }
+    if (B > 32) {
+        // 33-64 rows (NH = 2): qkv (3 tiles per block), the o-proj (1), gate/up (6) with K within eight phases of a four-way split; the down projection and
+        // the lm-head run as two launches of <= 32 rows (model.hip)
+        const int ks2 = p.wscale ? 64 : 32;
+        if (p.K % ks2 || p.K / ks2 < 4 || cdiv(p.K / ks2, 4) * ks2 > 8 * KP_PH * 32 || p.n_rows % 16 || p.attn_part) return -2;
+        if (MODE == GEMV_QKV && (p.head_dim % 16 || p.head_dim < 16)) return -2;
+        p.batch = B;
+        p.n_groups = p.n_rows / 16;
+        const int grid2 = p.n_groups < 256 ? p.n_groups : 256;
+        const int tpb2 = cdiv(p.n_groups, grid2);
+        if (grid_out) *grid_out = grid2;
+        const bool r32b = MODE == GEMV_RESID && p.h32 != nullptr;
+        if constexpr (MODE == GEMV_QKV) { if (tpb2 <= 3) return kp_launch_tm<MODE, NORM, 3, 8, 2>(p, grid2, r32b, false, stream); }
+        if constexpr (MODE == GEMV_RESID) { if (tpb2 <= 1) return kp_launch_tm<MODE, NORM, 1, 8, 2>(p, grid2, r32b, false, stream); }
+        if constexpr (MODE == GEMV_GATEUP) { if (tpb2 <= 6) return kp_launch_tm<MODE, NORM, 6, 8, 2>(p, grid2, r32b, false, stream); }
+        return -2;
     }
     // K in whole load steps (32 elements; 64 with fp8 tiles), at least one per wave, a wave's share within eleven phases
     const int ks_el = p.wscale ? 64 : 32;
@@ -478,7 +519,7 @@ int decode_kmp_init() {
 // p.W: the km copy of the matrix (launch_repack_km; fp8: decode_mfma.hip's e4m3 tiles of the permuted rows + p.wscale in the same row
 // order).  -2: shape outside this kernel (K not in whole load steps, a wave's share beyond eleven phases, the o-proj's split merge)
 int launch_decode_kmp(int mode, const GemvParams& p, int B, hipStream_t stream, int* grid_out) {
-    if (B < 17 || B > 32) return -2;
+    if (B < 17 || B > 64) return -2;
     if (decode_kmp_init() != 0) return -4;
     return kp_dispatch(mode, p, B, stream, grid_out, false);
 }
