@@ -34,6 +34,12 @@ constexpr int KP_RPL = KP_ROWS * KP_PH * 4 / 64;   // 16-byte chunks per lane an
 #ifndef KP_XD_LONG
 #define KP_XD_LONG 2
 #endif
+#ifndef KP_AUX2
+#define KP_AUX2 0
+#endif
+#ifndef KP_HALF_SYNC
+#define KP_HALF_SYNC 1
+#endif
 
 // phases of weights in flight (fp8 tiles carry 64 k per KiB: twice the phases for the same bytes)
 template <int TMAX, bool FP8> struct KpLook { static constexpr int L = (TMAX >= 4 ? 1 : TMAX >= 2 ? 2 : 4) * (FP8 ? 2 : 1); };
@@ -137,7 +143,9 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
         const int ks = ph * PHS + s;
         const int ok = (ph < KP_NPH && tl < ntb && ks < k_n) ? -1 : 0;
         const unsigned so = ((unsigned)(((t_lo + tl) * KT + k_lo + ks) * 1024) & (unsigned)ok) | (w_bytes & (unsigned)~ok);
-        w[((ph % LOOK) * TMAX + tl) * PHS + s] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, so, 2));   // aux 2 = nt
+        // aux 2 = nt (streamed once); NH = 2: the other half of the block requests the same tile -- default policy, so that the second request hits L2
+        // (with nt both went to HBM: gate/up at 64 rows 61.8 us = twice the 32-row launch)
+        w[((ph % LOOK) * TMAX + tl) * PHS + s] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, so, NH == 2 ? KP_AUX2 : 2));
     };
 
     // ---- activations of a phase: lane l holds chunk l & 15 (8 elements) of rows (l >> 4) + 4 j of the phase's 128-element slice ----
@@ -218,6 +226,11 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
 #define KP_RUN_PHASE(PHV)                                                                                               \
     {                                                                                                                   \
         constexpr int ph = PHV;                                                                                         \
+        /* NH = 2: the two halves request the same weight tiles -- kept within a phase of each other (one barrier per phase), \
+           so that the second request finds the line in flight or present in L2 instead of reading HBM again (PMC: gate/up  \
+           347 -> 201 MB per launch, 55 -> 44 us; qkv 183 -> 107 MB, 37 -> 35 us).  Not for the one-tile o-proj (14.8 -> 16.0 us) \
+           nor with fp8 tiles (half the bytes: the launch is bound by the L2 -> CU path either way, the barrier only costs) */ \
+        if constexpr (NH == 2 && KP_HALF_SYNC && !FP8 && TMAX >= 3) __syncthreads();                                    \
         /* the phase's fragments: batch tile nt, k-step s: row 16 nt + c16, chunk 4 s + g4 (wave-private window: only this  \
            wave's own LDS writes have to have landed, no barrier) */                                                    \
         bf16x8_t xf[KP_PH][2];                                                                                          \

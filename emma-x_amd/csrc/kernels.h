@@ -106,7 +106,8 @@ int launch_assemble_tokens(const void* pe, const void* pos, const void* cls, con
                            int n_patches, int n_prefix, int has_cls, int D, int ld, hipStream_t stream);
 int launch_copy_rows(const void* in, int ld_in, void* out, int B, int rows_in, int r_off, int rows_out, int D, int ld_out,
                      int col_off, hipStream_t stream);
-#define EMMAX_MAX_DECODE_BATCH 32   // rows of a decode step: two 16-wide MFMA batch tiles (decode_kmp.hip; one: decode_km.hip, 16 rows); rounds 1-4: 8
+#define EMMAX_MAX_DECODE_BATCH 64   // rows of a decode step: 17-32 = two 16-wide MFMA batch tiles, 33-64 = two halves of two (decode_kmp.hip; decode_km.hip: 16 rows); rounds 1-4: 8, round 5: 32
+#define EMMAX_KMP_ROWS 32           // rows one decode_kmp.hip half stages: the down projection and the lm-head of 33-64 rows run as two launches of <= 32
 #define EMMAX_MAX_STOP_IDS 16
 struct PrefillState {
     int B;

@@ -857,6 +857,12 @@ static void lmhead_params(emmax_session* s, int slot0, float* logits_out, GemvPa
 // slot0: first row of the B rows this call covers (slot prefill: one row in the middle of a live batch)
 static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, int slot0) {
     emmax_model* m = s->m;
+    if (B > EMMAX_KMP_ROWS) {   // 33-64 rows: two launches of <= 32 rows (each with its own finish: the argmax partials are laid out per launch)
+        int r = run_lm_head_step(s, EMMAX_KMP_ROWS, is_prefill, logits_out, do_finish, st, slot0);
+        if (r) return r;
+        return run_lm_head_step(s, B - EMMAX_KMP_ROWS, is_prefill, logits_out ? logits_out + (size_t)EMMAX_KMP_ROWS * m->vocab : nullptr, do_finish, st,
+                                slot0 + EMMAX_KMP_ROWS);
+    }
     GemvParams p;
     lmhead_params(s, slot0, logits_out, p);
     int lm_grid = 0;
@@ -1115,6 +1121,16 @@ static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStrea
             return 0;
         case STAGE_DOWN:
             stage_params(s, B, li, stage, p);
+            if (B > EMMAX_KMP_ROWS) {   // 33-64 rows: K = 11008 does not fit the eight phases of a four-way split -- two launches of <= 32 rows
+                GemvParams q = p;
+                KCHK(launch_proj(GEMV_RESID, q, L.wdown, L.wdown_fm, EMMAX_KMP_ROWS, st, &grid, L.wdown_sc, L.wdown_r8, F8_DOWN, L.wdown_fm, L.wdown_sc));
+                q = p;
+                q.x = (const bf16*)q.x + (size_t)EMMAX_KMP_ROWS * q.ldx;
+                q.y = (bf16*)q.y + (size_t)EMMAX_KMP_ROWS * q.ldy;
+                if (q.h32) q.h32 += (size_t)EMMAX_KMP_ROWS * q.ldh;
+                KCHK(launch_proj(GEMV_RESID, q, L.wdown, L.wdown_fm, B - EMMAX_KMP_ROWS, st, &grid, L.wdown_sc, L.wdown_r8, F8_DOWN, L.wdown_fm, L.wdown_sc));
+                return 0;
+            }
             KCHK(launch_proj(GEMV_RESID, p, L.wdown, L.wdown_fm, B, st, &grid, L.wdown_sc, L.wdown_r8, F8_DOWN, L.wdown_fm, L.wdown_sc));
             return 0;
         default:

@@ -94,7 +94,7 @@ def max_over_ranks(x: float, device) -> float:
     return float(t.item())
 
 
-MAX_ROWS = 32   # rows of one decode batch (EMMAX_MAX_DECODE_BATCH, emma-x_amd/csrc/kernels.h)
+MAX_ROWS = 64   # rows of one decode batch (EMMAX_MAX_DECODE_BATCH, emma-x_amd/csrc/kernels.h)
 
 
 def generate_actions_dp(model, frames_u8: torch.Tensor, prompt_rows, max_new_tokens: int = 512, stop_on_eos: bool = True,

@@ -50,7 +50,7 @@ class _Active:
     t_admit: float
 
 
-MAX_SLOTS = 32   # EMMAX_MAX_DECODE_BATCH (emma-x_amd/csrc/kernels.h): rows of a decode step
+MAX_SLOTS = 64   # EMMAX_MAX_DECODE_BATCH (emma-x_amd/csrc/kernels.h): rows of a decode step
 
 
 class SlotScheduler:

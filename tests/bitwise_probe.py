@@ -1,7 +1,7 @@
 """Run-to-run bit reproducibility probe: the full Emma-X-7B shape on random weights (seed 0), one packed
-ragged prefill + 64 teacher-forced decode steps with FIXED token ids, at B = 1, 8 and 32 (bf16-operand path: decode_ks / decode_km /
+ragged prefill + 64 teacher-forced decode steps with FIXED token ids, at B = 1, 8, 32 and 64 (bf16-operand path: decode_ks / decode_km /
 decode_kmp kernels, split-K and stream-K launches included), eager launches and hipGraph replay, plus the exact-numerics session at
-B = 1 and 2.  Every configuration runs TWICE in this process and must give bit-identical fp32 logits (sha256 over the prefill's
+B = 1, 2 and 8.  Every configuration runs TWICE in this process and must give bit-identical fp32 logits (sha256 over the prefill's
 last-position rows and every decode step's rows); the hashes are printed as one JSON line so that tests/test_bitwise_gpu.py can compare
 two PROCESSES.  Not a pytest module: started by that test (and by hand: `python tests/bitwise_probe.py`)."""
 import hashlib
@@ -43,16 +43,16 @@ def run(model, B, graph, rng_seed):
 def main():
     cfg = EmmaXConfig.emma_x_7b()
     out = {}
-    model = EmmaXForActionPrediction.from_synthetic(cfg, seed=0, device="cuda:0", max_batch=32, max_prompt=512, max_ctx=256 + 512 + T + 8)
-    for B in (1, 8, 32):
+    model = EmmaXForActionPrediction.from_synthetic(cfg, seed=0, device="cuda:0", max_batch=64, max_prompt=512, max_ctx=256 + 512 + T + 8)
+    for B in (1, 8, 32, 64):
         for graph in (0, 1):
             a, b = run(model, B, graph, 100 + B), run(model, B, graph, 100 + B)
             assert a == b, f"B={B} graph={graph}: two runs in one process differ"
             out[f"bf16_B{B}_{'graph' if graph else 'eager'}"] = a
     del model
     torch.cuda.empty_cache()
-    xm = EmmaXForActionPrediction.from_synthetic(EmmaXConfig.emma_x_7b(), seed=0, device="cuda:0", max_batch=2, max_prompt=512, max_ctx=256 + 512 + T + 8, exact=True)
-    for B in (1, 2):
+    xm = EmmaXForActionPrediction.from_synthetic(EmmaXConfig.emma_x_7b(), seed=0, device="cuda:0", max_batch=8, max_prompt=512, max_ctx=256 + 512 + T + 8, exact=True)
+    for B in (1, 2, 8):
         for graph in (0, 1):
             a, b = run(xm, B, graph, 200 + B), run(xm, B, graph, 200 + B)
             assert a == b, f"exact B={B} graph={graph}: two runs in one process differ"

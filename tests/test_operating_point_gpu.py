@@ -167,10 +167,12 @@ def test_bf16_decode_residual_stream_variants(device, setup, oracle_bf16, model_
 
 LENS16 = LENS8 + [509, 33, 512, 500, 128, 512, 7, 256]   # sixteen rows: one MFMA batch tile (decode_km.hip)
 LENS32 = LENS16 + [64, 511, 12, 300, 512, 200, 505, 31, 450, 512, 90, 128, 512, 5, 333, 508]   # thirty-two: two batch tiles (decode_kmp.hip)
+LENS64 = LENS32 + [77, 512, 400, 9, 256, 511, 130, 64, 512, 21, 345, 507, 18, 480, 512, 100, 3, 290, 512, 66, 444, 128, 510, 37, 512, 222, 12, 389, 500, 70, 512, 150]   # sixty-four: two halves of two batch tiles
 T16 = 12
 
 
-@pytest.mark.parametrize("nrows,fp8", [(16, False), (16, True), (32, False), (32, True)], ids=["16-bf16", "16-fp8", "32-bf16", "32-fp8"])
+@pytest.mark.parametrize("nrows,fp8", [(16, False), (16, True), (32, False), (32, True), (64, False), (64, True)],
+                         ids=["16-bf16", "16-fp8", "32-bf16", "32-fp8", "64-bf16", "64-fp8"])
 def test_decode_batches_of_nine_to_thirty_two_rows(device, setup, tune, nrows, fp8):
     """Round 5: decode batches of 9-32 rows.  9-16: decode_km.hip stages sixteen rows per wave (qkv / o-proj /
     gate-up / lm-head) and runs the down projection in four K phases; 17-32: decode_kmp.hip -- two 16-wide batch tiles per weight tile
@@ -179,7 +181,8 @@ def test_decode_batches_of_nine_to_thirty_two_rows(device, setup, tune, nrows, f
     sub-batches, shuffled rows, eager and hipGraph."""
     cfg, sd_bf, sd_ref, frames8, _ = setup
     rng = np.random.default_rng(1616)
-    lens = LENS16 if nrows == 16 else LENS32
+    lens = LENS16 if nrows == 16 else LENS32 if nrows == 32 else LENS64   # (64 rows, round 6: decode_kmp.hip's NH = 2 form -- two halves of four waves;
+    # the down projection and the lm-head as two launches of <= 32 rows)
     frames = np.concatenate([frames8, rng.integers(0, 256, size=(nrows - 8, 224, 224, 3), dtype=np.uint8)])
     rows = [[1] + [int(x) for x in rng.integers(3, 31744, size=n - 1)] for n in lens]
     if fp8:
@@ -196,9 +199,10 @@ def test_decode_batches_of_nine_to_thirty_two_rows(device, setup, tune, nrows, f
     if fp8:
         c.decode_weight_dtype = "fp8"
     model = EmmaXForActionPrediction(c, dict(sd_bf)).to(device, max_batch=nrows, max_prompt=512, max_ctx=256 + 512 + 32)
-    assert model.engine.max_decode_batch() == 32
+    assert model.engine.max_decode_batch() == 64
     sels = [list(range(16)), list(range(3, 12)), [15, 0, 7, 8, 1, 9, 2, 10, 3, 11, 4, 12]] if nrows == 16 else \
-           [list(range(32)), list(range(5, 22)), [31, 0, 30, 1, 29, 2, 28, 3, 27, 4, 26, 5, 25, 6, 24, 7, 23, 8, 22, 9, 21, 10, 20, 11, 19]]
+           [list(range(32)), list(range(5, 22)), [31, 0, 30, 1, 29, 2, 28, 3, 27, 4, 26, 5, 25, 6, 24, 7, 23, 8, 22, 9, 21, 10, 20, 11, 19]] if nrows == 32 else \
+           [list(range(64)), list(range(7, 40)), [(i * 37) % 64 for i in range(49)], list(range(10, 58))]   # 64, 33, 49 shuffled, 48 rows
     for graph in (0, 1):
         tune(graph=graph)
         for sel in sels:
@@ -353,13 +357,15 @@ def test_bf16_decode_over_the_fp8_kv_cache(device, setup, oracle_bf16, tune, sel
     assert out[0] < TOL and out[1] < 2.5 * TOL, out
 
 
-def test_thirty_two_slots_with_overlapped_admissions_at_7b_dims(device, setup, tune):
+@pytest.mark.parametrize("n_slots", [32, 64])
+def test_thirty_two_slots_with_overlapped_admissions_at_7b_dims(device, setup, tune, n_slots):
     """VERDICT r04 next #5 ("... extended to 32 slots"): the tiny config of tests/test_serving_gpu.py cannot decode more than 8 rows
     (its shapes lie outside decode_km.hip), so the 32-slot serving path is tested here at 7B layer dimensions: 44 ragged requests
     through a SlotScheduler with 32 slots and overlapped admissions (packed staged prefills of up to 32 rows on the second stream,
     piecemeal commits, refills while the others decode on decode_kmp.hip), each against its own bs = 1 `generate` and, where the two
     part, the fp32 oracle's margin at that step: a divergence must be a near-tie (margin <= 2 x the measured logit error); the
-    numbers go to gpurun_out/r05_slots32.json."""
+    numbers go to gpurun_out/r06_slots32.json.  Round 6: the same with 64 slots and 88 requests -- decode batches of 33-64 rows on
+    decode_kmp.hip's two-halves form (r06_slots64.json)."""
     import json
     import os
 
@@ -369,17 +375,17 @@ def test_thirty_two_slots_with_overlapped_admissions_at_7b_dims(device, setup, t
 
     cfg, sd_bf, sd_ref, _, _ = setup
     rng = np.random.default_rng(3232)
-    n_req, T = 44, 20
+    n_req, T = (44 if n_slots == 32 else 88), 20
     lens = [int(x) for x in rng.integers(8, 513, size=n_req)]
     lens[:4] = [512, 8, 511, 64]
     frames = rng.integers(0, 256, size=(n_req, 224, 224, 3), dtype=np.uint8)
     rows = [[1] + [int(x) for x in rng.integers(3, 31744, size=n - 1)] for n in lens]
     budgets = [T if i % 3 else 7 for i in range(n_req)]                        # short budgets: slots free up and refill early
     gens, traces = _oracle_rows(cfg, sd_ref, sd_ref, frames, rows, T)
-    model = EmmaXForActionPrediction(copy.deepcopy(cfg), dict(sd_bf)).to(device, max_batch=32, max_prompt=512, max_ctx=256 + 512 + 32)
+    model = EmmaXForActionPrediction(copy.deepcopy(cfg), dict(sd_bf)).to(device, max_batch=n_slots, max_prompt=512, max_ctx=256 + 512 + 32)
     eng = model.engine
     fr = torch.from_numpy(frames).to(device)
-    err = max(_teacher_forced(model, frames, rows, gens, traces, sel, 12, device)[0] for sel in ([0], list(range(32))))
+    err = max(_teacher_forced(model, frames, rows, gens, traces, sel, 12, device)[0] for sel in ([0], list(range(n_slots))))
     ids1 = []
     for i in range(n_req):
         new_ids, ln = model.generate_ids([rows[i]], frames_u8=fr[i:i + 1], max_new_tokens=budgets[i], stop_on_eos=False)
@@ -390,12 +396,12 @@ def test_thirty_two_slots_with_overlapped_admissions_at_7b_dims(device, setup, t
         return [pe[i] for i in range(len(fs))]
 
     eng.set_stop((), 0)
-    sch = SlotScheduler(eng, encode, n_slots=32, poll_every=4, encode_ahead=8, overlap=True)
-    assert eng.stage_rows == 32
+    sch = SlotScheduler(eng, encode, n_slots=n_slots, poll_every=4, encode_ahead=8, overlap=True)
+    assert eng.stage_rows == n_slots
     for i in range(n_req):
         sch.submit(Request(i, fr[i], rows[i], max_new_tokens=budgets[i]))
     res = {r.rid: r for r in sch.run()}
-    assert sorted(res) == list(range(n_req)) and sch.overlapped_admissions >= 2 and len({r.slot for r in res.values()}) == 32
+    assert sorted(res) == list(range(n_req)) and sch.overlapped_admissions >= 2 and len({r.slot for r in res.values()}) == n_slots
     report, unrated, same = [], [], 0
     for i in range(n_req):
         a, b = ids1[i], res[i].ids
@@ -410,13 +416,13 @@ def test_thirty_two_slots_with_overlapped_admissions_at_7b_dims(device, setup, t
             continue
         ref = traces[i][t]
         top2 = torch.topk(ref, 2).values
-        report.append({"request": i, "step": t, "margin": (top2[0] - top2[1]).item() / ref.abs().max().item(), "bs1": a[t], "slots32": b[t], "oracle": gens[i][t]})
-    out = {"what": "7B layer dims (2 layers), random weights, %d ragged requests, 32 slots, overlapped admissions: slot-served vs bs=1 generate" % n_req,
+        report.append({"request": i, "step": t, "margin": (top2[0] - top2[1]).item() / ref.abs().max().item(), "bs1": a[t], "slots": b[t], "oracle": gens[i][t]})
+    out = {"what": "7B layer dims (2 layers), random weights, %d ragged requests, %d slots, overlapped admissions: slot-served vs bs=1 generate" % (n_req, n_slots),
            "logit_err_rel": err, "requests_identical": same, "divergences": report, "unrated": unrated, "decode_steps": sch.steps,
            "overlapped_admissions": sch.overlapped_admissions}
-    print("\n32 slots vs bs=1:", json.dumps(out))
+    print("\n%d slots vs bs=1:" % n_slots, json.dumps(out))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r06_slots32.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r06_slots%d.json" % n_slots), "w") as f:
         json.dump(out, f, indent=1)
     assert same >= n_req // 2
     for d in report:

@@ -135,7 +135,7 @@ def test_encode_ahead_batches_the_vit_and_keeps_results():
 def test_bad_arguments():
     eng = FakeEngine({})
     with pytest.raises(ValueError):
-        SlotScheduler(eng, lambda f: f, n_slots=33)   # 32 = the decode step's row limit (round 5; rounds 1-4: 8)
+        SlotScheduler(eng, lambda f: f, n_slots=65)   # 64 = the decode step's row limit (round 6; round 5: 32; rounds 1-4: 8)
     with pytest.raises(ValueError):
         SlotScheduler(eng, lambda f: f, n_slots=2, poll_every=0)
     sch = SlotScheduler(eng, lambda f: f, n_slots=2)
