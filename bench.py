@@ -375,7 +375,7 @@ def main():
                         "finalize_s": round(eng.finalize_s, 3), "aux_build_s": round(eng.aux_build_s, 3)},
             "stage_us": {k: round(v, 2) for k, v in stage_us.items()},
             "stage_gbs": {k: round(stage_bytes[k] / (stage_us[k] * 1e-6) / 1e9, 1) for k in stage_names},
-            "roofline": {"kernel": ("emmax_decode_ks_kernel<B=%d,GATEUP,NORM,CPL=1%s>" % (B, ",EX" if args.exact else "") if B <= 2 and not args.fp8 else ("emmax_decode_kmp_kernel<GATEUP,NORM,TMAX=6> (B=%d)" % B if B > 16 else "emmax_decode_km_kernel<GATEUP,NORM%s> (B=%d)" % (",FP8" if args.fp8 else ",EX" if args.exact else "", B))) + " (gate/up projection + SiLU*mul)", "bound": "hbm",
+            "roofline": {"kernel": ("emmax_decode_ks_kernel<B=%d,GATEUP,NORM,CPL=1%s>" % (B, ",EX" if args.exact else "") if B <= 2 and not args.fp8 else ("emmax_decode_kmp_kernel<GATEUP,NORM,TMAX=6%s> (B=%d)" % (",NH=2" if B > 32 else "", B) if B > 16 else "emmax_decode_km_kernel<GATEUP,NORM%s> (B=%d)" % (",FP8" if args.fp8 else ",EX" if args.exact else "", B))) + " (gate/up projection + SiLU*mul)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "bytes_per_launch": stage_bytes[dom], "us_per_launch": round(stage_us[dom], 2), "traffic": traffic,
                          "traffic_source": "profiles/%s (rocprofv3 --pmc, offline)" % pmc_name if traffic else None},

@@ -100,7 +100,7 @@ MAX_ROWS = 64   # rows of one decode batch (EMMAX_MAX_DECODE_BATCH, emma-x_amd/c
 def generate_actions_dp(model, frames_u8: torch.Tensor, prompt_rows, max_new_tokens: int = 512, stop_on_eos: bool = True,
                         tokenizer=None):
     """Data-parallel `generate_actions_batch` (BASELINE config 3): every rank passes the SAME global batch (frames uint8
-    [B,H,W,3], B prompts); rank r computes its contiguous shard on its own GPU (sub-batches of <= 32 rows) and one
+    [B,H,W,3], B prompts); rank r computes its contiguous shard on its own GPU (sub-batches of <= 64 rows) and one
     all_gather returns (actions f32 [B,7], ids i32 [B,T], lens i32 [B]) in global order on every rank."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0

@@ -8,7 +8,7 @@ Keeps the surface of the reference's HF classes and of the native Emma-X entry p
   * README form  generate_actions(inputs, tokenizer, do_sample=False, max_new_tokens=512) -> (action, reasoning)
         README.md:27-50 (hub-only in the reference; rebuilt from the two sources above)
 Same argument meaning and error behaviour; all device math runs in libemmax_hip.so.  The reference is batch-size-1 for
-generation (modeling_prismatic.py:460-463); here rows of a batch (<= 32 per GPU) are independent and each equals the
+generation (modeling_prismatic.py:460-463); here rows of a batch (<= 64 per GPU) are independent and each equals the
 reference's bs=1 result for that row.
 """
 

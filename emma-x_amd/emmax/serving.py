@@ -60,7 +60,7 @@ class SlotScheduler:
              (emmax.engine.EmmaxEngine, or a fake in the CPU tests)
     encode   frames (list) -> patch embeddings, one [n_patches, hidden] bf16 tensor per frame; called once per admission
              round with every frame admitted in that round, so the ViT runs batched
-    n_slots  decode batch (<= 32; the engine's max_decode_batch())
+    n_slots  decode batch (<= 64; the engine's max_decode_batch())
     poll_every   decode steps between two device polls (a poll is one tiny D2H copy + sync; default 4 = ~13 ms at 7B shapes: a retired
                  slot is refilled within 4 steps -- 32 requests / 8 slots: 22.9 actions/s polling every 16 steps, 24.2 every 4)
     encode_ahead frames encoded per `encode` call: the frames being admitted plus the next ones in the queue, so the ViT

@@ -35,7 +35,7 @@ extern "C" {
 /* Bumped whenever emmax_config / emmax_tower_config change layout or an entry point changes signature.
  *   1: rounds 1-2;  2: emmax_config grew `decode_fp8` (round 2, not bumped then);  3: round 4 -- emmax_config_size / emmax_tuning_*
  *   added, the lab-only entry points (persistent layer chain, in-attention split merge) removed;  4: round 5 -- emmax_session_*_ex (staging rows
- *   are asked for, the plain calls give none), decode batches / slot counts up to 32 (emmax_model_max_decode_batch). */
+ *   are asked for, the plain calls give none), decode batches / slot counts up to 64 (emmax_model_max_decode_batch). */
 #define EMMAX_ABI_VERSION 5
 
 typedef enum emmax_status {
@@ -110,9 +110,9 @@ void emmax_model_destroy(emmax_model* m);
 int emmax_model_bind_weight(emmax_model* m, const char* hf_key, const void* ptr_dev, int dtype,
                             const int64_t* shape, int ndim);
 int64_t emmax_model_arena_bytes(const emmax_model* m);
-/* rows of one decode batch / slot set this model can run: 32 (bf16 or fp8 weights) when every LLM projection is a shape the K-split
- * MFMA kernels take (K % 256 == 0 and <= 4096, N <= 32768, intermediate size % 32 (fp8: % 64) == 0 and <= 11264: LLaMA-2-7B is), else 8 (round 5;
- * rounds 1-4: 8) */
+/* rows of one decode batch / slot set this model can run: 64 (bf16 or fp8 weights) when every LLM projection is a shape the K-split
+ * MFMA kernels take (K % 256 == 0 and <= 4096, N <= 32768, intermediate size % 32 (fp8: % 64) == 0 and <= 11264: LLaMA-2-7B is), else 8 (round 6;
+ * round 5: 32; rounds 1-4: 8).  Exact-numerics sessions: 8. */
 int emmax_model_max_decode_batch(const emmax_model* m);
 int emmax_model_finalize(emmax_model* m, void* arena_dev, int64_t arena_bytes, emmax_stream stream);
 /* bf16 models: decode batches >= 3 stream the LLM projections from MFMA-fragment-major copies that a model serving batches 1-2
