@@ -212,6 +212,14 @@ def test_decode_batches_of_nine_to_thirty_two_rows(device, setup, tune, nrows, f
             assert checked >= len(sel) and agree == checked, (fp8, graph, len(sel), agree, checked)
     del model
     torch.cuda.empty_cache()
+    if nrows == 64 and not fp8:   # ... and the 64 rows over the fp8 KV cache (the configuration VERDICT r05 next #7 names), with the e4m3 cache's budget
+        tune(graph=0, kv_fp8=1)
+        model = EmmaXForActionPrediction(copy.deepcopy(cfg), dict(sd_bf)).to(device, max_batch=64, max_prompt=512, max_ctx=256 + 512 + 32)
+        worst, checked, agree = _teacher_forced(model, frames, rows, gens, traces, list(range(64)), T16, device, budget=2.5 * ID_BUDGET_SHALLOW)
+        print(f"\n64 rows over the fp8 KV cache: worst |err|/max|ref| {worst:.2e}, argmax checked {checked} agreed {agree}")
+        assert worst < 2.5 * TOL and agree == checked and checked >= 64, (worst, agree, checked)
+        del model
+        torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipgraph"])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # THE profile pass of a round (run through gpurun; the one parameterised runner -- per-round one-off command scripts live in the
 # git-ignored tools/bin/): bench line with 50 timed calls, rocprofv3 kernel stats of the same command, bench variants (graph,
-# B = 8 / 16 / 32, fp8 weights, fp8 KV cache, exact numerics), decode-kernel HBM traffic (PMC: B = 1, 8, 16, 32), GEMM MFMA-pipe
+# B = 8 / 16 / 32 / 64, fp8 weights, fp8 KV cache, exact numerics), decode-kernel HBM traffic (PMC: B = 1, 8, 16, 32), GEMM MFMA-pipe
 # counters, stage / serve benches.
 #   usage: ROUND=r06 tools/profile_round.sh [part...]     parts: bench rocprof variants stage serve gemm pmc pmcgemm pmcattn (default: all) + pmcexact (the exact-numerics decode step)
 # Outputs: gpurun_out/prof_$ROUND/ (the summaries are copied into profiles/${ROUND}_* by hand)
@@ -20,7 +20,8 @@ for part in $parts; do
               rm -f $O/rocprof_b32/*/*kernel_trace.csv $O/rocprof_b32/*kernel_trace.csv ;;
     variants) : > $O/bench_variants.jsonl
               for v in "--exact" "--exact-fp32kv" "--exact --graph" "--exact --batch-per-gpu 2" "--exact --batch-per-gpu 8" "--graph" "--batch-per-gpu 8" "--batch-per-gpu 16" "--batch-per-gpu 32" "--fp8" "--fp8 --batch-per-gpu 8" "--fp8 --batch-per-gpu 8 --graph" "--fp8 --batch-per-gpu 16" \
-                       "--batch-per-gpu 8 --kv-fp8" "--batch-per-gpu 16 --kv-fp8" "--batch-per-gpu 32 --kv-fp8" "--fp8 --batch-per-gpu 8 --kv-fp8" "--fp8 --batch-per-gpu 16 --kv-fp8"; do
+                       "--batch-per-gpu 8 --kv-fp8" "--batch-per-gpu 16 --kv-fp8" "--batch-per-gpu 32 --kv-fp8" "--fp8 --batch-per-gpu 8 --kv-fp8" "--fp8 --batch-per-gpu 16 --kv-fp8" \
+                       "--batch-per-gpu 64" "--batch-per-gpu 64 --kv-fp8" "--fp8 --batch-per-gpu 32 --kv-fp8" "--fp8 --batch-per-gpu 64 --kv-fp8"; do
                 timeout 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline $v 2>/dev/null | tail -1 >> $O/bench_variants.jsonl
               done
               EMMAX_DIST_SINGLETON=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 2 --warmup 1 --batch-per-gpu 8 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_rccl_singleton_b8.json ;;
@@ -29,7 +30,10 @@ for part in $parts; do
               rm -f $O/rocprof_stage/*/*kernel_trace.csv $O/rocprof_stage/*kernel_trace.csv ;;
     serve)    timeout 900 python tools/serve_bench.py 2>/dev/null | tail -1 > $O/serve_bench.json
               timeout 900 python tools/serve_bench.py --requests 96 --slots 16 2>/dev/null | tail -1 > $O/serve_bench_16.json
-              timeout 1200 python tools/serve_bench.py --requests 128 --slots 32 2>/dev/null | tail -1 > $O/serve_bench_32.json ;;
+              timeout 1200 python tools/serve_bench.py --requests 128 --slots 32 2>/dev/null | tail -1 > $O/serve_bench_32.json
+              timeout 1200 python tools/serve_bench.py --requests 384 --slots 32 2>/dev/null | tail -1 > $O/serve_bench_32_384req.json
+              timeout 1200 python tools/serve_bench.py --requests 768 --slots 64 2>/dev/null | tail -1 > $O/serve_bench_64_768req.json
+              EMMAX_KV_FP8=1 timeout 1200 python tools/serve_bench.py --requests 768 --slots 64 2>/dev/null | tail -1 > $O/serve_bench_64_768req_kvfp8.json ;;
     gemm)     timeout 600 python tools/gemm_bench.py > $O/gemm_bench.txt 2>&1 ;;
     pmc)      for B in 1 8 16 32; do
                 for c in FETCH_SIZE WRITE_SIZE; do
