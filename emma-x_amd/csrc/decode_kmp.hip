@@ -139,6 +139,8 @@ __global__ __launch_bounds__(KP_THREADS, 2) void emmax_decode_kmp_kernel(GemvPar
     const unsigned voff = (unsigned)lane * 16u;
     u32x4_t w[RING];
     // unit (ph, tl, s) lives in register ((ph % LOOK) * TMAX + tl) * PHS + s; past the block's tiles / the slice: out of range = zeros, no traffic
+    // (measured and removed, profiles/r06_kmp_rot_ab.txt: blocks walking their phases in ROTATED order -- so that the CUs of an XCD would not ask L2 for the same
+    // row chunks at the same time -- is slower, qkv 23.0 -> 26.8 us, gate/up 33.6 -> 36.3 at 32 rows: the simultaneous requests for the same rows are what L2 merges)
     auto issue_w = [&](int ph, int tl, int s) {
         const int ks = ph * PHS + s;
         const int ok = (ph < KP_NPH && tl < ntb && ks < k_n) ? -1 : 0;
