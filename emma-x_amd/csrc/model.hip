@@ -857,11 +857,11 @@ static void lmhead_params(emmax_session* s, int slot0, float* logits_out, GemvPa
 // slot0: first row of the B rows this call covers (slot prefill: one row in the middle of a live batch)
 static int run_lm_head_step(emmax_session* s, int B, bool is_prefill, float* logits_out, bool do_finish, hipStream_t st, int slot0) {
     emmax_model* m = s->m;
-    if (B > EMMAX_KMP_ROWS) {   // 33-64 rows: two launches of <= 32 rows (each with its own finish: the argmax partials are laid out per launch)
-        int r = run_lm_head_step(s, EMMAX_KMP_ROWS, is_prefill, logits_out, do_finish, st, slot0);
+    const int chunk = s->exact ? 8 : EMMAX_KMP_ROWS;   // (exact numerics: the two-term MFMA kernels hold 8 rows)
+    if (B > chunk) {   // 33-64 rows: launches of <= 32 rows (each with its own finish: the argmax partials are laid out per launch)
+        int r = run_lm_head_step(s, chunk, is_prefill, logits_out, do_finish, st, slot0);
         if (r) return r;
-        return run_lm_head_step(s, B - EMMAX_KMP_ROWS, is_prefill, logits_out ? logits_out + (size_t)EMMAX_KMP_ROWS * m->vocab : nullptr, do_finish, st,
-                                slot0 + EMMAX_KMP_ROWS);
+        return run_lm_head_step(s, B - chunk, is_prefill, logits_out ? logits_out + (size_t)chunk * m->vocab : nullptr, do_finish, st, slot0 + chunk);
     }
     GemvParams p;
     lmhead_params(s, slot0, logits_out, p);
@@ -878,9 +878,11 @@ static int run_prefill(emmax_session* s, const int32_t* ids, const int32_t* lens
     emmax_model* m = s->m;
     const auto& c = m->cfg;
     if (!m->finalized) return fail(EMMAX_ERR_STATE, "model not finalized");
-    if (B <= 0 || B > s->max_batch || B > model_max_decode_batch(m))
+    // (an exact session was checked against the shapes its two-term kernels take when it was created, and chunks larger batches: check_exact)
+    const int max_rows = s->exact ? EMMAX_MAX_DECODE_BATCH : model_max_decode_batch(m);
+    if (B <= 0 || B > s->max_batch || B > max_rows)
         return fail(EMMAX_ERR_INVALID, "prefill batch %d outside 1..min(max_batch=%d, %d) (decode batches above 8 need the shapes decode_km.hip takes: emmax_model_max_decode_batch)",
-                    B, s->max_batch, model_max_decode_batch(m));
+                    B, s->max_batch, max_rows);
     if (B >= EMMAX_MFMA_MIN_BATCH && !m->aux_built)
         return fail(EMMAX_ERR_STATE, "batch %d decodes on the fragment-major weight copies: call emmax_model_build_aux first", B);
     const int np = patches ? m->tw[0].n_patches : 0;
@@ -1081,12 +1083,54 @@ static void lmhead_params(emmax_session* s, int slot0, float* logits_out, GemvPa
 }
 
 // one stage of decoder layer `li` (the unit the profiler times); the step is stages 0..4 of every layer + lm head
+// exact numerics, batches above 8 rows: the two-term MFMA kernels hold 8 rows (decode_km.hip EX: the two terms of a row in the sixteen batch columns), so a
+// projection stage runs in chunks of 8 rows -- each chunk streams the weights again: the conformance mode covers every batch the default path serves, at
+// ceil(B / 8) times its weight traffic.  (The attention launch takes any batch; the lm-head chunks in run_lm_head_step.)
+#define EMMAX_EXACT_ROWS 8
+static int run_decode_stage_x_chunks(emmax_session* s, int B, int li, int stage, hipStream_t st) {
+    emmax_model* m = s->m;
+    const LayerW& L = m->layers[li];
+    GemvParams p0;
+    stage_params(s, B, li, stage, p0);
+    for (int r = 0; r < B; r += EMMAX_EXACT_ROWS) {
+        GemvParams p = p0;
+        const int n = std::min(EMMAX_EXACT_ROWS, B - r);
+        int grid = 0;
+        if (p.h32) p.h32 += (size_t)r * p.ldh;
+        switch (stage) {
+            case STAGE_QKV:
+                p.y = (float*)p.y + (size_t)r * p.ldy;
+                p.ctx_len += r; p.page_table += (size_t)r * p.max_pages;
+                KCHK(launch_proj(GEMV_QKV, p, L.wqkv, L.wqkv_fm, n, st, &grid, L.wqkv_sc, L.wqkv_r8, F8_QKV, L.wqkv_km, L.wqkv_km_sc));
+                break;
+            case STAGE_OPROJ:
+                if (p.attn_part) p.attn_part += (size_t)r * p.Hq * p.nsplit * EMMAX_PSTRIDE;
+                else p.x = (const float*)p.x + (size_t)r * p.ldx;
+                p.y = (bf16*)p.y + (size_t)r * p.ldy;
+                KCHK(launch_proj(GEMV_RESID, p, L.wo, L.wo_fm, n, st, &grid, L.wo_sc, L.wo_r8, F8_OPROJ, L.wo_fm, L.wo_sc));
+                break;
+            case STAGE_GATEUP:
+                p.y = (float*)p.y + (size_t)r * p.ldy;
+                KCHK(launch_proj(GEMV_GATEUP, p, L.wgu, L.wgu_fm, n, st, &grid, L.wgu_sc, L.wgu_r8, F8_GATEUP, L.wgu_km, L.wgu_km_sc));
+                break;
+            case STAGE_DOWN:
+                p.x = (const float*)p.x + (size_t)r * p.ldx;
+                p.y = (bf16*)p.y + (size_t)r * p.ldy;
+                KCHK(launch_proj(GEMV_RESID, p, L.wdown, L.wdown_fm, n, st, &grid, L.wdown_sc, L.wdown_r8, F8_DOWN, L.wdown_fm, L.wdown_sc));
+                break;
+            default: return fail(EMMAX_ERR_INVALID, "unknown decode stage %d", stage);
+        }
+    }
+    return 0;
+}
+
 static int run_decode_stage(emmax_session* s, int B, int li, int stage, hipStream_t st) {
     emmax_model* m = s->m;
     const auto& c = m->cfg;
     const LayerW& L = m->layers[li];
     GemvParams p;
     int grid = 0;
+    if (s->exact && B > EMMAX_EXACT_ROWS && stage != STAGE_ATTN) return run_decode_stage_x_chunks(s, B, li, stage, st);
     switch (stage) {
         case STAGE_QKV:
             stage_params(s, B, li, stage, p);
@@ -1443,13 +1487,14 @@ static int check_exact(const emmax_model* m, int max_batch, int stage_rows) {
     // batch 1-2: decode_ks.hip's two-term dot products; batch 3-8: decode_km.hip's EX kernels (the two terms of a row in the MFMA's sixteen batch
     // columns), which need the shapes that file takes: K a multiple of 256 and <= 4096 for qkv / o-proj / gate-up / lm-head, at most 8 tiles per block,
     // the down projection within four phases of 12 fragments per wave
-    if (max_batch > 8) return fail(EMMAX_ERR_INVALID, "exact numerics serves batches of 1-8 rows; max_batch %d", max_batch);
+    // (batches above 8 rows run their projections in chunks of 8: run_decode_stage_x_chunks)
+    if (max_batch > EMMAX_MAX_DECODE_BATCH) return fail(EMMAX_ERR_INVALID, "exact numerics serves batches of 1-%d rows; max_batch %d", EMMAX_MAX_DECODE_BATCH, max_batch);
     if (max_batch > 2) {
         const bool k_ok = m->H % 256 == 0 && m->H <= 4096 && m->q_dim % 256 == 0 && m->q_dim <= 4096 && m->q_dim == m->cfg.n_heads * 128;
         const bool n_ok = m->qkv_dim % 16 == 0 && m->qkv_dim <= 32768 && 2 * m->inter_p <= 32768 && m->vocab_p <= 32768 && m->H % 16 == 0 && m->cfg.head_dim % 16 == 0;
         const bool d_ok = m->inter_p % 32 == 0 && m->inter_p / 32 >= 8 && (m->inter_p / 32 + 7) / 8 <= 48;
         if (!(k_ok && n_ok && d_ok && decode_km_enabled()))
-            return fail(EMMAX_ERR_INVALID, "exact numerics at batch 3-8 needs the shapes decode_km.hip takes (hidden / q widths in multiples of 256 up to 4096, head_dim 128); max_batch %d", max_batch);
+            return fail(EMMAX_ERR_INVALID, "exact numerics at batch >= 3 needs the shapes decode_km.hip takes (hidden / q widths in multiples of 256 up to 4096, head_dim 128); max_batch %d", max_batch);
     }
     if (m->H % 64 || m->q_dim % 64) return fail(EMMAX_ERR_INVALID, "exact numerics needs hidden and q widths in multiples of 64");
     return 0;
@@ -1745,8 +1790,9 @@ int emmax_session_set_stop(emmax_session* s, const int32_t* trigger_ids, int n_t
 
 int emmax_slots_open(emmax_session* s, int n_slots, emmax_stream stream) {
     if (!s) return fail(EMMAX_ERR_INVALID, "null argument");
-    if (n_slots < 1 || n_slots > s->max_batch || n_slots > model_max_decode_batch(s->m))
-        return fail(EMMAX_ERR_INVALID, "%d slots outside 1..min(max_batch=%d, %d)", n_slots, s->max_batch, model_max_decode_batch(s->m));
+    const int max_rows = s->exact ? EMMAX_MAX_DECODE_BATCH : model_max_decode_batch(s->m);
+    if (n_slots < 1 || n_slots > s->max_batch || n_slots > max_rows)
+        return fail(EMMAX_ERR_INVALID, "%d slots outside 1..min(max_batch=%d, %d)", n_slots, s->max_batch, max_rows);
     if (n_slots >= EMMAX_MFMA_MIN_BATCH && !s->m->aux_built)
         return fail(EMMAX_ERR_STATE, "%d slots decode on the fragment-major weight copies: call emmax_model_build_aux first", n_slots);
     hipStream_t user = (hipStream_t)stream, st;

@@ -154,8 +154,9 @@ class EmmaxEngine:
 
     def max_decode_batch(self) -> int:
         """Rows of one decode batch this model can run (16 for LLaMA-2-7B shapes, 8 for shapes outside decode_km.hip)."""
-        n = int(self.lib.emmax_model_max_decode_batch(self._model))
-        return min(n, 8) if self.exact else n     # exact numerics: two bf16 terms per row in the MFMA's sixteen batch columns
+        if self.exact:      # the two-term kernels take 8 rows per launch and larger batches run in chunks of 8, whatever the default kernels' shape limits
+            return 64
+        return int(self.lib.emmax_model_max_decode_batch(self._model))
 
     def weight_bytes(self) -> int:
         return int(self.arena.numel()) + (int(self.aux_arena.numel()) if self.aux_arena is not None else 0)
