@@ -141,7 +141,7 @@ class EmmaXForActionPrediction:
     def to(self, device: Union[str, torch.device], max_batch: int = 1, max_prompt: int = 512,
            max_ctx: Optional[int] = None, exact: Optional[bool] = None) -> "EmmaXForActionPrediction":
         """`exact=True`: exact numerics -- the reference's fp32 CPU arithmetic (prismatic.py:659-663 on CPU) instead of bf16 operands
-        (include/emmax.h, tuning switch `exact`; batches of 1-8 rows; None = the library's switch, EMMAX_EXACT)."""
+        (include/emmax.h, tuning switch `exact`; 8 rows per launch, larger batches in chunks; None = the library's switch, EMMAX_EXACT)."""
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("EmmaXForActionPrediction runs on MI355X (cuda:N) only; there is no CPU execution path")

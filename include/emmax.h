@@ -93,8 +93,8 @@ int emmax_config_size(void);
  * BASELINE configs[0]) instead of bf16 operands: fp32 activations end to end, every activation operand of a bf16 MFMA / dot2 as TWO bf16 terms
  * hi + lo (the checkpoint's weights are exact bf16), attention on the fp32 MFMA over an fp32 KV cache.  Read at emmax_model_finalize (the ViT
  * LayerNorms stay unfolded: the fold rounds W .* gamma) and at emmax_session_create (fp32 scratch, fp32 cache = twice the KV bytes).  Exact
- * sessions run batches of 1-8 rows (1-2: decode_ks.hip's two-term dot products; 3-8: decode_km.hip with the two terms of a row in the MFMA's sixteen
- * batch columns) on bf16 weights, slot serving included (up to 8 slots); emmax_session_exact() tells which kind a session is.  Logits sit
+ * sessions run on bf16 weights, 8 rows per projection launch (1-2: decode_ks.hip's two-term dot products; 3-8: decode_km.hip with the two terms of a row
+ * in the MFMA's sixteen batch columns; larger batches, up to 64 rows / slots, in chunks of 8 that each stream the weights again), slot serving included; emmax_session_exact() tells which kind a session is.  Logits sit
  * ~1e-5 of max|logit| from the fp32 restatement at full depth (default path: 2.4e-2) -- measured cost in DESIGN.md section 6.
  * Not thread-safe against concurrent launches; a session re-captures its decode graph after a change. */
 int emmax_tuning_set(const char* name, int value);
@@ -112,7 +112,7 @@ int emmax_model_bind_weight(emmax_model* m, const char* hf_key, const void* ptr_
 int64_t emmax_model_arena_bytes(const emmax_model* m);
 /* rows of one decode batch / slot set this model can run: 64 (bf16 or fp8 weights) when every LLM projection is a shape the K-split
  * MFMA kernels take (K % 256 == 0 and <= 4096, N <= 32768, intermediate size % 32 (fp8: % 64) == 0 and <= 11264: LLaMA-2-7B is), else 8 (round 6;
- * round 5: 32; rounds 1-4: 8).  Exact-numerics sessions: 8. */
+ * round 5: 32; rounds 1-4: 8).  Exact-numerics sessions: 64 whatever the shapes (8 rows per launch, larger batches in chunks). */
 int emmax_model_max_decode_batch(const emmax_model* m);
 int emmax_model_finalize(emmax_model* m, void* arena_dev, int64_t arena_bytes, emmax_stream stream);
 /* bf16 models: decode batches >= 3 stream the LLM projections from MFMA-fragment-major copies that a model serving batches 1-2
