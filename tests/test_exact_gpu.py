@@ -454,7 +454,7 @@ def test_exact_batch_8_rows_equal_their_bs1_runs(device):
         assert ids1[0, :T].cpu().tolist() == refs[b], b
 
 
-@pytest.mark.parametrize("n_slots,overlap", [(8, True), (3, False)])
+@pytest.mark.parametrize("n_slots,overlap", [(8, True), (3, False), (12, True)])
 def test_exact_slot_serving_equals_the_oracle_id_for_id(device, n_slots, overlap):
     """Slot serving in exact numerics (round 6: patch embeddings travel as fp32 rows, staged admissions beside the decode steps): 12 requests with ragged
     prompts and budgets over 8 (3) slots on RANDOM tiny weights -- every request emits EXACTLY the ids of the fp32 oracle's bs = 1 greedy run, with no
@@ -468,11 +468,11 @@ def test_exact_slot_serving_equals_the_oracle_id_for_id(device, n_slots, overlap
 
     cfg = EmmaXConfig.tiny()
     sd_bf = {k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(cfg, seed=13).items()}
-    model = EmmaXForActionPrediction(cfg, dict(sd_bf)).to(device, max_batch=8, max_prompt=40, exact=True)
+    model = EmmaXForActionPrediction(cfg, dict(sd_bf)).to(device, max_batch=max(8, n_slots), max_prompt=40, exact=True)   # (12 slots: decode steps in chunks of 8 rows)
     sd_ref = {k: v.float() for k, v in sd_bf.items()}
     eng = model.engine
     rng = np.random.default_rng(41)
-    n_req, T = 12, 24
+    n_req, T = (12 if n_slots <= 8 else 20), 24
     frames = rng.integers(0, 256, size=(n_req, 224, 224, 3), dtype=np.uint8)
     rows = [[1] + [int(x) for x in rng.integers(3, 31744, size=5 + (i * 7) % 23)] for i in range(n_req)]
     budgets = [T if i % 3 else 9 for i in range(n_req)]
