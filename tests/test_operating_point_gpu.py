@@ -205,7 +205,7 @@ def test_decode_batches_of_nine_to_thirty_two_rows(device, setup, tune, nrows, f
            [list(range(64)), list(range(7, 40)), [(i * 37) % 64 for i in range(49)]]   # 64, 33, 49 shuffled rows
     for graph in (0, 1):
         tune(graph=graph)
-        for sel in sels:
+        for sel in (sels if (graph == 0 or nrows < 64) else sels[:1]):     # (64 rows: the sub-batches in eager mode only -- suite time)
             worst, checked, agree = _teacher_forced(model, frames, rows, gens, traces, sel, T16, device)
             assert model.engine.graph_active() == bool(graph)
             assert worst < TOL, (fp8, graph, len(sel), worst)
@@ -372,7 +372,7 @@ def test_thirty_two_slots_with_overlapped_admissions_at_7b_dims(device, setup, t
     through a SlotScheduler with 32 slots and overlapped admissions (packed staged prefills of up to 32 rows on the second stream,
     piecemeal commits, refills while the others decode on decode_kmp.hip), each against its own bs = 1 `generate` and, where the two
     part, the fp32 oracle's margin at that step: a divergence must be a near-tie (margin <= 2 x the measured logit error); the
-    numbers go to gpurun_out/r06_slots32.json.  Round 6: the same with 64 slots and 76 requests -- decode batches of 33-64 rows on
+    numbers go to gpurun_out/r06_slots32.json.  Round 6: the same with 64 slots and 70 requests -- decode batches of 33-64 rows on
     decode_kmp.hip's two-halves form (r06_slots64.json)."""
     import json
     import os
@@ -383,7 +383,7 @@ def test_thirty_two_slots_with_overlapped_admissions_at_7b_dims(device, setup, t
 
     cfg, sd_bf, sd_ref, _, _ = setup
     rng = np.random.default_rng(3232)
-    n_req, T = (44 if n_slots == 32 else 76), 20
+    n_req, T = (44 if n_slots == 32 else 70), 20
     lens = [int(x) for x in rng.integers(8, 513, size=n_req)]
     lens[:4] = [512, 8, 511, 64]
     frames = rng.integers(0, 256, size=(n_req, 224, 224, 3), dtype=np.uint8)
